@@ -1,0 +1,182 @@
+/* muvo_hip.h — C ABI of libmuvo_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the MUVO
+ * world-model training step.  Plain pointers and sizes only (no torch types); every tensor is
+ * caller-allocated device memory, fp32 contiguous NCHW / NCDHW unless stated; `stream` is a hipStream_t
+ * passed as void* (NULL = default stream).  The library keeps no global state besides the last error
+ * string.  Every entry returns 0 on success, a negative MUVO_ERR_* otherwise; muvo_last_error() gives
+ * the message.  The host side (muvo_amd/ops.py) binds these through ctypes and raises RuntimeError.
+ *
+ * Each group cites the reference op it replaces (paths relative to the reference repository).
+ */
+#ifndef MUVO_HIP_H
+#define MUVO_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MUVO_OK 0
+#define MUVO_ERR_INVALID_ARG (-1)
+#define MUVO_ERR_HIP (-2)
+#define MUVO_ERR_RCCL (-3)
+
+#define MUVO_ACT_NONE 0
+#define MUVO_ACT_RELU 1
+#define MUVO_ACT_LEAKY 2 /* slope parameter */
+#define MUVO_ACT_ELU 3   /* alpha = 1 */
+#define MUVO_ACT_TANH 4
+
+const char* muvo_last_error(void);
+int muvo_abi_version(void);
+/* one-launch self test of the MFMA operand/accumulator lane maps; returns 0 when C = A*B is exact */
+int muvo_selftest_mfma(void* stream);
+
+/* ---- convolution family (conv_gemm.hip) -------------------------------------------------------
+ * Replaces nn.Conv2d / nn.Conv3d / nn.ConvTranspose2d forward, data-gradient and weight-gradient:
+ * muvo/models/common.py:549-632 (ConvDecoder), :161-202,498-546 (VoxelDecoder1), :102-130 (DecoderDS),
+ * :249-367 (1x1 heads), muvo/layers/layers.py:9-66, timm ResNet-18 (muvo/models/mile.py:24,81).
+ * Axes are (D,H,W); 2-D problems use D = 1, ksz[0] = 1, stride[0] = 1, pad[0] = 0, dil[0] = 1.
+ * Weight layout is PyTorch's: Conv [Cout][Cin][kD][kH][kW], ConvTranspose [Cin][Cout][kD][kH][kW]. */
+typedef struct muvo_conv_desc {
+  int32_t nd;         /* 2 or 3 */
+  int32_t transposed; /* 0 Conv, 1 ConvTranspose */
+  int32_t N, Cin, Cout;
+  int32_t in_sz[3], out_sz[3];
+  int32_t ksz[3], stride[3], pad[3], dil[3];
+} muvo_conv_desc;
+
+/* sizes (in floats) of the K-major packed weight buffers used by forward/wgrad and by dgrad */
+int muvo_conv_pack_sizes(const muvo_conv_desc* d, int64_t* fwd_floats, int64_t* dgrad_floats);
+/* repack w into wp_fwd and/or wp_dgrad (either may be NULL) */
+int muvo_conv_pack_weights(const muvo_conv_desc* d, const float* w, float* wp_fwd, float* wp_dgrad, void* stream);
+/* y = act(conv(x, w) + bias); bias may be NULL */
+int muvo_conv_forward(const muvo_conv_desc* d, const float* x, const float* wp_fwd, const float* bias, float* y, int act,
+                      float slope, void* stream);
+/* dx = conv_data_grad(dy, w) (dy already multiplied by act'(y) by the caller) */
+int muvo_conv_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp_dgrad, float* dx, void* stream);
+/* dw += conv_weight_grad(x, dy) (PyTorch layout); dbias += sum(dy) if non-NULL.
+ * dwp_scratch: fwd_floats floats of workspace (overwritten). */
+int muvo_conv_wgrad(const muvo_conv_desc* d, const float* x, const float* dy, float* dwp_scratch, float* dw, float* dbias,
+                    void* stream);
+
+/* db[m] += sum_{n,s} dy[n][m][s] (bias gradient of any NCHW-like tensor) */
+int muvo_bias_grad_nchw(const float* dy, float* db, int N, int M, int64_t S, void* stream);
+
+/* ---- strided batched GEMM (gemm.hip) ------------------------------------------------------------
+ * Replaces nn.Linear fwd/bwd (mile.py:151-161, transition.py, common.py:53-68,205-246), the matmuls of
+ * nn.MultiheadAttention (mile.py:96-101) and ConvTranspose2d on a 1x1 input (common.py:578-581).
+ * C[b1][b2][m][n] = act(alpha * sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn] + bias[n / bias_div])
+ * mode 1: C += alpha * A*B with float atomics (split-K; bias/act must be unset). */
+typedef struct muvo_gemm_desc {
+  int32_t M, N, K;
+  int64_t sam, sak, sbk, sbn, scm;
+  int32_t B1, B2;
+  int64_t a_b1, a_b2, b_b1, b_b2, c_b1, c_b2;
+  float alpha;
+  int32_t bias_div;
+  int32_t act;
+  float slope;
+  int32_t mode;
+} muvo_gemm_desc;
+int muvo_gemm(const muvo_gemm_desc* d, const float* A, const float* B, float* C, const float* bias, void* stream);
+
+/* ---- normalisation (norm.hip) --------------------------------------------------------------------
+ * Train-mode BatchNorm2d (batch statistics over N*S, running stats momentum update, unbiased running
+ * var) fused with ReLU and a residual add: res_mode 0 none, 1 add before ReLU (BasicBlock,
+ * layers.py:48-66), 2 add after ReLU (DecoderDS, common.py:128).  ws: 2*C doubles of workspace. */
+int muvo_bn_train_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+                      float* save_mean, float* save_rstd, float* running_mean, float* running_var, double* ws, int N, int C,
+                      int64_t S, float eps, float momentum, int res_mode, int relu, void* stream);
+/* mask_mode 0: no ReLU; 1: ReLU mask from y > 0; 2: ReLU mask from bn(x) > 0 (residual added after the ReLU).
+ * dgamma/dbeta are accumulated (+=). dres (may be NULL) receives the masked gradient for the residual branch. */
+int muvo_bn_train_bwd(const float* x, const float* y, const float* dy, const float* gamma, const float* beta,
+                      const float* save_mean, const float* save_rstd, float* dx, float* dres, float* dgamma, float* dbeta,
+                      double* ws, int N, int C, int64_t S, int mask_mode, void* stream);
+/* AdaptiveInstanceNorm3d (common.py:227-246): y = style[:, :C] * (x-mean)/sqrt(var+eps) + style[:, C:]
+ * x_batch_stride = 0 broadcasts one (C,S) tensor over the batch (VoxelDecoder1.constant_tensor). ws: 2*N*C doubles. */
+int muvo_adain_fwd(const float* x, const float* style, float* y, float* save_mean, float* save_rstd, double* ws, int N,
+                   int C, int64_t S, int64_t x_batch_stride, float eps, void* stream);
+int muvo_adain_bwd(const float* x, const float* style, const float* dy, const float* save_mean, const float* save_rstd,
+                   float* dx, float* dstyle, double* ws, int N, int C, int64_t S, int64_t x_batch_stride, void* stream);
+/* post-LN transformer sub-layer tail: z = x + dropout(a); y = LayerNorm(z) (nn.TransformerEncoderLayer, mile.py:96-101) */
+int muvo_add_dropout_layernorm_fwd(const float* x, const float* a, const float* gamma, const float* beta, float* y,
+                                   float* z, float* mean, float* rstd, int rows, int E, float eps, float p, uint64_t seed,
+                                   void* stream);
+int muvo_add_dropout_layernorm_bwd(const float* dy, const float* z, const float* mean, const float* rstd,
+                                   const float* gamma, float* dx, float* da, float* dgamma, float* dbeta, int rows, int E,
+                                   float p, uint64_t seed, void* stream);
+
+/* ---- elementwise / layout / pooling / resampling (elementwise.hip) ------------------------------- */
+int muvo_act_fwd(const float* x, float* y, int64_t n, int act, float slope, void* stream);
+int muvo_act_bwd(const float* y, const float* dy, float* dx, int64_t n, int act, float slope, void* stream);
+int muvo_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
+int muvo_axpby(const float* a, const float* b, float* out, int64_t n, float alpha, float beta, void* stream);
+int muvo_copy2d(const float* src, float* dst, int64_t rows, int64_t cols, int64_t ld_src, int64_t ld_dst, int accumulate,
+                void* stream);
+int muvo_colsum_acc(const float* x, float* out, int64_t rows, int64_t cols, int64_t ld, void* stream);
+int muvo_batchsum(const float* x, float* out, int N, int64_t inner, int accumulate, void* stream);
+/* tokens[(l0+l)][n][c] = x[n][c][l] + pos[c][l] + temb[c*temb_stride]  (mile.py:542-557) and its inverse (:560-561) */
+int muvo_nchw_to_tokens(const float* x, const float* pos, const float* temb, int temb_stride, float* tokens, int N, int C,
+                        int L, int l0, void* stream);
+int muvo_tokens_to_nchw(const float* tokens, float* x, int N, int C, int L, int l0, void* stream);
+int muvo_maxpool2d_fwd(const float* x, float* y, int32_t* idx, int64_t NC, int H, int W, int OH, int OW, int k, int s, int p,
+                       void* stream);
+int muvo_maxpool2d_bwd(const float* dy, const int32_t* idx, float* dx, int64_t NC, int H, int W, int OH, int OW, int k, int s,
+                       int p, void* stream);
+int muvo_avgpool_fwd(const float* x, float* y, int64_t G, int64_t S, void* stream);
+int muvo_avgpool_bwd(const float* dy, float* dx, int64_t G, int64_t S, void* stream);
+/* F.interpolate(scale_factor=2, mode='trilinear', align_corners=False) (common.py:169) */
+int muvo_upsample3d_x2_fwd(const float* x, float* y, int64_t NC, int D, int H, int W, void* stream);
+int muvo_upsample3d_x2_bwd(const float* dy, float* dx, int64_t NC, int D, int H, int W, void* stream);
+/* PreProcess (muvo/models/preprocess.py:102-225): u8 -> /255 -> crop -> (label, ImageNet-normalised) */
+int muvo_preprocess_image(const uint8_t* img, float* label, float* norm, int64_t NC, int C, int H, int W, int top, int left,
+                          int CH, int CW, const float* mean3, const float* std3, void* stream);
+int muvo_preprocess_route(const uint8_t* img, float* norm, int64_t NC, int C, int H, int W, int OH, int OW,
+                          const float* mean3, const float* std3, void* stream);
+int muvo_divide_scalar(const float* x, float* y, int64_t n, float divisor, void* stream);
+int muvo_resize_bilinear(const float* x, float* y, int64_t NC, int H, int W, int OH, int OW, void* stream);
+int muvo_resize_nearest_f32(const float* x, float* y, int64_t NC, int D, int H, int W, int OD, int OH, int OW, void* stream);
+int muvo_resize_nearest_u8(const uint8_t* x, uint8_t* y, int64_t NC, int D, int H, int W, int OD, int OH, int OW,
+                           void* stream);
+/* attention probabilities: P = softmax(S), Pd = dropout(P) (functional MHA dropout) */
+int muvo_softmax_dropout_fwd(const float* S, float* P, float* Pd, int64_t rows, int cols, float p, uint64_t seed, void* stream);
+int muvo_softmax_dropout_bwd(const float* P, const float* dPd, float* dS, int64_t rows, int cols, float p, uint64_t seed,
+                             void* stream);
+/* nn.GRUCell pointwise part and RepresentationModel sampling (muvo/models/transition.py:18-24,49-52,176-181) */
+int muvo_gru_fwd(const float* gi, const float* gh, const float* h, float* hnew, int B, int H, void* stream);
+int muvo_gru_bwd(const float* gi, const float* gh, const float* h, const float* dhnew, float* dgi, float* dgh, float* dh,
+                 int B, int H, void* stream);
+int muvo_rssm_sample_fwd(const float* mu_logsigma, const float* eps, int64_t eps_ld, float* mu, float* sigma, float* sample,
+                         int B, int S, float min_std, void* stream);
+int muvo_rssm_sample_bwd(const float* mu_logsigma, const float* eps, int64_t eps_ld, const float* dmu, const float* dsigma,
+                         const float* dsample, float* dmls, int B, int S, void* stream);
+
+/* ---- losses + optimiser (losses.hip): muvo/losses.py:53-287, muvo/trainer.py:251-390,1022-1060 ------ */
+/* SpatialRegressionLoss over channels [c0,c1) of (F,Ct,HW) tensors; loss = weight * masked mean; stats2: 2 doubles */
+int muvo_spatial_loss_fwd(const float* pred, const float* target, int64_t F, int Ct, int64_t HW, int c0, int c1, int norm,
+                          float ignore, float weight, double* stats2, float* loss, void* stream);
+int muvo_spatial_loss_bwd(const float* pred, const float* target, float* dpred, int64_t F, int Ct, int64_t HW, int c0, int c1,
+                          int norm, float ignore, float weight, const double* stats2, const float* gout, void* stream);
+/* VoxelLoss (CE mean) + SemScalLoss + GeoScalLoss in one pass; loss3 = {ce, sem_scal, geo_scal} * weight */
+int muvo_voxel_loss_stats_doubles(int C);
+int muvo_voxel_loss_coef_floats(int C);
+int muvo_voxel_loss_fwd(const float* logits, const uint8_t* target, int64_t F, int C, int64_t V, const float* class_w,
+                        float weight, double* stats, float* coef, float* loss3, void* stream);
+int muvo_voxel_loss_bwd(const float* logits, const uint8_t* target, float* dlogits, int64_t F, int C, int64_t V,
+                        const float* class_w, float weight, const float* coef, const float* gout3, void* stream);
+int muvo_l1_rows_fwd(const float* p, const float* t, int64_t rows, int cols, float weight, float* loss, void* stream);
+int muvo_l1_rows_bwd(const float* p, const float* t, float* dp, int64_t rows, int cols, float weight, const float* gout,
+                     void* stream);
+int muvo_kl_loss_fwd(const float* prior_mu, const float* prior_sigma, const float* post_mu, const float* post_sigma, int B,
+                     int T, int S, float weight, float* loss, void* stream);
+int muvo_kl_loss_bwd(const float* prior_mu, const float* prior_sigma, const float* post_mu, const float* post_sigma,
+                     float* d_prior_mu, float* d_prior_sigma, float* d_post_mu, float* d_post_sigma, int B, int T, int S,
+                     float weight, float alpha, const float* gout, void* stream);
+/* torch.optim.AdamW step over a flat parameter segment; grad_scale multiplies g (1/world_size after a sum all-reduce) */
+int muvo_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, int step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MUVO_HIP_H */

@@ -1,0 +1,106 @@
+// Shared helpers for the muvo_amd HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/muvo_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- error plumbing --------------------------------------------------------------------------
+void muvo_set_error(const char* fmt, ...);
+
+#define MUVO_CHECK_ARG(cond, ...)            \
+  do {                                       \
+    if (!(cond)) {                           \
+      muvo_set_error(__VA_ARGS__);           \
+      return MUVO_ERR_INVALID_ARG;           \
+    }                                        \
+  } while (0)
+
+#define MUVO_CHECK_LAUNCH(name)                                                   \
+  do {                                                                            \
+    hipError_t e__ = hipGetLastError();                                           \
+    if (e__ != hipSuccess) {                                                      \
+      muvo_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));      \
+      return MUVO_ERR_HIP;                                                        \
+    }                                                                             \
+  } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline int roundup(int a, int b) { return ((a + b - 1) / b) * b; }
+
+// Grid size for a grid-stride elementwise kernel: enough blocks to fill 256 CUs x 8.
+static inline int ew_grid(long n, int block = 256) {
+  long g = (n + block - 1) / block;
+  if (g > 256 * 16) g = 256 * 16;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ---- activations -----------------------------------------------------------------------------
+__device__ __forceinline__ float act_apply(float v, int act, float slope) {
+  switch (act) {
+    case MUVO_ACT_RELU: return v > 0.f ? v : 0.f;
+    case MUVO_ACT_LEAKY: return v > 0.f ? v : v * slope;
+    case MUVO_ACT_ELU: return v > 0.f ? v : expm1f(v);
+    case MUVO_ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
+// derivative expressed through the OUTPUT y = act(x)
+__device__ __forceinline__ float act_grad_from_out(float y, int act, float slope) {
+  switch (act) {
+    case MUVO_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+    case MUVO_ACT_LEAKY: return y > 0.f ? 1.f : slope;
+    case MUVO_ACT_ELU: return y > 0.f ? 1.f : y + 1.f;
+    case MUVO_ACT_TANH: return 1.f - y * y;
+    default: return 1.f;
+  }
+}
+
+// ---- wave / block reductions (wave = 64 lanes) --------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// Block-wide sum for blockDim.x <= 1024; `red` is >= 16 floats of LDS. Result valid in all threads.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---- counter-based RNG for dropout (stateless: same (seed, index) -> same bit in fwd and bwd) ----
+__device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 32);
+}
+// keep-probability test: returns 1/keep if kept, 0 if dropped (p = drop prob)
+__device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, float p) {
+  if (p <= 0.f) return 1.f;
+  const float u = (float)(hash_u32(seed, idx) >> 8) * (1.0f / 16777216.0f);
+  return u < p ? 0.f : 1.f / (1.f - p);
+}

@@ -1,0 +1,693 @@
+// Implicit-GEMM convolution family on fp32 MFMA (v_mfma_f32_32x32x2_f32), gfx950.
+//
+// One canonical "gather-conv" form covers Conv2d/Conv3d forward, ConvTranspose forward (as stride^nd
+// sub-pixel phases), and both data-gradients:
+//
+//   out[n][m][o(i)] = act(bias[m] + sum_{t<T, c<C} Wp[t*Cp + c][m] * in[n][c][i*is + ib + d[t]])
+//   o(i) = i*os + op,   i in the phase's sub-grid (SD,SH,SW)
+//
+// GEMM view: M = out channels (MFMA rows), N = output pixels (MFMA columns = lanes -> coalesced NCHW
+// stores), K = (tap, channel).  Weights arrive pre-packed K-major ([Kp][Mp], muvo_conv_pack_weights) so
+// the A tile is a coalesced float4 stream; the B tile is the im2col gather with lanes along pixels.
+// Weight-gradient is the transposed problem (K = pixels) with split-K and float atomics into the
+// packed layout, unpacked into the PyTorch layout afterwards.
+//
+// Replaces ATen/cuDNN conv ops used at muvo/models/common.py:549-632 (ConvDecoder), :161-202,498-546
+// (voxel decoder), timm ResNet-18 (mile.py:24,81; common.py:15), layers.py:9-66, common.py:102-130.
+#include "common.h"
+
+#define MAX_TAPS 64
+
+struct ConvPhase {
+  int N, C, Cp, M, Mp, T, Kp;
+  int ID, IH, IW;   // input spatial dims
+  int OD, OH, OW;   // output spatial dims (full tensor)
+  int SD, SH, SW;   // sub-grid enumerated by this phase
+  int os[3], op[3]; // out coord = i*os + op (z,y,x)
+  int is[3], ib[3]; // in coord0 = i*is + ib
+  int in_sC, out_sC;   // channel strides (elements)
+  long in_sN, out_sN;  // batch strides (elements)
+  int npix;            // N*SD*SH*SW
+  unsigned cp_magic;   // floor(2^32/Cp)+1 : k/Cp for k < 65536
+  int tap_d[MAX_TAPS]; // packed (dz+128)<<16 | (dy+128)<<8 | (dx+128)
+  int tap_w[MAX_TAPS]; // flat tap index into the PyTorch weight (r*S+s ...)
+  long wp_off;         // float offset of this phase inside the packed weight buffer
+  long wsm, wsc;       // PyTorch-weight strides of (m, c)
+};
+
+__device__ __forceinline__ void decode_pix(const ConvPhase& g, int p, int& n, int& iz, int& iy, int& ix) {
+  ix = p % g.SW;
+  int r = p / g.SW;
+  iy = r % g.SH;
+  r = r / g.SH;
+  iz = r % g.SD;
+  n = r / g.SD;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forward-type kernel.  256 threads = 4 waves arranged WM x WN; each wave owns TM x TN MFMA tiles of
+// 32x32.  BK = 16, double-buffered LDS, register-staged prefetch (one barrier per K tile).
+// RUN = number of consecutive k (channels) that share one tap within a thread's k-run.
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int RUN>
+__global__ void __launch_bounds__(256)
+conv_fwd_kernel(const ConvPhase g, const float* __restrict__ in, const float* __restrict__ wp,
+                const float* __restrict__ bias, float* __restrict__ out, int act, float slope) {
+  constexpr int BK = 16;
+  constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+  constexpr int KG = 256 / BN;   // thread groups along k for the gather
+  constexpr int KPT = BK / KG;   // k's per thread
+  constexpr int NSR = KPT / RUN; // sub-runs per thread
+  constexpr int LDA = BM + 4, LDB = BN + 4;
+  constexpr int NA4 = (BM * BK / 4 + 255) / 256;  // float4 A loads per thread
+  static_assert(KPT % RUN == 0, "RUN must divide KPT");
+
+  __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA + LDB)];
+  __shared__ int s_tap[MAX_TAPS];
+  float* As0 = smem;
+  float* Bs0 = smem + 2 * BK * LDA;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  if (tid < MAX_TAPS) s_tap[tid] = g.tap_d[tid < g.T ? tid : 0];
+
+  // ---- gather (B operand) setup: this thread's pixel is fixed for the whole kernel
+  const int pl = tid % BN;
+  const int kg = __builtin_amdgcn_readfirstlane(tid / BN);
+  const int p = blockIdx.x * BN + pl;
+  const bool pvalid = p < g.npix;
+  int n, iz, iy, ix;
+  decode_pix(g, pvalid ? p : 0, n, iz, iy, ix);
+  const int z0 = iz * g.is[0] + g.ib[0], y0 = iy * g.is[1] + g.ib[1], x0 = ix * g.is[2] + g.ib[2];
+  const float* inb = in + (size_t)n * g.in_sN;
+  const float* wpb = wp + g.wp_off;
+  const int m_tile = blockIdx.y * BM;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 areg[NA4];
+  float breg[KPT];
+  const int nk = g.Kp / BK;
+
+  auto load_tile = [&](int kt) {
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int r = 0; r < NA4; ++r) {
+      const int idx = tid + r * 256;
+      const int kk = idx / (BM / 4), m4 = idx % (BM / 4);
+      const int m = m_tile + 4 * m4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < BM * BK / 4 && m < g.Mp) v = *(const float4*)(wpb + (size_t)(k0 + kk) * g.Mp + m);
+      areg[r] = v;
+    }
+#pragma unroll
+    for (int sr = 0; sr < NSR; ++sr) {
+      const int k = k0 + kg * KPT + sr * RUN;  // wave-uniform
+      const int t = (int)(((unsigned long long)(unsigned)k * g.cp_magic) >> 32);
+      const int c0 = k - t * g.Cp;
+      const int d = s_tap[t < g.T ? t : 0];
+      const int z = z0 + ((d >> 16) & 255) - 128, y = y0 + ((d >> 8) & 255) - 128, x = x0 + (d & 255) - 128;
+      const bool ok = pvalid && t < g.T && (unsigned)z < (unsigned)g.ID && (unsigned)y < (unsigned)g.IH &&
+                      (unsigned)x < (unsigned)g.IW;
+      const int off = (z * g.IH + y) * g.IW + x;
+#pragma unroll
+      for (int e = 0; e < RUN; ++e) {
+        const int c = c0 + e;
+        float v = 0.f;
+        if (ok && c < g.C) v = inb[(size_t)c * g.in_sC + off];
+        breg[sr * RUN + e] = v;
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* As = As0 + buf * BK * LDA;
+    float* Bs = Bs0 + buf * BK * LDB;
+#pragma unroll
+    for (int r = 0; r < NA4; ++r) {
+      const int idx = tid + r * 256;
+      const int kk = idx / (BM / 4), m4 = idx % (BM / 4);
+      if (idx < BM * BK / 4) *(float4*)(As + kk * LDA + 4 * m4) = areg[r];
+    }
+#pragma unroll
+    for (int e = 0; e < KPT; ++e) Bs[(kg * KPT + e) * LDB + pl] = breg[e];
+  };
+
+  __syncthreads();  // s_tap visible
+  if (nk > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+    const float* As = As0 + buf * BK * LDA + wm * (TM * 32) + (lane & 31);
+    const float* Bs = Bs0 + buf * BK * LDB + wn * (TN * 32) + (lane & 31);
+#pragma unroll
+    for (int k2 = 0; k2 < BK / 2; ++k2) {
+      const int kr = 2 * k2 + (lane >> 5);
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = As[kr * LDA + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bs[kr * LDB + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias + activation, coalesced along pixels (MFMA column = lane&31)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int pj = blockIdx.x * BN + wn * (TN * 32) + j * 32 + (lane & 31);
+    if (pj >= g.npix) continue;
+    int nn, jz, jy, jx;
+    decode_pix(g, pj, nn, jz, jy, jx);
+    const size_t obase = (size_t)nn * g.out_sN +
+                         ((size_t)(jz * g.os[0] + g.op[0]) * g.OH + (jy * g.os[1] + g.op[1])) * g.OW +
+                         (jx * g.os[2] + g.op[2]);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m_tile + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < g.M) {
+          float v = acc[i][j][r];
+          if (bias) v += bias[m];
+          out[obase + (size_t)m * g.out_sC] = act_apply(v, act, slope);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight-gradient kernel: dWp[(t,c)][m] += sum_pix in[n][c][i*is+ib+d[t]] * dout[n][m][o(i)]
+// GEMM rows = (t,c) (BM), cols = m (BN), reduction over BK = 32 pixels per tile, split-K over pixel
+// tiles with float atomics into the packed (zero-initialised) dWp.
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(256)
+conv_wgrad_kernel(const ConvPhase g, const float* __restrict__ in, const float* __restrict__ dout,
+                  float* __restrict__ dwp, int tiles_per_split) {
+  constexpr int BK = 32;
+  constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+  constexpr int LDA = BM + 1, LDB = BN + 1;
+  constexpr int RPT = BM / 8, CPT = BN / 8;
+  __shared__ float smem[2 * BK * (LDA + LDB)];
+  __shared__ int4 s_row[BM];
+  float* As0 = smem;
+  float* Bs0 = smem + 2 * BK * LDA;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int row_tile = blockIdx.x * BM, col_tile = blockIdx.y * BN;
+
+  for (int r = tid; r < BM; r += 256) {
+    const int row = row_tile + r;
+    const int t = row / g.Cp, c = row - t * g.Cp;
+    int4 d;
+    if (t < g.T && c < g.C) {
+      const int td = g.tap_d[t];
+      d.x = c * g.in_sC;
+      d.y = ((td >> 16) & 255) - 128;
+      d.z = ((td >> 8) & 255) - 128;
+      d.w = (td & 255) - 128;
+    } else {
+      d.x = -1; d.y = 0; d.z = 0; d.w = 0;
+    }
+    s_row[r] = d;
+  }
+
+  const int pl = tid & 31, rg = tid >> 5;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int ntiles = (g.npix + BK - 1) / BK;
+  const int t_begin = blockIdx.z * tiles_per_split;
+  int t_end = t_begin + tiles_per_split;
+  if (t_end > ntiles) t_end = ntiles;
+
+  float areg[RPT], breg[CPT];
+  auto load_tile = [&](int pt) {
+    const int p = pt * BK + pl;
+    const bool pvalid = p < g.npix;
+    int n, iz, iy, ix;
+    decode_pix(g, pvalid ? p : 0, n, iz, iy, ix);
+    const int z0 = iz * g.is[0] + g.ib[0], y0 = iy * g.is[1] + g.ib[1], x0 = ix * g.is[2] + g.ib[2];
+    const float* inb = in + (size_t)n * g.in_sN;
+    const float* dob = dout + (size_t)n * g.out_sN +
+                       ((size_t)(iz * g.os[0] + g.op[0]) * g.OH + (iy * g.os[1] + g.op[1])) * g.OW +
+                       (ix * g.os[2] + g.op[2]);
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      const int4 d = s_row[rg * RPT + r];
+      const int z = z0 + d.y, y = y0 + d.z, x = x0 + d.w;
+      float v = 0.f;
+      if (pvalid && d.x >= 0 && (unsigned)z < (unsigned)g.ID && (unsigned)y < (unsigned)g.IH &&
+          (unsigned)x < (unsigned)g.IW)
+        v = inb[(size_t)d.x + (size_t)((z * g.IH + y) * g.IW + x)];
+      areg[r] = v;
+    }
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      const int col = col_tile + rg * CPT + c;
+      float v = 0.f;
+      if (pvalid && col < g.M) v = dob[(size_t)col * g.out_sC];
+      breg[c] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* As = As0 + buf * BK * LDA + pl * LDA + rg * RPT;
+    float* Bs = Bs0 + buf * BK * LDB + pl * LDB + rg * CPT;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) As[r] = areg[r];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) Bs[c] = breg[c];
+  };
+
+  __syncthreads();  // s_row
+  if (t_begin < t_end) {
+    load_tile(t_begin);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int pt = t_begin; pt < t_end; ++pt) {
+    const int buf = (pt - t_begin) & 1;
+    if (pt + 1 < t_end) load_tile(pt + 1);
+    const float* As = As0 + buf * BK * LDA + wm * (TM * 32) + (lane & 31);
+    const float* Bs = Bs0 + buf * BK * LDB + wn * (TN * 32) + (lane & 31);
+#pragma unroll
+    for (int k2 = 0; k2 < BK / 2; ++k2) {
+      const int kr = 2 * k2 + (lane >> 5);
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = As[kr * LDA + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bs[kr * LDB + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (pt + 1 < t_end) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+  if (t_begin >= t_end) return;
+
+  float* dwb = dwp + g.wp_off;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = col_tile + wn * (TN * 32) + j * 32 + (lane & 31);
+    if (col >= g.M) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row_tile + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < g.Kp) atomicAdd(dwb + (size_t)row * g.Mp + col, acc[i][j][r]);
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pack: Wp[t*Cp+c][m] = W[m*wsm + c*wsc + tap_w[t]] (zero padded);  unpack: dW[...] += dWp[...]
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pack_weights_kernel(const ConvPhase g, const float* __restrict__ w,
+                                                           float* __restrict__ wp) {
+  __shared__ int s_tw[MAX_TAPS];
+  if (threadIdx.x < MAX_TAPS) s_tw[threadIdx.x] = g.tap_w[threadIdx.x];
+  __syncthreads();
+  const long total = (long)g.Kp * g.Mp;
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int k = (int)(idx / g.Mp), m = (int)(idx - (long)k * g.Mp);
+    const int t = k / g.Cp, c = k - t * g.Cp;
+    float v = 0.f;
+    if (t < g.T && c < g.C && m < g.M) v = w[(size_t)m * g.wsm + (size_t)c * g.wsc + s_tw[t]];
+    wp[g.wp_off + idx] = v;
+  }
+}
+
+// One thread per (m, c, t) of the phase: coalesced along t/c on the PyTorch side.
+__global__ void __launch_bounds__(256) unpack_wgrad_kernel(const ConvPhase g, const float* __restrict__ dwp,
+                                                           float* __restrict__ dw) {
+  __shared__ int s_tw[MAX_TAPS];
+  if (threadIdx.x < MAX_TAPS) s_tw[threadIdx.x] = g.tap_w[threadIdx.x];
+  __syncthreads();
+  const long total = (long)g.M * g.C * g.T;
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    // order (outer->inner): the slower of (m,c) by weight stride first, taps innermost
+    int t = (int)(idx % g.T);
+    long r = idx / g.T;
+    int m, c;
+    if (g.wsm > g.wsc) { c = (int)(r % g.C); m = (int)(r / g.C); }
+    else { m = (int)(r % g.M); c = (int)(r / g.M); }
+    const float v = dwp[g.wp_off + (size_t)(t * g.Cp + c) * g.Mp + m];
+    dw[(size_t)m * g.wsm + (size_t)c * g.wsc + s_tw[t]] += v;
+  }
+}
+
+// per-channel bias gradient: db[m] += sum_{n, spatial} dy[n][m][...]
+__global__ void __launch_bounds__(256) bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db,
+                                                        int N, int M, long S) {
+  __shared__ float red[16];
+  const int m = blockIdx.x;
+  const int nchunk = gridDim.y;
+  float s = 0.f;
+  const long total = (long)N * S;
+  const long per = (total + nchunk - 1) / nchunk;
+  const long b0 = blockIdx.y * per;
+  long b1 = b0 + per;
+  if (b1 > total) b1 = total;
+  for (long i = b0 + threadIdx.x; i < b1; i += 256) {
+    const long n = i / S, sp = i - n * S;
+    s += dy[((size_t)n * M + m) * S + sp];
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) atomicAdd(db + m, s);
+}
+
+// ================================================================================================
+// Host side: geometry builders + C ABI
+// ================================================================================================
+static int check_desc(const muvo_conv_desc* d) {
+  MUVO_CHECK_ARG(d != nullptr, "conv desc is null");
+  MUVO_CHECK_ARG(d->nd == 2 || d->nd == 3, "conv desc: nd must be 2 or 3 (got %d)", d->nd);
+  MUVO_CHECK_ARG(d->N > 0 && d->Cin > 0 && d->Cout > 0, "conv desc: N/Cin/Cout must be positive");
+  for (int a = 0; a < 3; ++a) {
+    MUVO_CHECK_ARG(d->in_sz[a] > 0 && d->out_sz[a] > 0 && d->ksz[a] > 0 && d->stride[a] > 0 && d->dil[a] > 0 &&
+                       d->pad[a] >= 0,
+                   "conv desc: bad geometry on axis %d", a);
+    // shape consistency (same formulas as torch.nn.Conv*/ConvTranspose*)
+    if (!d->transposed) {
+      const int o = (d->in_sz[a] + 2 * d->pad[a] - d->dil[a] * (d->ksz[a] - 1) - 1) / d->stride[a] + 1;
+      MUVO_CHECK_ARG(o == d->out_sz[a], "conv desc: out_sz[%d]=%d inconsistent (expected %d)", a, d->out_sz[a], o);
+    } else {
+      const int lo = (d->in_sz[a] - 1) * d->stride[a] - 2 * d->pad[a] + d->dil[a] * (d->ksz[a] - 1) + 1;
+      MUVO_CHECK_ARG(d->out_sz[a] >= lo && d->out_sz[a] < lo + d->stride[a] + (d->stride[a] == 1),
+                     "convT desc: out_sz[%d]=%d inconsistent (min %d)", a, d->out_sz[a], lo);
+    }
+  }
+  return MUVO_OK;
+}
+
+static int choose_cp(int C) { return C <= 4 ? 4 : (C <= 8 ? 8 : roundup(C, 16)); }
+
+static void finish_phase(ConvPhase& g) {
+  g.Cp = choose_cp(g.C);
+  g.Mp = roundup(g.M, 32);
+  g.Kp = roundup(g.T * g.Cp, 16);
+  g.cp_magic = (unsigned)((0x100000000ull / (unsigned)g.Cp) + 1ull);
+  g.npix = g.N * g.SD * g.SH * g.SW;
+}
+
+// "conv form": out pixel o, in = o*stride - pad + r*dil.  in_dims/out_dims are the roles in THIS op.
+static int build_conv_form(const muvo_conv_desc* d, const int* in_dims, const int* out_dims, int C, int M,
+                           long wsm, long wsc, ConvPhase* ph) {
+  ConvPhase g;
+  memset(&g, 0, sizeof(g));
+  g.N = d->N; g.C = C; g.M = M;
+  g.ID = in_dims[0]; g.IH = in_dims[1]; g.IW = in_dims[2];
+  g.OD = out_dims[0]; g.OH = out_dims[1]; g.OW = out_dims[2];
+  g.SD = g.OD; g.SH = g.OH; g.SW = g.OW;
+  int T = 0;
+  for (int a = 0; a < 3; ++a) { g.os[a] = 1; g.op[a] = 0; g.is[a] = d->stride[a]; g.ib[a] = -d->pad[a]; }
+  const int ntap = d->ksz[0] * d->ksz[1] * d->ksz[2];
+  MUVO_CHECK_ARG(ntap <= MAX_TAPS, "conv: %d taps exceed MAX_TAPS=%d", ntap, MAX_TAPS);
+  for (int kz = 0; kz < d->ksz[0]; ++kz)
+    for (int ky = 0; ky < d->ksz[1]; ++ky)
+      for (int kx = 0; kx < d->ksz[2]; ++kx) {
+        const int dz = kz * d->dil[0], dy = ky * d->dil[1], dx = kx * d->dil[2];
+        MUVO_CHECK_ARG(dz < 120 && dy < 120 && dx < 120, "conv: tap delta out of range");
+        g.tap_d[T] = ((dz + 128) << 16) | ((dy + 128) << 8) | (dx + 128);
+        g.tap_w[T] = (kz * d->ksz[1] + ky) * d->ksz[2] + kx;
+        ++T;
+      }
+  g.T = T;
+  g.in_sC = g.ID * g.IH * g.IW; g.out_sC = g.OD * g.OH * g.OW;
+  g.in_sN = (long)C * g.in_sC; g.out_sN = (long)M * g.out_sC;
+  g.wsm = wsm; g.wsc = wsc;
+  finish_phase(g);
+  *ph = g;
+  return MUVO_OK;
+}
+
+// "transposed form": for input p, out h = p*stride - pad + r*dil.  One phase per output residue.
+// Returns number of phases via *nph (phases with empty sub-grids are dropped).
+static int build_transposed_form(const muvo_conv_desc* d, const int* in_dims, const int* out_dims, int C, int M,
+                                 long wsm, long wsc, ConvPhase* phs, int* nph) {
+  int count = 0;
+  const int s0 = d->stride[0], s1 = d->stride[1], s2 = d->stride[2];
+  MUVO_CHECK_ARG(s0 * s1 * s2 <= 8, "transposed form: too many phases");
+  for (int p0 = 0; p0 < s0; ++p0)
+    for (int p1 = 0; p1 < s1; ++p1)
+      for (int p2 = 0; p2 < s2; ++p2) {
+        const int php[3] = {p0, p1, p2};
+        ConvPhase g;
+        memset(&g, 0, sizeof(g));
+        g.N = d->N; g.C = C; g.M = M;
+        g.ID = in_dims[0]; g.IH = in_dims[1]; g.IW = in_dims[2];
+        g.OD = out_dims[0]; g.OH = out_dims[1]; g.OW = out_dims[2];
+        int sub[3];
+        bool empty = false;
+        // per-axis tap lists
+        int nt[3], tr[3][16], td[3][16];
+        for (int a = 0; a < 3; ++a) {
+          const int s = d->stride[a];
+          sub[a] = (out_dims[a] - php[a] + s - 1) / s;
+          if (sub[a] <= 0) empty = true;
+          g.os[a] = s; g.op[a] = php[a]; g.is[a] = 1; g.ib[a] = 0;
+          nt[a] = 0;
+          for (int r = 0; r < d->ksz[a]; ++r) {
+            const int num = php[a] + d->pad[a] - r * d->dil[a];
+            int mod = num % s; if (mod < 0) mod += s;
+            if (mod != 0) continue;
+            MUVO_CHECK_ARG(nt[a] < 16, "transposed form: too many taps per axis");
+            tr[a][nt[a]] = r;
+            td[a][nt[a]] = (num - mod) / s;  // exact (floor) division
+            if (num < 0) td[a][nt[a]] = -((-num) / s);
+            ++nt[a];
+          }
+        }
+        if (empty) continue;
+        g.SD = sub[0]; g.SH = sub[1]; g.SW = sub[2];
+        int T = 0;
+        MUVO_CHECK_ARG(nt[0] * nt[1] * nt[2] <= MAX_TAPS, "transposed form: too many taps");
+        for (int a0 = 0; a0 < nt[0]; ++a0)
+          for (int a1 = 0; a1 < nt[1]; ++a1)
+            for (int a2 = 0; a2 < nt[2]; ++a2) {
+              const int dz = td[0][a0], dy = td[1][a1], dx = td[2][a2];
+              MUVO_CHECK_ARG(dz > -120 && dz < 120 && dy > -120 && dy < 120 && dx > -120 && dx < 120,
+                             "transposed form: tap delta out of range");
+              g.tap_d[T] = ((dz + 128) << 16) | ((dy + 128) << 8) | (dx + 128);
+              g.tap_w[T] = (tr[0][a0] * d->ksz[1] + tr[1][a1]) * d->ksz[2] + tr[2][a2];
+              ++T;
+            }
+        g.T = T;
+        g.in_sC = g.ID * g.IH * g.IW; g.out_sC = g.OD * g.OH * g.OW;
+        g.in_sN = (long)C * g.in_sC; g.out_sN = (long)M * g.out_sC;
+        g.wsm = wsm; g.wsc = wsc;
+        finish_phase(g);
+        phs[count++] = g;
+      }
+  *nph = count;
+  return MUVO_OK;
+}
+
+struct ConvPlan {
+  ConvPhase fwd[8]; int nfwd;
+  ConvPhase dgr[8]; int ndgr;
+  long fwd_floats, dgr_floats;
+};
+
+static int build_plan(const muvo_conv_desc* d, ConvPlan* pl) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  const long taps = (long)d->ksz[0] * d->ksz[1] * d->ksz[2];
+  if (!d->transposed) {
+    // weight [Cout][Cin][taps]
+    pl->nfwd = 1;
+    rc = build_conv_form(d, d->in_sz, d->out_sz, d->Cin, d->Cout, d->Cin * taps, taps, &pl->fwd[0]);
+    if (rc) return rc;
+    rc = build_transposed_form(d, d->out_sz, d->in_sz, d->Cout, d->Cin, taps, d->Cin * taps, pl->dgr, &pl->ndgr);
+    if (rc) return rc;
+  } else {
+    // weight [Cin][Cout][taps]
+    rc = build_transposed_form(d, d->in_sz, d->out_sz, d->Cin, d->Cout, taps, d->Cout * taps, pl->fwd, &pl->nfwd);
+    if (rc) return rc;
+    pl->ndgr = 1;
+    rc = build_conv_form(d, d->out_sz, d->in_sz, d->Cout, d->Cin, d->Cout * taps, taps, &pl->dgr[0]);
+    if (rc) return rc;
+  }
+  long off = 0;
+  for (int i = 0; i < pl->nfwd; ++i) { pl->fwd[i].wp_off = off; off += (long)pl->fwd[i].Kp * pl->fwd[i].Mp; }
+  pl->fwd_floats = off;
+  off = 0;
+  for (int i = 0; i < pl->ndgr; ++i) { pl->dgr[i].wp_off = off; off += (long)pl->dgr[i].Kp * pl->dgr[i].Mp; }
+  pl->dgr_floats = off;
+  return MUVO_OK;
+}
+
+template <int BM, int BN, int WM, int WN>
+static void launch_fwd_run(const ConvPhase& g, const float* in, const float* wp, const float* bias, float* out,
+                           int act, float slope, hipStream_t st) {
+  dim3 grid(cdiv(g.npix, BN), cdiv(g.M, BM), 1);
+  constexpr int KPT = 16 / (256 / BN);
+  if (g.Cp == 4)
+    hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 4>), grid, dim3(256), 0, st, g, in, wp, bias, out, act, slope);
+  else if (g.Cp == 8 || KPT == 8)
+    hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 8>), grid, dim3(256), 0, st, g, in, wp, bias, out, act, slope);
+  else
+    hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, KPT>), grid, dim3(256), 0, st, g, in, wp, bias, out, act, slope);
+}
+
+static int launch_fwd_phase(const ConvPhase& g, const float* in, const float* wp, const float* bias, float* out,
+                            int act, float slope, hipStream_t st) {
+  if (g.npix <= 0) return MUVO_OK;
+  if (g.M > 64) launch_fwd_run<128, 128, 2, 2>(g, in, wp, bias, out, act, slope, st);
+  else if (g.M > 32) launch_fwd_run<64, 128, 2, 2>(g, in, wp, bias, out, act, slope, st);
+  else launch_fwd_run<32, 128, 1, 4>(g, in, wp, bias, out, act, slope, st);
+  MUVO_CHECK_LAUNCH("conv_fwd_kernel");
+  return MUVO_OK;
+}
+
+static int launch_wgrad_phase(const ConvPhase& g, const float* in, const float* dout, float* dwp, hipStream_t st) {
+  if (g.npix <= 0 || g.T == 0) return MUVO_OK;
+  const int ntiles = cdiv(g.npix, 32);
+  const int rows = g.Kp;
+  int bm, bn;
+  if (g.M > 64) bn = 128; else if (g.M > 32) bn = 64; else bn = 32;
+  bm = 128;
+  const int gx = cdiv(rows, bm), gy = cdiv(g.M, bn);
+  // split-K: aim for >= 1024 blocks, each with >= 8 pixel tiles
+  int nsplit = cdiv(1024, gx * gy);
+  if (nsplit > cdiv(ntiles, 8)) nsplit = cdiv(ntiles, 8);
+  if (nsplit < 1) nsplit = 1;
+  const int tps = cdiv(ntiles, nsplit);
+  nsplit = cdiv(ntiles, tps);
+  dim3 grid(gx, gy, nsplit);
+  if (bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, g, in, dout, dwp, tps);
+  else if (bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 2, 2>), grid, dim3(256), 0, st, g, in, dout, dwp, tps);
+  else hipLaunchKernelGGL((conv_wgrad_kernel<128, 32, 4, 1>), grid, dim3(256), 0, st, g, in, dout, dwp, tps);
+  MUVO_CHECK_LAUNCH("conv_wgrad_kernel");
+  return MUVO_OK;
+}
+
+extern "C" {
+
+int muvo_conv_pack_sizes(const muvo_conv_desc* d, int64_t* fwd_floats, int64_t* dgrad_floats) {
+  ConvPlan pl;
+  int rc = build_plan(d, &pl);
+  if (rc) return rc;
+  if (fwd_floats) *fwd_floats = pl.fwd_floats;
+  if (dgrad_floats) *dgrad_floats = pl.dgr_floats;
+  return MUVO_OK;
+}
+
+int muvo_conv_pack_weights(const muvo_conv_desc* d, const float* w, float* wp_fwd, float* wp_dgrad, void* stream) {
+  ConvPlan pl;
+  int rc = build_plan(d, &pl);
+  if (rc) return rc;
+  MUVO_CHECK_ARG(w != nullptr, "conv_pack_weights: w is null");
+  hipStream_t st = (hipStream_t)stream;
+  if (wp_fwd)
+    for (int i = 0; i < pl.nfwd; ++i) {
+      const long total = (long)pl.fwd[i].Kp * pl.fwd[i].Mp;
+      if (total == 0) continue;
+      hipLaunchKernelGGL(pack_weights_kernel, dim3(ew_grid(total)), dim3(256), 0, st, pl.fwd[i], w, wp_fwd);
+    }
+  if (wp_dgrad)
+    for (int i = 0; i < pl.ndgr; ++i) {
+      const long total = (long)pl.dgr[i].Kp * pl.dgr[i].Mp;
+      if (total == 0) continue;
+      hipLaunchKernelGGL(pack_weights_kernel, dim3(ew_grid(total)), dim3(256), 0, st, pl.dgr[i], w, wp_dgrad);
+    }
+  MUVO_CHECK_LAUNCH("pack_weights_kernel");
+  return MUVO_OK;
+}
+
+int muvo_conv_forward(const muvo_conv_desc* d, const float* x, const float* wp_fwd, const float* bias, float* y,
+                      int act, float slope, void* stream) {
+  ConvPlan pl;
+  int rc = build_plan(d, &pl);
+  if (rc) return rc;
+  MUVO_CHECK_ARG(x && wp_fwd && y, "conv_forward: null pointer");
+  for (int i = 0; i < pl.nfwd; ++i) {
+    rc = launch_fwd_phase(pl.fwd[i], x, wp_fwd, bias, y, act, slope, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  return MUVO_OK;
+}
+
+int muvo_conv_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp_dgrad, float* dx, void* stream) {
+  ConvPlan pl;
+  int rc = build_plan(d, &pl);
+  if (rc) return rc;
+  MUVO_CHECK_ARG(dy && wp_dgrad && dx, "conv_dgrad: null pointer");
+  for (int i = 0; i < pl.ndgr; ++i) {
+    rc = launch_fwd_phase(pl.dgr[i], dy, wp_dgrad, nullptr, dx, MUVO_ACT_NONE, 0.f, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  return MUVO_OK;
+}
+
+// dw (PyTorch layout) += grad;  dbias += sum(dy).  dwp_scratch: fwd_floats floats of workspace.
+int muvo_conv_wgrad(const muvo_conv_desc* d, const float* x, const float* dy, float* dwp_scratch, float* dw,
+                    float* dbias, void* stream) {
+  ConvPlan pl;
+  int rc = build_plan(d, &pl);
+  if (rc) return rc;
+  MUVO_CHECK_ARG(x && dy && dwp_scratch && dw, "conv_wgrad: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(dwp_scratch, 0, sizeof(float) * pl.fwd_floats, st) != hipSuccess) {
+    muvo_set_error("conv_wgrad: memset failed");
+    return MUVO_ERR_HIP;
+  }
+  for (int i = 0; i < pl.nfwd; ++i) {
+    rc = launch_wgrad_phase(pl.fwd[i], x, dy, dwp_scratch, st);
+    if (rc) return rc;
+  }
+  for (int i = 0; i < pl.nfwd; ++i) {
+    const long total = (long)pl.fwd[i].M * pl.fwd[i].C * pl.fwd[i].T;
+    if (total == 0) continue;
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(ew_grid(total)), dim3(256), 0, st, pl.fwd[i], dwp_scratch, dw);
+  }
+  MUVO_CHECK_LAUNCH("unpack_wgrad_kernel");
+  if (dbias) {
+    const long S = (long)d->out_sz[0] * d->out_sz[1] * d->out_sz[2];
+    int chunks = cdiv((long)d->N * S, 65536);
+    if (chunks > 64) chunks = 64;
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(d->Cout, chunks), dim3(256), 0, st, dy, dbias, d->N, d->Cout, S);
+    MUVO_CHECK_LAUNCH("bias_grad_kernel");
+  }
+  return MUVO_OK;
+}
+
+// db[m] += sum_{n,s} dy[n][m][s]
+int muvo_bias_grad_nchw(const float* dy, float* db, int N, int M, int64_t S, void* stream) {
+  MUVO_CHECK_ARG(dy && db && N > 0 && M > 0 && S > 0, "bias_grad_nchw: bad args");
+  int chunks = cdiv((long)N * S, 65536);
+  if (chunks > 64) chunks = 64;
+  hipLaunchKernelGGL(bias_grad_kernel, dim3(M, chunks), dim3(256), 0, (hipStream_t)stream, dy, db, N, M, (long)S);
+  MUVO_CHECK_LAUNCH("bias_grad_kernel");
+  return MUVO_OK;
+}
+
+}  // extern "C"

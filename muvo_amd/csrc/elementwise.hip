@@ -1,0 +1,653 @@
+// HBM-bound glue kernels of the training step: activation backward, dropout, strided copies (cat/split),
+// column sums (bias grads), NCHW<->token transposes with positional/type embedding (mile.py:542-569),
+// max/avg pooling (timm ResNet stem, common.py:127, mile.py:107), trilinear x2 upsampling
+// (common.py:169), PreProcess (preprocess.py:102-225), attention softmax(+dropout), GRU / RSSM pointwise
+// math (transition.py:18-24,160-181).  All coalesced, grid-stride.
+#include "common.h"
+
+#define GRID_STRIDE(i, n) for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
+
+// ------------------------------------------------------------------------------------------ basic
+__global__ void act_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dx, long n,
+                               int act, float slope) {
+  GRID_STRIDE(i, n) dx[i] = dy[i] * act_grad_from_out(y[i], act, slope);
+}
+__global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n, int act, float slope) {
+  GRID_STRIDE(i, n) y[i] = act_apply(x[i], act, slope);
+}
+__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float p, uint64_t seed) {
+  GRID_STRIDE(i, n) y[i] = x[i] * dropout_scale(seed, (uint64_t)i, p);
+}
+__global__ void axpby_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long n,
+                             float alpha, float beta) {
+  GRID_STRIDE(i, n) out[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
+}
+__global__ void copy2d_kernel(const float* __restrict__ src, float* __restrict__ dst, long rows, long cols, long lds,
+                              long ldd, int accumulate) {
+  const long n = rows * cols;
+  GRID_STRIDE(i, n) {
+    const long r = i / cols, c = i - r * cols;
+    if (accumulate) dst[r * ldd + c] += src[r * lds + c];
+    else dst[r * ldd + c] = src[r * lds + c];
+  }
+}
+// out[c] += sum_r x[r*ld + c]
+__global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long rows,
+                                                     long cols, long ld) {
+  // block handles 64 columns x a row chunk; 4 row-lanes per column
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const long c = blockIdx.x * 64L + cl;
+  const long per = (rows + gridDim.y - 1) / gridDim.y;
+  const long r0 = blockIdx.y * per;
+  long r1 = r0 + per;
+  if (r1 > rows) r1 = rows;
+  float s = 0.f;
+  if (c < cols)
+    for (long r = r0 + rl; r < r1; r += 4) s += x[r * ld + c];
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < cols) atomicAdd(&out[c], red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+}
+// out[j] = sum_n x[n*inner + j]  (batch reduction for broadcast parameters)
+__global__ void batchsum_kernel(const float* __restrict__ x, float* __restrict__ out, int N, long inner, int accumulate) {
+  GRID_STRIDE(j, inner) {
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += x[(long)n * inner + j];
+    if (accumulate) out[j] += s; else out[j] = s;
+  }
+}
+
+// -------------------------------------------------------------------------- NCHW <-> tokens (L,N,C)
+// tokens[(l0+l)*N*C + n*C + c] = x[n][c][l] + pos[c][l] + temb[c*temb_stride]
+__global__ void __launch_bounds__(256) nchw_to_tokens_kernel(const float* __restrict__ x, const float* __restrict__ pos,
+                                                             const float* __restrict__ temb, int temb_stride,
+                                                             float* __restrict__ tok, int N, int C, int L, int l0) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z;
+  const int c0 = blockIdx.y * 32, lb = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int k = ty; k < 32; k += 8) {
+    const int c = c0 + k, l = lb + tx;
+    float v = 0.f;
+    if (c < C && l < L) {
+      v = x[((long)n * C + c) * L + l];
+      if (pos) v += pos[(long)c * L + l];
+      if (temb) v += temb[(long)c * temb_stride];
+    }
+    tile[k][tx] = v;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int l = lb + k, c = c0 + tx;
+    if (c < C && l < L) tok[((long)(l0 + l) * N + n) * C + c] = tile[tx][k];
+  }
+}
+// x[n][c][l] = tokens[(l0+l)*N*C + n*C + c]
+__global__ void __launch_bounds__(256) tokens_to_nchw_kernel(const float* __restrict__ tok, float* __restrict__ x, int N,
+                                                             int C, int L, int l0) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z;
+  const int c0 = blockIdx.y * 32, lb = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8) {
+    const int l = lb + k, c = c0 + tx;
+    tile[k][tx] = (c < C && l < L) ? tok[((long)(l0 + l) * N + n) * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int c = c0 + k, l = lb + tx;
+    if (c < C && l < L) x[((long)n * C + c) * L + l] = tile[tx][k];
+  }
+}
+
+// ---------------------------------------------------------------------------------------- pooling
+__global__ void maxpool2d_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int* __restrict__ idx, long NC,
+                                     int H, int W, int OH, int OW, int k, int s, int p) {
+  const long n = NC * OH * OW;
+  GRID_STRIDE(i, n) {
+    const int ow = (int)(i % OW);
+    long r = i / OW;
+    const int oh = (int)(r % OH);
+    const long nc = r / OH;
+    const float* xp = x + nc * H * W;
+    float best = -INFINITY;
+    int bi = -1;
+    for (int a = 0; a < k; ++a) {
+      const int h = oh * s - p + a;
+      if ((unsigned)h >= (unsigned)H) continue;
+      for (int b = 0; b < k; ++b) {
+        const int w = ow * s - p + b;
+        if ((unsigned)w >= (unsigned)W) continue;
+        const float v = xp[h * W + w];
+        if (v > best || bi < 0) { best = v; bi = h * W + w; }   // first max wins (PyTorch semantics)
+      }
+    }
+    y[i] = best;
+    idx[i] = bi;
+  }
+}
+__global__ void maxpool2d_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ idx, float* __restrict__ dx,
+                                     long NC, int H, int W, int OH, int OW, int k, int s, int p) {
+  const long n = NC * H * W;
+  GRID_STRIDE(i, n) {
+    const int w = (int)(i % W);
+    long r = i / W;
+    const int h = (int)(r % H);
+    const long nc = r / H;
+    const int me = h * W + w;
+    int oh0 = (h + p - k + s) / s; if (h + p - k + 1 <= 0) oh0 = 0;
+    int ow0 = (w + p - k + s) / s; if (w + p - k + 1 <= 0) ow0 = 0;
+    int oh1 = (h + p) / s; if (oh1 > OH - 1) oh1 = OH - 1;
+    int ow1 = (w + p) / s; if (ow1 > OW - 1) ow1 = OW - 1;
+    float g = 0.f;
+    for (int oh = oh0; oh <= oh1; ++oh)
+      for (int ow = ow0; ow <= ow1; ++ow) {
+        const long o = (nc * OH + oh) * OW + ow;
+        if (idx[o] == me) g += dy[o];
+      }
+    dx[i] = g;
+  }
+}
+// y[g] = mean_s x[g*S + s]; one wave per group
+__global__ void __launch_bounds__(256) avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long G, long S) {
+  const long g = blockIdx.x * 4L + (threadIdx.x >> 6);
+  if (g >= G) return;
+  const int lane = threadIdx.x & 63;
+  float s = 0.f;
+  for (long i = lane; i < S; i += 64) s += x[g * S + i];
+  s = wave_sum(s);
+  if (lane == 0) y[g] = s / (float)S;
+}
+__global__ void avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long G, long S) {
+  const long n = G * S;
+  const float inv = 1.f / (float)S;
+  GRID_STRIDE(i, n) dx[i] = dy[i / S] * inv;
+}
+
+// ------------------------------------------------------------------------- trilinear x2 upsample
+__device__ __forceinline__ void lin_src(int d, int n_in, int& i0, int& i1, float& w1) {
+  float src = 0.5f * ((float)d + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  i0 = (int)src;
+  i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+  w1 = src - (float)i0;
+}
+__global__ void upsample3d_x2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long NC, int D, int H, int W) {
+  const int OD = 2 * D, OH = 2 * H, OW = 2 * W;
+  const long n = NC * OD * OH * OW;
+  GRID_STRIDE(i, n) {
+    const int ow = (int)(i % OW);
+    long r = i / OW;
+    const int oh = (int)(r % OH);
+    r /= OH;
+    const int od = (int)(r % OD);
+    const long nc = r / OD;
+    int d0, d1, h0, h1, w0, w1;
+    float fd, fh, fw;
+    lin_src(od, D, d0, d1, fd);
+    lin_src(oh, H, h0, h1, fh);
+    lin_src(ow, W, w0, w1, fw);
+    const float* xp = x + nc * D * H * W;
+    const float v000 = xp[(d0 * H + h0) * W + w0], v001 = xp[(d0 * H + h0) * W + w1];
+    const float v010 = xp[(d0 * H + h1) * W + w0], v011 = xp[(d0 * H + h1) * W + w1];
+    const float v100 = xp[(d1 * H + h0) * W + w0], v101 = xp[(d1 * H + h0) * W + w1];
+    const float v110 = xp[(d1 * H + h1) * W + w0], v111 = xp[(d1 * H + h1) * W + w1];
+    const float a = (1.f - fd), b = (1.f - fh), c = (1.f - fw);
+    y[i] = a * (b * (c * v000 + fw * v001) + fh * (c * v010 + fw * v011)) +
+           fd * (b * (c * v100 + fw * v101) + fh * (c * v110 + fw * v111));
+  }
+}
+// per-axis weight with which output index d reads input index i
+__device__ __forceinline__ float lin_w(int d, int i, int n_in) {
+  int i0, i1; float w1;
+  lin_src(d, n_in, i0, i1, w1);
+  return (i0 == i ? 1.f - w1 : 0.f) + (i1 == i ? w1 : 0.f);
+}
+__global__ void upsample3d_x2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long NC, int D, int H, int W) {
+  const int OD = 2 * D, OH = 2 * H, OW = 2 * W;
+  const long n = NC * D * H * W;
+  GRID_STRIDE(i, n) {
+    const int w = (int)(i % W);
+    long r = i / W;
+    const int h = (int)(r % H);
+    r /= H;
+    const int d = (int)(r % D);
+    const long nc = r / D;
+    const float* gp = dy + nc * OD * OH * OW;
+    float acc = 0.f;
+    for (int a = 2 * d - 1; a <= 2 * d + 2; ++a) {
+      if ((unsigned)a >= (unsigned)OD) continue;
+      const float wa = lin_w(a, d, D);
+      if (wa == 0.f) continue;
+      for (int b = 2 * h - 1; b <= 2 * h + 2; ++b) {
+        if ((unsigned)b >= (unsigned)OH) continue;
+        const float wb = lin_w(b, h, H);
+        if (wb == 0.f) continue;
+        float row = 0.f;
+        for (int c = 2 * w - 1; c <= 2 * w + 2; ++c) {
+          if ((unsigned)c >= (unsigned)OW) continue;
+          row += lin_w(c, w, W) * gp[((long)a * OH + b) * OW + c];
+        }
+        acc += wa * wb * row;
+      }
+    }
+    dx[i] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------ preprocess
+// u8 (NC, H, W) -> crop (top,left,CH,CW) -> /255 -> label ; (label-mean[c])/std[c] -> normalised
+__global__ void preprocess_image_kernel(const uint8_t* __restrict__ img, float* __restrict__ label,
+                                        float* __restrict__ norm, long NC, int C, int H, int W, int top, int left, int CH,
+                                        int CW, float m0, float m1, float m2, float s0, float s1, float s2) {
+  const long n = NC * CH * CW;
+  GRID_STRIDE(i, n) {
+    const int x = (int)(i % CW);
+    long r = i / CW;
+    const int y = (int)(r % CH);
+    const long nc = r / CH;
+    const int c = (int)(nc % C);
+    const float v = (float)img[(nc * H + (y + top)) * W + (x + left)] / 255.f;
+    if (label) label[i] = v;
+    const float m = c == 0 ? m0 : (c == 1 ? m1 : m2), s = c == 0 ? s0 : (c == 1 ? s1 : s2);
+    norm[i] = (v - m) / s;
+  }
+}
+// route map: u8 (NC,H,W) -> /255 -> nearest resize (OH,OW) -> normalise
+__global__ void preprocess_route_kernel(const uint8_t* __restrict__ img, float* __restrict__ norm, long NC, int C, int H,
+                                        int W, int OH, int OW, float m0, float m1, float m2, float s0, float s1, float s2) {
+  const long n = NC * OH * OW;
+  const float sh = (float)H / (float)OH, sw = (float)W / (float)OW;
+  GRID_STRIDE(i, n) {
+    const int x = (int)(i % OW);
+    long r = i / OW;
+    const int y = (int)(r % OH);
+    const long nc = r / OH;
+    const int c = (int)(nc % C);
+    int sy = (int)floorf((float)y * sh); if (sy > H - 1) sy = H - 1;
+    int sx = (int)floorf((float)x * sw); if (sx > W - 1) sx = W - 1;
+    const float v = (float)img[(nc * H + sy) * W + sx] / 255.f;
+    const float m = c == 0 ? m0 : (c == 1 ? m1 : m2), s = c == 0 ? s0 : (c == 1 ? s1 : s2);
+    norm[i] = (v - m) / s;
+  }
+}
+__global__ void scale_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float inv) {
+  GRID_STRIDE(i, n) y[i] = x[i] / inv;
+}
+// bilinear, align_corners=False, no antialias (torchvision 0.15 tensor resize / F.interpolate)
+__global__ void resize_bilinear_kernel(const float* __restrict__ x, float* __restrict__ y, long NC, int H, int W, int OH,
+                                       int OW) {
+  const long n = NC * OH * OW;
+  const float sh = (float)H / (float)OH, sw = (float)W / (float)OW;
+  GRID_STRIDE(i, n) {
+    const int ox = (int)(i % OW);
+    long r = i / OW;
+    const int oy = (int)(r % OH);
+    const long nc = r / OH;
+    float fy = sh * ((float)oy + 0.5f) - 0.5f; if (fy < 0.f) fy = 0.f;
+    float fx = sw * ((float)ox + 0.5f) - 0.5f; if (fx < 0.f) fx = 0.f;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float* xp = x + nc * H * W;
+    y[i] = hy * (hx * xp[y0 * W + x0] + lx * xp[y0 * W + x1]) + ly * (hx * xp[y1 * W + x0] + lx * xp[y1 * W + x1]);
+  }
+}
+// nearest (legacy 'nearest': src = floor(dst * in/out)), up to 3 spatial dims, element size 1 or 4 bytes
+template <typename T>
+__global__ void resize_nearest_kernel(const T* __restrict__ x, T* __restrict__ y, long NC, int D, int H, int W, int OD,
+                                      int OH, int OW) {
+  const long n = NC * OD * OH * OW;
+  const float sd = (float)D / (float)OD, sh = (float)H / (float)OH, sw = (float)W / (float)OW;
+  GRID_STRIDE(i, n) {
+    const int ox = (int)(i % OW);
+    long r = i / OW;
+    const int oy = (int)(r % OH);
+    r /= OH;
+    const int oz = (int)(r % OD);
+    const long nc = r / OD;
+    int z = (int)floorf((float)oz * sd); if (z > D - 1) z = D - 1;
+    int yy = (int)floorf((float)oy * sh); if (yy > H - 1) yy = H - 1;
+    int xx = (int)floorf((float)ox * sw); if (xx > W - 1) xx = W - 1;
+    y[i] = x[((nc * D + z) * H + yy) * W + xx];
+  }
+}
+
+// ----------------------------------------------------------------------------------- attention
+// P = softmax(S) over cols (S already scaled); Pd = dropout(P).  One wave per row, cols <= 64*MAXV.
+template <int MAXV>
+__global__ void __launch_bounds__(256) softmax_dropout_fwd_kernel(const float* __restrict__ S, float* __restrict__ P,
+                                                                  float* __restrict__ Pd, long rows, int cols, float p,
+                                                                  uint64_t seed) {
+  const int lane = threadIdx.x & 63;
+  const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float v[MAXV];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int c = lane + 64 * k;
+    v[k] = c < cols ? S[row * cols + c] : -INFINITY;
+    mx = fmaxf(mx, v[k]);
+  }
+  mx = wave_max(mx);
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int c = lane + 64 * k;
+    v[k] = c < cols ? expf(v[k] - mx) : 0.f;
+    s += v[k];
+  }
+  const float inv = 1.f / wave_sum(s);
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int c = lane + 64 * k;
+    if (c < cols) {
+      const long idx = row * cols + c;
+      const float pv = v[k] * inv;
+      P[idx] = pv;
+      if (Pd) Pd[idx] = pv * dropout_scale(seed, (uint64_t)idx, p);
+    }
+  }
+}
+// dS = P * (dP - sum(dP*P)), dP = dPd * dropmask
+template <int MAXV>
+__global__ void __launch_bounds__(256) softmax_dropout_bwd_kernel(const float* __restrict__ P, const float* __restrict__ dPd,
+                                                                  float* __restrict__ dS, long rows, int cols, float p,
+                                                                  uint64_t seed) {
+  const int lane = threadIdx.x & 63;
+  const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float pv[MAXV], g[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int c = lane + 64 * k;
+    pv[k] = 0.f; g[k] = 0.f;
+    if (c < cols) {
+      const long idx = row * cols + c;
+      pv[k] = P[idx];
+      g[k] = dPd[idx] * dropout_scale(seed, (uint64_t)idx, p);
+      s += pv[k] * g[k];
+    }
+  }
+  s = wave_sum(s);
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int c = lane + 64 * k;
+    if (c < cols) dS[row * cols + c] = pv[k] * (g[k] - s);
+  }
+}
+
+// ---------------------------------------------------------------------------------------- RSSM
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// torch.nn.GRUCell: r = s(gi_r+gh_r), z = s(gi_z+gh_z), n = tanh(gi_n + r*gh_n), h' = (1-z)*n + z*h
+__global__ void gru_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ gh, const float* __restrict__ h,
+                               float* __restrict__ hn, int B, int H) {
+  const long n = (long)B * H;
+  GRID_STRIDE(i, n) {
+    const long b = i / H, j = i - b * H;
+    const float* a = gi + b * 3 * H;
+    const float* c = gh + b * 3 * H;
+    const float r = sigmoidf_(a[j] + c[j]);
+    const float z = sigmoidf_(a[H + j] + c[H + j]);
+    const float nn = tanhf(a[2 * H + j] + r * c[2 * H + j]);
+    hn[i] = (1.f - z) * nn + z * h[i];
+  }
+}
+__global__ void gru_bwd_kernel(const float* __restrict__ gi, const float* __restrict__ gh, const float* __restrict__ h,
+                               const float* __restrict__ dhn, float* __restrict__ dgi, float* __restrict__ dgh,
+                               float* __restrict__ dh, int B, int H) {
+  const long n = (long)B * H;
+  GRID_STRIDE(i, n) {
+    const long b = i / H, j = i - b * H;
+    const float* a = gi + b * 3 * H;
+    const float* c = gh + b * 3 * H;
+    const float r = sigmoidf_(a[j] + c[j]);
+    const float z = sigmoidf_(a[H + j] + c[H + j]);
+    const float ghn = c[2 * H + j];
+    const float nn = tanhf(a[2 * H + j] + r * ghn);
+    const float g = dhn[i];
+    const float dn = g * (1.f - z);
+    const float dz = g * (h[i] - nn);
+    const float dpre_n = dn * (1.f - nn * nn);
+    const float dr = dpre_n * ghn;
+    const float dpre_r = dr * r * (1.f - r);
+    const float dpre_z = dz * z * (1.f - z);
+    float* da = dgi + b * 3 * H;
+    float* dc = dgh + b * 3 * H;
+    da[j] = dpre_r; dc[j] = dpre_r;
+    da[H + j] = dpre_z; dc[H + j] = dpre_z;
+    da[2 * H + j] = dpre_n; dc[2 * H + j] = dpre_n * r;
+    dh[i] = g * z;
+  }
+}
+// (mu | log_sigma) (B, 2S) -> mu, sigma = 2*sigmoid(ls/2)+min_std, sample = mu + sigma*eps   (transition.py:18-24,176-181)
+__global__ void rssm_sample_fwd_kernel(const float* __restrict__ mls, const float* __restrict__ eps, long eps_ld,
+                                       float* __restrict__ mu, float* __restrict__ sigma, float* __restrict__ sample,
+                                       int B, int S, float min_std) {
+  const long n = (long)B * S;
+  GRID_STRIDE(i, n) {
+    const long b = i / S, j = i - b * S;
+    const float m = mls[b * 2 * S + j];
+    const float sg = 2.f * sigmoidf_(mls[b * 2 * S + S + j] * 0.5f) + min_std;
+    mu[i] = m;
+    sigma[i] = sg;
+    sample[i] = m + sg * (eps ? eps[b * eps_ld + j] : 0.f);
+  }
+}
+__global__ void rssm_sample_bwd_kernel(const float* __restrict__ mls, const float* __restrict__ eps, long eps_ld,
+                                       const float* __restrict__ dmu, const float* __restrict__ dsigma,
+                                       const float* __restrict__ dsample, float* __restrict__ dmls, int B, int S) {
+  const long n = (long)B * S;
+  GRID_STRIDE(i, n) {
+    const long b = i / S, j = i - b * S;
+    const float s = sigmoidf_(mls[b * 2 * S + S + j] * 0.5f);
+    const float dsm = dsample ? dsample[i] : 0.f;
+    const float e = eps ? eps[b * eps_ld + j] : 0.f;
+    dmls[b * 2 * S + j] = (dmu ? dmu[i] : 0.f) + dsm;
+    dmls[b * 2 * S + S + j] = ((dsigma ? dsigma[i] : 0.f) + dsm * e) * s * (1.f - s);
+  }
+}
+
+// =============================================================================================== ABI
+#define ST ((hipStream_t)stream)
+extern "C" {
+
+int muvo_act_bwd(const float* y, const float* dy, float* dx, int64_t n, int act, float slope, void* stream) {
+  MUVO_CHECK_ARG(y && dy && dx && n >= 0, "act_bwd: bad args");
+  if (n == 0) return MUVO_OK;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, ST, y, dy, dx, (long)n, act, slope);
+  MUVO_CHECK_LAUNCH("act_bwd");
+  return MUVO_OK;
+}
+int muvo_act_fwd(const float* x, float* y, int64_t n, int act, float slope, void* stream) {
+  MUVO_CHECK_ARG(x && y && n >= 0, "act_fwd: bad args");
+  if (n == 0) return MUVO_OK;
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_grid(n)), dim3(256), 0, ST, x, y, (long)n, act, slope);
+  MUVO_CHECK_LAUNCH("act_fwd");
+  return MUVO_OK;
+}
+int muvo_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream) {
+  MUVO_CHECK_ARG(x && y && n >= 0 && p >= 0.f && p < 1.f, "dropout: bad args");
+  if (n == 0) return MUVO_OK;
+  hipLaunchKernelGGL(dropout_kernel, dim3(ew_grid(n)), dim3(256), 0, ST, x, y, (long)n, p, seed);
+  MUVO_CHECK_LAUNCH("dropout");
+  return MUVO_OK;
+}
+int muvo_axpby(const float* a, const float* b, float* out, int64_t n, float alpha, float beta, void* stream) {
+  MUVO_CHECK_ARG(a && out && n >= 0, "axpby: bad args");
+  if (n == 0) return MUVO_OK;
+  hipLaunchKernelGGL(axpby_kernel, dim3(ew_grid(n)), dim3(256), 0, ST, a, b, out, (long)n, alpha, beta);
+  MUVO_CHECK_LAUNCH("axpby");
+  return MUVO_OK;
+}
+int muvo_copy2d(const float* src, float* dst, int64_t rows, int64_t cols, int64_t ld_src, int64_t ld_dst, int accumulate,
+                void* stream) {
+  MUVO_CHECK_ARG(src && dst && rows >= 0 && cols >= 0 && ld_src >= cols && ld_dst >= cols, "copy2d: bad args");
+  if (rows * cols == 0) return MUVO_OK;
+  hipLaunchKernelGGL(copy2d_kernel, dim3(ew_grid(rows * cols)), dim3(256), 0, ST, src, dst, (long)rows, (long)cols,
+                     (long)ld_src, (long)ld_dst, accumulate);
+  MUVO_CHECK_LAUNCH("copy2d");
+  return MUVO_OK;
+}
+int muvo_colsum_acc(const float* x, float* out, int64_t rows, int64_t cols, int64_t ld, void* stream) {
+  MUVO_CHECK_ARG(x && out && rows > 0 && cols > 0 && ld >= cols, "colsum: bad args");
+  int chunks = cdiv(rows, 256);
+  if (chunks > 128) chunks = 128;
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 64), chunks), dim3(256), 0, ST, x, out, (long)rows, (long)cols, (long)ld);
+  MUVO_CHECK_LAUNCH("colsum");
+  return MUVO_OK;
+}
+int muvo_batchsum(const float* x, float* out, int N, int64_t inner, int accumulate, void* stream) {
+  MUVO_CHECK_ARG(x && out && N > 0 && inner > 0, "batchsum: bad args");
+  hipLaunchKernelGGL(batchsum_kernel, dim3(ew_grid(inner)), dim3(256), 0, ST, x, out, N, (long)inner, accumulate);
+  MUVO_CHECK_LAUNCH("batchsum");
+  return MUVO_OK;
+}
+int muvo_nchw_to_tokens(const float* x, const float* pos, const float* temb, int temb_stride, float* tokens, int N, int C,
+                        int L, int l0, void* stream) {
+  MUVO_CHECK_ARG(x && tokens && N > 0 && C > 0 && L > 0 && l0 >= 0, "nchw_to_tokens: bad args");
+  hipLaunchKernelGGL(nchw_to_tokens_kernel, dim3(cdiv(L, 32), cdiv(C, 32), N), dim3(256), 0, ST, x, pos, temb, temb_stride,
+                     tokens, N, C, L, l0);
+  MUVO_CHECK_LAUNCH("nchw_to_tokens");
+  return MUVO_OK;
+}
+int muvo_tokens_to_nchw(const float* tokens, float* x, int N, int C, int L, int l0, void* stream) {
+  MUVO_CHECK_ARG(x && tokens && N > 0 && C > 0 && L > 0 && l0 >= 0, "tokens_to_nchw: bad args");
+  hipLaunchKernelGGL(tokens_to_nchw_kernel, dim3(cdiv(L, 32), cdiv(C, 32), N), dim3(256), 0, ST, tokens, x, N, C, L, l0);
+  MUVO_CHECK_LAUNCH("tokens_to_nchw");
+  return MUVO_OK;
+}
+int muvo_maxpool2d_fwd(const float* x, float* y, int32_t* idx, int64_t NC, int H, int W, int OH, int OW, int k, int s,
+                       int p, void* stream) {
+  MUVO_CHECK_ARG(x && y && idx && NC > 0 && k > 0 && s > 0 && p >= 0 && p < k, "maxpool2d_fwd: bad args");
+  MUVO_CHECK_ARG(OH == (H + 2 * p - k) / s + 1 && OW == (W + 2 * p - k) / s + 1, "maxpool2d_fwd: bad output size");
+  hipLaunchKernelGGL(maxpool2d_fwd_kernel, dim3(ew_grid(NC * OH * OW)), dim3(256), 0, ST, x, y, idx, (long)NC, H, W, OH, OW,
+                     k, s, p);
+  MUVO_CHECK_LAUNCH("maxpool2d_fwd");
+  return MUVO_OK;
+}
+int muvo_maxpool2d_bwd(const float* dy, const int32_t* idx, float* dx, int64_t NC, int H, int W, int OH, int OW, int k,
+                       int s, int p, void* stream) {
+  MUVO_CHECK_ARG(dy && dx && idx && NC > 0 && k > 0 && s > 0, "maxpool2d_bwd: bad args");
+  hipLaunchKernelGGL(maxpool2d_bwd_kernel, dim3(ew_grid(NC * H * W)), dim3(256), 0, ST, dy, idx, dx, (long)NC, H, W, OH, OW,
+                     k, s, p);
+  MUVO_CHECK_LAUNCH("maxpool2d_bwd");
+  return MUVO_OK;
+}
+int muvo_avgpool_fwd(const float* x, float* y, int64_t G, int64_t S, void* stream) {
+  MUVO_CHECK_ARG(x && y && G > 0 && S > 0, "avgpool_fwd: bad args");
+  hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(cdiv(G, 4)), dim3(256), 0, ST, x, y, (long)G, (long)S);
+  MUVO_CHECK_LAUNCH("avgpool_fwd");
+  return MUVO_OK;
+}
+int muvo_avgpool_bwd(const float* dy, float* dx, int64_t G, int64_t S, void* stream) {
+  MUVO_CHECK_ARG(dy && dx && G > 0 && S > 0, "avgpool_bwd: bad args");
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(ew_grid(G * S)), dim3(256), 0, ST, dy, dx, (long)G, (long)S);
+  MUVO_CHECK_LAUNCH("avgpool_bwd");
+  return MUVO_OK;
+}
+int muvo_upsample3d_x2_fwd(const float* x, float* y, int64_t NC, int D, int H, int W, void* stream) {
+  MUVO_CHECK_ARG(x && y && NC > 0 && D > 0 && H > 0 && W > 0, "upsample3d_fwd: bad args");
+  hipLaunchKernelGGL(upsample3d_x2_fwd_kernel, dim3(ew_grid(NC * D * H * W * 8)), dim3(256), 0, ST, x, y, (long)NC, D, H, W);
+  MUVO_CHECK_LAUNCH("upsample3d_fwd");
+  return MUVO_OK;
+}
+int muvo_upsample3d_x2_bwd(const float* dy, float* dx, int64_t NC, int D, int H, int W, void* stream) {
+  MUVO_CHECK_ARG(dy && dx && NC > 0 && D > 0 && H > 0 && W > 0, "upsample3d_bwd: bad args");
+  hipLaunchKernelGGL(upsample3d_x2_bwd_kernel, dim3(ew_grid(NC * D * H * W)), dim3(256), 0, ST, dy, dx, (long)NC, D, H, W);
+  MUVO_CHECK_LAUNCH("upsample3d_bwd");
+  return MUVO_OK;
+}
+int muvo_preprocess_image(const uint8_t* img, float* label, float* norm, int64_t NC, int C, int H, int W, int top, int left,
+                          int CH, int CW, const float* mean3, const float* std3, void* stream) {
+  MUVO_CHECK_ARG(img && norm && mean3 && std3 && C == 3, "preprocess_image: bad args");
+  MUVO_CHECK_ARG(top >= 0 && left >= 0 && top + CH <= H && left + CW <= W, "preprocess_image: crop outside the image");
+  hipLaunchKernelGGL(preprocess_image_kernel, dim3(ew_grid(NC * CH * CW)), dim3(256), 0, ST, img, label, norm, (long)NC, C, H,
+                     W, top, left, CH, CW, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+  MUVO_CHECK_LAUNCH("preprocess_image");
+  return MUVO_OK;
+}
+int muvo_preprocess_route(const uint8_t* img, float* norm, int64_t NC, int C, int H, int W, int OH, int OW,
+                          const float* mean3, const float* std3, void* stream) {
+  MUVO_CHECK_ARG(img && norm && mean3 && std3 && C == 3, "preprocess_route: bad args");
+  hipLaunchKernelGGL(preprocess_route_kernel, dim3(ew_grid(NC * OH * OW)), dim3(256), 0, ST, img, norm, (long)NC, C, H, W, OH,
+                     OW, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+  MUVO_CHECK_LAUNCH("preprocess_route");
+  return MUVO_OK;
+}
+int muvo_divide_scalar(const float* x, float* y, int64_t n, float divisor, void* stream) {
+  MUVO_CHECK_ARG(x && y && n > 0 && divisor != 0.f, "divide_scalar: bad args");
+  hipLaunchKernelGGL(scale_kernel, dim3(ew_grid(n)), dim3(256), 0, ST, x, y, (long)n, divisor);
+  MUVO_CHECK_LAUNCH("divide_scalar");
+  return MUVO_OK;
+}
+int muvo_resize_bilinear(const float* x, float* y, int64_t NC, int H, int W, int OH, int OW, void* stream) {
+  MUVO_CHECK_ARG(x && y && NC > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, "resize_bilinear: bad args");
+  hipLaunchKernelGGL(resize_bilinear_kernel, dim3(ew_grid(NC * OH * OW)), dim3(256), 0, ST, x, y, (long)NC, H, W, OH, OW);
+  MUVO_CHECK_LAUNCH("resize_bilinear");
+  return MUVO_OK;
+}
+int muvo_resize_nearest_f32(const float* x, float* y, int64_t NC, int D, int H, int W, int OD, int OH, int OW, void* stream) {
+  MUVO_CHECK_ARG(x && y && NC > 0, "resize_nearest_f32: bad args");
+  hipLaunchKernelGGL((resize_nearest_kernel<float>), dim3(ew_grid(NC * OD * OH * OW)), dim3(256), 0, ST, x, y, (long)NC, D, H,
+                     W, OD, OH, OW);
+  MUVO_CHECK_LAUNCH("resize_nearest_f32");
+  return MUVO_OK;
+}
+int muvo_resize_nearest_u8(const uint8_t* x, uint8_t* y, int64_t NC, int D, int H, int W, int OD, int OH, int OW,
+                           void* stream) {
+  MUVO_CHECK_ARG(x && y && NC > 0, "resize_nearest_u8: bad args");
+  hipLaunchKernelGGL((resize_nearest_kernel<uint8_t>), dim3(ew_grid(NC * OD * OH * OW)), dim3(256), 0, ST, x, y, (long)NC, D,
+                     H, W, OD, OH, OW);
+  MUVO_CHECK_LAUNCH("resize_nearest_u8");
+  return MUVO_OK;
+}
+int muvo_softmax_dropout_fwd(const float* S, float* P, float* Pd, int64_t rows, int cols, float p, uint64_t seed,
+                             void* stream) {
+  MUVO_CHECK_ARG(S && P && rows > 0 && cols > 0 && cols <= 512, "softmax_fwd: bad args (cols=%d, max 512)", cols);
+  hipLaunchKernelGGL((softmax_dropout_fwd_kernel<8>), dim3(cdiv(rows, 4)), dim3(256), 0, ST, S, P, Pd, (long)rows, cols, p, seed);
+  MUVO_CHECK_LAUNCH("softmax_fwd");
+  return MUVO_OK;
+}
+int muvo_softmax_dropout_bwd(const float* P, const float* dPd, float* dS, int64_t rows, int cols, float p, uint64_t seed,
+                             void* stream) {
+  MUVO_CHECK_ARG(P && dPd && dS && rows > 0 && cols > 0 && cols <= 512, "softmax_bwd: bad args");
+  hipLaunchKernelGGL((softmax_dropout_bwd_kernel<8>), dim3(cdiv(rows, 4)), dim3(256), 0, ST, P, dPd, dS, (long)rows, cols, p, seed);
+  MUVO_CHECK_LAUNCH("softmax_bwd");
+  return MUVO_OK;
+}
+int muvo_gru_fwd(const float* gi, const float* gh, const float* h, float* hnew, int B, int H, void* stream) {
+  MUVO_CHECK_ARG(gi && gh && h && hnew && B > 0 && H > 0, "gru_fwd: bad args");
+  hipLaunchKernelGGL(gru_fwd_kernel, dim3(ew_grid((long)B * H)), dim3(256), 0, ST, gi, gh, h, hnew, B, H);
+  MUVO_CHECK_LAUNCH("gru_fwd");
+  return MUVO_OK;
+}
+int muvo_gru_bwd(const float* gi, const float* gh, const float* h, const float* dhnew, float* dgi, float* dgh, float* dh,
+                 int B, int H, void* stream) {
+  MUVO_CHECK_ARG(gi && gh && h && dhnew && dgi && dgh && dh && B > 0 && H > 0, "gru_bwd: bad args");
+  hipLaunchKernelGGL(gru_bwd_kernel, dim3(ew_grid((long)B * H)), dim3(256), 0, ST, gi, gh, h, dhnew, dgi, dgh, dh, B, H);
+  MUVO_CHECK_LAUNCH("gru_bwd");
+  return MUVO_OK;
+}
+int muvo_rssm_sample_fwd(const float* mu_logsigma, const float* eps, int64_t eps_ld, float* mu, float* sigma, float* sample,
+                         int B, int S, float min_std, void* stream) {
+  MUVO_CHECK_ARG(mu_logsigma && mu && sigma && sample && B > 0 && S > 0, "rssm_sample_fwd: bad args");
+  hipLaunchKernelGGL(rssm_sample_fwd_kernel, dim3(ew_grid((long)B * S)), dim3(256), 0, ST, mu_logsigma, eps, (long)eps_ld, mu,
+                     sigma, sample, B, S, min_std);
+  MUVO_CHECK_LAUNCH("rssm_sample_fwd");
+  return MUVO_OK;
+}
+int muvo_rssm_sample_bwd(const float* mu_logsigma, const float* eps, int64_t eps_ld, const float* dmu, const float* dsigma,
+                         const float* dsample, float* dmls, int B, int S, void* stream) {
+  MUVO_CHECK_ARG(mu_logsigma && dmls && B > 0 && S > 0, "rssm_sample_bwd: bad args");
+  hipLaunchKernelGGL(rssm_sample_bwd_kernel, dim3(ew_grid((long)B * S)), dim3(256), 0, ST, mu_logsigma, eps, (long)eps_ld, dmu,
+                     dsigma, dsample, dmls, B, S);
+  MUVO_CHECK_LAUNCH("rssm_sample_bwd");
+  return MUVO_OK;
+}
+
+}  // extern "C"

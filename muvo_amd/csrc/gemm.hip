@@ -1,0 +1,212 @@
+// Strided, two-level-batched GEMM on fp32 MFMA for the dense contractions of the path:
+// nn.Linear fwd/dgrad/wgrad (transformer, RSSM, policy, style affines), attention QK^T / PV and their
+// backward products, and the 1x1-input ConvTranspose of ConvDecoder (common.py:578-581) as a GEMM.
+//
+//   C[b1][b2][m][n] (op)= act(alpha * sum_k A(m,k) * B(k,n) + bias[n / bias_div])
+//   A(m,k) = A[m*sam + k*sak],  B(k,n) = B[k*sbk + n*sbn],  C(m,n) = C[m*scm + n]
+//
+// The loader of each operand is chosen from its unit stride so global reads are coalesced
+// ("lanes along k" when the operand is k-contiguous, else "lanes along m/n"); both produce the same
+// k-major LDS tiles consumed by v_mfma_f32_32x32x2_f32.  mode 1 = float-atomic accumulate (split-K and
+// gradient accumulation into .grad buffers).
+#include "common.h"
+
+struct GemmArgs {
+  int M, N, K;
+  long sam, sak, sbk, sbn, scm;
+  int B1, B2;
+  long a_b1, a_b2, b_b1, b_b2, c_b1, c_b2;
+  float alpha;
+  const float* bias;
+  int bias_div;
+  int act;
+  float slope;
+  int mode;    // 0 store, 1 atomic add
+  int ksplit;  // number of K splits (mode 1 only)
+};
+
+// LAY 0: lanes along the m/n index, 1: lanes along k
+template <int BMN, int LAY>
+struct TileLoader {
+  static constexpr int BK = 16;
+  static constexpr int EPT = BMN * BK / 256;  // elements per thread
+  // returns registers
+  __device__ static void load(const float* __restrict__ base, long s_mn, long s_k, int mn0, int mn_lim, int k0,
+                              int k_lim, int tid, float (&reg)[EPT]) {
+    if (LAY == 0) {
+      constexpr int KG = 256 / BMN, KPT = BK / KG;
+      static_assert(KPT == EPT, "");
+      const int ml = tid % BMN, kg = tid / BMN;
+      const int mn = mn0 + ml;
+      const bool ok = mn < mn_lim;
+      const float* p = base + (long)mn * s_mn;
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int k = k0 + kg * KPT + e;
+        reg[e] = (ok && k < k_lim) ? p[(long)k * s_k] : 0.f;
+      }
+    } else {
+      const int kl = tid & 15, g = tid >> 4;
+      const int k = k0 + kl;
+      const bool kok = k < k_lim;
+      const float* p = base + (long)k * s_k;
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int mn = mn0 + g + 16 * e;
+        reg[e] = (kok && mn < mn_lim) ? p[(long)mn * s_mn] : 0.f;
+      }
+    }
+  }
+  __device__ static void store(float* __restrict__ tile, int ld, int tid, const float (&reg)[EPT]) {
+    if (LAY == 0) {
+      constexpr int KG = 256 / BMN, KPT = BK / KG;
+      const int ml = tid % BMN, kg = tid / BMN;
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) tile[(kg * KPT + e) * ld + ml] = reg[e];
+    } else {
+      const int kl = tid & 15, g = tid >> 4;
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) tile[kl * ld + g + 16 * e] = reg[e];
+    }
+  }
+};
+
+template <int BM, int BN, int WM, int WN, int ALAY, int BLAY>
+__global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g, const float* __restrict__ A,
+                                                   const float* __restrict__ B, float* __restrict__ C) {
+  constexpr int BK = 16;
+  constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+  constexpr int LDA = BM + 4, LDB = BN + 4;
+  __shared__ float smem[2 * BK * (LDA + LDB)];
+  float* As0 = smem;
+  float* Bs0 = smem + 2 * BK * LDA;
+  using LA = TileLoader<BM, ALAY>;
+  using LB = TileLoader<BN, BLAY>;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int zb = blockIdx.z / g.ksplit, ks = blockIdx.z % g.ksplit;
+  const int b1 = zb / g.B2, b2 = zb % g.B2;
+  const float* Ab = A + b1 * g.a_b1 + b2 * g.a_b2;
+  const float* Bb = B + b1 * g.b_b1 + b2 * g.b_b2;
+  float* Cb = C + b1 * g.c_b1 + b2 * g.c_b2;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+  const int nk_total = (g.K + BK - 1) / BK;
+  const int per = (nk_total + g.ksplit - 1) / g.ksplit;
+  const int kt0 = ks * per;
+  int kt1 = kt0 + per;
+  if (kt1 > nk_total) kt1 = nk_total;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float areg[LA::EPT], breg[LB::EPT];
+  if (kt0 < kt1) {
+    LA::load(Ab, g.sam, g.sak, m0, g.M, kt0 * BK, g.K, tid, areg);
+    LB::load(Bb, g.sbn, g.sbk, n0, g.N, kt0 * BK, g.K, tid, breg);
+    LA::store(As0, LDA, tid, areg);
+    LB::store(Bs0, LDB, tid, breg);
+  }
+  __syncthreads();
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int buf = (kt - kt0) & 1;
+    if (kt + 1 < kt1) {
+      LA::load(Ab, g.sam, g.sak, m0, g.M, (kt + 1) * BK, g.K, tid, areg);
+      LB::load(Bb, g.sbn, g.sbk, n0, g.N, (kt + 1) * BK, g.K, tid, breg);
+    }
+    const float* As = As0 + buf * BK * LDA + wm * (TM * 32) + (lane & 31);
+    const float* Bs = Bs0 + buf * BK * LDB + wn * (TN * 32) + (lane & 31);
+#pragma unroll
+    for (int k2 = 0; k2 < BK / 2; ++k2) {
+      const int kr = 2 * k2 + (lane >> 5);
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = As[kr * LDA + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = Bs[kr * LDB + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < kt1) {
+      LA::store(As0 + (buf ^ 1) * BK * LDA, LDA, tid, areg);
+      LB::store(Bs0 + (buf ^ 1) * BK * LDB, LDB, tid, breg);
+    }
+    __syncthreads();
+  }
+  if (kt0 >= kt1 && g.mode == 1) return;
+
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * (TN * 32) + j * 32 + (lane & 31);
+    if (n >= g.N) continue;
+    const float bv = g.bias ? g.bias[n / g.bias_div] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < g.M) {
+          float* dst = Cb + (long)m * g.scm + n;
+          const float v = g.alpha * acc[i][j][r];
+          if (g.mode == 1) atomicAdd(dst, v);
+          else *dst = act_apply(v + bv, g.act, g.slope);
+        }
+      }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+static void launch_gemm_lay(const GemmArgs& g, const float* A, const float* B, float* C, dim3 grid, hipStream_t st) {
+  const int al = (g.sam == 1 && g.sak != 1) ? 0 : (g.sak == 1 ? 1 : 0);
+  const int bl = (g.sbn == 1) ? 0 : (g.sbk == 1 ? 1 : 0);
+  if (al == 0 && bl == 0) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 0, 0>), grid, dim3(256), 0, st, g, A, B, C);
+  else if (al == 0 && bl == 1) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 0, 1>), grid, dim3(256), 0, st, g, A, B, C);
+  else if (al == 1 && bl == 0) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 1, 0>), grid, dim3(256), 0, st, g, A, B, C);
+  else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 1, 1>), grid, dim3(256), 0, st, g, A, B, C);
+}
+
+extern "C" int muvo_gemm(const muvo_gemm_desc* d, const float* A, const float* B, float* C, const float* bias,
+                         void* stream) {
+  MUVO_CHECK_ARG(d && A && B && C, "gemm: null pointer");
+  MUVO_CHECK_ARG(d->M > 0 && d->N > 0 && d->K >= 0, "gemm: bad sizes M=%d N=%d K=%d", d->M, d->N, d->K);
+  MUVO_CHECK_ARG(d->B1 > 0 && d->B2 > 0, "gemm: bad batch sizes");
+  MUVO_CHECK_ARG(d->mode == 0 || d->mode == 1, "gemm: mode must be 0 (store) or 1 (atomic add)");
+  MUVO_CHECK_ARG(!(d->mode == 1 && (bias || d->act != MUVO_ACT_NONE)), "gemm: bias/act not allowed in accumulate mode");
+  GemmArgs g;
+  g.M = d->M; g.N = d->N; g.K = d->K;
+  g.sam = d->sam; g.sak = d->sak; g.sbk = d->sbk; g.sbn = d->sbn; g.scm = d->scm;
+  g.B1 = d->B1; g.B2 = d->B2;
+  g.a_b1 = d->a_b1; g.a_b2 = d->a_b2; g.b_b1 = d->b_b1; g.b_b2 = d->b_b2; g.c_b1 = d->c_b1; g.c_b2 = d->c_b2;
+  g.alpha = d->alpha; g.bias = bias; g.bias_div = d->bias_div > 0 ? d->bias_div : 1;
+  g.act = d->act; g.slope = d->slope; g.mode = d->mode;
+  const int nb = d->B1 * d->B2;
+  hipStream_t st = (hipStream_t)stream;
+  int bm, bn;
+  if (d->M <= 32) { bm = 32; bn = 128; }
+  else if (d->N <= 64) { bm = 128; bn = 64; }
+  else { bm = 128; bn = 128; }
+  const int gx = cdiv(d->N, bn), gy = cdiv(d->M, bm);
+  int ksplit = 1;
+  if (d->mode == 1) {
+    const int nkt = cdiv(d->K, 16);
+    ksplit = cdiv(768, gx * gy * nb);
+    if (ksplit > cdiv(nkt, 8)) ksplit = cdiv(nkt, 8);
+    if (ksplit < 1) ksplit = 1;
+  }
+  g.ksplit = ksplit;
+  dim3 grid(gx, gy, nb * ksplit);
+  if (bm == 32) launch_gemm_lay<32, 128, 1, 4>(g, A, B, C, grid, st);
+  else if (bn == 64) launch_gemm_lay<128, 64, 2, 2>(g, A, B, C, grid, st);
+  else launch_gemm_lay<128, 128, 2, 2>(g, A, B, C, grid, st);
+  MUVO_CHECK_LAUNCH("gemm_kernel");
+  return MUVO_OK;
+}

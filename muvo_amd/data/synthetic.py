@@ -1,0 +1,59 @@
+"""Synthetic batches with the reference batch schema (muvo/data/dataset.py:231-369 keys/dtypes).
+
+Values are hash-generated (see utils/detinit.py) so the same (seed, shape) gives the same batch on
+any host.  batch k of a run uses seed 1234 + k.
+"""
+import numpy as np
+import torch
+
+from muvo_amd.utils import detinit
+
+
+def make_batch(b: int, s: int, seed: int = 1234, image_hw=(600, 960), route_hw=(64, 64),
+               range_hw=(64, 1024), voxel=(192, 192, 64), n_voxel_classes: int = 2, device='cpu'):
+    def key(tag):
+        return detinit.name_key(f'batch:{seed}:{tag}')
+
+    out = {}
+    n = b * s * 3 * image_hw[0] * image_hw[1]
+    out['image'] = torch.from_numpy(
+        (detinit.hash_u64(key('image'), n) >> np.uint64(56)).astype(np.uint8).reshape(b, s, 3, *image_hw))
+    n = b * s * 3 * route_hw[0] * route_hw[1]
+    out['route_map'] = torch.from_numpy(
+        (detinit.hash_u64(key('route'), n) >> np.uint64(56)).astype(np.uint8).reshape(b, s, 3, *route_hw))
+    # range view: xyz in [0, 50), d = |xyz|, ~10% holes with xyz = 0 and d = -1
+    npix = b * s * range_hw[0] * range_hw[1]
+    xyz = detinit.uniform_01(key('xyz'), npix * 3).reshape(b, s, range_hw[0], range_hw[1], 3) * np.float32(50.0)
+    hole = detinit.uniform_01(key('hole'), npix).reshape(b, s, range_hw[0], range_hw[1]) < np.float32(0.1)
+    d = np.sqrt((xyz.astype(np.float64) ** 2).sum(-1)).astype(np.float32)
+    xyz[hole] = 0
+    d[hole] = -1
+    rv = np.concatenate([xyz, d[..., None]], axis=-1).transpose(0, 1, 4, 2, 3)
+    out['range_view_pcd_xyzd'] = torch.from_numpy(np.ascontiguousarray(rv))
+    nv = b * s * voxel[0] * voxel[1] * voxel[2]
+    occ = detinit.uniform_01(key('voxel'), nv) < np.float32(0.1)
+    if n_voxel_classes > 2:
+        cls = (detinit.hash_u64(key('voxcls'), nv) >> np.uint64(40)) % np.uint64(n_voxel_classes - 1) + np.uint64(1)
+        vox = np.where(occ, cls.astype(np.uint8), np.uint8(0))
+    else:
+        vox = occ.astype(np.uint8)
+    out['voxel'] = torch.from_numpy(vox.reshape(b, s, 1, *voxel))
+    out['speed'] = torch.from_numpy(detinit.uniform_01(key('speed'), b * s).reshape(b, s, 1) * np.float32(10.0))
+    out['throttle_brake'] = torch.from_numpy(detinit.uniform_pm1(key('tb'), b * s).reshape(b, s, 1).copy())
+    out['steering'] = torch.from_numpy(detinit.uniform_pm1(key('steer'), b * s).reshape(b, s, 1).copy())
+    intr = np.array([[402.8, 0, 480.0], [0, 402.8, 300.0], [0, 0, 1]], dtype=np.float32)
+    out['intrinsics'] = torch.from_numpy(np.broadcast_to(intr, (b, s, 3, 3)).copy())
+    out['extrinsics'] = torch.from_numpy(np.broadcast_to(np.eye(4, dtype=np.float32), (b, s, 4, 4)).copy())
+    if device != 'cpu':
+        out = {k: v.to(device) for k, v in out.items()}
+    return out
+
+
+def make_noise(b: int, s: int, state_dim: int = 512, seed: int = 1234, use_prior_prob: float = 0.15):
+    """RSSM noise eps (b, s, 2, state_dim): [:, :, 0] prior, [:, :, 1] posterior sample noise
+    (reference draws: transition.py:179), and the per-timestep 'use prior sample' coin (transition.py:118)."""
+    k = detinit.name_key(f'noise:{seed}')
+    eps = torch.from_numpy(detinit.normal(k, b * s * 2 * state_dim).reshape(b, s, 2, state_dim).copy())
+    coin = detinit.uniform_01(k + 7, s)
+    use_prior = [bool(t > 0 and coin[t] < use_prior_prob) for t in range(s)]
+    return eps, use_prior

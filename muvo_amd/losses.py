@@ -1,0 +1,68 @@
+"""Loss modules with the reference's names/signatures (muvo/losses.py:53-287) on the fused HIP loss kernels.
+`WorldModelTrainer.compute_loss` uses the fused multi-part entry points directly; these classes exist so code
+written against the reference's loss objects keeps working."""
+import torch.nn as nn
+
+from muvo_amd import ops
+
+
+class RegressionLoss(nn.Module):
+    def __init__(self, norm, channel_dim=-1):
+        super().__init__()
+        if norm != 1:
+            raise NotImplementedError('hot path uses RegressionLoss(norm=1) only (trainer.py:57)')
+        self.norm = norm
+
+    def forward(self, prediction, target):
+        return ops.l1_rows_loss(prediction, target, 1.0)[0]
+
+
+class SpatialRegressionLoss(nn.Module):
+    def __init__(self, norm, ignore_index=255):
+        super().__init__()
+        if norm not in (1, 2):
+            raise ValueError(f'Expected norm 1 or 2, but got norm={norm}')
+        self.norm, self.ignore_index = norm, ignore_index
+
+    def forward(self, prediction, target, instance_mask=None):
+        assert prediction.dim() == 5, 'Must be a 5D tensor'
+        if instance_mask is not None:
+            raise NotImplementedError('instance_mask (LOSSES.RGB_INSTANCE) is outside the base_1d path')
+        c = prediction.shape[2]
+        return ops.spatial_losses(prediction, target, [(0, c, self.norm, 1.0)], float(self.ignore_index))[0]
+
+
+class KLLoss(nn.Module):
+    def __init__(self, alpha):
+        super().__init__()
+        self.alpha = alpha
+
+    def forward(self, prior, posterior):
+        return ops.kl_loss(prior['mu'], prior['sigma'], posterior['mu'], posterior['sigma'], 1.0, self.alpha)[0]
+
+
+class _VoxelTriple(nn.Module):
+    index = 0
+
+    def __init__(self, *a, **k):
+        super().__init__()
+
+    def forward(self, prediction, target):
+        return ops.voxel_losses(prediction, target, 1.0)[self.index]
+
+
+class VoxelLoss(_VoxelTriple):
+    index = 0
+
+    def __init__(self, use_top_k=False, top_k_ratio=1.0, use_weights=False, poly_one=False, poly_one_coefficient=0.0):
+        super().__init__()
+        if use_top_k or use_weights or poly_one:
+            raise NotImplementedError('VoxelLoss top-k / class weights / poly-1 are off in base_1d (muvo.yml:56-60)')
+
+
+class SemScalLoss(_VoxelTriple):
+    index = 1
+
+
+class GeoScalLoss(_VoxelTriple):
+    index = 2

@@ -1,0 +1,245 @@
+"""Model building blocks of the hot path, mirroring muvo/models/common.py (names = state_dict keys) with every
+op executed by the gfx950 kernels in muvo_amd.ops.
+
+Covered (base_1d): RouteEncode (common.py:12-23), Policy (:53-68), DecoderDS (:102-130), DecoderBlock3d (:161-172),
+ConvInstanceNorm3d (:190-202), AdaptiveInstanceNorm3d (:227-246), RGBHead/LidarReHead/VoxelSemHead (:274-303,354-367),
+VoxelDecoder1 (:498-546), ConvDecoder (:549-632), PositionEmbeddingSine (:636-678).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from muvo_amd import nn as hnn
+from muvo_amd import ops
+from muvo_amd.models.resnet import ResNet18Features
+
+
+class RouteEncode(nn.Module):
+    def __init__(self, out_channels, backbone='resnet18'):
+        super().__init__()
+        assert backbone == 'resnet18'
+        self.backbone = ResNet18Features(in_chans=3, out_indices=(4,))
+        self.out_channels = out_channels
+        self.fc = hnn.Linear(512, out_channels)
+
+    def forward(self, route):
+        x = self.backbone(route)[0]
+        return self.fc(ops.global_avg_pool(x))
+
+
+class Policy(nn.Module):
+    def __init__(self, in_channels):
+        super().__init__()
+        c = in_channels
+        self.fc = nn.Sequential(hnn.Linear(c, c), hnn.Placeholder(), hnn.Linear(c, c), hnn.Placeholder(),
+                                hnn.Linear(c, c // 2), hnn.Placeholder(), hnn.Linear(c // 2, 2), hnn.Placeholder())
+
+    def forward(self, x):
+        x = self.fc[0](x, act=ops.ACT_RELU)
+        x = self.fc[2](x, act=ops.ACT_RELU)
+        x = self.fc[4](x, act=ops.ACT_RELU)
+        return self.fc[6](x, act=ops.ACT_TANH)
+
+
+def _conv_bn_relu(cin, cout):
+    return nn.Sequential(hnn.Conv2d(cin, cout, 3, 1, 1, bias=False), hnn.BatchNorm2d(cout), hnn.Placeholder())
+
+
+class DecoderDS(nn.Module):
+    def __init__(self, feature_info, out_channels):
+        super().__init__()
+        self.conv1 = _conv_bn_relu(feature_info[0]['num_chs'], out_channels)
+        self.downsample_skip_convs = nn.ModuleList(
+            _conv_bn_relu(feature_info[i]['num_chs'], out_channels) for i in range(1, len(feature_info)))
+        self.out_channels = out_channels
+
+    def forward(self, xs):
+        x = self.conv1[1](self.conv1[0](xs[0]), relu=True)
+        for i, conv in enumerate(self.downsample_skip_convs):
+            stride = xs[i].shape[-1] // xs[i + 1].shape[-1]
+            pooled = ops.max_pool2d(x, stride)
+            # relu(bn(conv(x_{i+1}))) + max_pool(x): residual added AFTER the ReLU (common.py:128)
+            x = conv[1](conv[0](xs[i + 1]), residual=pooled, res_mode=2, relu=True)
+        return x
+
+
+class AdaptiveInstanceNorm3d(nn.Module):
+    def __init__(self, latent_n_channels, out_channels, epsilon=1e-8):
+        super().__init__()
+        self.out_channels = out_channels
+        self.epsilon = epsilon
+        self.latent_affine = hnn.Linear(latent_n_channels, 2 * out_channels)
+
+    def forward(self, x, style):
+        return ops.adain(x, self.latent_affine(style), self.epsilon, style.shape[0])
+
+
+class ConvInstanceNorm3d(nn.Module):
+    def __init__(self, in_channels, out_channels, latent_n_channels):
+        super().__init__()
+        self.conv_act = nn.Sequential(hnn.Conv3d(in_channels, out_channels, 3, 1, 1), hnn.Placeholder())
+        self.adaptive_norm = AdaptiveInstanceNorm3d(latent_n_channels, out_channels)
+
+    def forward(self, x, w):
+        x = self.conv_act[0](x, act=ops.ACT_LEAKY, slope=0.2)
+        return self.adaptive_norm(x, w)
+
+
+class DecoderBlock3d(nn.Module):
+    def __init__(self, in_channels, out_channels, latent_n_channels, upsample=False):
+        super().__init__()
+        self.upsample = upsample
+        self.conv1 = ConvInstanceNorm3d(in_channels, out_channels, latent_n_channels)
+        self.conv2 = ConvInstanceNorm3d(out_channels, out_channels, latent_n_channels)
+
+    def forward(self, x, w):
+        if self.upsample:
+            x = ops.upsample3d_x2(x)
+        return self.conv2(self.conv1(x, w), w)
+
+
+class _Head(nn.Module):
+    """1x1(x1) conv head; attr/key names follow RGBHead / LidarReHead / VoxelSemHead."""
+
+    def __init__(self, attr, key, conv, downsample_factor):
+        super().__init__()
+        self.downsample_factor = downsample_factor
+        self._attr, self._key = attr, key
+        setattr(self, attr, nn.Sequential(conv))
+
+    def forward(self, x):
+        return {f'{self._key}_{self.downsample_factor}': getattr(self, self._attr)[0](x)}
+
+
+def RGBHead(in_channels, n_classes, downsample_factor):
+    return _Head('rgb_head', 'rgb', hnn.Conv2d(in_channels, n_classes, 1, 1, 0), downsample_factor)
+
+
+def LidarReHead(in_channels, n_classes, downsample_factor):
+    return _Head('lidar_re_head', 'lidar_reconstruction', hnn.Conv2d(in_channels, n_classes, 1, 1, 0), downsample_factor)
+
+
+def VoxelSemHead(in_channels, n_classes, downsample_factor):
+    return _Head('segmentation_head', 'voxel', hnn.Conv3d(in_channels, n_classes, 1, 1, 0), downsample_factor)
+
+
+class VoxelDecoder1(nn.Module):
+    def __init__(self, latent_n_channels, semantic_n_channels, feature_channels=512, constant_size=(3, 3, 1)):
+        super().__init__()
+        n = feature_channels
+        self.constant_tensor = nn.Parameter(torch.randn((2 * n, *constant_size), dtype=torch.float32))
+        self.first_norm = AdaptiveInstanceNorm3d(latent_n_channels, out_channels=2 * n)
+        self.first_conv = ConvInstanceNorm3d(2 * n, n, latent_n_channels)
+        self.middle_conv = nn.ModuleList(DecoderBlock3d(n, n, latent_n_channels, upsample=True) for _ in range(3))
+        self.conv1 = DecoderBlock3d(n, n // 2, latent_n_channels, upsample=True)
+        self.head_4 = VoxelSemHead(n // 2, semantic_n_channels, downsample_factor=4)
+        self.conv2 = DecoderBlock3d(n // 2, n // 4, latent_n_channels, upsample=True)
+        self.head_2 = VoxelSemHead(n // 4, semantic_n_channels, downsample_factor=2)
+        self.conv3 = DecoderBlock3d(n // 4, n // 8, latent_n_channels, upsample=True)
+        self.head_1 = VoxelSemHead(n // 8, semantic_n_channels, downsample_factor=1)
+
+    def forward(self, w):
+        # constant_tensor is broadcast over the batch inside the AdaIN kernel (no repeat() copy)
+        x = self.first_norm(self.constant_tensor, w)
+        x = self.first_conv(x, w)
+        for module in self.middle_conv:
+            x = module(x, w)
+        x = self.conv1(x, w)
+        output_4 = self.head_4(x)
+        x = self.conv2(x, w)
+        output_2 = self.head_2(x)
+        x = self.conv3(x, w)
+        output_1 = self.head_1(x)
+        return {**output_4, **output_2, **output_1}
+
+
+class _Seed1x1ConvTFn(torch.autograd.Function):
+    """ConvTranspose2d(C, Co, k) applied to a (N, C, 1, 1) input == one GEMM
+    y[n][(co,t)] = sum_ci x[n][ci] W[ci][(co,t)] + b[co], fused ELU (common.py:578-581)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        x = x.contiguous()
+        n, ci = x.shape[0], x.shape[1]
+        co, kh, kw = weight.shape[1:]
+        ncol = co * kh * kw
+        y = torch.empty(n, co, kh, kw, device=x.device, dtype=torch.float32)
+        ops.gemm(x, weight, y, n, ncol, ci, ci, 1, ncol, 1, ncol, bias=bias, bias_div=kh * kw, act=act)
+        ctx.weight, ctx.bias, ctx.act = weight, bias, act
+        ctx.save_for_backward(x, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import ctypes as C
+        x, y = ctx.saved_tensors
+        weight, bias = ctx.weight, ctx.bias
+        n, ci = x.shape[0], x.shape[1]
+        co, kh, kw = weight.shape[1:]
+        ncol = co * kh * kw
+        dy = dy.contiguous()
+        dz = torch.empty_like(dy)
+        L = ops.lib()
+        ops._ck(L.muvo_act_bwd(ops._f(y), ops._f(dy), ops._f(dz), ops._i64(dy.numel()), ctx.act, ops._fl(0.0), ops._st()))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            ops.gemm(dz, weight, dx, n, ci, ncol, ncol, 1, 1, ncol, ci)
+        ops.gemm(x, dz, ops.grad_of(weight), ci, ncol, n, 1, ci, ncol, 1, ncol, mode=1)
+        if bias is not None:
+            ops._ck(L.muvo_bias_grad_nchw(ops._f(dz), ops._f(ops.grad_of(bias)), n, co, ops._i64(kh * kw), ops._st()))
+        return dx, None, None, None
+
+
+class ConvDecoder(nn.Module):
+    def __init__(self, latent_n_channels, out_channels, constant_size=(5, 13), head='rgb'):
+        super().__init__()
+        n_channels = 512
+        self.linear = nn.Sequential(hnn.Linear(latent_n_channels, n_channels), hnn.Placeholder())
+        P = hnn.Placeholder
+        self.pre_transpose_conv = nn.Sequential(
+            hnn.ConvTranspose2d(n_channels, n_channels, constant_size), P(),
+            hnn.ConvTranspose2d(n_channels, n_channels, 5, 2, 2, 1), P(),
+            hnn.ConvTranspose2d(n_channels, n_channels, 5, 2, 2, 1), P(),
+            hnn.ConvTranspose2d(n_channels, n_channels, 6, 2, 2), P())
+        head_module = {'rgb': RGBHead, 'lidar_re': LidarReHead}[head]
+        self.trans_conv1 = nn.Sequential(hnn.ConvTranspose2d(n_channels, 256, 6, 2, 2), P())
+        self.head_4 = head_module(256, out_channels, downsample_factor=4)
+        self.trans_conv2 = nn.Sequential(hnn.ConvTranspose2d(256, 128, 6, 2, 2), P())
+        self.head_2 = head_module(128, out_channels, downsample_factor=2)
+        self.trans_conv3 = nn.Sequential(hnn.ConvTranspose2d(128, 64, 6, 2, 2), P())
+        self.head_1 = head_module(64, out_channels, downsample_factor=1)
+
+    def forward(self, x):
+        x = self.linear[0](x)  # (N, 512); Unflatten to (N,512,1,1) is a view
+        seed = self.pre_transpose_conv[0]
+        x = _Seed1x1ConvTFn.apply(x.view(x.shape[0], -1, 1, 1), seed.weight, seed.bias, ops.ACT_ELU)
+        for i in (2, 4, 6):
+            x = self.pre_transpose_conv[i](x, act=ops.ACT_ELU)
+        x = self.trans_conv1[0](x, act=ops.ACT_ELU)
+        output_4 = self.head_4(x)
+        x = self.trans_conv2[0](x, act=ops.ACT_ELU)
+        output_2 = self.head_2(x)
+        x = self.trans_conv3[0](x, act=ops.ACT_ELU)
+        output_1 = self.head_1(x)
+        return {**output_4, **output_2, **output_1}
+
+
+def position_embedding_sine(h, w, num_pos_feats, temperature=10000, scale=2 * math.pi):
+    """Constant (2*num_pos_feats, h*w) table of PositionEmbeddingSine(normalize=True) (common.py:636-678),
+    evaluated once on the host in float32 with the reference's operation order."""
+    ones = torch.ones((1, h, w), dtype=torch.float32)
+    y_embed = ones.cumsum(1, dtype=torch.float32)
+    x_embed = ones.cumsum(2, dtype=torch.float32)
+    eps = 1e-6
+    y_embed = y_embed / (y_embed[:, -1:, :] + eps) * scale
+    x_embed = x_embed / (x_embed[:, :, -1:] + eps) * scale
+    dim_t = torch.arange(num_pos_feats, dtype=torch.float32)
+    dim_t = temperature ** (2 * (dim_t // 2) / num_pos_feats)
+    pos_x = x_embed[:, :, :, None] / dim_t
+    pos_y = y_embed[:, :, :, None] / dim_t
+    pos_x = torch.stack((pos_x[:, :, :, 0::2].sin(), pos_x[:, :, :, 1::2].cos()), dim=4).flatten(3)
+    pos_y = torch.stack((pos_y[:, :, :, 0::2].sin(), pos_y[:, :, :, 1::2].cos()), dim=4).flatten(3)
+    pos = torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2)
+    return pos.reshape(2 * num_pos_feats, h * w).contiguous()

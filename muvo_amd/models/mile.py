@@ -1,0 +1,133 @@
+"""Mile world model (muvo/models/mile.py:16-161,284-402 construction; :404-593 forward/encode), base_1d branch
+(resnet18 image + range-view encoders, DecoderDS, 6-layer transformer fusion, RSSM, policy, RGB / range-view /
+voxel decoders), every op on the gfx950 kernels.  Parameter names equal the reference's state_dict."""
+import torch
+import torch.nn as nn
+
+from muvo_amd import nn as hnn
+from muvo_amd import ops
+from muvo_amd.layers.layers import BasicBlock
+from muvo_amd.models.common import (ConvDecoder, DecoderDS, Policy, RouteEncode, VoxelDecoder1,
+                                    position_embedding_sine)
+from muvo_amd.models.resnet import ResNet18Features
+from muvo_amd.models.transition import RSSM
+from muvo_amd.utils.network_utils import pack_sequence_dim, unpack_sequence_dim
+
+
+class _FeatureConv(nn.Sequential):
+    """BasicBlock(s2, downsample) -> BasicBlock -> global avg pool -> flatten (mile.py:104-115)."""
+
+    def __init__(self, cin, cout):
+        super().__init__(BasicBlock(cin, cout, stride=2, downsample=True), BasicBlock(cout, cout),
+                         hnn.Placeholder(), hnn.Placeholder())
+
+    def forward(self, x):
+        return ops.global_avg_pool(self[1](self[0](x)))
+
+
+class Mile(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.receptive_field = cfg.RECEPTIVE_FIELD
+        m = cfg.MODEL
+        unsupported = []
+        if m.ENCODER.NAME != 'resnet18' or m.LIDAR.ENCODER != 'resnet18':
+            unsupported.append('non-resnet18 encoders')
+        if not m.TRANSFORMER.ENABLED or m.TRANSFORMER.BEV or m.TRANSFORMER.LARGE:
+            unsupported.append('TRANSFORMER.{ENABLED=False,BEV,LARGE}')
+        if not m.LIDAR.ENABLED or m.LIDAR.POINT_PILLAR.ENABLED:
+            unsupported.append('LIDAR off / POINT_PILLAR')
+        if m.MEASUREMENTS.ENABLED or m.REWARD.ENABLED or not m.TRANSITION.ENABLED or not m.ROUTE.ENABLED:
+            unsupported.append('MEASUREMENTS/REWARD/TRANSITION off/ROUTE off')
+        if cfg.SEMANTIC_SEG.ENABLED or cfg.LIDAR_SEG.ENABLED or cfg.SEMANTIC_IMAGE.ENABLED or cfg.DEPTH.ENABLED:
+            unsupported.append('SEMANTIC_SEG/LIDAR_SEG/SEMANTIC_IMAGE/DEPTH heads')
+        if unsupported:
+            raise NotImplementedError('muvo_amd implements the base_1d hot path (SURVEY.md §8); not in scope: '
+                                      + ', '.join(unsupported))
+        emb, tc = m.EMBEDDING_DIM, m.TRANSFORMER.CHANNELS
+        self.encoder = ResNet18Features(3, (2, 3, 4))
+        feature_info = self.encoder.feature_info.get_dicts(keys=['num_chs', 'reduction'])
+        self.feat_decoder = DecoderDS(feature_info, tc)
+        self.range_view_encoder = ResNet18Features(4, (2, 3, 4))
+        self.range_view_decoder = DecoderDS(self.range_view_encoder.feature_info.get_dicts(keys=['num_chs', 'reduction']), tc)
+        self.type_embedding = nn.Parameter(torch.zeros(1, 1, tc, 2))
+        # registered but never used in forward, exactly like the reference (mile.py:96-101)
+        self.encoder_layer = hnn.TransformerEncoderLayer(tc, 8, dropout=0.1)
+        self.transformer_encoder = hnn.TransformerEncoder(tc, 8, num_layers=6, dropout=0.1)
+        self.image_feature_conv = _FeatureConv(tc, emb)
+        self.lidar_feature_conv = _FeatureConv(tc, emb)
+        feature_n_channels = 2 * emb
+        self.backbone_route = RouteEncode(m.ROUTE.CHANNELS, m.ROUTE.BACKBONE)
+        feature_n_channels += m.ROUTE.CHANNELS
+        self.speed_enc = nn.Sequential(hnn.Linear(1, m.SPEED.CHANNELS), hnn.Placeholder(),
+                                       hnn.Linear(m.SPEED.CHANNELS, m.SPEED.CHANNELS), hnn.Placeholder())
+        feature_n_channels += m.SPEED.CHANNELS
+        self.speed_normalisation = cfg.SPEED.NORMALISATION
+        self.features_combine = hnn.Linear(feature_n_channels, emb)
+        self.rssm = RSSM(embedding_dim=emb, action_dim=m.ACTION_DIM, hidden_state_dim=m.TRANSITION.HIDDEN_STATE_DIM,
+                         state_dim=m.TRANSITION.STATE_DIM, action_latent_dim=m.TRANSITION.ACTION_LATENT_DIM,
+                         receptive_field=self.receptive_field, use_dropout=m.TRANSITION.USE_DROPOUT,
+                         dropout_probability=m.TRANSITION.DROPOUT_PROBABILITY)
+        state_dim = m.TRANSITION.HIDDEN_STATE_DIM + m.TRANSITION.STATE_DIM
+        self.policy = Policy(in_channels=state_dim)
+        if cfg.EVAL.RGB_SUPERVISION:
+            self.rgb_decoder = ConvDecoder(state_dim, 3, constant_size=(5, 13), head='rgb')
+        if cfg.LIDAR_RE.ENABLED:
+            self.lidar_re = ConvDecoder(state_dim, cfg.LIDAR_RE.N_CHANNELS, constant_size=(1, 16), head='lidar_re')
+        if cfg.VOXEL_SEG.ENABLED:
+            self.voxel_decoder = VoxelDecoder1(state_dim, cfg.VOXEL_SEG.N_CLASSES, cfg.VOXEL_SEG.DIMENSION, (3, 3, 1))
+        self._pos_cache = {}
+        self._step_seed = 0
+        self.dropout_seed = 0x5EED
+
+    def _pos(self, h, w, device):
+        key = (h, w, str(device))
+        if key not in self._pos_cache:
+            self._pos_cache[key] = position_embedding_sine(h, w, self.cfg.MODEL.TRANSFORMER.CHANNELS // 2).to(device)
+        return self._pos_cache[key]
+
+    def forward(self, batch, deployment=False, noise=None, use_prior=None):
+        if deployment:
+            raise NotImplementedError('deployment_forward is outside the training hot path')
+        embedding = self.encode(batch)
+        b, s = batch['image'].shape[:2]
+        action = ops.cat_last([pack_sequence_dim(batch['throttle_brake']), pack_sequence_dim(batch['steering'])])
+        action = action.view(b, s, -1)
+        state_dict = self.rssm(embedding, action, use_sample=True, policy=self.policy, noise=noise, use_prior=use_prior)
+        output = {**state_dict}
+        post = state_dict['posterior']
+        state = ops.cat_last([pack_sequence_dim(post['hidden_state']), pack_sequence_dim(post['sample'])])
+        pol = self.policy(state)
+        output['throttle_brake'] = unpack_sequence_dim(ops.slice_last(pol, 0, 1), b, s)
+        output['steering'] = unpack_sequence_dim(ops.slice_last(pol, 1, 2), b, s)
+        if self.cfg.EVAL.RGB_SUPERVISION:
+            output.update(unpack_sequence_dim(self.rgb_decoder(state), b, s))
+        if self.cfg.LIDAR_RE.ENABLED:
+            output.update(unpack_sequence_dim(self.lidar_re(state), b, s))
+        if self.cfg.VOXEL_SEG.ENABLED:
+            output.update(unpack_sequence_dim(self.voxel_decoder(state), b, s))
+        return output, state_dict
+
+    def encode(self, batch):
+        b, s = batch['image'].shape[:2]
+        image = pack_sequence_dim(batch['image'])
+        speed = pack_sequence_dim(batch['speed'])
+        x = self.feat_decoder(self.encoder(image))
+        lidar_features = self.range_view_decoder(self.range_view_encoder(pack_sequence_dim(batch['range_view_pcd_xyzd'])))
+        hi, wi = x.shape[-2:]
+        hl, wl = lidar_features.shape[-2:]
+        # x + pos -> flatten/permute -> + type embedding -> concat (mile.py:542-557), one transpose kernel per sensor
+        tokens = ops.make_tokens(x, lidar_features, self._pos(hi, wi, x.device), self._pos(hl, wl, x.device),
+                                 self.type_embedding)
+        self._step_seed += 1
+        tokens_out = self.transformer_encoder(tokens, self.dropout_seed + 1000 * self._step_seed)
+        image_tokens_out = ops.untoken(tokens_out, 0, hi, wi)
+        lidar_tokens_out = ops.untoken(tokens_out, hi * wi, hl, wl)
+        features = [self.image_feature_conv(image_tokens_out), self.lidar_feature_conv(lidar_tokens_out),
+                    self.backbone_route(pack_sequence_dim(batch['route_map']))]
+        sp = ops.divide_scalar(speed.float(), self.speed_normalisation)
+        sp = self.speed_enc[2](self.speed_enc[0](sp, act=ops.ACT_RELU), act=ops.ACT_RELU)
+        features.append(sp)
+        embedding = self.features_combine(ops.cat_last(features))
+        return unpack_sequence_dim(embedding, b, s)

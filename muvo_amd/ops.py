@@ -1,0 +1,1101 @@
+"""ctypes binding of libmuvo_hip.so (include/muvo_hip.h) + torch.autograd glue.
+
+PyTorch is used here only as plumbing: device memory (torch.empty), the current HIP stream, and the
+autograd tape.  Every arithmetic op of the training step is a call into the hand-written gfx950
+kernels; there is NO eager/CPU fallback — if the shared library is missing or a call fails, a
+RuntimeError is raised (the product path must fail loudly).
+
+Parameter gradients are accumulated by the kernels straight into `param.grad` (pre-allocated, usually a
+view into one flat gradient buffer, see muvo_amd/param_store.py); the autograd Functions therefore
+return None for parameters and only propagate activation gradients.
+"""
+import ctypes as C
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, 'libmuvo_hip.so')
+_lib = None
+_lock = threading.Lock()
+
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_ELU, ACT_TANH = 0, 1, 2, 3, 4
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [('nd', C.c_int32), ('transposed', C.c_int32), ('N', C.c_int32), ('Cin', C.c_int32), ('Cout', C.c_int32),
+                ('in_sz', C.c_int32 * 3), ('out_sz', C.c_int32 * 3), ('ksz', C.c_int32 * 3), ('stride', C.c_int32 * 3),
+                ('pad', C.c_int32 * 3), ('dil', C.c_int32 * 3)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [('M', C.c_int32), ('N', C.c_int32), ('K', C.c_int32),
+                ('sam', C.c_int64), ('sak', C.c_int64), ('sbk', C.c_int64), ('sbn', C.c_int64), ('scm', C.c_int64),
+                ('B1', C.c_int32), ('B2', C.c_int32),
+                ('a_b1', C.c_int64), ('a_b2', C.c_int64), ('b_b1', C.c_int64), ('b_b2', C.c_int64),
+                ('c_b1', C.c_int64), ('c_b2', C.c_int64),
+                ('alpha', C.c_float), ('bias_div', C.c_int32), ('act', C.c_int32), ('slope', C.c_float),
+                ('mode', C.c_int32)]
+
+
+# every exported symbol of include/muvo_hip.h (tests/test_abi.py checks this list against the header)
+EXPORTS = [
+    'muvo_last_error', 'muvo_abi_version', 'muvo_selftest_mfma',
+    'muvo_conv_pack_sizes', 'muvo_conv_pack_weights', 'muvo_conv_forward', 'muvo_conv_dgrad', 'muvo_conv_wgrad', 'muvo_bias_grad_nchw',
+    'muvo_gemm',
+    'muvo_bn_train_fwd', 'muvo_bn_train_bwd', 'muvo_adain_fwd', 'muvo_adain_bwd',
+    'muvo_add_dropout_layernorm_fwd', 'muvo_add_dropout_layernorm_bwd',
+    'muvo_act_fwd', 'muvo_act_bwd', 'muvo_dropout', 'muvo_axpby', 'muvo_copy2d', 'muvo_colsum_acc', 'muvo_batchsum',
+    'muvo_nchw_to_tokens', 'muvo_tokens_to_nchw', 'muvo_maxpool2d_fwd', 'muvo_maxpool2d_bwd', 'muvo_avgpool_fwd',
+    'muvo_avgpool_bwd', 'muvo_upsample3d_x2_fwd', 'muvo_upsample3d_x2_bwd', 'muvo_preprocess_image',
+    'muvo_preprocess_route', 'muvo_divide_scalar', 'muvo_resize_bilinear', 'muvo_resize_nearest_f32',
+    'muvo_resize_nearest_u8', 'muvo_softmax_dropout_fwd', 'muvo_softmax_dropout_bwd', 'muvo_gru_fwd', 'muvo_gru_bwd',
+    'muvo_rssm_sample_fwd', 'muvo_rssm_sample_bwd',
+    'muvo_spatial_loss_fwd', 'muvo_spatial_loss_bwd', 'muvo_voxel_loss_stats_doubles', 'muvo_voxel_loss_coef_floats',
+    'muvo_voxel_loss_fwd', 'muvo_voxel_loss_bwd', 'muvo_l1_rows_fwd', 'muvo_l1_rows_bwd', 'muvo_kl_loss_fwd',
+    'muvo_kl_loss_bwd', 'muvo_adamw_step',
+]
+
+
+def lib():
+    """Load the shared library (once). Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(_LIB_PATH):
+                    raise RuntimeError(f'{_LIB_PATH} not found: build it with `python -m muvo_amd.build` '
+                                       '(there is no fallback path)')
+                L = C.CDLL(_LIB_PATH)
+                L.muvo_last_error.restype = C.c_char_p
+                for name in EXPORTS:
+                    getattr(L, name)  # AttributeError if a declared symbol is missing
+                _lib = L
+    return _lib
+
+
+def _ck(rc):
+    if rc != 0:
+        raise RuntimeError(f'muvo_hip error {rc}: {lib().muvo_last_error().decode()}')
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return C.c_void_p(0)
+    assert t.is_cuda and t.is_contiguous(), 'muvo_hip ops need contiguous device tensors'
+    return C.c_void_p(t.data_ptr())
+
+
+def _f(t):
+    assert t is None or t.dtype == torch.float32
+    return _p(t)
+
+
+def _i64(v):
+    return C.c_int64(int(v))
+
+
+def _fl(v):
+    return C.c_float(float(v))
+
+
+_weight_epoch = [0]
+
+
+def bump_weight_epoch():
+    """Call after parameters were modified outside torch (the fused AdamW kernel) to invalidate packed weights."""
+    _weight_epoch[0] += 1
+
+
+def grad_of(p):
+    """The gradient buffer the kernels accumulate into (allocated on demand)."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)
+    return p.grad
+
+
+_scratch = {}
+
+
+def scratch(name, nfloats, device, dtype=torch.float32):
+    t = _scratch.get((name, device, dtype))
+    if t is None or t.numel() < nfloats:
+        t = torch.empty(int(nfloats), device=device, dtype=dtype)
+        _scratch[(name, device, dtype)] = t
+    return t
+
+
+# ================================================================================================ GEMM
+def gemm(A, B, Cout, M, N, K, sam, sak, sbk, sbn, scm, bias=None, alpha=1.0, act=ACT_NONE, slope=0.0, mode=0,
+         B1=1, B2=1, a_b=(0, 0), b_b=(0, 0), c_b=(0, 0), bias_div=1, a_off=0, b_off=0, c_off=0):
+    """Raw strided GEMM on storage pointers (+ element offsets)."""
+    d = GemmDesc(M, N, K, sam, sak, sbk, sbn, scm, B1, B2, a_b[0], a_b[1], b_b[0], b_b[1], c_b[0], c_b[1], alpha,
+                 bias_div, act, slope, mode)
+    pa = C.c_void_p(A.data_ptr() + 4 * a_off)
+    pb = C.c_void_p(B.data_ptr() + 4 * b_off)
+    pc = C.c_void_p(Cout.data_ptr() + 4 * c_off)
+    _ck(lib().muvo_gemm(C.byref(d), pa, pb, pc, _f(bias), _st()))
+
+
+class LinearFn(torch.autograd.Function):
+    """y = act(x @ W^T + b) on the last dim; x (..., in) contiguous.  W grads go to W.grad."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, slope):
+        x = x.contiguous()
+        out_f, in_f = weight.shape
+        rows = x.numel() // in_f
+        y = torch.empty(*x.shape[:-1], out_f, device=x.device, dtype=torch.float32)
+        gemm(x, weight, y, rows, out_f, in_f, in_f, 1, 1, in_f, out_f, bias=bias, act=act, slope=slope)
+        ctx.act, ctx.slope = act, slope
+        ctx.weight, ctx.bias = weight, bias
+        ctx.save_for_backward(x, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        weight, bias = ctx.weight, ctx.bias
+        out_f, in_f = weight.shape
+        rows = x.numel() // in_f
+        dy = dy.contiguous()
+        if ctx.act != ACT_NONE:
+            dz = torch.empty_like(dy)
+            _ck(lib().muvo_act_bwd(_f(y), _f(dy), _f(dz), _i64(dy.numel()), ctx.act, _fl(ctx.slope), _st()))
+        else:
+            dz = dy
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            # dx[r][i] = sum_o dz[r][o] W[o][i]
+            gemm(dz, weight, dx, rows, in_f, out_f, out_f, 1, in_f, 1, in_f)
+        if weight.requires_grad:
+            # dW[o][i] += sum_r dz[r][o] x[r][i]
+            gemm(dz, x, grad_of(weight), out_f, in_f, rows, 1, out_f, in_f, 1, in_f, mode=1)
+            if bias is not None:
+                _ck(lib().muvo_colsum_acc(_f(dz), _f(grad_of(bias)), _i64(rows), _i64(out_f), _i64(out_f), _st()))
+        return dx, None, None, None, None
+
+
+def linear(x, weight, bias=None, act=ACT_NONE, slope=0.0):
+    return LinearFn.apply(x, weight, bias, act, slope)
+
+
+# ================================================================================================ conv
+_plan_cache = {}
+
+
+class ConvGeom:
+    """Static geometry of a conv layer (everything but the batch/input size)."""
+
+    def __init__(self, nd, transposed, cin, cout, ksz, stride=1, pad=0, dil=1, out_pad=0):
+        def t3(v):
+            v = (v,) * nd if isinstance(v, int) else tuple(v)
+            return (1,) * (3 - nd) + v if nd == 2 and len(v) == 2 else v
+        self.nd, self.transposed, self.cin, self.cout = nd, int(transposed), cin, cout
+        self.ksz, self.stride, self.dil = t3(ksz), t3(stride), t3(dil)
+        p, op = t3(pad), t3(out_pad)
+        if nd == 2:
+            p = (0,) + p[1:]
+            op = (0,) + op[1:]
+            self.stride = (1,) + self.stride[1:]
+            self.dil = (1,) + self.dil[1:]
+        self.pad, self.out_pad = p, op
+
+    def out_size(self, in_sz):
+        o = []
+        for a in range(3):
+            if not self.transposed:
+                o.append((in_sz[a] + 2 * self.pad[a] - self.dil[a] * (self.ksz[a] - 1) - 1) // self.stride[a] + 1)
+            else:
+                o.append((in_sz[a] - 1) * self.stride[a] - 2 * self.pad[a] + self.dil[a] * (self.ksz[a] - 1) + 1 +
+                         self.out_pad[a])
+        return tuple(o)
+
+    def plan(self, n, in_sz):
+        key = (id(self), n, in_sz)
+        pl = _plan_cache.get(key)
+        if pl is None:
+            out_sz = self.out_size(in_sz)
+            d = ConvDesc(self.nd, self.transposed, n, self.cin, self.cout, (C.c_int32 * 3)(*in_sz),
+                         (C.c_int32 * 3)(*out_sz), (C.c_int32 * 3)(*self.ksz), (C.c_int32 * 3)(*self.stride),
+                         (C.c_int32 * 3)(*self.pad), (C.c_int32 * 3)(*self.dil))
+            ff, df = C.c_int64(0), C.c_int64(0)
+            _ck(lib().muvo_conv_pack_sizes(C.byref(d), C.byref(ff), C.byref(df)))
+            pl = (d, out_sz, ff.value, df.value)
+            _plan_cache[key] = pl
+        return pl
+
+
+class _PackedWeights:
+    """Per-layer K-major packed copies of the weight, refreshed when the weight changed."""
+
+    def __init__(self):
+        self.fwd = self.dgr = None
+        self.fwd_key = self.dgr_key = None
+
+
+def _wkey(w):
+    return (w._version, _weight_epoch[0], w.data_ptr())
+
+
+class ConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, geom, packed, act, slope):
+        x = x.contiguous()
+        n = x.shape[0]
+        in_sz = tuple(x.shape[2:]) if geom.nd == 3 else (1,) + tuple(x.shape[2:])
+        d, out_sz, ff, df = geom.plan(n, in_sz)
+        L = lib()
+        if packed.fwd is None or packed.fwd.numel() < ff:
+            packed.fwd = torch.empty(ff, device=x.device, dtype=torch.float32)
+            packed.fwd_key = None
+        k = _wkey(weight)
+        if packed.fwd_key != k:
+            _ck(L.muvo_conv_pack_weights(C.byref(d), _f(weight), _f(packed.fwd), None, _st()))
+            packed.fwd_key = k
+        oshape = (n, geom.cout) + (out_sz if geom.nd == 3 else out_sz[1:])
+        y = torch.empty(oshape, device=x.device, dtype=torch.float32)
+        _ck(L.muvo_conv_forward(C.byref(d), _f(x), _f(packed.fwd), _f(bias), _f(y), act, _fl(slope), _st()))
+        ctx.geom, ctx.packed, ctx.act, ctx.slope = geom, packed, act, slope
+        ctx.weight, ctx.bias, ctx.in_sz = weight, bias, in_sz
+        ctx.save_for_backward(x, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        geom, packed, weight, bias = ctx.geom, ctx.packed, ctx.weight, ctx.bias
+        d, out_sz, ff, df = geom.plan(x.shape[0], ctx.in_sz)
+        L = lib()
+        dy = dy.contiguous()
+        if ctx.act != ACT_NONE:
+            dz = torch.empty_like(dy)
+            _ck(L.muvo_act_bwd(_f(y), _f(dy), _f(dz), _i64(dy.numel()), ctx.act, _fl(ctx.slope), _st()))
+        else:
+            dz = dy
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if packed.dgr is None or packed.dgr.numel() < df:
+                packed.dgr = torch.empty(df, device=x.device, dtype=torch.float32)
+                packed.dgr_key = None
+            k = _wkey(weight)
+            if packed.dgr_key != k:
+                _ck(L.muvo_conv_pack_weights(C.byref(d), _f(weight), None, _f(packed.dgr), _st()))
+                packed.dgr_key = k
+            dx = torch.empty_like(x)
+            _ck(L.muvo_conv_dgrad(C.byref(d), _f(dz), _f(packed.dgr), _f(dx), _st()))
+        if weight.requires_grad:
+            ws = scratch('wgrad', ff, x.device)
+            db = grad_of(bias) if bias is not None else None
+            _ck(L.muvo_conv_wgrad(C.byref(d), _f(x), _f(dz), _f(ws), _f(grad_of(weight)), _f(db), _st()))
+        return dx, None, None, None, None, None, None
+
+
+def conv(x, weight, bias, geom, packed, act=ACT_NONE, slope=0.0):
+    return ConvFn.apply(x, weight, bias, geom, packed, act, slope)
+
+
+# ================================================================================================ norms
+class BNActFn(torch.autograd.Function):
+    """Train-mode BatchNorm2d + optional residual + ReLU.  res_mode 1: relu(bn(x)+res); 2: relu(bn(x))+res."""
+
+    @staticmethod
+    def forward(ctx, x, residual, bn, res_mode, relu, training):
+        x = x.contiguous()
+        n, c = x.shape[:2]
+        s = x.numel() // (n * c)
+        y = torch.empty_like(x)
+        mean = torch.empty(c, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(c, device=x.device, dtype=torch.float32)
+        ws = torch.empty(2 * c, device=x.device, dtype=torch.float64)
+        if residual is not None:
+            residual = residual.contiguous()
+        if not training:
+            raise RuntimeError('eval-mode BatchNorm is not part of the training hot path (reference keeps train() mode '
+                               'even in validation, trainer.py:405)')
+        _ck(lib().muvo_bn_train_fwd(_f(x), _f(bn.weight), _f(bn.bias), _f(residual), _f(y), _f(mean), _f(rstd),
+                                    _f(bn.running_mean), _f(bn.running_var), _p(ws), n, c, _i64(s), _fl(bn.eps),
+                                    _fl(bn.momentum), res_mode if residual is not None else 0, int(relu), _st()))
+        bn.num_batches_tracked += 1
+        ctx.bn, ctx.dims = bn, (n, c, s)
+        ctx.mask_mode = 0 if not relu else (2 if (residual is not None and res_mode == 2) else 1)
+        ctx.has_res, ctx.res_mode = residual is not None, res_mode
+        ctx.save_for_backward(x, y if ctx.mask_mode == 1 else None, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, rstd = ctx.saved_tensors
+        bn = ctx.bn
+        n, c, s = ctx.dims
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dres = None
+        if ctx.has_res and ctx.needs_input_grad[1]:
+            dres = torch.empty_like(x) if ctx.res_mode == 1 else dy
+        ws = torch.empty(2 * c, device=x.device, dtype=torch.float64)
+        _ck(lib().muvo_bn_train_bwd(_f(x), _f(y), _f(dy), _f(bn.weight), _f(bn.bias), _f(mean), _f(rstd), _f(dx),
+                                    _f(dres) if (ctx.has_res and ctx.res_mode == 1) else None,
+                                    _f(grad_of(bn.weight)), _f(grad_of(bn.bias)), _p(ws), n, c, _i64(s), ctx.mask_mode,
+                                    _st()))
+        return dx, dres, None, None, None, None
+
+
+def bn_act(x, bn, residual=None, res_mode=1, relu=True):
+    return BNActFn.apply(x, residual, bn, res_mode, relu, bn.training)
+
+
+class AdaINFn(torch.autograd.Function):
+    """AdaptiveInstanceNorm3d. x: (N,C,D,H,W) or a broadcast (C,D,H,W) parameter; style: (N, 2C)."""
+
+    @staticmethod
+    def forward(ctx, x, style, eps, n_batch):
+        x = x.contiguous()
+        style = style.contiguous()
+        bcast = x.dim() == 4
+        c = x.shape[0] if bcast else x.shape[1]
+        s = x.numel() // c if bcast else x.numel() // (x.shape[0] * c)
+        n = n_batch
+        y = torch.empty((n, c) + tuple(x.shape[-3:]), device=x.device, dtype=torch.float32)
+        mean = torch.empty(n * c, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(n * c, device=x.device, dtype=torch.float32)
+        ws = torch.empty(2 * n * c, device=x.device, dtype=torch.float64)
+        _ck(lib().muvo_adain_fwd(_f(x), _f(style), _f(y), _f(mean), _f(rstd), _p(ws), n, c, _i64(s),
+                                 _i64(0 if bcast else c * s), _fl(eps), _st()))
+        ctx.dims = (n, c, s, bcast)
+        ctx.save_for_backward(x, style, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, style, mean, rstd = ctx.saved_tensors
+        n, c, s, bcast = ctx.dims
+        dy = dy.contiguous()
+        dxf = torch.empty_like(dy)
+        dstyle = torch.empty_like(style)
+        ws = torch.empty(2 * n * c, device=x.device, dtype=torch.float64)
+        _ck(lib().muvo_adain_bwd(_f(x), _f(style), _f(dy), _f(mean), _f(rstd), _f(dxf), _f(dstyle), _p(ws), n, c,
+                                 _i64(s), _i64(0 if bcast else c * s), _st()))
+        if bcast:
+            dx = torch.empty_like(x)
+            _ck(lib().muvo_batchsum(_f(dxf), _f(dx), n, _i64(c * s), 0, _st()))
+        else:
+            dx = dxf
+        return dx, dstyle, None, None
+
+
+def adain(x, style, eps, n_batch):
+    return AdaINFn.apply(x, style, eps, n_batch)
+
+
+class AddDropoutLNFn(torch.autograd.Function):
+    """y = LayerNorm(x + dropout(a)) over the last dim."""
+
+    @staticmethod
+    def forward(ctx, x, a, ln, p, seed):
+        x = x.contiguous()
+        a = a.contiguous()
+        e = x.shape[-1]
+        rows = x.numel() // e
+        y = torch.empty_like(x)
+        z = torch.empty_like(x)
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+        _ck(lib().muvo_add_dropout_layernorm_fwd(_f(x), _f(a), _f(ln.weight), _f(ln.bias), _f(y), _f(z), _f(mean),
+                                                 _f(rstd), rows, e, _fl(ln.eps), _fl(p), C.c_uint64(seed), _st()))
+        ctx.ln, ctx.p, ctx.seed, ctx.dims = ln, p, seed, (rows, e)
+        ctx.save_for_backward(z, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, mean, rstd = ctx.saved_tensors
+        ln = ctx.ln
+        rows, e = ctx.dims
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        da = torch.empty_like(dy)
+        _ck(lib().muvo_add_dropout_layernorm_bwd(_f(dy), _f(z), _f(mean), _f(rstd), _f(ln.weight), _f(dx), _f(da),
+                                                 _f(grad_of(ln.weight)), _f(grad_of(ln.bias)), rows, e, _fl(ctx.p),
+                                                 C.c_uint64(ctx.seed), _st()))
+        return dx, da, None, None, None
+
+
+def add_dropout_layernorm(x, a, ln, p, seed):
+    return AddDropoutLNFn.apply(x, a, ln, p, seed)
+
+
+# ================================================================================================ misc
+class ActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act, slope):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        _ck(lib().muvo_act_fwd(_f(x), _f(y), _i64(x.numel()), act, _fl(slope), _st()))
+        ctx.act, ctx.slope = act, slope
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        _ck(lib().muvo_act_bwd(_f(y), _f(dy), _f(dx), _i64(dy.numel()), ctx.act, _fl(ctx.slope), _st()))
+        return dx, None, None
+
+
+def activation(x, act, slope=0.0):
+    return ActFn.apply(x, act, slope)
+
+
+class DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        _ck(lib().muvo_dropout(_f(x), _f(y), _i64(x.numel()), _fl(p), C.c_uint64(seed), _st()))
+        ctx.p, ctx.seed = p, seed
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        _ck(lib().muvo_dropout(_f(dy), _f(dx), _i64(dy.numel()), _fl(ctx.p), C.c_uint64(ctx.seed), _st()))
+        return dx, None, None
+
+
+def dropout(x, p, seed):
+    if p <= 0.0:
+        return x
+    return DropoutFn.apply(x, p, seed)
+
+
+class CatLastFn(torch.autograd.Function):
+    """torch.cat(tensors, dim=-1) for 2-D row-major tensors, via strided 2-D copies."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        rows = xs[0].shape[0]
+        widths = [x.shape[1] for x in xs]
+        tot = sum(widths)
+        y = torch.empty(rows, tot, device=xs[0].device, dtype=torch.float32)
+        off = 0
+        for x, w in zip(xs, widths):
+            x = x.contiguous()
+            _ck(lib().muvo_copy2d(_f(x), C.c_void_p(y.data_ptr() + 4 * off), _i64(rows), _i64(w), _i64(w), _i64(tot), 0,
+                                  _st()))
+            off += w
+        ctx.widths, ctx.rows = widths, rows
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        tot = sum(ctx.widths)
+        outs, off = [], 0
+        for i, w in enumerate(ctx.widths):
+            if ctx.needs_input_grad[i]:
+                g = torch.empty(ctx.rows, w, device=dy.device, dtype=torch.float32)
+                _ck(lib().muvo_copy2d(C.c_void_p(dy.data_ptr() + 4 * off), _f(g), _i64(ctx.rows), _i64(w), _i64(tot),
+                                      _i64(w), 0, _st()))
+                outs.append(g)
+            else:
+                outs.append(None)
+            off += w
+        return tuple(outs)
+
+
+def cat_last(xs):
+    return CatLastFn.apply(*xs)
+
+
+class SliceLastFn(torch.autograd.Function):
+    """x[:, a:b] as a fresh contiguous tensor (2-D)."""
+
+    @staticmethod
+    def forward(ctx, x, a, b):
+        x = x.contiguous()
+        rows, tot = x.shape
+        y = torch.empty(rows, b - a, device=x.device, dtype=torch.float32)
+        _ck(lib().muvo_copy2d(C.c_void_p(x.data_ptr() + 4 * a), _f(y), _i64(rows), _i64(b - a), _i64(tot), _i64(b - a), 0,
+                              _st()))
+        ctx.a, ctx.b, ctx.tot, ctx.rows = a, b, tot, rows
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dx = torch.zeros(ctx.rows, ctx.tot, device=dy.device, dtype=torch.float32)
+        _ck(lib().muvo_copy2d(_f(dy), C.c_void_p(dx.data_ptr() + 4 * ctx.a), _i64(ctx.rows), _i64(ctx.b - ctx.a),
+                              _i64(ctx.b - ctx.a), _i64(ctx.tot), 0, _st()))
+        return dx, None, None
+
+
+def slice_last(x, a, b):
+    return SliceLastFn.apply(x, a, b)
+
+
+class TokensFn(torch.autograd.Function):
+    """(N,C,h,w) feature maps of the two sensors -> (L_img+L_lidar, N, C) tokens with positional + type embedding."""
+
+    @staticmethod
+    def forward(ctx, xi, xl, pos_i, pos_l, type_emb):
+        xi, xl = xi.contiguous(), xl.contiguous()
+        n, c = xi.shape[:2]
+        li, ll = xi.shape[2] * xi.shape[3], xl.shape[2] * xl.shape[3]
+        tok = torch.empty(li + ll, n, c, device=xi.device, dtype=torch.float32)
+        L = lib()
+        te = type_emb.contiguous()  # (1,1,C,2): element [c][k] at c*2+k
+        _ck(L.muvo_nchw_to_tokens(_f(xi), _f(pos_i), _f(te), 2, _f(tok), n, c, li, 0, _st()))
+        _ck(L.muvo_nchw_to_tokens(_f(xl), _f(pos_l), C.c_void_p(te.data_ptr() + 4), 2, _f(tok), n, c, ll, li, _st()))
+        ctx.shapes = (xi.shape, xl.shape, li, ll, n, c)
+        ctx.type_emb = type_emb
+        return tok
+
+    @staticmethod
+    def backward(ctx, dtok):
+        dtok = dtok.contiguous()
+        si, sl, li, ll, n, c = ctx.shapes
+        L = lib()
+        dxi = torch.empty(si, device=dtok.device, dtype=torch.float32)
+        dxl = torch.empty(sl, device=dtok.device, dtype=torch.float32)
+        _ck(L.muvo_tokens_to_nchw(_f(dtok), _f(dxi), n, c, li, 0, _st()))
+        _ck(L.muvo_tokens_to_nchw(_f(dtok), _f(dxl), n, c, ll, li, _st()))
+        te = ctx.type_emb
+        if te.requires_grad:
+            tmp = torch.zeros(2, c, device=dtok.device, dtype=torch.float32)
+            _ck(L.muvo_colsum_acc(_f(dtok), _f(tmp[0]), _i64(li * n), _i64(c), _i64(c), _st()))
+            _ck(L.muvo_colsum_acc(C.c_void_p(dtok.data_ptr() + 4 * li * n * c), _f(tmp[1]), _i64(ll * n), _i64(c),
+                                  _i64(c), _st()))
+            # grad layout (1,1,C,2): interleave the two columns with strided copies
+            g = grad_of(te)
+            for k in range(2):
+                _ck(L.muvo_copy2d(_f(tmp[k]), C.c_void_p(g.data_ptr() + 4 * k), _i64(c), _i64(1), _i64(1), _i64(2), 1,
+                                  _st()))
+        return dxi, dxl, None, None, None
+
+
+def make_tokens(xi, xl, pos_i, pos_l, type_emb):
+    return TokensFn.apply(xi, xl, pos_i, pos_l, type_emb)
+
+
+class UntokenFn(torch.autograd.Function):
+    """tokens[l0:l0+h*w] (L,N,C) -> (N,C,h,w)."""
+
+    @staticmethod
+    def forward(ctx, tok, l0, h, w):
+        tok = tok.contiguous()
+        ltot, n, c = tok.shape
+        x = torch.empty(n, c, h, w, device=tok.device, dtype=torch.float32)
+        _ck(lib().muvo_tokens_to_nchw(_f(tok), _f(x), n, c, h * w, l0, _st()))
+        ctx.dims = (ltot, n, c, l0, h * w)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        dx = dx.contiguous()
+        ltot, n, c, l0, l = ctx.dims
+        dtok = torch.zeros(ltot, n, c, device=dx.device, dtype=torch.float32)
+        _ck(lib().muvo_nchw_to_tokens(_f(dx), None, None, 0, _f(dtok), n, c, l, l0, _st()))
+        return dtok, None, None, None
+
+
+def untoken(tok, l0, h, w):
+    return UntokenFn.apply(tok, l0, h, w)
+
+
+class MaxPool2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k, s, p):
+        x = x.contiguous()
+        n, c, h, w = x.shape
+        oh, ow = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+        y = torch.empty(n, c, oh, ow, device=x.device, dtype=torch.float32)
+        idx = torch.empty(n, c, oh, ow, device=x.device, dtype=torch.int32)
+        _ck(lib().muvo_maxpool2d_fwd(_f(x), _f(y), _p(idx), _i64(n * c), h, w, oh, ow, k, s, p, _st()))
+        ctx.dims = (n, c, h, w, oh, ow, k, s, p)
+        ctx.save_for_backward(idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        n, c, h, w, oh, ow, k, s, p = ctx.dims
+        dy = dy.contiguous()
+        dx = torch.empty(n, c, h, w, device=dy.device, dtype=torch.float32)
+        _ck(lib().muvo_maxpool2d_bwd(_f(dy), _p(idx), _f(dx), _i64(n * c), h, w, oh, ow, k, s, p, _st()))
+        return dx, None, None, None
+
+
+def max_pool2d(x, k, s=None, p=0):
+    return MaxPool2dFn.apply(x, k, s or k, p)
+
+
+class GlobalAvgPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        n, c = x.shape[:2]
+        s = x.numel() // (n * c)
+        y = torch.empty(n, c, device=x.device, dtype=torch.float32)
+        _ck(lib().muvo_avgpool_fwd(_f(x), _f(y), _i64(n * c), _i64(s), _st()))
+        ctx.shape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        shape = ctx.shape
+        dx = torch.empty(shape, device=dy.device, dtype=torch.float32)
+        g = shape[0] * shape[1]
+        _ck(lib().muvo_avgpool_bwd(_f(dy), _f(dx), _i64(g), _i64(dx.numel() // g), _st()))
+        return dx
+
+
+def global_avg_pool(x):
+    return GlobalAvgPoolFn.apply(x)
+
+
+class Upsample3dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        n, c, d, h, w = x.shape
+        y = torch.empty(n, c, 2 * d, 2 * h, 2 * w, device=x.device, dtype=torch.float32)
+        _ck(lib().muvo_upsample3d_x2_fwd(_f(x), _f(y), _i64(n * c), d, h, w, _st()))
+        ctx.shape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        n, c, d, h, w = ctx.shape
+        dx = torch.empty(ctx.shape, device=dy.device, dtype=torch.float32)
+        _ck(lib().muvo_upsample3d_x2_bwd(_f(dy), _f(dx), _i64(n * c), d, h, w, _st()))
+        return dx
+
+
+def upsample3d_x2(x):
+    return Upsample3dFn.apply(x)
+
+
+# ================================================================================================ attention
+class AttentionFn(torch.autograd.Function):
+    """Multi-head self-attention core on a packed (L, N, 3E) qkv tensor -> (L, N, E).
+
+    QK^T and PV are strided batched MFMA GEMMs straight on the packed layout (no head split copies);
+    softmax + attention-probability dropout is one wave-per-row kernel."""
+
+    @staticmethod
+    def forward(ctx, qkv, nheads, p, seed):
+        qkv = qkv.contiguous()
+        l, n, e3 = qkv.shape
+        e = e3 // 3
+        dh = e // nheads
+        scale = 1.0 / (dh ** 0.5)
+        dev = qkv.device
+        S = torch.empty(n, nheads, l, l, device=dev, dtype=torch.float32)
+        # S[n][h][i][j] = scale * sum_d q[i][n][h*dh+d] * k[j][n][e + h*dh + d]
+        gemm(qkv, qkv, S, l, l, dh, n * e3, 1, 1, n * e3, l, alpha=scale, B1=n, B2=nheads,
+             a_b=(e3, dh), b_b=(e3, dh), c_b=(nheads * l * l, l * l), b_off=e)
+        P = torch.empty_like(S)
+        Pd = torch.empty_like(S) if p > 0 else None
+        _ck(lib().muvo_softmax_dropout_fwd(_f(S), _f(P), _f(Pd), _i64(n * nheads * l), l, _fl(p), C.c_uint64(seed),
+                                           _st()))
+        del S
+        o = torch.empty(l, n, e, device=dev, dtype=torch.float32)
+        pa = Pd if Pd is not None else P
+        # o[i][n][h*dh+d] = sum_j P[n][h][i][j] * v[j][n][2e + h*dh + d]
+        gemm(pa, qkv, o, l, dh, l, l, 1, n * e3, 1, n * e, B1=n, B2=nheads, a_b=(nheads * l * l, l * l),
+             b_b=(e3, dh), c_b=(e, dh), b_off=2 * e)
+        ctx.dims = (l, n, e, nheads, dh, scale, p, seed)
+        ctx.save_for_backward(qkv, P)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, P = ctx.saved_tensors
+        l, n, e, nheads, dh, scale, p, seed = ctx.dims
+        e3 = 3 * e
+        do = do.contiguous()
+        dev = do.device
+        dqkv = torch.empty_like(qkv)
+        if p > 0:
+            Pd = torch.empty_like(P)
+            _ck(lib().muvo_dropout(_f(P), _f(Pd), _i64(P.numel()), _fl(p), C.c_uint64(seed), _st()))
+        else:
+            Pd = P
+        bP = (nheads * l * l, l * l)
+        # dV[j][n][h*dh+d] = sum_i Pd[i][j] * do[i][n][h*dh+d]   (A(m=j,k=i)=Pd[i*l+j])
+        gemm(Pd, do, dqkv, l, dh, l, 1, l, n * e, 1, n * e3, B1=n, B2=nheads, a_b=bP, b_b=(e, dh), c_b=(e3, dh),
+             c_off=2 * e)
+        # dPd[i][j] = sum_d do[i][n][h*dh+d] * v[j][n][2e+h*dh+d]
+        dPd = torch.empty_like(P)
+        gemm(do, qkv, dPd, l, l, dh, n * e, 1, 1, n * e3, l, B1=n, B2=nheads, a_b=(e, dh), b_b=(e3, dh), c_b=bP,
+             b_off=2 * e)
+        dS = dPd  # in place
+        _ck(lib().muvo_softmax_dropout_bwd(_f(P), _f(dPd), _f(dS), _i64(n * nheads * l), l, _fl(p), C.c_uint64(seed),
+                                           _st()))
+        # dQ[i][.] = scale * sum_j dS[i][j] * k[j][.]
+        gemm(dS, qkv, dqkv, l, dh, l, l, 1, n * e3, 1, n * e3, alpha=scale, B1=n, B2=nheads, a_b=bP, b_b=(e3, dh),
+             c_b=(e3, dh), b_off=e)
+        # dK[j][.] = scale * sum_i dS[i][j] * q[i][.]
+        gemm(dS, qkv, dqkv, l, dh, l, 1, l, n * e3, 1, n * e3, alpha=scale, B1=n, B2=nheads, a_b=bP, b_b=(e3, dh),
+             c_b=(e3, dh), c_off=e)
+        return dqkv, None, None, None
+
+
+def attention(qkv, nheads, p, seed):
+    return AttentionFn.apply(qkv, nheads, p, seed)
+
+
+# ================================================================================================ RSSM
+class GRUPointwiseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gi, gh, h):
+        gi, gh, h = gi.contiguous(), gh.contiguous(), h.contiguous()
+        b, hd = h.shape
+        hn = torch.empty_like(h)
+        _ck(lib().muvo_gru_fwd(_f(gi), _f(gh), _f(h), _f(hn), b, hd, _st()))
+        ctx.save_for_backward(gi, gh, h)
+        return hn
+
+    @staticmethod
+    def backward(ctx, dhn):
+        gi, gh, h = ctx.saved_tensors
+        b, hd = h.shape
+        dhn = dhn.contiguous()
+        dgi, dgh, dh = torch.empty_like(gi), torch.empty_like(gh), torch.empty_like(h)
+        _ck(lib().muvo_gru_bwd(_f(gi), _f(gh), _f(h), _f(dhn), _f(dgi), _f(dgh), _f(dh), b, hd, _st()))
+        return dgi, dgh, dh
+
+
+def gru_pointwise(gi, gh, h):
+    return GRUPointwiseFn.apply(gi, gh, h)
+
+
+class RSSMSampleFn(torch.autograd.Function):
+    """(mu|log_sigma) -> mu, sigma = 2*sigmoid(ls/2)+0.1, sample = mu + sigma*eps."""
+
+    @staticmethod
+    def forward(ctx, mls, eps, min_std):
+        mls = mls.contiguous()
+        b, s2 = mls.shape
+        s = s2 // 2
+        mu, sigma, sample = (torch.empty(b, s, device=mls.device, dtype=torch.float32) for _ in range(3))
+        if eps is not None:
+            assert eps.stride(-1) == 1 and eps.shape == (b, s)
+            eld = eps.stride(0)
+            pe = C.c_void_p(eps.data_ptr())
+        else:
+            eld, pe = 0, None
+        _ck(lib().muvo_rssm_sample_fwd(_f(mls), pe, _i64(eld), _f(mu), _f(sigma), _f(sample), b, s, _fl(min_std), _st()))
+        ctx.eps = eps
+        ctx.save_for_backward(mls)
+        return mu, sigma, sample
+
+    @staticmethod
+    def backward(ctx, dmu, dsigma, dsample):
+        (mls,) = ctx.saved_tensors
+        b, s2 = mls.shape
+        s = s2 // 2
+        eps = ctx.eps
+        if eps is not None:
+            eld, pe = eps.stride(0), C.c_void_p(eps.data_ptr())
+        else:
+            eld, pe = 0, None
+
+        def cg(t):
+            return None if t is None else t.contiguous()
+        dmu, dsigma, dsample = cg(dmu), cg(dsigma), cg(dsample)
+        dmls = torch.empty_like(mls)
+        _ck(lib().muvo_rssm_sample_bwd(_f(mls), pe, _i64(eld), _f(dmu), _f(dsigma), _f(dsample), _f(dmls), b, s, _st()))
+        return dmls, None, None
+
+
+def rssm_sample(mls, eps, min_std=0.1):
+    return RSSMSampleFn.apply(mls, eps, min_std)
+
+
+# ================================================================================================ preprocess (no grad)
+def preprocess_image(img_u8, crop, mean, std):
+    """(B,S,3,H,W) u8 -> (label (B,S,3,h,w) in [0,1], normalised image)."""
+    img_u8 = img_u8.contiguous()
+    b, s, c, h, w = img_u8.shape
+    left, top, right, bottom = crop
+    ch, cw = bottom - top, right - left
+    label = torch.empty(b, s, c, ch, cw, device=img_u8.device, dtype=torch.float32)
+    norm = torch.empty_like(label)
+    m = (C.c_float * 3)(*mean)
+    sd = (C.c_float * 3)(*std)
+    _ck(lib().muvo_preprocess_image(_p(img_u8), _f(label), _f(norm), _i64(b * s * c), c, h, w, top, left, ch, cw, m, sd,
+                                    _st()))
+    return label, norm
+
+
+def preprocess_route(route_u8, size, mean, std):
+    route_u8 = route_u8.contiguous()
+    b, s, c, h, w = route_u8.shape
+    out = torch.empty(b, s, c, size, size, device=route_u8.device, dtype=torch.float32)
+    m = (C.c_float * 3)(*mean)
+    sd = (C.c_float * 3)(*std)
+    _ck(lib().muvo_preprocess_route(_p(route_u8), _f(out), _i64(b * s * c), c, h, w, size, size, m, sd, _st()))
+    return out
+
+
+def divide_scalar(x, divisor):
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    _ck(lib().muvo_divide_scalar(_f(x), _f(y), _i64(x.numel()), _fl(divisor), _st()))
+    return y
+
+
+def resize_bilinear(x, oh, ow):
+    """x (..., H, W) -> (..., oh, ow), bilinear align_corners=False without antialias."""
+    x = x.contiguous()
+    h, w = x.shape[-2:]
+    y = torch.empty(*x.shape[:-2], oh, ow, device=x.device, dtype=torch.float32)
+    _ck(lib().muvo_resize_bilinear(_f(x), _f(y), _i64(x.numel() // (h * w)), h, w, oh, ow, _st()))
+    return y
+
+
+def resize_nearest(x, out_sz):
+    """nearest resize of the trailing len(out_sz) dims (2 or 3), float32 or uint8."""
+    x = x.contiguous()
+    nd = len(out_sz)
+    in_sz = tuple(x.shape[-nd:])
+    i3 = (1,) * (3 - nd) + in_sz
+    o3 = (1,) * (3 - nd) + tuple(out_sz)
+    y = torch.empty(*x.shape[:-nd], *out_sz, device=x.device, dtype=x.dtype)
+    nc = x.numel() // (i3[0] * i3[1] * i3[2])
+    fn = lib().muvo_resize_nearest_u8 if x.dtype == torch.uint8 else lib().muvo_resize_nearest_f32
+    assert x.dtype in (torch.uint8, torch.float32)
+    _ck(fn(_p(x), _p(y), _i64(nc), *i3, *o3, _st()))
+    return y
+
+
+# ================================================================================================ losses
+class SpatialLossFn(torch.autograd.Function):
+    """weight * SpatialRegressionLoss(norm) over channel ranges of (B,S,C,H,W) tensors.
+
+    `parts` = list of (c0, c1, norm, weight); returns one scalar per part (stacked 1-D tensor)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, parts, ignore):
+        pred, target = pred.contiguous(), target.contiguous()
+        b, s, c, h, w = pred.shape
+        f, hw = b * s, h * w
+        losses = torch.empty(len(parts), device=pred.device, dtype=torch.float32)
+        stats = torch.empty(len(parts), 2, device=pred.device, dtype=torch.float64)
+        for i, (c0, c1, norm, weight) in enumerate(parts):
+            _ck(lib().muvo_spatial_loss_fwd(_f(pred), _f(target), _i64(f), c, _i64(hw), c0, c1, norm, _fl(ignore),
+                                            _fl(weight), C.c_void_p(stats.data_ptr() + 16 * i),
+                                            C.c_void_p(losses.data_ptr() + 4 * i), _st()))
+        ctx.parts, ctx.ignore, ctx.dims = parts, ignore, (f, c, hw)
+        ctx.save_for_backward(pred, target, stats)
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target, stats = ctx.saved_tensors
+        f, c, hw = ctx.dims
+        g = g.contiguous()
+        covered = sum(c1 - c0 for c0, c1, _, _ in ctx.parts)
+        dpred = torch.empty_like(pred) if covered == c else torch.zeros_like(pred)
+        for i, (c0, c1, norm, weight) in enumerate(ctx.parts):
+            _ck(lib().muvo_spatial_loss_bwd(_f(pred), _f(target), _f(dpred), _i64(f), c, _i64(hw), c0, c1, norm,
+                                            _fl(ctx.ignore), _fl(weight), C.c_void_p(stats.data_ptr() + 16 * i),
+                                            C.c_void_p(g.data_ptr() + 4 * i), _st()))
+        return dpred, None, None, None
+
+
+def spatial_losses(pred, target, parts, ignore=255.0):
+    return SpatialLossFn.apply(pred, target, parts, ignore)
+
+
+class VoxelLossFn(torch.autograd.Function):
+    """(weight*CE mean, weight*SemScal, weight*GeoScal) for logits (B,S,C,X,Y,Z), labels u8 (B,S,1,X,Y,Z)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, weight, class_w):
+        logits, target = logits.contiguous(), target.contiguous()
+        b, s, c = logits.shape[:3]
+        v = logits.numel() // (b * s * c)
+        L = lib()
+        stats = torch.empty(L.muvo_voxel_loss_stats_doubles(c), device=logits.device, dtype=torch.float64)
+        coef = torch.empty(L.muvo_voxel_loss_coef_floats(c), device=logits.device, dtype=torch.float32)
+        loss3 = torch.empty(3, device=logits.device, dtype=torch.float32)
+        _ck(L.muvo_voxel_loss_fwd(_f(logits), _p(target), _i64(b * s), c, _i64(v), _f(class_w), _fl(weight), _p(stats),
+                                  _f(coef), _f(loss3), _st()))
+        ctx.dims, ctx.weight, ctx.class_w = (b * s, c, v), weight, class_w
+        ctx.save_for_backward(logits, target, coef)
+        return loss3
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, coef = ctx.saved_tensors
+        f, c, v = ctx.dims
+        g = g.contiguous()
+        dl = torch.empty_like(logits)
+        _ck(lib().muvo_voxel_loss_bwd(_f(logits), _p(target), _f(dl), _i64(f), c, _i64(v), _f(ctx.class_w),
+                                      _fl(ctx.weight), _f(coef), _f(g), _st()))
+        return dl, None, None, None
+
+
+def voxel_losses(logits, target, weight, class_w=None):
+    return VoxelLossFn.apply(logits, target, weight, class_w)
+
+
+class L1RowsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, weight):
+        pred, target = pred.contiguous(), target.contiguous()
+        cols = pred.shape[-1]
+        rows = pred.numel() // cols
+        loss = torch.empty(1, device=pred.device, dtype=torch.float32)
+        _ck(lib().muvo_l1_rows_fwd(_f(pred), _f(target), _i64(rows), cols, _fl(weight), _f(loss), _st()))
+        ctx.dims, ctx.weight = (rows, cols), weight
+        ctx.save_for_backward(pred, target)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target = ctx.saved_tensors
+        rows, cols = ctx.dims
+        dp = torch.empty_like(pred)
+        _ck(lib().muvo_l1_rows_bwd(_f(pred), _f(target), _f(dp), _i64(rows), cols, _fl(ctx.weight), _f(g.contiguous()),
+                                   _st()))
+        return dp, None, None
+
+
+def l1_rows_loss(pred, target, weight):
+    return L1RowsFn.apply(pred, target, weight)
+
+
+class KLLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pm, ps, qm, qs, weight, alpha):
+        pm, ps, qm, qs = (t.contiguous() for t in (pm, ps, qm, qs))
+        b, t, s = pm.shape
+        loss = torch.empty(1, device=pm.device, dtype=torch.float32)
+        _ck(lib().muvo_kl_loss_fwd(_f(pm), _f(ps), _f(qm), _f(qs), b, t, s, _fl(weight), _f(loss), _st()))
+        ctx.args = (b, t, s, weight, alpha)
+        ctx.save_for_backward(pm, ps, qm, qs)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        pm, ps, qm, qs = ctx.saved_tensors
+        b, t, s, weight, alpha = ctx.args
+        d = [torch.empty_like(pm) for _ in range(4)]
+        _ck(lib().muvo_kl_loss_bwd(_f(pm), _f(ps), _f(qm), _f(qs), _f(d[0]), _f(d[1]), _f(d[2]), _f(d[3]), b, t, s,
+                                   _fl(weight), _fl(alpha), _f(g.contiguous()), _st()))
+        return d[0], d[1], d[2], d[3], None, None
+
+
+def kl_loss(pm, ps, qm, qs, weight, alpha):
+    return KLLossFn.apply(pm, ps, qm, qs, weight, alpha)
+
+
+# ================================================================================================ optimiser
+def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    _ck(lib().muvo_adamw_step(_f(p), _f(g), _f(m), _f(v), _i64(p.numel()), _fl(lr), _fl(beta1), _fl(beta2), _fl(eps),
+                              _fl(weight_decay), int(step), _fl(grad_scale), _st()))
+
+
+# ================================================================================================ time stack / unstack
+class StackTimeFn(torch.autograd.Function):
+    """list of s tensors (b, D) -> (b, s, D) via strided 2-D copies."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        s = len(xs)
+        b, d = xs[0].shape
+        y = torch.empty(b, s, d, device=xs[0].device, dtype=torch.float32)
+        for t, x in enumerate(xs):
+            x = x.contiguous()
+            _ck(lib().muvo_copy2d(_f(x), C.c_void_p(y.data_ptr() + 4 * t * d), _i64(b), _i64(d), _i64(d), _i64(s * d), 0,
+                                  _st()))
+        ctx.dims = (b, s, d)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        b, s, d = ctx.dims
+        dy = dy.contiguous()
+        outs = []
+        for t in range(s):
+            if ctx.needs_input_grad[t]:
+                g = torch.empty(b, d, device=dy.device, dtype=torch.float32)
+                _ck(lib().muvo_copy2d(C.c_void_p(dy.data_ptr() + 4 * t * d), _f(g), _i64(b), _i64(d), _i64(s * d), _i64(d),
+                                      0, _st()))
+                outs.append(g)
+            else:
+                outs.append(None)
+        return tuple(outs)
+
+
+def stack_time(xs):
+    return StackTimeFn.apply(*xs)
+
+
+class UnstackTimeFn(torch.autograd.Function):
+    """(b, s, D) -> tuple of s contiguous (b, D) tensors."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        b, s, d = x.shape
+        outs = []
+        for t in range(s):
+            g = torch.empty(b, d, device=x.device, dtype=torch.float32)
+            _ck(lib().muvo_copy2d(C.c_void_p(x.data_ptr() + 4 * t * d), _f(g), _i64(b), _i64(d), _i64(s * d), _i64(d), 0,
+                                  _st()))
+            outs.append(g)
+        ctx.dims = (b, s, d)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        b, s, d = ctx.dims
+        dev = next(g.device for g in gs if g is not None)
+        dx = torch.zeros(b, s, d, device=dev, dtype=torch.float32)
+        for t, g in enumerate(gs):
+            if g is None:
+                continue
+            g = g.contiguous()
+            _ck(lib().muvo_copy2d(_f(g), C.c_void_p(dx.data_ptr() + 4 * t * d), _i64(b), _i64(d), _i64(d), _i64(s * d), 0,
+                                  _st()))
+        return dx
+
+
+def unstack_time(x):
+    return UnstackTimeFn.apply(x)
+
+
+class SumScalarsFn(torch.autograd.Function):
+    """total = sum of 0-d tensors (trainer.py:511-513 loss_reducing)."""
+
+    @staticmethod
+    def forward(ctx, *vals):
+        out = torch.zeros(1, device=vals[0].device, dtype=torch.float32)
+        for v in vals:
+            _ck(lib().muvo_copy2d(C.c_void_p(v.data_ptr()), _f(out), _i64(1), _i64(1), _i64(1), _i64(1), 1, _st()))
+        ctx.n = len(vals)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(g for _ in range(ctx.n))
+
+
+def sum_scalars(vals):
+    return SumScalarsFn.apply(*vals)

@@ -1,0 +1,143 @@
+"""WorldModelTrainer — drop-in for muvo/trainer.py's LightningModule on the MI355X-native step.
+
+Same constructor `(hparams, path_to_conf_file=None, pretrained_path=None)`, attributes (`cfg`, `rf`, `fh`,
+`preprocess`, `model`) and methods (`forward`, `compute_loss`, `shared_step(mode='train')`, `training_step`,
+`configure_optimizers`, `load_pretrained_weights`) as trainer.py:26-231,251-402,511-513,1022-1073.  If
+`lightning` is importable the class derives from `pl.LightningModule`, otherwise from `torch.nn.Module` with
+the same hooks so the build's own loop (bench.py / train.py) can drive it.  Validation/visualisation
+(trainer.py:404-1020) are outside the training hot path."""
+import os
+
+import torch
+
+from muvo_amd import ops
+from muvo_amd.config import get_cfg
+from muvo_amd.models.mile import Mile
+from muvo_amd.models.preprocess import PreProcess
+from muvo_amd.optim import FusedAdamW
+from muvo_amd.param_store import ParamStore
+
+try:  # optional: Lightning is not a dependency of the hot path
+    import lightning.pytorch as pl
+    _Base = pl.LightningModule
+except Exception:  # pragma: no cover
+    pl = None
+    _Base = torch.nn.Module
+
+
+class WorldModelTrainer(_Base):
+    def __init__(self, hparams, path_to_conf_file=None, pretrained_path=None, device=None):
+        super().__init__()
+        if pl is not None:
+            self.save_hyperparameters()
+        self.cfg = get_cfg(cfg_dict=hparams)
+        if path_to_conf_file:
+            self.cfg.merge_from_file(path_to_conf_file)
+        if pretrained_path:
+            self.cfg.PRETRAINED.PATH = pretrained_path
+        self.vis_step = -1
+        self.rf = self.cfg.RECEPTIVE_FIELD
+        self.fh = self.cfg.FUTURE_HORIZON
+        ops.lib()  # fail loudly, before building anything, if the HIP library is missing
+        self.preprocess = PreProcess(self.cfg)
+        if device is None:
+            device = torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else None
+        if device is None:
+            raise RuntimeError('muvo_amd needs a GPU (gfx950): no CUDA/HIP device visible and there is no CPU path')
+        with torch.device(device):
+            self.model = Mile(self.cfg)
+        self.load_pretrained_weights()
+        self.store = None
+        self._optimizer = None
+        self._reducer = None
+
+    # ------------------------------------------------------------------ weights
+    def load_pretrained_weights(self):
+        path = self.cfg.PRETRAINED.PATH
+        if path:
+            if os.path.isfile(path):
+                checkpoint = torch.load(path, map_location='cpu')['state_dict']
+                checkpoint = {key[6:]: value for key, value in checkpoint.items() if key[:5] == 'model'}
+                self.model.load_state_dict(checkpoint, strict=True)
+                print(f'Loaded weights from: {path}')
+            else:
+                raise FileExistsError(path)
+
+    # ------------------------------------------------------------------ forward / losses
+    def forward(self, batch, deployment=False, noise=None, use_prior=None):
+        batch = self.preprocess(batch)
+        output, state_dict = self.model.forward(batch, deployment=deployment, noise=noise, use_prior=use_prior)
+        return output, state_dict
+
+    def shared_step(self, batch, mode='train', predict_action=False, noise=None, use_prior=None):
+        if mode != 'train':
+            raise NotImplementedError("only mode='train' is on the hot path (validation/imagination: next rows)")
+        output, state_dict = self.forward(batch, noise=noise, use_prior=use_prior)
+        losses = self.compute_loss(batch, output)
+        return losses, output, [], []
+
+    def compute_loss(self, batch, output):
+        """The reference's 21 weighted loss terms (trainer.py:251-390), computed by fused kernels."""
+        cfg = self.cfg
+        losses = {}
+        w_act = cfg.LOSSES.WEIGHT_ACTION
+        if 'throttle_brake' in output:
+            losses['throttle_brake'] = ops.l1_rows_loss(output['throttle_brake'], batch['throttle_brake'], w_act)[0]
+        if 'steering' in output:
+            losses['steering'] = ops.l1_rows_loss(output['steering'], batch['steering'], w_act)[0]
+        if cfg.MODEL.TRANSITION.ENABLED and 'prior' in output and 'posterior' in output:
+            pr, po = output['prior'], output['posterior']
+            losses['probabilistic'] = ops.kl_loss(pr['mu'], pr['sigma'], po['mu'], po['sigma'],
+                                                  cfg.LOSSES.WEIGHT_PROBABILISTIC, cfg.LOSSES.KL_BALANCING_ALPHA)[0]
+        if cfg.EVAL.RGB_SUPERVISION:
+            for f in (1, 2, 4):
+                w = 0.1 * (1 / f)  # rgb_weight literal 0.1 (trainer.py:296)
+                pred = output[f'rgb_{f}']
+                losses[f'rgb_{f}'] = ops.spatial_losses(pred, batch[f'rgb_label_{f}'], [(0, pred.shape[2], 1, w)])[0]
+        if cfg.LIDAR_RE.ENABLED:
+            for f in (1, 2, 4):
+                w = (1 / f) * cfg.LOSSES.WEIGHT_LIDAR_RE
+                pred = output[f'lidar_reconstruction_{f}']
+                c = pred.shape[2]
+                both = ops.spatial_losses(pred, batch[f'range_view_label_{f}'], [(0, 3, 2, w), (c - 1, c, 1, w)])
+                losses[f'lidar_re_{f}'] = both[0]
+                losses[f'lidar_depth_{f}'] = both[1]
+        if cfg.VOXEL_SEG.ENABLED:
+            for f in (1, 2, 4):
+                w = (1 / f) * cfg.LOSSES.WEIGHT_VOXEL
+                three = ops.voxel_losses(output[f'voxel_{f}'], batch[f'voxel_label_{f}'], w)
+                losses[f'voxel_{f}'] = three[0]
+                losses[f'sem_scal_{f}'] = three[1]
+                losses[f'geo_scal_{f}'] = three[2]
+        return losses
+
+    def loss_reducing(self, loss):
+        vals = list(loss.values())
+        return ops.sum_scalars(vals)
+
+    def training_step(self, batch, batch_idx=0, noise=None, use_prior=None):
+        losses, output, _, _ = self.shared_step(batch, mode='train', noise=noise, use_prior=use_prior)
+        self.last_losses = losses
+        return self.loss_reducing(losses)
+
+    # ------------------------------------------------------------------ optimiser
+    def configure_optimizers(self):
+        cfg = self.cfg
+        if cfg.OPTIMIZER.FROZEN.ENABLED:
+            keep = tuple(cfg.OPTIMIZER.FROZEN.TRAIN_LIST)
+            for name, param in self.model.named_parameters():
+                if not name.startswith(keep):
+                    param.requires_grad = False
+        self.store = ParamStore(self.model)
+        unused = [p for _, p in self.store.unused]
+        optimizer = FusedAdamW(self.store, lr=cfg.OPTIMIZER.LR, weight_decay=cfg.OPTIMIZER.WEIGHT_DECAY,
+                               extra_unused=unused)
+        if cfg.SCHEDULER.NAME == 'none':
+            sched = torch.optim.lr_scheduler.LambdaLR(optimizer, lambda lr: 1)
+        elif cfg.SCHEDULER.NAME == 'OneCycleLR':
+            sched = torch.optim.lr_scheduler.OneCycleLR(optimizer, max_lr=cfg.OPTIMIZER.LR, total_steps=cfg.STEPS,
+                                                        pct_start=cfg.SCHEDULER.PCT_START)
+        else:
+            raise ValueError(cfg.SCHEDULER.NAME)
+        self._optimizer = optimizer
+        return [optimizer], [{'scheduler': sched, 'interval': 'step'}]

@@ -1,0 +1,544 @@
+"""ORACLE — test infrastructure only.  Never imported by the product path (muvo_amd/*).
+
+A plain PyTorch-CPU fp32 restatement of the reference training step, written from the
+behaviour of the reference (not copied), each piece citing the reference file:line it
+follows.  Pinned against the real reference imported in the build container
+(oracle/refimport/make_golden.py -> tests/golden/*.json|npz); the reference itself has
+no tests, so those fixtures are the only pin ("parity unpinned by the reference's own
+tests").
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+
+Module/parameter names equal the reference's Mile.state_dict() (680 entries) so the
+deterministic weights keyed by name load into both.
+"""
+import math
+from typing import Dict, List
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------- config
+def base_1d_cfg() -> dict:
+    """Effective test_base_1d.yml values that gate the hot path."""
+    return dict(
+        TRANSFORMER_CHANNELS=384, EMBEDDING_DIM=512, HIDDEN_STATE_DIM=1024, STATE_DIM=512,
+        ACTION_LATENT_DIM=64, ACTION_DIM=2, ROUTE_CHANNELS=16, SPEED_CHANNELS=16, SPEED_NORM=5.0,
+        VOXEL_DIMENSION=64, VOXEL_N_CLASSES=2, LIDAR_RE_CHANNELS=4, LIDAR_RE_SCALE=50.0,
+        CROP=(64, 138, 896, 458), ROUTE_SIZE=64, MEAN=(0.485, 0.456, 0.406), STD=(0.229, 0.224, 0.225),
+        W_ACTION=1.0, W_PROB=1e-3, KL_ALPHA=0.75, W_LIDAR_RE=0.1, W_VOXEL=0.1, W_RGB=0.1,
+        USE_PRIOR_PROB=0.15, LR=1e-4, WEIGHT_DECAY=0.01,
+    )
+
+
+# --------------------------------------------------------------------------- preprocess
+def preprocess(batch: Dict[str, torch.Tensor], cfg: dict) -> Dict[str, torch.Tensor]:
+    """muvo/models/preprocess.py:201-225 (+ prepare_bev_labels :102-186), augmentation off."""
+    out = dict(batch)
+    img = batch['image'].float() / 255
+    route = batch['route_map'].float() / 255
+    b, s = img.shape[:2]
+    rs = cfg['ROUTE_SIZE']
+    if tuple(route.shape[-2:]) != (rs, rs):  # functional_resize default = NEAREST (preprocess.py:207,277)
+        route = F.interpolate(route.flatten(0, 1), size=(rs, rs), mode='nearest').view(b, s, 3, rs, rs)
+    left, top, right, bottom = cfg['CROP']
+    img = img[..., top:bottom, left:right]
+    intr = batch['intrinsics'].clone()
+    intr[..., 0, 2] -= left
+    intr[..., 1, 2] -= top
+    out['intrinsics'] = intr
+    # rgb labels: bilinear (no antialias), each level from the previous (preprocess.py:104-113)
+    out['rgb_label_1'] = img
+    h, w = img.shape[-2:]
+    prev = img
+    for f in (2, 4):
+        prev = F.interpolate(prev.flatten(0, 1), size=(h // f, w // f), mode='bilinear',
+                             align_corners=False).view(b, s, 3, h // f, w // f)
+        out[f'rgb_label_{f}'] = prev
+    # range view (preprocess.py:150-162)
+    rv = batch['range_view_pcd_xyzd'].float() / cfg['LIDAR_RE_SCALE']
+    out['range_view_pcd_xyzd'] = rv
+    out['range_view_label_1'] = rv
+    h, w = rv.shape[-2:]
+    prev = rv
+    for f in (2, 4):
+        prev = F.interpolate(prev.flatten(0, 1), size=(h // f, w // f), mode='nearest').view(b, s, -1, h // f, w // f)
+        out[f'range_view_label_{f}'] = prev
+    # voxel labels: nearest on uint8 (preprocess.py:176-186)
+    vox = batch['voxel']
+    out['voxel_label_1'] = vox
+    x, y, z = vox.shape[-3:]
+    prev = vox
+    for f in (2, 4):
+        prev = F.interpolate(prev.flatten(0, 1), size=(x // f, y // f, z // f), mode='nearest').view(
+            b, s, 1, x // f, y // f, z // f)
+        out[f'voxel_label_{f}'] = prev
+    mean = torch.tensor(cfg['MEAN']).view(3, 1, 1)
+    std = torch.tensor(cfg['STD']).view(3, 1, 1)
+    out['image'] = (img - mean) / std
+    out['route_map'] = (route - mean) / std
+    return out
+
+
+# --------------------------------------------------------------------------- building blocks
+class ResBlock(nn.Module):
+    """timm BasicBlock / muvo/layers/layers.py:9-66."""
+
+    def __init__(self, cin, cout, stride=1, downsample=False):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.downsample = None
+        if downsample:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, 2, 0, bias=False), nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        y = F.relu(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        sc = x if self.downsample is None else self.downsample(x)
+        return F.relu(y + sc)
+
+
+class ResNet18(nn.Module):
+    """timm resnet18 features_only (mile.py:24-26,81-83; common.py:15)."""
+
+    def __init__(self, in_chans=3, out_indices=(2, 3, 4)):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_chans, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        cin = 64
+        for i, c in enumerate((64, 128, 256, 512)):
+            st = 1 if i == 0 else 2
+            setattr(self, f'layer{i + 1}', nn.Sequential(ResBlock(cin, c, st, st != 1), ResBlock(c, c)))
+            cin = c
+        self.out_indices = out_indices
+
+    def forward(self, x):
+        feats = []
+        x = F.relu(self.bn1(self.conv1(x)))
+        feats.append(x)
+        x = F.max_pool2d(x, 3, 2, 1)
+        for i in range(4):
+            x = getattr(self, f'layer{i + 1}')(x)
+            feats.append(x)
+        return [feats[i] for i in self.out_indices]
+
+
+def _cbr(cin, cout):
+    return nn.Sequential(nn.Conv2d(cin, cout, 3, 1, 1, bias=False), nn.BatchNorm2d(cout), nn.ReLU())
+
+
+class DecoderDS(nn.Module):
+    """common.py:102-130."""
+
+    def __init__(self, chans, cout):
+        super().__init__()
+        self.conv1 = _cbr(chans[0], cout)
+        self.downsample_skip_convs = nn.ModuleList(_cbr(c, cout) for c in chans[1:])
+
+    def forward(self, xs):
+        x = self.conv1(xs[0])
+        for i, conv in enumerate(self.downsample_skip_convs):
+            stride = xs[i].shape[-1] // xs[i + 1].shape[-1]
+            x = conv(xs[i + 1]) + F.max_pool2d(x, stride)
+        return x
+
+
+def position_embedding_sine(h, w, num_pos_feats, temperature=10000.0):
+    """common.py:636-678 with normalize=True, scale=2*pi. Returns (1, 2*num_pos_feats, h, w)."""
+    ones = torch.ones((1, h, w))
+    y_embed = ones.cumsum(1, dtype=torch.float32)
+    x_embed = ones.cumsum(2, dtype=torch.float32)
+    eps = 1e-6
+    y_embed = y_embed / (y_embed[:, -1:, :] + eps) * (2 * math.pi)
+    x_embed = x_embed / (x_embed[:, :, -1:] + eps) * (2 * math.pi)
+    dim_t = torch.arange(num_pos_feats, dtype=torch.float32)
+    dim_t = temperature ** (2 * (dim_t // 2) / num_pos_feats)
+    pos_x = x_embed[:, :, :, None] / dim_t
+    pos_y = y_embed[:, :, :, None] / dim_t
+    pos_x = torch.stack((pos_x[..., 0::2].sin(), pos_x[..., 1::2].cos()), dim=4).flatten(3)
+    pos_y = torch.stack((pos_y[..., 0::2].sin(), pos_y[..., 1::2].cos()), dim=4).flatten(3)
+    return torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2)
+
+
+class RouteEncode(nn.Module):
+    """common.py:12-23."""
+
+    def __init__(self, cout):
+        super().__init__()
+        self.backbone = ResNet18(3, (4,))
+        self.fc = nn.Linear(512, cout)
+
+    def forward(self, x):
+        x = self.backbone(x)[0]
+        return self.fc(x.mean(dim=(-1, -2)))
+
+
+class FeatureConv(nn.Sequential):
+    """mile.py:104-115 (BasicBlock s2 + BasicBlock + global avg pool + flatten)."""
+
+    def __init__(self, cin, cout):
+        super().__init__(ResBlock(cin, cout, 2, True), ResBlock(cout, cout), nn.AdaptiveAvgPool2d(1), nn.Flatten(1))
+
+
+class Representation(nn.Module):
+    """transition.py:5-25; nn.LeakyReLU(True) has slope 1.0 == identity."""
+
+    def __init__(self, cin, latent):
+        super().__init__()
+        self.latent = latent
+        self.module = nn.Sequential(nn.Linear(cin, cin), nn.Identity(), nn.Linear(cin, 2 * latent))
+
+    def forward(self, x):
+        mu, ls = torch.split(self.module(x), self.latent, dim=-1)
+        return mu, 2 * torch.sigmoid(ls / 2) + 0.1
+
+
+class RSSM(nn.Module):
+    """transition.py:28-173, with the RNG made explicit (noise (b,s,2,S), use_prior flags)."""
+
+    def __init__(self, emb, act, hid, st, alat):
+        super().__init__()
+        self.hid, self.st = hid, st
+        self.pre_gru_net = nn.Sequential(nn.Linear(st, hid), nn.Identity())
+        self.recurrent_model = nn.GRUCell(hid, hid)
+        self.posterior_action_module = nn.Sequential(nn.Linear(act, alat), nn.Identity())
+        self.posterior = Representation(hid + emb + alat, st)
+        self.prior_action_module = nn.Sequential(nn.Linear(act, alat), nn.Identity())
+        self.prior = Representation(hid + alat, st)
+
+    def forward(self, emb, action, noise, use_prior):
+        b, s, _ = emb.shape
+        h = emb.new_zeros(b, self.hid)
+        z = emb.new_zeros(b, self.st)
+        keys = ('hidden_state', 'sample', 'mu', 'sigma')
+        pri = {k: [] for k in keys}
+        pos = {k: [] for k in keys}
+        for t in range(s):
+            a = torch.zeros_like(action[:, 0]) if t == 0 else action[:, t - 1]
+            h = self.recurrent_model(self.pre_gru_net(z), h)
+            pm, ps = self.prior(torch.cat([h, self.prior_action_module(a)], -1))
+            pz = pm + ps * noise[:, t, 0]
+            qm, qs = self.posterior(torch.cat([h, emb[:, t], self.posterior_action_module(a)], -1))
+            qz = qm + qs * noise[:, t, 1]
+            for d, vals in ((pri, (h, pz, pm, ps)), (pos, (h, qz, qm, qs))):
+                for k, v in zip(keys, vals):
+                    d[k].append(v)
+            z = pz if use_prior[t] else qz
+        return ({k: torch.stack(v, 1) for k, v in pri.items()}, {k: torch.stack(v, 1) for k, v in pos.items()})
+
+
+class Policy(nn.Module):
+    """common.py:53-68."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.fc = nn.Sequential(nn.Linear(c, c), nn.ReLU(), nn.Linear(c, c), nn.ReLU(), nn.Linear(c, c // 2),
+                                nn.ReLU(), nn.Linear(c // 2, 2), nn.Tanh())
+
+    def forward(self, x):
+        return self.fc(x)
+
+
+class _Head(nn.Module):
+    def __init__(self, attr, conv):
+        super().__init__()
+        setattr(self, attr, nn.Sequential(conv))
+        self._attr = attr
+
+    def forward(self, x):
+        return getattr(self, self._attr)(x)
+
+
+class ConvDecoder(nn.Module):
+    """common.py:549-632."""
+
+    def __init__(self, latent, cout, const_size, head_attr, out_key):
+        super().__init__()
+        c = 512
+        self.out_key = out_key
+        self.linear = nn.Sequential(nn.Linear(latent, c), nn.Unflatten(-1, (c, 1, 1)))
+        self.pre_transpose_conv = nn.Sequential(
+            nn.ConvTranspose2d(c, c, const_size), nn.ELU(),
+            nn.ConvTranspose2d(c, c, 5, 2, 2, 1), nn.ELU(),
+            nn.ConvTranspose2d(c, c, 5, 2, 2, 1), nn.ELU(),
+            nn.ConvTranspose2d(c, c, 6, 2, 2), nn.ELU())
+        self.trans_conv1 = nn.Sequential(nn.ConvTranspose2d(c, 256, 6, 2, 2), nn.ELU())
+        self.head_4 = _Head(head_attr, nn.Conv2d(256, cout, 1))
+        self.trans_conv2 = nn.Sequential(nn.ConvTranspose2d(256, 128, 6, 2, 2), nn.ELU())
+        self.head_2 = _Head(head_attr, nn.Conv2d(128, cout, 1))
+        self.trans_conv3 = nn.Sequential(nn.ConvTranspose2d(128, 64, 6, 2, 2), nn.ELU())
+        self.head_1 = _Head(head_attr, nn.Conv2d(64, cout, 1))
+
+    def forward(self, x):
+        x = self.pre_transpose_conv(self.linear(x))
+        x = self.trans_conv1(x)
+        o4 = self.head_4(x)
+        x = self.trans_conv2(x)
+        o2 = self.head_2(x)
+        x = self.trans_conv3(x)
+        o1 = self.head_1(x)
+        return {f'{self.out_key}_4': o4, f'{self.out_key}_2': o2, f'{self.out_key}_1': o1}
+
+
+class AdaIN3d(nn.Module):
+    """common.py:227-246."""
+
+    def __init__(self, latent, c):
+        super().__init__()
+        self.c = c
+        self.latent_affine = nn.Linear(latent, 2 * c)
+
+    def forward(self, x, w):
+        mean = x.mean(dim=(-1, -2, -3), keepdim=True)
+        x = x - mean
+        std = torch.sqrt(torch.mean(x ** 2, dim=(-1, -2, -3), keepdim=True) + 1e-8)
+        x = x / std
+        style = self.latent_affine(w)[:, :, None, None, None]
+        scale, bias = torch.split(style, self.c, dim=1)
+        return scale * x + bias
+
+
+class ConvIN3d(nn.Module):
+    """common.py:190-202."""
+
+    def __init__(self, cin, cout, latent):
+        super().__init__()
+        self.conv_act = nn.Sequential(nn.Conv3d(cin, cout, 3, 1, 1), nn.LeakyReLU(0.2))
+        self.adaptive_norm = AdaIN3d(latent, cout)
+
+    def forward(self, x, w):
+        return self.adaptive_norm(self.conv_act(x), w)
+
+
+class DecBlock3d(nn.Module):
+    """common.py:161-172 (upsample=True)."""
+
+    def __init__(self, cin, cout, latent):
+        super().__init__()
+        self.conv1 = ConvIN3d(cin, cout, latent)
+        self.conv2 = ConvIN3d(cout, cout, latent)
+
+    def forward(self, x, w):
+        x = F.interpolate(x, scale_factor=2.0, mode='trilinear', align_corners=False)
+        return self.conv2(self.conv1(x, w), w)
+
+
+class VoxelDecoder1(nn.Module):
+    """common.py:498-546."""
+
+    def __init__(self, latent, n_classes, fc, const_size=(3, 3, 1)):
+        super().__init__()
+        self.constant_tensor = nn.Parameter(torch.randn(2 * fc, *const_size))
+        self.first_norm = AdaIN3d(latent, 2 * fc)
+        self.first_conv = ConvIN3d(2 * fc, fc, latent)
+        self.middle_conv = nn.ModuleList(DecBlock3d(fc, fc, latent) for _ in range(3))
+        self.conv1 = DecBlock3d(fc, fc // 2, latent)
+        self.head_4 = _Head('segmentation_head', nn.Conv3d(fc // 2, n_classes, 1))
+        self.conv2 = DecBlock3d(fc // 2, fc // 4, latent)
+        self.head_2 = _Head('segmentation_head', nn.Conv3d(fc // 4, n_classes, 1))
+        self.conv3 = DecBlock3d(fc // 4, fc // 8, latent)
+        self.head_1 = _Head('segmentation_head', nn.Conv3d(fc // 8, n_classes, 1))
+
+    def forward(self, w):
+        x = self.constant_tensor.unsqueeze(0).repeat(w.shape[0], 1, 1, 1, 1)
+        x = self.first_conv(self.first_norm(x, w), w)
+        for m in self.middle_conv:
+            x = m(x, w)
+        x = self.conv1(x, w)
+        o4 = self.head_4(x)
+        x = self.conv2(x, w)
+        o2 = self.head_2(x)
+        x = self.conv3(x, w)
+        o1 = self.head_1(x)
+        return {'voxel_4': o4, 'voxel_2': o2, 'voxel_1': o1}
+
+
+class MileRef(nn.Module):
+    """muvo/models/mile.py:16-161,284-402 (construction), :404-593 (forward/encode), base_1d branch."""
+
+    def __init__(self, cfg: dict = None):
+        super().__init__()
+        cfg = cfg or base_1d_cfg()
+        self.cfg = cfg
+        tc, emb = cfg['TRANSFORMER_CHANNELS'], cfg['EMBEDDING_DIM']
+        self.encoder = ResNet18(3)
+        self.feat_decoder = DecoderDS((128, 256, 512), tc)
+        self.range_view_encoder = ResNet18(4)
+        self.range_view_decoder = DecoderDS((128, 256, 512), tc)
+        self.type_embedding = nn.Parameter(torch.zeros(1, 1, tc, 2))
+        self.encoder_layer = nn.TransformerEncoderLayer(d_model=tc, nhead=8, dropout=0.1)  # registered, unused
+        self.transformer_encoder = nn.TransformerEncoder(
+            nn.TransformerEncoderLayer(d_model=tc, nhead=8, dropout=0.1), num_layers=6, enable_nested_tensor=False)
+        self.image_feature_conv = FeatureConv(tc, emb)
+        self.lidar_feature_conv = FeatureConv(tc, emb)
+        self.backbone_route = RouteEncode(cfg['ROUTE_CHANNELS'])
+        sc = cfg['SPEED_CHANNELS']
+        self.speed_enc = nn.Sequential(nn.Linear(1, sc), nn.ReLU(), nn.Linear(sc, sc), nn.ReLU())
+        self.features_combine = nn.Linear(2 * emb + cfg['ROUTE_CHANNELS'] + sc, emb)
+        self.rssm = RSSM(emb, cfg['ACTION_DIM'], cfg['HIDDEN_STATE_DIM'], cfg['STATE_DIM'], cfg['ACTION_LATENT_DIM'])
+        sd = cfg['HIDDEN_STATE_DIM'] + cfg['STATE_DIM']
+        self.policy = Policy(sd)
+        self.rgb_decoder = ConvDecoder(sd, 3, (5, 13), 'rgb_head', 'rgb')
+        self.lidar_re = ConvDecoder(sd, cfg['LIDAR_RE_CHANNELS'], (1, 16), 'lidar_re_head', 'lidar_reconstruction')
+        self.voxel_decoder = VoxelDecoder1(sd, cfg['VOXEL_N_CLASSES'], cfg['VOXEL_DIMENSION'])
+
+    def set_dropout(self, p: float):
+        for m in self.modules():
+            if isinstance(m, nn.Dropout):
+                m.p = p
+            if isinstance(m, nn.MultiheadAttention):
+                m.dropout = p
+
+    def encode(self, batch):
+        b, s = batch['image'].shape[:2]
+        image = batch['image'].flatten(0, 1)
+        x = self.feat_decoder(self.encoder(image))
+        lf = self.range_view_decoder(self.range_view_encoder(batch['range_view_pcd_xyzd'].flatten(0, 1)))
+        nf = self.cfg['TRANSFORMER_CHANNELS'] // 2
+        it = x + position_embedding_sine(x.shape[2], x.shape[3], nf)
+        lt = lf + position_embedding_sine(lf.shape[2], lf.shape[3], nf)
+        it = it.flatten(2).permute(2, 0, 1) + self.type_embedding[:, :, :, 0]
+        lt = lt.flatten(2).permute(2, 0, 1) + self.type_embedding[:, :, :, 1]
+        li = it.shape[0]
+        tok = self.transformer_encoder(torch.cat([it, lt], 0))
+        io = tok[:li].permute(1, 2, 0).reshape(x.shape[0], -1, x.shape[2], x.shape[3])
+        lo = tok[li:].permute(1, 2, 0).reshape(lf.shape[0], -1, lf.shape[2], lf.shape[3])
+        feats = [self.image_feature_conv(io), self.lidar_feature_conv(lo),
+                 self.backbone_route(batch['route_map'].flatten(0, 1)),
+                 self.speed_enc(batch['speed'].flatten(0, 1) / self.cfg['SPEED_NORM'])]
+        return self.features_combine(torch.cat(feats, -1)).view(b, s, -1)
+
+    def forward(self, batch, noise, use_prior):
+        b, s = batch['image'].shape[:2]
+        emb = self.encode(batch)
+        action = torch.cat([batch['throttle_brake'], batch['steering']], -1)
+        prior, post = self.rssm(emb, action, noise, use_prior)
+        out = {'prior': prior, 'posterior': post, 'embedding': emb}
+        state = torch.cat([post['hidden_state'], post['sample']], -1).flatten(0, 1)
+        pol = self.policy(state)
+        out['throttle_brake'] = pol[:, :1].view(b, s, 1)
+        out['steering'] = pol[:, 1:].view(b, s, 1)
+        for dec in (self.rgb_decoder, self.lidar_re, self.voxel_decoder):
+            for k, v in dec(state).items():
+                out[k] = v.view(b, s, *v.shape[1:])
+        return out
+
+
+# --------------------------------------------------------------------------- losses
+def _spatial_regression(pred, target, norm):
+    """losses.py:74-99 (mask = target channel 0 != 255; channel-sum; masked mean)."""
+    mask = target[:, :, :1] != 255
+    if mask.sum() == 0:
+        return pred.new_zeros(())
+    loss = (pred - target).abs() if norm == 1 else (pred - target) ** 2
+    loss = loss.sum(dim=-3, keepdim=True)
+    return loss[mask].mean()
+
+
+def _kl(prior_mu, prior_sigma, post_mu, post_sigma):
+    """losses.py:102-126."""
+    qv, pv = post_sigma[:, 1:] ** 2, prior_sigma[:, 1:] ** 2
+    qls, pls = torch.log(post_sigma[:, 1:]), torch.log(prior_sigma[:, 1:])
+    kl = pls - qls - 0.5 + (qv + (post_mu[:, 1:] - prior_mu[:, 1:]) ** 2) / (2 * pv)
+    # Reference quirk (losses.py:120): the "first timestep" term indexes the ALREADY time-shifted
+    # log-sigma / variance ([:, 1:][:, :1] = t=1) but the unshifted mean (t=0).  Reproduced as is.
+    first = -qls[:, :1] - 0.5 + (qv[:, :1] + post_mu[:, :1] ** 2) / 2
+    return torch.cat([first, kl], 1).sum(-1).mean()
+
+
+def _sem_scal(logits, target):
+    """losses.py:191-251 (logits (N,C,X,Y,Z), target uint8 (N,X,Y,Z))."""
+    p_all = F.softmax(logits, dim=1)
+    mask = target != 255
+    loss, count = 0.0, 0.0
+    for i in range(p_all.shape[1]):
+        p = p_all[:, i][mask]
+        ct = (target[mask] == i).float()
+        if ct.sum() > 0:
+            count += 1.0
+            nom = (p * ct).sum()
+            lc = 0.0
+            if p.sum() > 0:
+                prec = nom / p.sum()
+                if 0 <= prec <= 1:
+                    lc = lc - torch.log(prec).clamp(min=-100)
+            rec = nom / ct.sum()
+            if 0 <= rec <= 1:
+                lc = lc - torch.log(rec).clamp(min=-100)
+            if (1 - ct).sum() > 0:
+                spec = ((1 - p) * (1 - ct)).sum() / (1 - ct).sum()
+                if 0 <= spec <= 1:
+                    lc = lc - torch.log(spec).clamp(min=-100)
+            loss = loss + lc
+    return loss / count
+
+
+def _geo_scal(logits, target):
+    """losses.py:254-287."""
+    p = F.softmax(logits, dim=1)
+    empty = p[:, 0]
+    mask = target != 255
+    ne_t = (target != 0)[mask].float()
+    ne_p = (1 - empty)[mask]
+    e_p = empty[mask]
+    inter = (ne_t * ne_p).sum()
+    prec = inter / ne_p.sum()
+    rec = inter / ne_t.sum()
+    spec = ((1 - ne_t) * e_p).sum() / (1 - ne_t).sum()
+    return -(torch.log(prec).clamp(min=-100) + torch.log(rec).clamp(min=-100) + torch.log(spec).clamp(min=-100))
+
+
+def compute_losses(batch, out, cfg) -> Dict[str, torch.Tensor]:
+    """trainer.py:251-390, base_1d branch: 21 keys."""
+    L = {}
+    L['throttle_brake'] = cfg['W_ACTION'] * (out['throttle_brake'] - batch['throttle_brake']).abs().sum(-1, keepdim=True).mean()
+    L['steering'] = cfg['W_ACTION'] * (out['steering'] - batch['steering']).abs().sum(-1, keepdim=True).mean()
+    pr, po = out['prior'], out['posterior']
+    a = cfg['KL_ALPHA']
+    kl = a * _kl(pr['mu'], pr['sigma'], po['mu'].detach(), po['sigma'].detach()) + \
+        (1 - a) * _kl(pr['mu'].detach(), pr['sigma'].detach(), po['mu'], po['sigma'])
+    L['probabilistic'] = cfg['W_PROB'] * kl
+    for f in (1, 2, 4):
+        d = 1 / f
+        L[f'rgb_{f}'] = cfg['W_RGB'] * d * _spatial_regression(out[f'rgb_{f}'], batch[f'rgb_label_{f}'], 1)
+    for f in (1, 2, 4):
+        d = 1 / f
+        p, t = out[f'lidar_reconstruction_{f}'], batch[f'range_view_label_{f}']
+        L[f'lidar_re_{f}'] = _spatial_regression(p[:, :, :3], t[:, :, :3], 2) * d * cfg['W_LIDAR_RE']
+        L[f'lidar_depth_{f}'] = _spatial_regression(p[:, :, -1:], t[:, :, -1:], 1) * d * cfg['W_LIDAR_RE']
+    for f in (1, 2, 4):
+        d = 1 / f
+        logits = out[f'voxel_{f}'].flatten(0, 1)
+        tgt = batch[f'voxel_label_{f}'].flatten(0, 1)[:, 0]
+        L[f'voxel_{f}'] = d * cfg['W_VOXEL'] * F.cross_entropy(logits, tgt.long(), reduction='none').mean()
+        L[f'sem_scal_{f}'] = d * cfg['W_VOXEL'] * _sem_scal(logits, tgt)
+        L[f'geo_scal_{f}'] = d * cfg['W_VOXEL'] * _geo_scal(logits, tgt)
+    return L
+
+
+def make_optimizer(model: nn.Module, cfg: dict):
+    """trainer.py:1022-1060: 1-D params -> no decay; rest decay 0.01; AdamW lr 1e-4."""
+    no_decay, decay = [], []
+    for _, p in model.named_parameters():
+        (no_decay if p.dim() == 1 else decay).append(p)
+    opt = torch.optim.AdamW([{'params': no_decay, 'weight_decay': 0.0},
+                             {'params': decay, 'weight_decay': cfg['WEIGHT_DECAY']}], lr=cfg['LR'], weight_decay=0.0)
+    # trainer.py:1064-1071: OneCycleLR(max_lr=LR, total_steps=STEPS, pct_start=0.2), stepped every step;
+    # constructing it already sets lr = max_lr / 25.
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=cfg['LR'], total_steps=cfg.get('STEPS', 100000),
+                                                pct_start=cfg.get('PCT_START', 0.2))
+    return opt, sched
+
+
+def training_step(model: MileRef, raw_batch, noise, use_prior):
+    """forward + 21 losses + total (trainer.py:213-231,392-402,511-513). Returns (total, losses, out, batch)."""
+    batch = preprocess(raw_batch, model.cfg)
+    out = model(batch, noise, use_prior)
+    losses = compute_losses(batch, out, model.cfg)
+    total = sum(losses.values())
+    return total, losses, out, batch

@@ -1,0 +1,451 @@
+"""-m gpu: every HIP kernel family against a plain PyTorch fp32 CPU reference of the same op (through the C ABI via
+muvo_amd.ops).  Tolerances are stated per test; sizes are small so the CPU side finishes in seconds."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, rtol=2e-4, atol=2e-5, name=''):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    assert a.shape == b.shape, f'{name}: shape {tuple(a.shape)} vs {tuple(b.shape)}'
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item()
+    assert torch.allclose(a, b, rtol=rtol, atol=atol + rtol * ref * 0.1), f'{name}: max err {err:.3e} (ref max {ref:.3e})'
+
+
+def test_mfma_selftest(dev):
+    from muvo_amd import ops
+    assert ops.lib().muvo_selftest_mfma(None) == 0, ops.lib().muvo_last_error()
+
+
+CONV_CASES = [
+    # nd, transposed, cin, cout, k, stride, pad, out_pad, in_sz, bias, act
+    (2, False, 3, 64, 7, 2, 3, 0, (38, 50), False, 0),
+    (2, False, 4, 64, 7, 2, 3, 0, (16, 64), False, 0),
+    (2, False, 64, 64, 3, 1, 1, 0, (19, 25), False, 0),
+    (2, False, 64, 128, 3, 2, 1, 0, (20, 26), False, 0),
+    (2, False, 64, 128, 1, 2, 0, 0, (20, 26), False, 0),
+    (2, False, 48, 160, 3, 1, 1, 0, (10, 26), False, 0),
+    (2, False, 64, 3, 1, 1, 0, 0, (24, 40), True, 0),
+    (2, False, 20, 4, 1, 1, 0, 0, (16, 64), True, 0),
+    (2, True, 40, 24, 5, 2, 2, 1, (5, 13), True, 3),
+    (2, True, 24, 40, 6, 2, 2, 0, (10, 26), True, 3),
+    (2, True, 32, 16, 6, 2, 2, 0, (8, 64), True, 3),
+    (2, True, 130, 70, 6, 2, 2, 0, (5, 7), True, 0),
+    (3, False, 16, 8, 3, 1, 1, 0, (6, 6, 4), True, 2),
+    (3, False, 40, 20, 3, 1, 1, 0, (3, 3, 1), True, 2),
+    (3, False, 8, 2, 1, 1, 0, 0, (6, 6, 4), True, 0),
+    (3, False, 6, 8, 3, 1, 1, 0, (8, 8, 4), True, 2),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[str(i) for i in range(len(CONV_CASES))])
+def test_conv_family(dev, case):
+    from muvo_amd import nn as hnn
+    from muvo_amd import ops
+    nd, transposed, cin, cout, k, stride, pad, out_pad, in_sz, bias, act = case
+    torch.manual_seed(0)
+    n = 3
+    with torch.device(dev):
+        if nd == 3:
+            m = hnn.Conv3d(cin, cout, k, stride, pad, bias=bias)
+        elif transposed:
+            m = hnn.ConvTranspose2d(cin, cout, k, stride, pad, out_pad, bias=bias)
+        else:
+            m = hnn.Conv2d(cin, cout, k, stride, pad, bias=bias)
+    x = torch.randn(n, cin, *in_sz)
+    xg = x.to(dev).requires_grad_(True)
+    slope = 0.2
+    y = m(xg, act=act, slope=slope)
+    w = m.weight.detach().cpu().requires_grad_(True)
+    b = m.bias.detach().cpu().requires_grad_(True) if bias else None
+    xc = x.clone().requires_grad_(True)
+    if nd == 3:
+        yr = F.conv3d(xc, w, b, stride, pad)
+    elif transposed:
+        yr = F.conv_transpose2d(xc, w, b, stride, pad, out_pad)
+    else:
+        yr = F.conv2d(xc, w, b, stride, pad)
+    if act == 2:
+        yr = F.leaky_relu(yr, slope)
+    elif act == 3:
+        yr = F.elu(yr)
+    _close(y, yr, name='fwd')
+    g = torch.randn_like(yr)
+    yr.backward(g)
+    m.weight.grad = torch.zeros_like(m.weight)
+    if bias:
+        m.bias.grad = torch.zeros_like(m.bias)
+    y.backward(g.to(dev))
+    _close(xg.grad, xc.grad, name='dgrad')
+    _close(m.weight.grad, w.grad, rtol=5e-4, name='wgrad')
+    if bias:
+        _close(m.bias.grad, b.grad, rtol=5e-4, name='dbias')
+    # second backward accumulates into .grad (kernels add)
+    y2 = m(xg, act=act, slope=slope)
+    y2.backward(g.to(dev))
+    _close(m.weight.grad, 2 * w.grad, rtol=5e-4, name='wgrad accumulate')
+
+
+GEMM_SHAPES = [(7, 33, 5), (130, 257, 70), (324, 48, 324), (2, 1600, 1088), (300, 1, 16), (64, 64, 1)]
+
+
+@pytest.mark.parametrize('shape', GEMM_SHAPES)
+def test_linear(dev, shape):
+    from muvo_amd import nn as hnn
+    from muvo_amd import ops
+    rows, out_f, in_f = shape
+    torch.manual_seed(1)
+    with torch.device(dev):
+        lin = hnn.Linear(in_f, out_f)
+    x = torch.randn(rows, in_f)
+    for act in (0, 1, 4):
+        xg = x.to(dev).requires_grad_(True)
+        lin.weight.grad = torch.zeros_like(lin.weight)
+        lin.bias.grad = torch.zeros_like(lin.bias)
+        y = lin(xg, act=act)
+        w = lin.weight.detach().cpu().requires_grad_(True)
+        b = lin.bias.detach().cpu().requires_grad_(True)
+        xc = x.clone().requires_grad_(True)
+        yr = F.linear(xc, w, b)
+        yr = F.relu(yr) if act == 1 else (torch.tanh(yr) if act == 4 else yr)
+        _close(y, yr, name=f'linear fwd act{act}')
+        g = torch.randn_like(yr)
+        yr.backward(g)
+        y.backward(g.to(dev))
+        _close(xg.grad, xc.grad, name='linear dx')
+        _close(lin.weight.grad, w.grad, rtol=5e-4, name='linear dW')
+        _close(lin.bias.grad, b.grad, rtol=5e-4, name='linear db')
+
+
+def test_seed_convt_as_gemm(dev):
+    from muvo_amd.models.common import _Seed1x1ConvTFn
+    from muvo_amd import ops
+    torch.manual_seed(2)
+    n, ci, co, kh, kw = 4, 48, 20, 5, 13
+    w = (torch.randn(ci, co, kh, kw) * 0.1)
+    b = torch.randn(co) * 0.1
+    x = torch.randn(n, ci, 1, 1)
+    wg = torch.nn.Parameter(w.to(dev))
+    bg = torch.nn.Parameter(b.to(dev))
+    wg.grad, bg.grad = torch.zeros_like(wg), torch.zeros_like(bg)
+    xg = x.to(dev).requires_grad_(True)
+    y = _Seed1x1ConvTFn.apply(xg, wg, bg, ops.ACT_ELU)
+    wc, bc, xc = w.clone().requires_grad_(True), b.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    yr = F.elu(F.conv_transpose2d(xc, wc, bc))
+    _close(y, yr, name='seed fwd')
+    g = torch.randn_like(yr)
+    yr.backward(g)
+    y.backward(g.to(dev))
+    _close(xg.grad, xc.grad, name='seed dx')
+    _close(wg.grad, wc.grad, name='seed dW')
+    _close(bg.grad, bc.grad, name='seed db')
+
+
+@pytest.mark.parametrize('res_mode,relu', [(0, True), (0, False), (1, True), (2, True)])
+def test_batchnorm(dev, res_mode, relu):
+    from muvo_amd import nn as hnn
+    torch.manual_seed(3)
+    n, c, h, w = 5, 24, 9, 14
+    with torch.device(dev):
+        bn = hnn.BatchNorm2d(c)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    x = torch.randn(n, c, h, w) * 2 + 0.5
+    r = torch.randn(n, c, h, w)
+    xg = x.to(dev).requires_grad_(True)
+    rg = r.to(dev).requires_grad_(True)
+    bn.weight.grad, bn.bias.grad = torch.zeros_like(bn.weight), torch.zeros_like(bn.bias)
+    y = bn(xg, residual=rg if res_mode else None, res_mode=res_mode or 1, relu=relu)
+    ref = torch.nn.BatchNorm2d(c)
+    with torch.no_grad():
+        ref.weight.copy_(bn.weight.cpu())
+        ref.bias.copy_(bn.bias.cpu())
+    ref.train()
+    xc, rc = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+    yr = ref(xc)
+    if res_mode == 1:
+        yr = yr + rc
+    if relu:
+        yr = F.relu(yr)
+    if res_mode == 2:
+        yr = yr + rc
+    _close(y, yr, name='bn fwd')
+    _close(bn.running_mean, ref.running_mean, name='running_mean')
+    _close(bn.running_var, ref.running_var, name='running_var')
+    g = torch.randn_like(yr)
+    yr.backward(g)
+    y.backward(g.to(dev))
+    _close(xg.grad, xc.grad, rtol=5e-4, name='bn dx')
+    _close(bn.weight.grad, ref.weight.grad, rtol=5e-4, name='bn dgamma')
+    _close(bn.bias.grad, ref.bias.grad, rtol=5e-4, name='bn dbeta')
+    if res_mode:
+        _close(rg.grad, rc.grad, name='bn dres')
+
+
+def test_adain(dev):
+    from muvo_amd import ops
+    torch.manual_seed(4)
+    n, c = 3, 10
+    for shape, bcast in (((n, c, 6, 6, 4), False), ((c, 3, 3, 1), True)):
+        x = torch.randn(*shape) + 0.3
+        style = torch.randn(n, 2 * c)
+        xg, sg = x.to(dev).requires_grad_(True), style.to(dev).requires_grad_(True)
+        y = ops.adain(xg, sg, 1e-8, n)
+        xc, sc = x.clone().requires_grad_(True), style.clone().requires_grad_(True)
+        xx = xc.unsqueeze(0).repeat(n, 1, 1, 1, 1) if bcast else xc
+        mean = xx.mean(dim=(-1, -2, -3), keepdim=True)
+        xm = xx - mean
+        std = torch.sqrt((xm ** 2).mean(dim=(-1, -2, -3), keepdim=True) + 1e-8)
+        yr = sc[:, :c, None, None, None] * (xm / std) + sc[:, c:, None, None, None]
+        _close(y, yr, name='adain fwd')
+        g = torch.randn_like(yr)
+        yr.backward(g)
+        y.backward(g.to(dev))
+        _close(xg.grad, xc.grad, rtol=5e-4, name='adain dx')
+        _close(sg.grad, sc.grad, rtol=5e-4, name='adain dstyle')
+
+
+def test_transformer_layer(dev):
+    from muvo_amd import nn as hnn
+    torch.manual_seed(5)
+    l, n, e = 70, 3, 96
+    with torch.device(dev):
+        layer = hnn.TransformerEncoderLayer(e, 8, dim_ff=160, dropout=0.0)
+    ref = torch.nn.TransformerEncoderLayer(e, 8, dim_feedforward=160, dropout=0.0)
+    ref.load_state_dict({k: v.cpu() for k, v in layer.state_dict().items()})
+    ref.train()
+    x = torch.randn(l, n, e)
+    xg, xc = x.to(dev).requires_grad_(True), x.clone().requires_grad_(True)
+    for p in layer.parameters():
+        p.grad = torch.zeros_like(p)
+    y = layer(xg, seed=1)
+    yr = ref(xc)
+    _close(y, yr, rtol=5e-4, name='transformer fwd')
+    g = torch.randn_like(yr)
+    yr.backward(g)
+    y.backward(g.to(dev))
+    _close(xg.grad, xc.grad, rtol=1e-3, name='transformer dx')
+    refp = dict(ref.named_parameters())
+    for k, p in layer.named_parameters():
+        _close(p.grad, refp[k].grad, rtol=1e-3, atol=1e-4, name=f'transformer grad {k}')
+
+
+def test_dropout_statistics(dev):
+    from muvo_amd import ops
+    x = torch.ones(1 << 20, device=dev, requires_grad=True)
+    y = ops.dropout(x, 0.1, 1234)
+    keep = (y > 0).float().mean().item()
+    assert abs(keep - 0.9) < 5e-3
+    assert abs(y.mean().item() - 1.0) < 1e-2
+    y.sum().backward()
+    assert torch.equal(x.grad, y.detach())  # same mask, same scale in backward
+    y2 = ops.dropout(x, 0.1, 1235)
+    assert not torch.equal(y2, y)
+
+
+def test_tokens_roundtrip(dev):
+    from muvo_amd import ops
+    torch.manual_seed(6)
+    n, c = 3, 40
+    xi, xl = torch.randn(n, c, 5, 7), torch.randn(n, c, 2, 9)
+    pi, pl = torch.randn(c, 35), torch.randn(c, 18)
+    te = torch.randn(1, 1, c, 2)
+    teg = torch.nn.Parameter(te.to(dev))
+    teg.grad = torch.zeros_like(teg)
+    xig, xlg = xi.to(dev).requires_grad_(True), xl.to(dev).requires_grad_(True)
+    tok = ops.make_tokens(xig, xlg, pi.to(dev), pl.to(dev), teg)
+    xic, xlc, tec = xi.clone().requires_grad_(True), xl.clone().requires_grad_(True), te.clone().requires_grad_(True)
+    it = (xic + pi.view(1, c, 5, 7)).flatten(2).permute(2, 0, 1) + tec[:, :, :, 0]
+    lt = (xlc + pl.view(1, c, 2, 9)).flatten(2).permute(2, 0, 1) + tec[:, :, :, 1]
+    ref = torch.cat([it, lt], 0)
+    _close(tok, ref, name='tokens')
+    back_i = ops.untoken(tok, 0, 5, 7)
+    back_l = ops.untoken(tok, 35, 2, 9)
+    ri = ref[:35].permute(1, 2, 0).reshape(n, c, 5, 7)
+    rl = ref[35:].permute(1, 2, 0).reshape(n, c, 2, 9)
+    _close(back_i, ri, name='untoken img')
+    _close(back_l, rl, name='untoken lidar')
+    gi, gl = torch.randn_like(ri), torch.randn_like(rl)
+    (ri * gi).sum().backward(retain_graph=True)
+    (rl * gl).sum().backward()
+    ((back_i * gi.to(dev)).sum() + (back_l * gl.to(dev)).sum()).backward()
+    _close(xig.grad, xic.grad, name='tokens dxi')
+    _close(xlg.grad, xlc.grad, name='tokens dxl')
+    _close(teg.grad, tec.grad, rtol=5e-4, name='tokens dtype_emb')
+
+
+def test_pooling_and_upsample(dev):
+    from muvo_amd import ops
+    torch.manual_seed(7)
+    x = torch.randn(2, 5, 13, 18)
+    for k, s, p in ((3, 2, 1), (2, 2, 0)):
+        xg, xc = x.to(dev).requires_grad_(True), x.clone().requires_grad_(True)
+        y, yr = ops.max_pool2d(xg, k, s, p), F.max_pool2d(xc, k, s, p)
+        _close(y, yr, rtol=0, atol=0, name='maxpool fwd')
+        g = torch.randn_like(yr)
+        yr.backward(g)
+        y.backward(g.to(dev))
+        _close(xg.grad, xc.grad, name='maxpool bwd')
+    xg, xc = x.to(dev).requires_grad_(True), x.clone().requires_grad_(True)
+    y, yr = ops.global_avg_pool(xg), xc.mean(dim=(-1, -2))
+    _close(y, yr, name='avgpool')
+    g = torch.randn_like(yr)
+    yr.backward(g)
+    y.backward(g.to(dev))
+    _close(xg.grad, xc.grad, name='avgpool bwd')
+    v = torch.randn(2, 3, 3, 5, 2)
+    vg, vc = v.to(dev).requires_grad_(True), v.clone().requires_grad_(True)
+    y = ops.upsample3d_x2(vg)
+    yr = F.interpolate(vc, scale_factor=2.0, mode='trilinear', align_corners=False)
+    _close(y, yr, name='upsample3d fwd')
+    g = torch.randn_like(yr)
+    yr.backward(g)
+    y.backward(g.to(dev))
+    _close(vg.grad, vc.grad, name='upsample3d bwd')
+    v1 = torch.randn(1, 2, 3, 3, 1)  # degenerate depth 1 (VoxelDecoder1 first levels)
+    _close(ops.upsample3d_x2(v1.to(dev)), F.interpolate(v1, scale_factor=2.0, mode='trilinear', align_corners=False),
+           name='upsample3d depth1')
+
+
+def test_preprocess_kernels(dev):
+    from muvo_amd import ops
+    torch.manual_seed(8)
+    img = torch.randint(0, 256, (1, 2, 3, 60, 96), dtype=torch.uint8)
+    crop = (6, 14, 90, 46)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    label, norm = ops.preprocess_image(img.to(dev), crop, mean, std)
+    ref = (img.float() / 255)[..., 14:46, 6:90]
+    assert torch.equal(label.cpu(), ref)
+    refn = (ref - torch.tensor(mean).view(3, 1, 1)) / torch.tensor(std).view(3, 1, 1)
+    _close(norm, refn, rtol=1e-6, atol=1e-6, name='normalise')
+    l2 = ops.resize_bilinear(label, 16, 42)
+    r2 = F.interpolate(ref.flatten(0, 1), size=(16, 42), mode='bilinear', align_corners=False).view(1, 2, 3, 16, 42)
+    _close(l2, r2, rtol=1e-6, atol=1e-6, name='bilinear /2')
+    route = torch.randint(0, 256, (1, 2, 3, 80, 80), dtype=torch.uint8)
+    rn = ops.preprocess_route(route.to(dev), 64, mean, std)
+    rr = F.interpolate((route.float() / 255).flatten(0, 1), size=(64, 64), mode='nearest').view(1, 2, 3, 64, 64)
+    rr = (rr - torch.tensor(mean).view(3, 1, 1)) / torch.tensor(std).view(3, 1, 1)
+    _close(rn, rr, rtol=1e-6, atol=1e-6, name='route')
+    rv = torch.randn(1, 2, 4, 8, 32)
+    d = ops.divide_scalar(rv.to(dev), 50.0)
+    assert torch.equal(d.cpu(), rv / 50.0)
+    n2 = ops.resize_nearest(d, (4, 16))
+    assert torch.equal(n2.cpu(), F.interpolate((rv / 50.0).flatten(0, 1), size=(4, 16), mode='nearest').view(1, 2, 4, 4, 16))
+    vox = (torch.rand(1, 2, 1, 12, 12, 8) < 0.2).to(torch.uint8)
+    v2 = ops.resize_nearest(vox.to(dev), (6, 6, 4))
+    assert torch.equal(v2.cpu(), F.interpolate(vox.flatten(0, 1), size=(6, 6, 4), mode='nearest').view(1, 2, 1, 6, 6, 4))
+
+
+def test_gru_and_sample(dev):
+    from muvo_amd import nn as hnn
+    from muvo_amd import ops
+    torch.manual_seed(9)
+    b, h = 2, 96
+    with torch.device(dev):
+        cell = hnn.GRUCell(h, h)
+    ref = torch.nn.GRUCell(h, h)
+    ref.load_state_dict({k: v.cpu() for k, v in cell.state_dict().items()})
+    x, h0 = torch.randn(b, h), torch.randn(b, h)
+    xg, hg = x.to(dev).requires_grad_(True), h0.to(dev).requires_grad_(True)
+    xc, hc = x.clone().requires_grad_(True), h0.clone().requires_grad_(True)
+    for p in cell.parameters():
+        p.grad = torch.zeros_like(p)
+    y, yr = cell(xg, hg), ref(xc, hc)
+    _close(y, yr, name='gru fwd')
+    g = torch.randn_like(yr)
+    yr.backward(g)
+    y.backward(g.to(dev))
+    _close(xg.grad, xc.grad, name='gru dx')
+    _close(hg.grad, hc.grad, name='gru dh')
+    for k, p in cell.named_parameters():
+        _close(p.grad, dict(ref.named_parameters())[k].grad, rtol=5e-4, name=f'gru {k}')
+    s = 40
+    mls, eps = torch.randn(b, 2 * s), torch.randn(b, 3, 2, s)
+    mg, mc = mls.to(dev).requires_grad_(True), mls.clone().requires_grad_(True)
+    mu, sigma, sample = ops.rssm_sample(mg, eps.to(dev)[:, 1, 0], 0.1)
+    rmu, rls = torch.split(mc, s, dim=-1)
+    rsig = 2 * torch.sigmoid(rls / 2) + 0.1
+    rsmp = rmu + rsig * eps[:, 1, 0]
+    _close(mu, rmu, name='mu'); _close(sigma, rsig, name='sigma'); _close(sample, rsmp, name='sample')
+    g1, g2, g3 = torch.randn(b, s), torch.randn(b, s), torch.randn(b, s)
+    (rmu * g1 + rsig * g2 + rsmp * g3).sum().backward()
+    (mu * g1.to(dev) + sigma * g2.to(dev) + sample * g3.to(dev)).sum().backward()
+    _close(mg.grad, mc.grad, name='sample bwd')
+
+
+def test_losses(dev):
+    import sys
+    from muvo_amd import ops
+    from oracle import muvo_ref as R
+    torch.manual_seed(10)
+    b, s = 2, 3
+    # spatial losses incl. ignore value and the partial-channel lidar form
+    pred, tgt = torch.randn(b, s, 4, 6, 10), torch.randn(b, s, 4, 6, 10)
+    tgt[0, 1, 0, 2, 3] = 255.0
+    tgt[1, 0, 3, 1, 1] = 255.0
+    pg, pc = pred.to(dev).requires_grad_(True), pred.clone().requires_grad_(True)
+    out = ops.spatial_losses(pg, tgt.to(dev), [(0, 3, 2, 0.05), (3, 4, 1, 0.05)])
+    r0 = 0.05 * R._spatial_regression(pc[:, :, :3], tgt[:, :, :3], 2)
+    r1 = 0.05 * R._spatial_regression(pc[:, :, -1:], tgt[:, :, -1:], 1)
+    _close(out[0], r0, name='lidar_re'); _close(out[1], r1, name='lidar_depth')
+    (r0 * 1.5 + r1 * 0.5).backward()
+    (out[0] * 1.5 + out[1] * 0.5).backward()
+    _close(pg.grad, pc.grad, name='spatial bwd')
+    # empty mask -> 0 (losses.py:91-92)
+    t255 = torch.full_like(tgt, 255.0)
+    z = ops.spatial_losses(pred.to(dev), t255.to(dev), [(0, 4, 1, 1.0)])
+    assert z[0].item() == 0.0
+    # voxel losses: 3 classes incl. an absent class and an ignore voxel
+    logits = torch.randn(b, s, 3, 6, 5, 4)
+    lab = torch.randint(0, 2, (b, s, 1, 6, 5, 4), dtype=torch.uint8)  # class 2 absent
+    lg, lc = logits.to(dev).requires_grad_(True), logits.clone().requires_grad_(True)
+    three = ops.voxel_losses(lg, lab.to(dev), 0.1)
+    fl, ft = lc.flatten(0, 1), lab.flatten(0, 1)[:, 0]
+    ce = 0.1 * F.cross_entropy(fl, ft.long(), reduction='none').mean()
+    sem = 0.1 * R._sem_scal(fl, ft)
+    geo = 0.1 * R._geo_scal(fl, ft)
+    _close(three[0], ce, name='voxel ce'); _close(three[1], sem, name='sem_scal'); _close(three[2], geo, name='geo_scal')
+    (ce * 1.0 + sem * 2.0 + geo * 3.0).backward()
+    (three[0] * 1.0 + three[1] * 2.0 + three[2] * 3.0).backward()
+    _close(lg.grad, lc.grad, rtol=5e-4, name='voxel bwd')
+    lab255 = lab.clone(); lab255[0, 0, 0, 0, 0, 0] = 255
+    t2 = ops.voxel_losses(logits.to(dev), lab255.to(dev), 1.0)
+    _close(t2[1], R._sem_scal(logits.flatten(0, 1), lab255.flatten(0, 1)[:, 0]), name='sem_scal ignore')
+    _close(t2[2], R._geo_scal(logits.flatten(0, 1), lab255.flatten(0, 1)[:, 0]), name='geo_scal ignore')
+    # KL with the reference's first-step quirk, action L1
+    pm, ps, qm, qs = (torch.randn(b, 4, 16) for _ in range(4))
+    ps, qs = ps.abs() + 0.2, qs.abs() + 0.2
+    gp = [t.to(dev).requires_grad_(True) for t in (pm, ps, qm, qs)]
+    cp = [t.clone().requires_grad_(True) for t in (pm, ps, qm, qs)]
+    kl = ops.kl_loss(*gp, 1e-3, 0.75)
+    a = 0.75
+    klr = 1e-3 * (a * R._kl(cp[0], cp[1], cp[2].detach(), cp[3].detach()) + (1 - a) * R._kl(cp[0].detach(), cp[1].detach(), cp[2], cp[3]))
+    _close(kl[0], klr, name='kl')
+    klr.backward(); kl[0].backward()
+    for i, nme in enumerate(('pm', 'ps', 'qm', 'qs')):
+        _close(gp[i].grad, cp[i].grad, name=f'kl d{nme}')
+    p1, t1 = torch.randn(b, s, 1), torch.randn(b, s, 1)
+    p1g, p1c = p1.to(dev).requires_grad_(True), p1.clone().requires_grad_(True)
+    l1 = ops.l1_rows_loss(p1g, t1.to(dev), 1.0)
+    l1r = (p1c - t1).abs().sum(-1, keepdim=True).mean()
+    _close(l1[0], l1r, name='l1'); l1r.backward(); l1[0].backward()
+    _close(p1g.grad, p1c.grad, name='l1 bwd')
+
+
+def test_adamw_matches_torch(dev):
+    from muvo_amd import ops
+    torch.manual_seed(11)
+    n = 10007
+    p0, g = torch.randn(n), torch.randn(n)
+    pr = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([pr], lr=3e-4, betas=(0.95, 0.999), eps=1e-8, weight_decay=0.01)
+    p, m, v = p0.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    for step in range(1, 4):
+        pr.grad = g * step
+        opt.step()
+        ops.adamw_step(p, (g * step).to(dev), m, v, 3e-4, 0.95, 0.999, 1e-8, 0.01, step)
+    _close(p, pr.data, rtol=1e-6, atol=1e-7, name='adamw')

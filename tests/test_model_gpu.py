@@ -1,0 +1,135 @@
+"""-m gpu: the full HIP training step (preprocess -> forward -> 21 losses -> backward -> fused AdamW, through the
+C ABI) against the golden fixture generated from the REAL reference (tests/golden/base1d_b1s2*.{json,npz},
+oracle/refimport/make_golden.py).  Tolerance: 1e-3 relative fp32 (BASELINE.json north_star); voxel argmax bit-exact."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+@pytest.fixture(scope='module')
+def run(dev):
+    from muvo_amd.config import base_1d_cfg
+    from muvo_amd.data.synthetic import make_batch, make_noise
+    from muvo_amd.trainer import WorldModelTrainer
+    from muvo_amd.utils import detinit
+    fx = json.load(open(os.path.join(GOLD, 'base1d_b1s2.json')))
+    smp = np.load(os.path.join(GOLD, 'base1d_b1s2_samples.npz'))
+    b, s, seed = fx['b'], fx['s'], fx['seed']
+    cfg = base_1d_cfg(RECEPTIVE_FIELD=s, FUTURE_HORIZON=0, STEPS=100000)
+    tr = WorldModelTrainer(cfg.convert_to_dict(), device=dev)
+    tr.train()
+    detinit.fill_state_dict_(tr.model)
+    for layer in tr.model.transformer_encoder.layers:
+        layer.p = 0.0
+    opts, scheds = tr.configure_optimizers()
+    opt, sched = opts[0], scheds[0]['scheduler']
+    eps, use_prior = make_noise(b, s, seed=seed)
+    assert use_prior == fx['use_prior']
+    eps = eps.to(dev)
+    recs = []
+    for step in range(len(fx['steps'])):
+        batch = make_batch(b, s, seed=seed + step, device=dev)
+        opt.zero_grad()
+        losses, output, _, _ = tr.shared_step(batch, mode='train', noise=eps, use_prior=use_prior)
+        total = tr.loss_reducing(losses)
+        total.backward()
+        rec = dict(total=total.item(), losses={k: v.item() for k, v in losses.items()})
+        if step == 0:
+            rec['output'] = {k: v.detach() for k, v in output.items() if torch.is_tensor(v)}
+            for grp in ('prior', 'posterior'):
+                for k, v in output[grp].items():
+                    rec['output'][f'{grp}.{k}'] = v.detach()
+            rec['batch'] = {k: v for k, v in batch.items() if torch.is_tensor(v)}
+            rec['grad_l2'] = {n: (None if (p.grad is None) else p.grad.double().pow(2).sum().sqrt().item())
+                              for n, p in tr.model.named_parameters()}
+            rec['grads'] = {n: p.grad.detach().clone() for n, p in tr.model.named_parameters() if p.grad is not None}
+        rec['lr'] = [g['lr'] for g in opt.param_groups]
+        opt.step()
+        sched.step()
+        rec['checks'] = {n: [p.detach().double().sum().item(), p.detach().double().abs().sum().item()]
+                         for n, p in tr.model.named_parameters()}
+        recs.append(rec)
+    return fx, smp, recs
+
+
+def _rel(a, b):
+    return abs(a - b) / max(abs(b), 1e-12)
+
+
+def test_losses_match_reference(run):
+    fx, _, recs = run
+    for step, (rec, g) in enumerate(zip(recs, fx['steps'])):
+        assert set(rec['losses']) == set(g['losses'])
+        assert len(rec['losses']) == 21
+        tol = 1e-3 if step == 0 else 2e-3
+        for k, v in g['losses'].items():
+            assert _rel(rec['losses'][k], v) < tol, f'step {step} loss {k}: {rec["losses"][k]} vs {v}'
+        assert _rel(rec['total'], g['total']) < tol
+        assert np.allclose(rec['lr'], g['lr'], rtol=1e-6)
+
+
+def test_outputs_match_reference(run):
+    fx, smp, recs = run
+    outs = fx['steps'][0]['outputs']
+    for k, st in outs.items():
+        t = recs[0]['batch'][k[6:]] if k.startswith('batch.') else recs[0]['output'][k]
+        assert list(t.shape) == st['shape'], k
+        f = t.float().contiguous().view(-1)
+        l2 = f.double().pow(2).sum().sqrt().item()
+        assert _rel(l2, st['l2']) < 1e-3, f'{k}: l2 {l2} vs {st["l2"]}'
+        ref = torch.from_numpy(smp[('' if k.startswith('batch.') else 'out.') + k])
+        got = f[::st['stride']][:ref.numel()].cpu()
+        scale = max(st['absmean'], 1e-6)
+        err = (got - ref).abs().max().item()
+        assert err < 2e-3 * max(scale, ref.abs().max().item()), f'{k}: sample max err {err} (scale {scale})'
+
+
+def test_voxel_argmax_bit_exact(run):
+    fx, _, recs = run
+    g = fx['steps'][0]
+    v = recs[0]['output']['voxel_1']
+    am = v.argmax(dim=2).to(torch.uint8).cpu().numpy()
+    pops = [int(x) for x in am.reshape(am.shape[0] * am.shape[1], -1).sum(1)]
+    digest = hashlib.sha256(np.packbits(am.astype(bool)).tobytes()).hexdigest()
+    assert pops == g['voxel_1_argmax_popcounts'], (pops, g['voxel_1_argmax_popcounts'])
+    assert digest == g['voxel_1_argmax_sha256']
+
+
+def test_gradients_match_reference(run):
+    fx, smp, recs = run
+    g = fx['steps'][0]['grad_l2']
+    bad = []
+    for n, ref in g.items():
+        got = recs[0]['grad_l2'][n]
+        if ref is None:
+            assert got is None or got == 0.0, n  # never-used encoder_layer.* 
+            continue
+        if _rel(got, ref) > 2e-3 and abs(got - ref) > 1e-7:
+            bad.append((n, got, ref))
+    assert not bad, f'{len(bad)} gradient norms off, first: {bad[:5]}'
+    for key in smp.files:
+        if key.startswith('grad.'):
+            n = key[5:]
+            ref = torch.from_numpy(smp[key])
+            t = recs[0]['grads'][n].float().contiguous().view(-1)
+            stride = max(1, t.numel() // 1024)
+            got = t[::stride][:ref.numel()].cpu()
+            assert (got - ref).abs().max().item() < 2e-3 * max(ref.abs().max().item(), 1e-8), n
+
+
+def test_adamw_steps_match_reference(run):
+    fx, _, recs = run
+    for step, (rec, g) in enumerate(zip(recs, fx['steps'])):
+        bad = []
+        for n, (s_ref, a_ref) in g['param_checksums_after_step'].items():
+            s_got, a_got = rec['checks'][n]
+            if _rel(a_got, a_ref) > 1e-5 or abs(s_got - s_ref) > 1e-5 * max(a_ref, 1.0):
+                bad.append((n, s_got, s_ref, a_got, a_ref))
+        assert not bad, f'step {step}: {len(bad)} parameter checksums off, first {bad[:3]}'
