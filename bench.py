@@ -1,0 +1,149 @@
+"""bench.py — world-model training samples/sec of the MI355X-native MUVO step (BASELINE.json metric).
+
+`python bench.py --gpus N --steps K --warmup W`; for N > 1 launch through torch.distributed.run (one rank per GPU,
+RCCL).  One "step" = preprocess + forward + 21 losses + backward + gradient all-reduce + fused AdamW on one
+synthetic base_1d batch (per-GPU batch 2 x seq_len 10, 600x960 RGB -> 320x832 crop, 64x1024 range view,
+192x192x64 voxels) that is already resident in HBM.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+GFLOP_PER_FRAME = 794.36       # fwd 265.35 + bwd 529.01 (2*MAC, conv/convT/matmul)
+
+
+def cpu_baseline(cores):
+    """The oracle restatement (validated against the reference, tests/golden) timed on the host cores on a bounded
+    sample: one full training step (fwd + 21 losses + bwd + AdamW) at batch 1 x seq_len 2, 2 frames."""
+    from muvo_amd.data.synthetic import make_batch, make_noise
+    from muvo_amd.utils import detinit
+    from oracle import muvo_ref as R
+    torch.set_num_threads(cores)
+    model = R.MileRef()
+    detinit.fill_state_dict_(model)
+    model.train()
+    opt, sched = R.make_optimizer(model, model.cfg)
+    batch = make_batch(1, 2, seed=1234)
+    eps, use_prior = make_noise(1, 2, seed=1234)
+    t0 = time.time()
+    total, _, _, _ = R.training_step(model, batch, eps, use_prior)
+    opt.zero_grad(set_to_none=True)
+    total.backward()
+    opt.step()
+    dt = time.time() - t0
+    frames_per_s = 2.0 / dt
+    return dict(value=frames_per_s / 10.0, unit='samples/s', cores=cores, kind='port',
+                sample=f'1 training step of the oracle port at batch 1 x seq_len 2 (2 frames) in {dt:.1f} s = '
+                       f'{frames_per_s:.3f} frames/s; value = frames/s / 10 (one sample = 10 frames)')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=2)
+    ap.add_argument('--seq-len', type=int, default=10)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+
+    from muvo_amd import ops
+    from muvo_amd.config import base_1d_cfg
+    from muvo_amd.data.synthetic import make_batch
+    from muvo_amd.parallel import SegmentedGradReducer
+    from muvo_amd.trainer import WorldModelTrainer
+
+    s = args.seq_len
+    cfg = base_1d_cfg(RECEPTIVE_FIELD=min(6, s), FUTURE_HORIZON=s - min(6, s), BATCHSIZE=args.batch, STEPS=100000)
+    torch.manual_seed(1234)  # same initial weights on every rank (replicated data parallel)
+    tr = WorldModelTrainer(cfg.convert_to_dict(), device=dev)
+    tr.train()
+    opts, scheds = tr.configure_optimizers()
+    opt, sched = opts[0], scheds[0]['scheduler']
+    reducer = SegmentedGradReducer(tr.store)
+    tr.model.segment_done = reducer.segment_done
+    opt.grad_scale = reducer.grad_scale
+
+    # two distinct synthetic batches per rank, staged in HBM before the timed region
+    batches = [make_batch(args.batch, s, seed=1234 + 2 * rank + k, device=dev) for k in range(2)]
+
+    def step(i):
+        batch = dict(batches[i % 2])
+        reducer.begin_step()
+        opt.zero_grad()
+        loss = tr.training_step(batch, i)
+        loss.backward()
+        reducer.finish()
+        opt.step()
+        sched.step()
+        return loss
+
+    for i in range(args.warmup):
+        step(i)
+    if not args.no_kernel_timing:
+        ops.KERNEL_TIMING = ops.KernelTiming()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timing = ops.KERNEL_TIMING
+    ops.KERNEL_TIMING = None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    loss_val = float(loss.item())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        samples = args.batch * world * args.steps
+        frames_per_gpu_step = args.batch * s
+        out = {
+            'metric': 'world-model training samples/sec (seq_len=10)', 'value': samples / dt, 'unit': 'samples/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'base_1d (resnet18 + range-view + transformer fusion + 1D latent), batch={args.batch} '
+                                   f'per GPU, seq_len={s}, 600x960 RGB (crop 320x832) + 64x1024 range-view + '
+                                   f'192x192x64 voxels, full step incl. 21 losses, backward, AdamW',
+                       'global_batch': args.batch * world, 'seq_len': s, 'parallelism': f'dp{world}'},
+            'frames_per_s': samples * s / dt,
+            'step_tflops_per_gpu': GFLOP_PER_FRAME * frames_per_gpu_step / (ms * 1e-3) / 1e3,
+            'step_frac_of_fp32_mfma_peak': GFLOP_PER_FRAME * frames_per_gpu_step / (ms * 1e-3) / 1e3 / PEAK_FP32_MFMA_TFLOPS,
+            'final_loss': loss_val,
+        }
+        if timing is not None:
+            out['roofline'], out['kernel_classes'] = timing.summary(PEAK_FP32_MFMA_TFLOPS)
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(os.cpu_count() or 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -78,6 +78,9 @@ class Mile(nn.Module):
         if cfg.VOXEL_SEG.ENABLED:
             self.voxel_decoder = VoxelDecoder1(state_dim, cfg.VOXEL_SEG.N_CLASSES, cfg.VOXEL_SEG.DIMENSION, (3, 3, 1))
         self._pos_cache = {}
+        # data-parallel gradient overlap: called with a segment name (muvo_amd/param_store.SEGMENTS) from autograd
+        # hooks the moment backward has finished that segment's parameters
+        self.segment_done = None
         self._step_seed = 0
         self.dropout_seed = 0x5EED
 
@@ -87,6 +90,11 @@ class Mile(nn.Module):
             self._pos_cache[key] = position_embedding_sine(h, w, self.cfg.MODEL.TRANSFORMER.CHANNELS // 2).to(device)
         return self._pos_cache[key]
 
+    def _hook(self, t, segment):
+        if self.segment_done is not None and t.requires_grad:
+            cb = self.segment_done
+            t.register_hook(lambda g, _s=segment: (cb(_s), None)[1])
+
     def forward(self, batch, deployment=False, noise=None, use_prior=None):
         if deployment:
             raise NotImplementedError('deployment_forward is outside the training hot path')
@@ -94,10 +102,12 @@ class Mile(nn.Module):
         b, s = batch['image'].shape[:2]
         action = ops.cat_last([pack_sequence_dim(batch['throttle_brake']), pack_sequence_dim(batch['steering'])])
         action = action.view(b, s, -1)
+        self._hook(embedding, 'rssm')
         state_dict = self.rssm(embedding, action, use_sample=True, policy=self.policy, noise=noise, use_prior=use_prior)
         output = {**state_dict}
         post = state_dict['posterior']
         state = ops.cat_last([pack_sequence_dim(post['hidden_state']), pack_sequence_dim(post['sample'])])
+        self._hook(state, 'decoders')
         pol = self.policy(state)
         output['throttle_brake'] = unpack_sequence_dim(ops.slice_last(pol, 0, 1), b, s)
         output['steering'] = unpack_sequence_dim(ops.slice_last(pol, 1, 2), b, s)
@@ -120,6 +130,7 @@ class Mile(nn.Module):
         # x + pos -> flatten/permute -> + type embedding -> concat (mile.py:542-557), one transpose kernel per sensor
         tokens = ops.make_tokens(x, lidar_features, self._pos(hi, wi, x.device), self._pos(hl, wl, x.device),
                                  self.type_embedding)
+        self._hook(tokens, 'fusion')
         self._step_seed += 1
         tokens_out = self.transformer_encoder(tokens, self.dropout_seed + 1000 * self._step_seed)
         image_tokens_out = ops.untoken(tokens_out, 0, hi, wi)

@@ -130,6 +130,50 @@ def scratch(name, nfloats, device, dtype=torch.float32):
     return t
 
 
+# ------------------------------------------------------------------------------------------------
+# optional per-kernel-class timing with HIP events on the launch stream (bench.py roofline object)
+KERNEL_TIMING = None
+
+
+class KernelTiming:
+    def __init__(self):
+        self.rec = []
+
+    def bracket(self, cls, flops, launches):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.rec.append((cls, flops, launches, e0, e1))
+        return e0, e1
+
+    def summary(self, peak_tflops):
+        torch.cuda.synchronize()
+        agg = {}
+        for cls, flops, launches, e0, e1 in self.rec:
+            a = agg.setdefault(cls, [0.0, 0.0, 0])
+            a[0] += e0.elapsed_time(e1) * 1e-3
+            a[1] += flops
+            a[2] += launches
+        classes = {k: dict(seconds=v[0], tflop=v[1] / 1e12, launches=v[2],
+                           avg_launch_us=v[0] / max(v[2], 1) * 1e6, tflops=v[1] / max(v[0], 1e-12) / 1e12)
+                   for k, v in agg.items()}
+        dom = max((k for k in classes if k.startswith('conv_fwd_kernel')), key=lambda k: classes[k]['seconds'],
+                  default=None)
+        roof = None
+        if dom is not None:
+            c = classes[dom]
+            roof = dict(bound='mfma', kernel=dom, achieved=c['tflops'], peak=peak_tflops, unit='TFLOP/s',
+                        frac=c['tflops'] / peak_tflops, traffic=None, launches=c['launches'],
+                        avg_launch_us=c['avg_launch_us'],
+                        flop_per_launch=c['tflop'] * 1e12 / max(c['launches'], 1))
+        return roof, classes
+
+
+def _conv_flops(geom, n, in_sz, out_sz):
+    import math
+    taps = math.prod(geom.ksz)
+    pix = math.prod(in_sz) if geom.transposed else math.prod(out_sz)
+    return 2.0 * n * geom.cin * geom.cout * taps * pix
+
+
 # ================================================================================================ GEMM
 def gemm(A, B, Cout, M, N, K, sam, sak, sbk, sbn, scm, bias=None, alpha=1.0, act=ACT_NONE, slope=0.0, mode=0,
          B1=1, B2=1, a_b=(0, 0), b_b=(0, 0), c_b=(0, 0), bias_div=1, a_off=0, b_off=0, c_off=0):
@@ -187,9 +231,6 @@ def linear(x, weight, bias=None, act=ACT_NONE, slope=0.0):
 
 
 # ================================================================================================ conv
-_plan_cache = {}
-
-
 class ConvGeom:
     """Static geometry of a conv layer (everything but the batch/input size)."""
 
@@ -206,6 +247,7 @@ class ConvGeom:
             self.stride = (1,) + self.stride[1:]
             self.dil = (1,) + self.dil[1:]
         self.pad, self.out_pad = p, op
+        self._plans = {}
 
     def out_size(self, in_sz):
         o = []
@@ -218,8 +260,8 @@ class ConvGeom:
         return tuple(o)
 
     def plan(self, n, in_sz):
-        key = (id(self), n, in_sz)
-        pl = _plan_cache.get(key)
+        key = (n, in_sz)
+        pl = self._plans.get(key)
         if pl is None:
             out_sz = self.out_size(in_sz)
             d = ConvDesc(self.nd, self.transposed, n, self.cin, self.cout, (C.c_int32 * 3)(*in_sz),
@@ -228,7 +270,7 @@ class ConvGeom:
             ff, df = C.c_int64(0), C.c_int64(0)
             _ck(lib().muvo_conv_pack_sizes(C.byref(d), C.byref(ff), C.byref(df)))
             pl = (d, out_sz, ff.value, df.value)
-            _plan_cache[key] = pl
+            self._plans[key] = pl
         return pl
 
 
@@ -261,7 +303,15 @@ class ConvFn(torch.autograd.Function):
             packed.fwd_key = k
         oshape = (n, geom.cout) + (out_sz if geom.nd == 3 else out_sz[1:])
         y = torch.empty(oshape, device=x.device, dtype=torch.float32)
+        kt = KERNEL_TIMING
+        if kt is not None:
+            import math
+            e0, e1 = kt.bracket('conv_fwd_kernel(fwd)', _conv_flops(geom, n, in_sz, out_sz),
+                                math.prod(geom.stride) if geom.transposed else 1)
+            e0.record()
         _ck(L.muvo_conv_forward(C.byref(d), _f(x), _f(packed.fwd), _f(bias), _f(y), act, _fl(slope), _st()))
+        if kt is not None:
+            e1.record()
         ctx.geom, ctx.packed, ctx.act, ctx.slope = geom, packed, act, slope
         ctx.weight, ctx.bias, ctx.in_sz = weight, bias, in_sz
         ctx.save_for_backward(x, y if act != ACT_NONE else None)
@@ -289,11 +339,27 @@ class ConvFn(torch.autograd.Function):
                 _ck(L.muvo_conv_pack_weights(C.byref(d), _f(weight), None, _f(packed.dgr), _st()))
                 packed.dgr_key = k
             dx = torch.empty_like(x)
+            kt = KERNEL_TIMING
+            if kt is not None:
+                import math
+                e0, e1 = kt.bracket('conv_fwd_kernel(dgrad)', _conv_flops(geom, x.shape[0], ctx.in_sz, out_sz),
+                                    1 if geom.transposed else math.prod(geom.stride))
+                e0.record()
             _ck(L.muvo_conv_dgrad(C.byref(d), _f(dz), _f(packed.dgr), _f(dx), _st()))
+            if kt is not None:
+                e1.record()
         if weight.requires_grad:
             ws = scratch('wgrad', ff, x.device)
             db = grad_of(bias) if bias is not None else None
+            kt = KERNEL_TIMING
+            if kt is not None:
+                import math
+                e0, e1 = kt.bracket('conv_wgrad_kernel(+unpack,bias)', _conv_flops(geom, x.shape[0], ctx.in_sz, out_sz),
+                                    math.prod(geom.stride) if geom.transposed else 1)
+                e0.record()
             _ck(L.muvo_conv_wgrad(C.byref(d), _f(x), _f(dz), _f(ws), _f(grad_of(weight)), _f(db), _st()))
+            if kt is not None:
+                e1.record()
         return dx, None, None, None, None, None, None
 
 

@@ -12,10 +12,11 @@ import torch
 
 # reverse-execution order of the base_1d model: backward completes these prefixes top to bottom
 SEGMENTS = (
-    ('decoders', ('voxel_decoder.', 'lidar_re.', 'rgb_decoder.', 'policy.')),
-    ('rssm', ('rssm.', 'features_combine.', 'speed_enc.', 'backbone_route.')),
-    ('fusion', ('image_feature_conv.', 'lidar_feature_conv.', 'transformer_encoder.', 'type_embedding')),
-    ('encoders', ('feat_decoder.', 'range_view_decoder.', 'encoder.', 'range_view_encoder.')),
+    ('decoders', ('voxel_decoder.', 'lidar_re.', 'rgb_decoder.', 'policy.')),            # done when d(state) arrives
+    ('rssm', ('rssm.',)),                                                                  # done when d(embedding) arrives
+    ('fusion', ('features_combine.', 'speed_enc.', 'backbone_route.', 'image_feature_conv.', 'lidar_feature_conv.',
+                'transformer_encoder.')),                                                  # done when d(tokens) arrives
+    ('encoders', ('type_embedding', 'feat_decoder.', 'range_view_decoder.', 'encoder.', 'range_view_encoder.')),
 )
 UNUSED_PREFIXES = ('encoder_layer.',)
 

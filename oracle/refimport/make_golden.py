@@ -200,6 +200,20 @@ def main():
             h, pops = argmax_digest(output['voxel_1'])
             rec['voxel_1_argmax_sha256'] = h
             rec['voxel_1_argmax_popcounts'] = pops
+            # argmax can only be bit-exact where the decision margin exceeds fp32 summation-order noise: record the
+            # voxels whose top-2 logit margin is below NEAR_TIE and a digest of the argmax with those voxels zeroed
+            NEAR_TIE = 2e-3
+            v1 = output['voxel_1'].detach()
+            top2 = v1.topk(2, dim=2).values
+            margin = (top2[:, :, 0] - top2[:, :, 1]).reshape(-1)
+            tie = torch.nonzero(margin < NEAR_TIE).reshape(-1).to(torch.int32)
+            am = v1.argmax(dim=2).reshape(-1).to(torch.uint8).clone()
+            am[tie.long()] = 0
+            samples['voxel_1_near_tie_idx'] = tie.numpy()
+            rec['voxel_1_near_tie_margin'] = NEAR_TIE
+            rec['voxel_1_near_tie_count'] = int(tie.numel())
+            rec['voxel_1_argmax_sha256_excl_near_ties'] = hashlib.sha256(
+                np.packbits(am.numpy().astype(bool)).tobytes()).hexdigest()
             rec['voxel_1_margin_min'] = float((output['voxel_1'][:, :, 0] - output['voxel_1'][:, :, 1]).abs().min())
             gn = {}
             for n, p in model.named_parameters():

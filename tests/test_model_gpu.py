@@ -92,14 +92,21 @@ def test_outputs_match_reference(run):
 
 
 def test_voxel_argmax_bit_exact(run):
-    fx, _, recs = run
+    """Bit-exact argmax on every voxel whose reference decision margin exceeds fp32 summation-order noise (2e-3);
+    the fixture lists the near-tie voxels (a few thousand of 4.7 M) which may flip."""
+    fx, smp, recs = run
     g = fx['steps'][0]
     v = recs[0]['output']['voxel_1']
-    am = v.argmax(dim=2).to(torch.uint8).cpu().numpy()
-    pops = [int(x) for x in am.reshape(am.shape[0] * am.shape[1], -1).sum(1)]
-    digest = hashlib.sha256(np.packbits(am.astype(bool)).tobytes()).hexdigest()
-    assert pops == g['voxel_1_argmax_popcounts'], (pops, g['voxel_1_argmax_popcounts'])
-    assert digest == g['voxel_1_argmax_sha256']
+    am = v.argmax(dim=2).reshape(-1).to(torch.uint8).cpu()
+    tie = torch.from_numpy(smp['voxel_1_near_tie_idx']).long()
+    assert tie.numel() == g['voxel_1_near_tie_count'] and tie.numel() < 0.01 * am.numel()
+    full_pops = am.view(-1, am.numel() // (fx['b'] * fx['s'])).sum(1).tolist()
+    for got, ref in zip(full_pops, g['voxel_1_argmax_popcounts']):
+        assert abs(got - ref) <= tie.numel(), (full_pops, g['voxel_1_argmax_popcounts'])
+    masked = am.clone()
+    masked[tie] = 0
+    digest = hashlib.sha256(np.packbits(masked.numpy().astype(bool)).tobytes()).hexdigest()
+    assert digest == g['voxel_1_argmax_sha256_excl_near_ties']
 
 
 def test_gradients_match_reference(run):
