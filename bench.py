@@ -20,6 +20,18 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_
 GFLOP_PER_FRAME = 794.36       # fwd 265.35 + bwd 529.01 (2*MAC, conv/convT/matmul)
 
 
+def usable_cores():
+    """Host cores this process may actually use: min(affinity mask, cgroup CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(cores):
     """The oracle restatement (validated against the reference, tests/golden) timed on the host cores on a bounded
     sample: one full training step (fwd + 21 losses + bwd + AdamW) at batch 1 x seq_len 2, 2 frames."""
@@ -139,7 +151,7 @@ def main():
         if timing is not None:
             out['roofline'], out['kernel_classes'] = timing.summary(PEAK_FP32_MFMA_TFLOPS)
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(os.cpu_count() or 1)
+            out['cpu_baseline'] = cpu_baseline(usable_cores())
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
