@@ -66,6 +66,7 @@ def main():
     ap.add_argument('--seq-len', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--layer-table', default='', help='write the per-layer conv timing table to this file')
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -148,6 +149,9 @@ def main():
             'step_frac_of_fp32_mfma_peak': GFLOP_PER_FRAME * frames_per_gpu_step / (ms * 1e-3) / 1e3 / PEAK_FP32_MFMA_TFLOPS,
             'final_loss': loss_val,
         }
+        if timing is not None and args.layer_table:
+            with open(args.layer_table, 'w') as f:
+                f.write(timing.layer_table() + '\n')
         if timing is not None:
             out['roofline'], out['kernel_classes'] = timing.summary(PEAK_FP32_MFMA_TFLOPS)
         if world == 1 and not args.no_cpu_baseline:

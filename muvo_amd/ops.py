@@ -139,15 +139,30 @@ class KernelTiming:
     def __init__(self):
         self.rec = []
 
-    def bracket(self, cls, flops, launches):
+    def bracket(self, cls, flops, launches, tag=''):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        self.rec.append((cls, flops, launches, e0, e1))
+        self.rec.append((cls, flops, launches, e0, e1, tag))
         return e0, e1
+
+    def layer_table(self):
+        """Per (kernel class, layer shape) rows sorted by time: the optimisation worklist."""
+        torch.cuda.synchronize()
+        agg = {}
+        for cls, flops, launches, e0, e1, tag in self.rec:
+            a = agg.setdefault((cls, tag), [0.0, 0.0, 0])
+            a[0] += e0.elapsed_time(e1) * 1e-3
+            a[1] += flops
+            a[2] += 1
+        rows = sorted(agg.items(), key=lambda kv: -kv[1][0])
+        out = [f'{"ms/call":>9} {"calls":>5} {"TFLOP/s":>8} {"GFLOP":>9}  class | layer']
+        for (cls, tag), (sec, fl, n) in rows:
+            out.append(f'{sec / n * 1e3:9.3f} {n:5d} {fl / max(sec, 1e-12) / 1e12:8.1f} {fl / n / 1e9:9.2f}  {cls} | {tag}')
+        return '\n'.join(out)
 
     def summary(self, peak_tflops):
         torch.cuda.synchronize()
         agg = {}
-        for cls, flops, launches, e0, e1 in self.rec:
+        for cls, flops, launches, e0, e1, _tag in self.rec:
             a = agg.setdefault(cls, [0.0, 0.0, 0])
             a[0] += e0.elapsed_time(e1) * 1e-3
             a[1] += flops
@@ -165,6 +180,11 @@ class KernelTiming:
                         avg_launch_us=c['avg_launch_us'],
                         flop_per_launch=c['tflop'] * 1e12 / max(c['launches'], 1))
         return roof, classes
+
+
+def _conv_tag(geom, n, in_sz):
+    return (f'{"convT" if geom.transposed else "conv"}{geom.nd}d {geom.cin}->{geom.cout} k{geom.ksz} s{geom.stride} '
+            f'n{n} in{tuple(in_sz)}')
 
 
 def _conv_flops(geom, n, in_sz, out_sz):
@@ -307,7 +327,7 @@ class ConvFn(torch.autograd.Function):
         if kt is not None:
             import math
             e0, e1 = kt.bracket('conv_fwd_kernel(fwd)', _conv_flops(geom, n, in_sz, out_sz),
-                                math.prod(geom.stride) if geom.transposed else 1)
+                                math.prod(geom.stride) if geom.transposed else 1, _conv_tag(geom, n, in_sz))
             e0.record()
         _ck(L.muvo_conv_forward(C.byref(d), _f(x), _f(packed.fwd), _f(bias), _f(y), act, _fl(slope), _st()))
         if kt is not None:
@@ -343,7 +363,7 @@ class ConvFn(torch.autograd.Function):
             if kt is not None:
                 import math
                 e0, e1 = kt.bracket('conv_fwd_kernel(dgrad)', _conv_flops(geom, x.shape[0], ctx.in_sz, out_sz),
-                                    1 if geom.transposed else math.prod(geom.stride))
+                                    1 if geom.transposed else math.prod(geom.stride), _conv_tag(geom, x.shape[0], ctx.in_sz))
                 e0.record()
             _ck(L.muvo_conv_dgrad(C.byref(d), _f(dz), _f(packed.dgr), _f(dx), _st()))
             if kt is not None:
@@ -355,7 +375,7 @@ class ConvFn(torch.autograd.Function):
             if kt is not None:
                 import math
                 e0, e1 = kt.bracket('conv_wgrad_kernel(+unpack,bias)', _conv_flops(geom, x.shape[0], ctx.in_sz, out_sz),
-                                    math.prod(geom.stride) if geom.transposed else 1)
+                                    math.prod(geom.stride) if geom.transposed else 1, _conv_tag(geom, x.shape[0], ctx.in_sz))
                 e0.record()
             _ck(L.muvo_conv_wgrad(C.byref(d), _f(x), _f(dz), _f(ws), _f(grad_of(weight)), _f(db), _st()))
             if kt is not None:
