@@ -15,6 +15,7 @@
 // Replaces ATen/cuDNN conv ops used at muvo/models/common.py:549-632 (ConvDecoder), :161-202,498-546
 // (voxel decoder), timm ResNet-18 (mile.py:24,81; common.py:15), layers.py:9-66, common.py:102-130.
 #include "common.h"
+#include "conv_vox.h"
 
 #define MAX_TAPS 64
 
@@ -596,6 +597,9 @@ int muvo_conv_pack_sizes(const muvo_conv_desc* d, int64_t* fwd_floats, int64_t* 
   ConvPlan pl;
   int rc = build_plan(d, &pl);
   if (rc) return rc;
+  // the small-channel Conv3d path (conv_vox.hip) keeps its own layout in the same buffers
+  if (vox_fwd_applicable(d) && vox_pack_floats(d) > pl.fwd_floats) pl.fwd_floats = vox_pack_floats(d);
+  if (vox_dgrad_applicable(d) && vox_pack_floats(d) > pl.dgr_floats) pl.dgr_floats = vox_pack_floats(d);
   if (fwd_floats) *fwd_floats = pl.fwd_floats;
   if (dgrad_floats) *dgrad_floats = pl.dgr_floats;
   return MUVO_OK;
@@ -607,6 +611,16 @@ int muvo_conv_pack_weights(const muvo_conv_desc* d, const float* w, float* wp_fw
   if (rc) return rc;
   MUVO_CHECK_ARG(w != nullptr, "conv_pack_weights: w is null");
   hipStream_t st = (hipStream_t)stream;
+  if (wp_fwd && vox_fwd_applicable(d)) {
+    rc = vox_pack(d, w, wp_fwd, 0, st);
+    if (rc) return rc;
+    wp_fwd = nullptr;
+  }
+  if (wp_dgrad && vox_dgrad_applicable(d)) {
+    rc = vox_pack(d, w, wp_dgrad, 1, st);
+    if (rc) return rc;
+    wp_dgrad = nullptr;
+  }
   if (wp_fwd)
     for (int i = 0; i < pl.nfwd; ++i) {
       const long total = (long)pl.fwd[i].Kp * pl.fwd[i].Mp;
@@ -629,6 +643,7 @@ int muvo_conv_forward(const muvo_conv_desc* d, const float* x, const float* wp_f
   int rc = build_plan(d, &pl);
   if (rc) return rc;
   MUVO_CHECK_ARG(x && wp_fwd && y, "conv_forward: null pointer");
+  if (vox_fwd_applicable(d)) return vox_forward(d, x, wp_fwd, bias, y, act, slope, (hipStream_t)stream);
   for (int i = 0; i < pl.nfwd; ++i) {
     rc = launch_fwd_phase(pl.fwd[i], x, wp_fwd, bias, y, act, slope, (hipStream_t)stream);
     if (rc) return rc;
@@ -641,6 +656,7 @@ int muvo_conv_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp_dg
   int rc = build_plan(d, &pl);
   if (rc) return rc;
   MUVO_CHECK_ARG(dy && wp_dgrad && dx, "conv_dgrad: null pointer");
+  if (vox_dgrad_applicable(d)) return vox_dgrad(d, dy, wp_dgrad, dx, (hipStream_t)stream);
   for (int i = 0; i < pl.ndgr; ++i) {
     rc = launch_fwd_phase(pl.dgr[i], dy, wp_dgrad, nullptr, dx, MUVO_ACT_NONE, 0.f, (hipStream_t)stream);
     if (rc) return rc;
@@ -656,6 +672,7 @@ int muvo_conv_wgrad(const muvo_conv_desc* d, const float* x, const float* dy, fl
   if (rc) return rc;
   MUVO_CHECK_ARG(x && dy && dwp_scratch && dw, "conv_wgrad: null pointer");
   hipStream_t st = (hipStream_t)stream;
+  if (vox_wgrad_applicable(d)) return vox_wgrad(d, x, dy, dw, dbias, st);
   if (hipMemsetAsync(dwp_scratch, 0, sizeof(float) * pl.fwd_floats, st) != hipSuccess) {
     muvo_set_error("conv_wgrad: memset failed");
     return MUVO_ERR_HIP;

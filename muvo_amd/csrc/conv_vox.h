@@ -1,0 +1,14 @@
+// Internal interface of conv_vox.hip (small-channel 3x3x3 Conv3d on the 4x4x1 MFMA); called from the C ABI
+// entry points in conv_gemm.hip.
+#pragma once
+#include "common.h"
+
+bool vox_fwd_applicable(const muvo_conv_desc* d);
+bool vox_dgrad_applicable(const muvo_conv_desc* d);
+bool vox_wgrad_applicable(const muvo_conv_desc* d);
+long vox_pack_floats(const muvo_conv_desc* d);
+int vox_pack(const muvo_conv_desc* d, const float* w, float* wp, int dgrad, hipStream_t st);
+int vox_forward(const muvo_conv_desc* d, const float* x, const float* wp, const float* bias, float* y, int act, float slope,
+                hipStream_t st);
+int vox_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp, float* dx, hipStream_t st);
+int vox_wgrad(const muvo_conv_desc* d, const float* x, const float* dz, float* dw, float* dbias, hipStream_t st);

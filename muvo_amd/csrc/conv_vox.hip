@@ -1,0 +1,448 @@
+// Small-channel 3x3x3 Conv3d (stride 1, pad 1) on v_mfma_f32_4x4x1_16b_f32 — the top two levels of the voxel
+// decoder (muvo/models/common.py:161-202,498-546: 16->8, 8->8 at 192x192x64 and 32->16, 16->16 at 96x96x32).
+//
+// Why a separate kernel family: with 8 or 16 output channels the 32x32x2 implicit-GEMM tile of conv_gemm.hip is
+// 50-75 % padding, and these layers carry 37 GFLOP/frame forward.  The 16-block 4x4x1 MFMA computes, for every
+// lane's voxel, a 4-channel outer-product update D_b[i][j] += A_b[i] * B_b[j] (block b = 4 lanes) at the same
+// 64 FLOP/clk/SIMD as the big tiles, so with  A = weight W[4q+i]  (same for all blocks)  and  B = the input value
+// of the lane's voxel  there is no padding at all: lane <-> voxel, accumulator register i <-> output channel 4q+i.
+//
+//   forward / data-gradient (vox_conv_kernel): one wave owns TY rows x (64/Z) planes x Z voxels; input rows are
+//     loaded straight from global memory (coalesced 256-B rows) into registers, the z-1 / z+1 taps are wave-wide DPP
+//     shifts of the same registers, and each loaded row feeds 9 taps x TY rows x Cout/4 MFMAs.  Weights sit in LDS
+//     in the order the lanes read them ([tap][ci][co%4][co/4]).
+//   weight-gradient (vox_wgrad_kernel): i <-> 4 output channels, j <-> 4 input channels, block b <-> 16 consecutive
+//     voxels; nine waves per workgroup take the nine (tx,ty) tap pairs, the workgroup walks along x with a 3-plane
+//     LDS ring of the input tile (transposed to [y][z][ci%4][ci/4] so one ds_read_b128 feeds four MFMAs) and the
+//     per-wave accumulators are reduced over the 16 blocks once at the end and added to dW (PyTorch layout) with
+//     float atomics; the bias gradient is accumulated by the centre-tap wave from the same registers.
+#include "common.h"
+#include "conv_vox.h"
+
+struct VoxArgs {
+  int N, Cin, Cout, X, Y;
+  int ytiles, xgroups;
+  int XYZ;           // X*Y*Z
+  long sN_in, sN_out;  // batch strides (floats)
+};
+
+__device__ __forceinline__ float dpp_wave_shr1(float v) {  // lane l <- lane l-1, lane 0 <- 0
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_wave_shl1(float v) {  // lane l <- lane l+1, lane 63 <- 0
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward-type kernel (also the data gradient, with flipped/transposed packed weights)
+// ------------------------------------------------------------------------------------------------
+template <int CQ, int TY, int Z>
+__global__ void __launch_bounds__(256)
+vox_conv_kernel(const VoxArgs a, const float* __restrict__ in, const float* __restrict__ wp,
+                const float* __restrict__ bias, float* __restrict__ out, int act, float slope) {
+  extern __shared__ __attribute__((aligned(16))) float s_w[];  // 27 * Cin * Cout floats
+  constexpr int SUB = 64 / Z;
+  constexpr int R = TY + 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  {
+    const int nw4 = 27 * a.Cin * a.Cout / 4;
+    for (int i = tid; i < nw4; i += 256) ((float4*)s_w)[i] = ((const float4*)wp)[i];
+  }
+  __syncthreads();
+  const long wid = (long)blockIdx.x * 4 + wave;
+  const long nwaves = (long)a.N * a.xgroups * a.ytiles;
+  if (wid >= nwaves) return;
+  const int yt = (int)(wid % a.ytiles);
+  const long t0 = wid / a.ytiles;
+  const int xg = (int)(t0 % a.xgroups), n = (int)(t0 / a.xgroups);
+  const int sub = lane / Z, z = lane % Z;
+  const int x = xg * SUB + sub;
+  const int y0 = yt * TY;
+  const bool xok = x < a.X;
+  const int YZ = a.Y * Z;
+  const float* inn = in + (size_t)n * a.sN_in;
+
+  f32x4 acc[TY][CQ];
+#pragma unroll
+  for (int g = 0; g < TY; ++g)
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) acc[g][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto load_rows = [&](int it, float* v) {
+    const int ci = it / 3, tx = it - 3 * ci;
+    const int xin = x + tx - 1;
+    const bool ok = xok && (unsigned)xin < (unsigned)a.X;
+    const float* p = inn + (size_t)ci * a.XYZ;
+    const int off = xin * YZ + z;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int y = y0 - 1 + r;  // wave-uniform
+      float val = 0.f;
+      if (ok && (unsigned)y < (unsigned)a.Y) val = p[off + y * Z];
+      v[r] = val;
+    }
+  };
+
+  const int total = 3 * a.Cin;
+  const int wl = (lane & 3) * CQ;
+  const int wstride = a.Cin * 4 * CQ;  // floats between consecutive taps
+  float cur[R], nxt[R];
+  load_rows(0, cur);
+  for (int it = 0; it < total; ++it) {
+    const int ci = it / 3, tx = it - 3 * ci;
+    if (it + 1 < total) load_rows(it + 1, nxt);
+    float lf[R], rt[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float l = dpp_wave_shr1(cur[r]), rr = dpp_wave_shl1(cur[r]);
+      lf[r] = z > 0 ? l : 0.f;
+      rt[r] = z < Z - 1 ? rr : 0.f;
+    }
+    const float* wb = s_w + (size_t)(tx * 9 * a.Cin + ci) * 4 * CQ + wl;
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) {
+#pragma unroll
+      for (int tz = 0; tz < 3; ++tz) {
+        const float* wq = wb + (ty * 3 + tz) * wstride;
+        float w[CQ];
+        if constexpr (CQ == 2) {
+          const float2 t = *(const float2*)wq;
+          w[0] = t.x; w[1] = t.y;
+        } else {
+          const float4 t = *(const float4*)wq;
+          w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w;
+        }
+#pragma unroll
+        for (int g = 0; g < TY; ++g) {
+          const float src = tz == 0 ? lf[g + ty] : (tz == 1 ? cur[g + ty] : rt[g + ty]);
+#pragma unroll
+          for (int q = 0; q < CQ; ++q) acc[g][q] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[q], src, acc[g][q], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) cur[r] = nxt[r];
+  }
+
+  if (!xok) return;
+  float* on = out + (size_t)n * a.sN_out + (size_t)x * YZ + z;
+#pragma unroll
+  for (int g = 0; g < TY; ++g) {
+    const int y = y0 + g;
+    if (y >= a.Y) break;
+#pragma unroll
+    for (int q = 0; q < CQ; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int co = 4 * q + i;
+        float v = acc[g][q][i];
+        if (bias) v += bias[co];
+        on[(size_t)co * a.XYZ + y * Z] = act_apply(v, act, slope);
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight-gradient kernel
+// ------------------------------------------------------------------------------------------------
+template <int CQB, int RQB, int Z, int TYB>
+__global__ void __launch_bounds__(576)
+vox_wgrad_kernel(const VoxArgs a, const float* __restrict__ in, const float* __restrict__ dz, float* __restrict__ dw,
+                 float* __restrict__ dbias, int xsplit, int nqc) {
+  constexpr int ZP = Z + 2;
+  constexpr int SLOT = (TYB + 2) * ZP * 4 * RQB;  // floats per ring slot
+  constexpr int DBUF = TYB * Z * 4 * CQB;         // floats per dz buffer
+  constexpr int NIN = ((TYB + 2) * Z * 4 + 575) / 576;  // staging items per thread (input plane)
+  constexpr int NDZ = (TYB * Z * 4 + 575) / 576;
+  constexpr int ZS = Z / 16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* P = smem;              // [3][TYB+2][ZP][4][RQB]
+  float* D = smem + 3 * SLOT;   // [2][TYB][Z][4][CQB]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tx = wave / 3, ty = wave - 3 * tx;
+  const int qc = blockIdx.y % nqc, rc = blockIdx.y / nqc;
+  // block -> (n, ytile, xpart)
+  int bid = blockIdx.x;
+  const int xp = bid % xsplit; bid /= xsplit;
+  const int yt = bid % a.ytiles;
+  const int n = bid / a.ytiles;
+  const int xlen = (a.X + xsplit - 1) / xsplit;
+  const int xa = xp * xlen;
+  int xb = xa + xlen;
+  if (xb > a.X) xb = a.X;
+  const int y0 = yt * TYB;
+  const int YZ = a.Y * Z;
+  const float* inn = in + (size_t)n * a.sN_in + (size_t)(rc * RQB * 4) * a.XYZ;
+  const float* dzn = dz + (size_t)n * a.sN_out + (size_t)(qc * CQB * 4) * a.XYZ;
+
+  for (int i = tid; i < 3 * SLOT; i += 576) P[i] = 0.f;  // z halos stay zero for the whole kernel
+  __syncthreads();
+
+  float pin[NIN][RQB], pdz[NDZ][CQB];
+  auto fetch_in = [&](int xin) {  // plane xin -> registers
+    const bool xok = (unsigned)xin < (unsigned)a.X;
+#pragma unroll
+    for (int k = 0; k < NIN; ++k) {
+      const int item = tid + k * 576;
+      const int j = item & 3, zz = (item >> 2) % Z, r = (item >> 2) / Z;
+      const int y = y0 - 1 + r;
+      const bool ok = xok && r < TYB + 2 && (unsigned)y < (unsigned)a.Y;
+      const int off = xin * YZ + y * Z + zz;
+#pragma unroll
+      for (int e = 0; e < RQB; ++e) pin[k][e] = ok ? inn[(size_t)(4 * e + j) * a.XYZ + off] : 0.f;
+    }
+  };
+  auto store_in = [&](int slot) {
+    float* S = P + slot * SLOT;
+#pragma unroll
+    for (int k = 0; k < NIN; ++k) {
+      const int item = tid + k * 576;
+      const int j = item & 3, zz = (item >> 2) % Z, r = (item >> 2) / Z;
+      if (r < TYB + 2) {
+        float* d = S + ((r * ZP + zz + 1) * 4 + j) * RQB;
+        if constexpr (RQB == 4) *(float4*)d = make_float4(pin[k][0], pin[k][1], pin[k][2], pin[k][3]);
+        else *(float2*)d = make_float2(pin[k][0], pin[k][1]);
+      }
+    }
+  };
+  auto fetch_dz = [&](int xx) {
+#pragma unroll
+    for (int k = 0; k < NDZ; ++k) {
+      const int item = tid + k * 576;
+      const int i = item & 3, zz = (item >> 2) % Z, r = (item >> 2) / Z;
+      const int y = y0 + r;
+      const bool ok = xx < xb && r < TYB && y < a.Y;
+      const int off = xx * YZ + y * Z + zz;
+#pragma unroll
+      for (int e = 0; e < CQB; ++e) pdz[k][e] = ok ? dzn[(size_t)(4 * e + i) * a.XYZ + off] : 0.f;
+    }
+  };
+  auto store_dz = [&](int buf) {
+    float* S = D + buf * DBUF;
+#pragma unroll
+    for (int k = 0; k < NDZ; ++k) {
+      const int item = tid + k * 576;
+      const int i = item & 3, zz = (item >> 2) % Z, r = (item >> 2) / Z;
+      if (r < TYB) {
+        float* d = S + ((r * Z + zz) * 4 + i) * CQB;
+        if constexpr (CQB == 4) *(float4*)d = make_float4(pdz[k][0], pdz[k][1], pdz[k][2], pdz[k][3]);
+        else *(float2*)d = make_float2(pdz[k][0], pdz[k][1]);
+      }
+    }
+  };
+  auto slot_of = [](int xx) { return (xx + 3) % 3; };
+
+  f32x4 acc[CQB][RQB][3];
+#pragma unroll
+  for (int q = 0; q < CQB; ++q)
+#pragma unroll
+    for (int r = 0; r < RQB; ++r)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) acc[q][r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float db[CQB];
+#pragma unroll
+  for (int q = 0; q < CQB; ++q) db[q] = 0.f;
+
+  // prologue: planes xa-1, xa, xa+1 and dz(xa)
+  fetch_in(xa - 1); store_in(slot_of(xa - 1));
+  fetch_in(xa);     store_in(slot_of(xa));
+  fetch_in(xa + 1); store_in(slot_of(xa + 1));
+  fetch_dz(xa);     store_dz(xa & 1);
+  __syncthreads();
+
+  const int b = lane >> 2, lj = lane & 3;
+  for (int x = xa; x < xb; ++x) {
+    const bool more = x + 1 < xb;
+    if (more) { fetch_in(x + 2); fetch_dz(x + 1); }   // global loads in flight during the MFMA phase
+    const float* S = P + slot_of(x + tx - 1) * SLOT;
+    const float* Dz = D + (x & 1) * DBUF;
+#pragma unroll 1
+    for (int row = 0; row < TYB; ++row) {
+#pragma unroll
+      for (int zs = 0; zs < ZS; ++zs) {
+        const int zz = zs * 16 + b;
+        float av[CQB];
+        {
+          const float* pa = Dz + ((row * Z + zz) * 4 + lj) * CQB;
+          if constexpr (CQB == 4) { const float4 t = *(const float4*)pa; av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w; }
+          else { const float2 t = *(const float2*)pa; av[0] = t.x; av[1] = t.y; }
+        }
+        float bv[3][RQB];
+#pragma unroll
+        for (int tz = 0; tz < 3; ++tz) {
+          const float* pb = S + (((row + ty) * ZP + zz + tz) * 4 + lj) * RQB;
+          if constexpr (RQB == 4) { const float4 t = *(const float4*)pb; bv[tz][0] = t.x; bv[tz][1] = t.y; bv[tz][2] = t.z; bv[tz][3] = t.w; }
+          else { const float2 t = *(const float2*)pb; bv[tz][0] = t.x; bv[tz][1] = t.y; }
+        }
+#pragma unroll
+        for (int tz = 0; tz < 3; ++tz)
+#pragma unroll
+          for (int q = 0; q < CQB; ++q)
+#pragma unroll
+            for (int r = 0; r < RQB; ++r)
+              acc[q][r][tz] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q], bv[tz][r], acc[q][r][tz], 0, 0, 0);
+        if (wave == 4) {
+#pragma unroll
+          for (int q = 0; q < CQB; ++q) db[q] += av[q];
+        }
+      }
+    }
+    __syncthreads();  // everyone is done reading slot(x-1) and dz buffer (x&1)
+    if (more) { store_in(slot_of(x + 2)); store_dz((x + 1) & 1); }
+    __syncthreads();
+  }
+
+  // reduce over the 16 blocks (lane bits 2..5), then lanes 0..3 publish
+#pragma unroll
+  for (int q = 0; q < CQB; ++q)
+#pragma unroll
+    for (int r = 0; r < RQB; ++r)
+#pragma unroll
+      for (int tz = 0; tz < 3; ++tz)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = acc[q][r][tz][i];
+          v += __shfl_xor(v, 4, 64);
+          v += __shfl_xor(v, 8, 64);
+          v += __shfl_xor(v, 16, 64);
+          v += __shfl_xor(v, 32, 64);
+          if (lane < 4) {
+            const int co = (qc * CQB + q) * 4 + i, ci = (rc * RQB + r) * 4 + lane;
+            atomicAdd(dw + ((size_t)co * a.Cin + ci) * 27 + (tx * 3 + ty) * 3 + tz, v);
+          }
+        }
+  if (wave == 4 && rc == 0 && dbias != nullptr) {
+#pragma unroll
+    for (int q = 0; q < CQB; ++q) {
+      float v = db[q];
+      v += __shfl_xor(v, 4, 64);
+      v += __shfl_xor(v, 8, 64);
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (lane < 4) atomicAdd(dbias + (qc * CQB + q) * 4 + lane, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: fwd  wp[((tap*Cin + ci)*4 + i)*CQ + q] = W[4q+i][ci][tap]          (CQ = Cout/4)
+//                 dgrad wp[((tap*Cout + co)*4 + i)*CQ' + q] = W[co][4q+i][26 - tap]   (CQ' = Cin/4)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) vox_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout,
+                                                       int dgrad) {
+  const int total = 27 * Cin * Cout;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    const int ci_k = dgrad ? Cout : Cin;   // reduction channels of this direction
+    const int co_k = dgrad ? Cin : Cout;   // produced channels
+    const int cq = co_k / 4;
+    const int q = idx % cq;
+    int r = idx / cq;
+    const int i = r & 3; r >>= 2;
+    const int ck = r % ci_k, tap = r / ci_k;
+    const int cp = 4 * q + i;
+    float v;
+    if (!dgrad) v = w[((size_t)cp * Cin + ck) * 27 + tap];
+    else v = w[((size_t)ck * Cin + cp) * 27 + (26 - tap)];
+    wp[idx] = v;
+  }
+}
+
+// ================================================================================================ host side
+static bool vox_geometry_ok(const muvo_conv_desc* d) {
+  if (d->nd != 3 || d->transposed) return false;
+  for (int a = 0; a < 3; ++a)
+    if (d->ksz[a] != 3 || d->stride[a] != 1 || d->pad[a] != 1 || d->dil[a] != 1) return false;
+  const int Z = d->in_sz[2];
+  if (Z != 64 && Z != 32) return false;
+  if (d->Cin % 4 || d->Cout % 4) return false;
+  if ((long)d->in_sz[0] * d->in_sz[1] * Z * (long)(d->Cin > d->Cout ? d->Cin : d->Cout) >= (1l << 31)) return false;
+  return true;
+}
+bool vox_fwd_applicable(const muvo_conv_desc* d) {
+  return vox_geometry_ok(d) && (d->Cout == 8 || d->Cout == 16) && 27l * d->Cin * d->Cout * 4 <= 64 * 1024;
+}
+bool vox_dgrad_applicable(const muvo_conv_desc* d) {
+  return vox_geometry_ok(d) && (d->Cin == 8 || d->Cin == 16) && 27l * d->Cin * d->Cout * 4 <= 64 * 1024;
+}
+bool vox_wgrad_applicable(const muvo_conv_desc* d) {
+  return vox_geometry_ok(d) && d->Cout % 8 == 0 && d->Cin % 8 == 0 && d->Cout <= 32 && d->Cin <= 64;
+}
+long vox_pack_floats(const muvo_conv_desc* d) { return 27l * d->Cin * d->Cout; }
+
+int vox_pack(const muvo_conv_desc* d, const float* w, float* wp, int dgrad, hipStream_t st) {
+  const int total = 27 * d->Cin * d->Cout;
+  hipLaunchKernelGGL(vox_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, wp, d->Cin, d->Cout, dgrad);
+  MUVO_CHECK_LAUNCH("vox_pack_kernel");
+  return MUVO_OK;
+}
+
+template <int CQ, int TY, int Z>
+static int launch_vox_conv(const muvo_conv_desc* d, int Cin, int Cout, const float* in, const float* wp, const float* bias,
+                           float* out, int act, float slope, hipStream_t st) {
+  VoxArgs a;
+  a.N = d->N; a.Cin = Cin; a.Cout = Cout; a.X = d->in_sz[0]; a.Y = d->in_sz[1];
+  a.ytiles = cdiv(a.Y, TY);
+  a.xgroups = cdiv(a.X, 64 / Z);
+  a.XYZ = a.X * a.Y * Z;
+  a.sN_in = (long)Cin * a.XYZ; a.sN_out = (long)Cout * a.XYZ;
+  const long nwaves = (long)a.N * a.xgroups * a.ytiles;
+  const size_t lds = (size_t)27 * Cin * Cout * sizeof(float);
+  hipLaunchKernelGGL((vox_conv_kernel<CQ, TY, Z>), dim3(cdiv(nwaves, 4)), dim3(256), lds, st, a, in, wp, bias, out, act, slope);
+  MUVO_CHECK_LAUNCH("vox_conv_kernel");
+  return MUVO_OK;
+}
+
+static int vox_conv_dispatch(const muvo_conv_desc* d, int Cin, int Cout, const float* in, const float* wp, const float* bias,
+                             float* out, int act, float slope, hipStream_t st) {
+  const int Z = d->in_sz[2];
+  if (Cout == 8 && Z == 64) return launch_vox_conv<2, 6, 64>(d, Cin, Cout, in, wp, bias, out, act, slope, st);
+  if (Cout == 8 && Z == 32) return launch_vox_conv<2, 6, 32>(d, Cin, Cout, in, wp, bias, out, act, slope, st);
+  if (Cout == 16 && Z == 64) return launch_vox_conv<4, 4, 64>(d, Cin, Cout, in, wp, bias, out, act, slope, st);
+  if (Cout == 16 && Z == 32) return launch_vox_conv<4, 4, 32>(d, Cin, Cout, in, wp, bias, out, act, slope, st);
+  muvo_set_error("vox_conv: unsupported shape Cout=%d Z=%d", Cout, Z);
+  return MUVO_ERR_INVALID_ARG;
+}
+
+int vox_forward(const muvo_conv_desc* d, const float* x, const float* wp, const float* bias, float* y, int act, float slope,
+                hipStream_t st) {
+  return vox_conv_dispatch(d, d->Cin, d->Cout, x, wp, bias, y, act, slope, st);
+}
+int vox_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp, float* dx, hipStream_t st) {
+  return vox_conv_dispatch(d, d->Cout, d->Cin, dy, wp, nullptr, dx, MUVO_ACT_NONE, 0.f, st);
+}
+
+template <int CQB, int RQB, int Z, int TYB>
+static int launch_vox_wgrad(const muvo_conv_desc* d, const float* x, const float* dz, float* dw, float* dbias,
+                            hipStream_t st) {
+  VoxArgs a;
+  a.N = d->N; a.Cin = d->Cin; a.Cout = d->Cout; a.X = d->in_sz[0]; a.Y = d->in_sz[1];
+  a.ytiles = cdiv(a.Y, TYB);
+  a.xgroups = 0;
+  a.XYZ = a.X * a.Y * Z;
+  a.sN_in = (long)a.Cin * a.XYZ; a.sN_out = (long)a.Cout * a.XYZ;
+  const int nqc = d->Cout / (4 * CQB), nrc = d->Cin / (4 * RQB);
+  int xsplit = 1;
+  while ((long)a.N * a.ytiles * xsplit * nqc * nrc < 1536 && a.X / (xsplit * 2) >= 8) xsplit *= 2;
+  constexpr size_t lds = sizeof(float) * (3 * (TYB + 2) * (Z + 2) * 4 * RQB + 2 * TYB * Z * 4 * CQB);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)vox_wgrad_kernel<CQB, RQB, Z, TYB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess) {
+      muvo_set_error("vox_wgrad: cannot raise the dynamic LDS limit to %zu bytes", lds);
+      return MUVO_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  dim3 grid(a.N * a.ytiles * xsplit, nqc * nrc);
+  hipLaunchKernelGGL((vox_wgrad_kernel<CQB, RQB, Z, TYB>), grid, dim3(576), lds, st, a, x, dz, dw, dbias, xsplit, nqc);
+  MUVO_CHECK_LAUNCH("vox_wgrad_kernel");
+  return MUVO_OK;
+}
+
+int vox_wgrad(const muvo_conv_desc* d, const float* x, const float* dz, float* dw, float* dbias, hipStream_t st) {
+  const int Z = d->in_sz[2];
+  const bool r4 = d->Cin % 16 == 0;
+  if (Z == 64) return r4 ? launch_vox_wgrad<2, 4, 64, 4>(d, x, dz, dw, dbias, st) : launch_vox_wgrad<2, 2, 64, 4>(d, x, dz, dw, dbias, st);
+  return r4 ? launch_vox_wgrad<2, 4, 32, 8>(d, x, dz, dw, dbias, st) : launch_vox_wgrad<2, 2, 32, 8>(d, x, dz, dw, dbias, st);
+}

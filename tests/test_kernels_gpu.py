@@ -38,6 +38,13 @@ CONV_CASES = [
     (3, False, 40, 20, 3, 1, 1, 0, (3, 3, 1), True, 2),
     (3, False, 8, 2, 1, 1, 0, 0, (6, 6, 4), True, 0),
     (3, False, 6, 8, 3, 1, 1, 0, (8, 8, 4), True, 2),
+    # small-channel Conv3d path (conv_vox.hip: 4x4x1 MFMA fwd/dgrad/wgrad), Z in {64, 32}, ragged X/Y
+    (3, False, 16, 8, 3, 1, 1, 0, (5, 13, 64), True, 2),
+    (3, False, 8, 8, 3, 1, 1, 0, (4, 7, 32), True, 2),
+    (3, False, 32, 16, 3, 1, 1, 0, (3, 9, 32), True, 2),
+    (3, False, 16, 16, 3, 1, 1, 0, (6, 5, 64), False, 0),
+    (3, False, 8, 8, 3, 1, 1, 0, (1, 1, 64), True, 0),
+    (3, False, 16, 8, 3, 1, 1, 0, (19, 12, 32), True, 2),
 ]
 
 
