@@ -45,6 +45,15 @@ typedef struct muvo_conv_desc {
   int32_t ksz[3], stride[3], pad[3], dil[3];
 } muvo_conv_desc;
 
+/* Matrix-pipe arithmetic of the large contractions (process-wide; packed weights depend on it, so repack after a
+ * change).  MUVO_CONV_F32: exact fp32-input MFMA (157 TFLOP/s peak).  MUVO_CONV_BF16X3: every fp32 operand is split
+ * into bf16 hi + lo and each product formed as hi*hi + hi*lo + lo*hi on bf16 MFMA with fp32 accumulation
+ * (3/16 of the fp32-MFMA cost, per-product relative error <= ~1e-5).  Initial value: env MUVO_CONV_MFMA=f32|bf16x3. */
+#define MUVO_CONV_F32 0
+#define MUVO_CONV_BF16X3 1
+#define MUVO_CONV_MODE_DEFAULT MUVO_CONV_F32
+int muvo_conv_set_mode(int mode);
+int muvo_conv_get_mode(void);
 /* sizes (in floats) of the K-major packed weight buffers used by forward/wgrad and by dgrad */
 int muvo_conv_pack_sizes(const muvo_conv_desc* d, int64_t* fwd_floats, int64_t* dgrad_floats);
 /* repack w into wp_fwd and/or wp_dgrad (either may be NULL) */

@@ -1,0 +1,9 @@
+// Internal interface of conv_bf3.hip: the implicit-GEMM convolution on bf16 MFMA with fp32-equivalent split products.
+#pragma once
+#include "conv_plan.h"
+
+// Layout rule of a bf16x3 phase: Cp = roundup(C, 8), Kp = roundup(T*Cp, 32), Mp = roundup(M, 64 or 128).
+void bf3_finish_phase(ConvPhase& g);
+int bf3_pack_phase(const ConvPhase& g, const float* w, float* wp, hipStream_t st);
+int bf3_launch_fwd_phase(const ConvPhase& g, const float* in, const float* wp, const float* bias, float* out, int act,
+                         float slope, hipStream_t st);

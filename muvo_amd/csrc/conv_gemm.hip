@@ -16,34 +16,8 @@
 // (voxel decoder), timm ResNet-18 (mile.py:24,81; common.py:15), layers.py:9-66, common.py:102-130.
 #include "common.h"
 #include "conv_vox.h"
-
-#define MAX_TAPS 64
-
-struct ConvPhase {
-  int N, C, Cp, M, Mp, T, Kp;
-  int ID, IH, IW;   // input spatial dims
-  int OD, OH, OW;   // output spatial dims (full tensor)
-  int SD, SH, SW;   // sub-grid enumerated by this phase
-  int os[3], op[3]; // out coord = i*os + op (z,y,x)
-  int is[3], ib[3]; // in coord0 = i*is + ib
-  int in_sC, out_sC;   // channel strides (elements)
-  long in_sN, out_sN;  // batch strides (elements)
-  int npix;            // N*SD*SH*SW
-  unsigned cp_magic;   // floor(2^32/Cp)+1 : k/Cp for k < 65536
-  int tap_d[MAX_TAPS]; // packed (dz+128)<<16 | (dy+128)<<8 | (dx+128)
-  int tap_w[MAX_TAPS]; // flat tap index into the PyTorch weight (r*S+s ...)
-  long wp_off;         // float offset of this phase inside the packed weight buffer
-  long wsm, wsc;       // PyTorch-weight strides of (m, c)
-};
-
-__device__ __forceinline__ void decode_pix(const ConvPhase& g, int p, int& n, int& iz, int& iy, int& ix) {
-  ix = p % g.SW;
-  int r = p / g.SW;
-  iy = r % g.SH;
-  r = r / g.SH;
-  iz = r % g.SD;
-  n = r / g.SD;
-}
+#include "conv_plan.h"
+#include "conv_bf3.h"
 
 // ------------------------------------------------------------------------------------------------
 // Forward-type kernel.  256 threads = 4 waves arranged WM x WN; each wave owns TM x TN MFMA tiles of
@@ -411,7 +385,36 @@ static int check_desc(const muvo_conv_desc* d) {
 
 static int choose_cp(int C) { return C <= 4 ? 4 : (C <= 8 ? 8 : roundup(C, 16)); }
 
+// 0: exact fp32 MFMA everywhere; 1: bf16x3 split-product MFMA for phases with more than 32 output channels
+static int g_conv_mode = -1;
+static thread_local int t_plan_mode = 0;
+static int conv_mode() {
+  if (g_conv_mode < 0) {
+    const char* e = getenv("MUVO_CONV_MFMA");
+    g_conv_mode = (e && strcmp(e, "f32") == 0) ? 0 : ((e && strcmp(e, "bf16x3") == 0) ? 1 : MUVO_CONV_MODE_DEFAULT);
+  }
+  return g_conv_mode;
+}
+
+static double bf3_min_gflop() {
+  static double v = -1.0;
+  if (v < 0.0) {
+    const char* e = getenv("MUVO_BF16X3_MIN_GFLOP");
+    v = e ? atof(e) : 2.0;
+  }
+  return v;
+}
+
 static void finish_phase(ConvPhase& g) {
+  g.bf3 = 0;
+  // bf16x3 only where it pays: phases with >= MUVO_BF16X3_MIN_GFLOP (default 2) GFLOP of work per batch item, i.e.
+  // the ConvDecoder stacks and the widest DecoderDS conv; the rest (encoders, voxel trunk) stays on exact fp32 MFMA.
+  const double gflop = 2.0 * g.M * g.T * g.C * (double)g.SD * g.SH * g.SW * 1e-9;
+  if (t_plan_mode == 1 && g.M > 32 && (long)g.T * g.C >= 32 && gflop >= bf3_min_gflop()) {
+    g.bf3 = 1;
+    bf3_finish_phase(g);
+    return;
+  }
   g.Cp = choose_cp(g.C);
   g.Mp = roundup(g.M, 32);
   g.Kp = roundup(g.T * g.Cp, 16);
@@ -518,9 +521,10 @@ struct ConvPlan {
   long fwd_floats, dgr_floats;
 };
 
-static int build_plan(const muvo_conv_desc* d, ConvPlan* pl) {
+static int build_plan(const muvo_conv_desc* d, ConvPlan* pl, int mode = -1) {
   int rc = check_desc(d);
   if (rc) return rc;
+  t_plan_mode = mode < 0 ? conv_mode() : mode;
   const long taps = (long)d->ksz[0] * d->ksz[1] * d->ksz[2];
   if (!d->transposed) {
     // weight [Cout][Cin][taps]
@@ -562,6 +566,7 @@ static void launch_fwd_run(const ConvPhase& g, const float* in, const float* wp,
 static int launch_fwd_phase(const ConvPhase& g, const float* in, const float* wp, const float* bias, float* out,
                             int act, float slope, hipStream_t st) {
   if (g.npix <= 0) return MUVO_OK;
+  if (g.bf3) return bf3_launch_fwd_phase(g, in, wp, bias, out, act, slope, st);
   if (g.M > 64) launch_fwd_run<128, 128, 2, 2>(g, in, wp, bias, out, act, slope, st);
   else if (g.M > 32) launch_fwd_run<64, 128, 2, 2>(g, in, wp, bias, out, act, slope, st);
   else launch_fwd_run<32, 128, 1, 4>(g, in, wp, bias, out, act, slope, st);
@@ -593,10 +598,23 @@ static int launch_wgrad_phase(const ConvPhase& g, const float* in, const float* 
 
 extern "C" {
 
+int muvo_conv_set_mode(int mode) {
+  MUVO_CHECK_ARG(mode == MUVO_CONV_F32 || mode == MUVO_CONV_BF16X3, "conv_set_mode: unknown mode %d", mode);
+  g_conv_mode = mode;
+  return MUVO_OK;
+}
+int muvo_conv_get_mode(void) { return conv_mode(); }
+
 int muvo_conv_pack_sizes(const muvo_conv_desc* d, int64_t* fwd_floats, int64_t* dgrad_floats) {
   ConvPlan pl;
   int rc = build_plan(d, &pl);
   if (rc) return rc;
+  {  // wgrad always runs on the fp32-layout plan and uses fwd_floats of scratch
+    ConvPlan pf;
+    rc = build_plan(d, &pf, 0);
+    if (rc) return rc;
+    if (pf.fwd_floats > pl.fwd_floats) pl.fwd_floats = pf.fwd_floats;
+  }
   // the small-channel Conv3d path (conv_vox.hip) keeps its own layout in the same buffers
   if (vox_fwd_applicable(d) && vox_pack_floats(d) > pl.fwd_floats) pl.fwd_floats = vox_pack_floats(d);
   if (vox_dgrad_applicable(d) && vox_pack_floats(d) > pl.dgr_floats) pl.dgr_floats = vox_pack_floats(d);
@@ -625,12 +643,22 @@ int muvo_conv_pack_weights(const muvo_conv_desc* d, const float* w, float* wp_fw
     for (int i = 0; i < pl.nfwd; ++i) {
       const long total = (long)pl.fwd[i].Kp * pl.fwd[i].Mp;
       if (total == 0) continue;
+      if (pl.fwd[i].bf3) {
+        rc = bf3_pack_phase(pl.fwd[i], w, wp_fwd, st);
+        if (rc) return rc;
+        continue;
+      }
       hipLaunchKernelGGL(pack_weights_kernel, dim3(ew_grid(total)), dim3(256), 0, st, pl.fwd[i], w, wp_fwd);
     }
   if (wp_dgrad)
     for (int i = 0; i < pl.ndgr; ++i) {
       const long total = (long)pl.dgr[i].Kp * pl.dgr[i].Mp;
       if (total == 0) continue;
+      if (pl.dgr[i].bf3) {
+        rc = bf3_pack_phase(pl.dgr[i], w, wp_dgrad, st);
+        if (rc) return rc;
+        continue;
+      }
       hipLaunchKernelGGL(pack_weights_kernel, dim3(ew_grid(total)), dim3(256), 0, st, pl.dgr[i], w, wp_dgrad);
     }
   MUVO_CHECK_LAUNCH("pack_weights_kernel");

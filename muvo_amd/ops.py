@@ -42,7 +42,7 @@ class GemmDesc(C.Structure):
 # every exported symbol of include/muvo_hip.h (tests/test_abi.py checks this list against the header)
 EXPORTS = [
     'muvo_last_error', 'muvo_abi_version', 'muvo_selftest_mfma',
-    'muvo_conv_pack_sizes', 'muvo_conv_pack_weights', 'muvo_conv_forward', 'muvo_conv_dgrad', 'muvo_conv_wgrad', 'muvo_bias_grad_nchw',
+    'muvo_conv_set_mode', 'muvo_conv_get_mode', 'muvo_conv_pack_sizes', 'muvo_conv_pack_weights', 'muvo_conv_forward', 'muvo_conv_dgrad', 'muvo_conv_wgrad', 'muvo_bias_grad_nchw',
     'muvo_gemm',
     'muvo_bn_train_fwd', 'muvo_bn_train_bwd', 'muvo_adain_fwd', 'muvo_adain_bwd',
     'muvo_add_dropout_layernorm_fwd', 'muvo_add_dropout_layernorm_bwd',
@@ -110,6 +110,24 @@ _weight_epoch = [0]
 def bump_weight_epoch():
     """Call after parameters were modified outside torch (the fused AdamW kernel) to invalidate packed weights."""
     _weight_epoch[0] += 1
+
+
+CONV_F32, CONV_BF16X3 = 0, 1
+
+
+def set_conv_mode(mode):
+    """Select the matrix-pipe arithmetic of the large convolutions (CONV_F32 exact / CONV_BF16X3 split products).
+    Packed weights and plans depend on it, so both caches are invalidated."""
+    _ck(lib().muvo_conv_set_mode(int(mode)))
+    bump_weight_epoch()
+    _plan_epoch[0] += 1
+
+
+def get_conv_mode():
+    return lib().muvo_conv_get_mode()
+
+
+_plan_epoch = [0]
 
 
 def grad_of(p):
@@ -280,7 +298,7 @@ class ConvGeom:
         return tuple(o)
 
     def plan(self, n, in_sz):
-        key = (n, in_sz)
+        key = (n, in_sz, _plan_epoch[0])
         pl = self._plans.get(key)
         if pl is None:
             out_sz = self.out_size(in_sz)

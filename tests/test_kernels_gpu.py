@@ -48,8 +48,18 @@ CONV_CASES = [
 ]
 
 
+@pytest.fixture(params=['f32', 'bf16x3'])
+def conv_mode(request):
+    """Both matrix-pipe arithmetics of the conv family: exact fp32 MFMA and the bf16x3 split-product kernel."""
+    from muvo_amd import ops
+    old = ops.get_conv_mode()
+    ops.set_conv_mode(ops.CONV_BF16X3 if request.param == 'bf16x3' else ops.CONV_F32)
+    yield request.param
+    ops.set_conv_mode(old)
+
+
 @pytest.mark.parametrize('case', CONV_CASES, ids=[str(i) for i in range(len(CONV_CASES))])
-def test_conv_family(dev, case):
+def test_conv_family(dev, case, conv_mode):
     from muvo_amd import nn as hnn
     from muvo_amd import ops
     nd, transposed, cin, cout, k, stride, pad, out_pad, in_sz, bias, act = case
