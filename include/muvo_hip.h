@@ -54,15 +54,21 @@ typedef struct muvo_conv_desc {
 #define MUVO_CONV_MODE_DEFAULT MUVO_CONV_F32
 int muvo_conv_set_mode(int mode);
 int muvo_conv_get_mode(void);
+/* In MUVO_CONV_BF16X3 mode only phases with at least this much work per batch item (GFLOP, 2*MAC) use the split-product
+ * kernel; smaller ones stay on exact fp32 MFMA.  Initial value: env MUVO_BF16X3_MIN_GFLOP, default 2.0. */
+int muvo_conv_set_bf16x3_min_gflop(double gflop_per_item);
 /* sizes (in floats) of the K-major packed weight buffers used by forward/wgrad and by dgrad */
 int muvo_conv_pack_sizes(const muvo_conv_desc* d, int64_t* fwd_floats, int64_t* dgrad_floats);
 /* repack w into wp_fwd and/or wp_dgrad (either may be NULL) */
 int muvo_conv_pack_weights(const muvo_conv_desc* d, const float* w, float* wp_fwd, float* wp_dgrad, void* stream);
-/* y = act(conv(x, w) + bias); bias may be NULL */
+/* bytes of workspace `ws` that forward (op 0) / dgrad (op 1) need for this shape in the current mode (0 = none; the
+ * bf16x3 kernel reads a channels-last bf16 hi/lo copy of its activation operand that it writes there first) */
+int64_t muvo_conv_workspace_bytes(const muvo_conv_desc* d, int op);
+/* y = act(conv(x, w) + bias); bias may be NULL; ws may be NULL when muvo_conv_workspace_bytes(d, 0) == 0 */
 int muvo_conv_forward(const muvo_conv_desc* d, const float* x, const float* wp_fwd, const float* bias, float* y, int act,
-                      float slope, void* stream);
+                      float slope, void* ws, void* stream);
 /* dx = conv_data_grad(dy, w) (dy already multiplied by act'(y) by the caller) */
-int muvo_conv_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp_dgrad, float* dx, void* stream);
+int muvo_conv_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp_dgrad, float* dx, void* ws, void* stream);
 /* dw += conv_weight_grad(x, dy) (PyTorch layout); dbias += sum(dy) if non-NULL.
  * dwp_scratch: fwd_floats floats of workspace (overwritten). */
 int muvo_conv_wgrad(const muvo_conv_desc* d, const float* x, const float* dy, float* dwp_scratch, float* dw, float* dbias,

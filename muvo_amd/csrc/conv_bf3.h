@@ -5,5 +5,8 @@
 // Layout rule of a bf16x3 phase: Cp = roundup(C, 8), Kp = roundup(T*Cp, 32), Mp = roundup(M, 64 or 128).
 void bf3_finish_phase(ConvPhase& g);
 int bf3_pack_phase(const ConvPhase& g, const float* w, float* wp, hipStream_t st);
-int bf3_launch_fwd_phase(const ConvPhase& g, const float* in, const float* wp, const float* bias, float* out, int act,
+// workspace = channels-last bf16 hi/lo copy of the activation operand (N*S*roundup(C,8)*4 bytes)
+long bf3_workspace_bytes(int N, int C, long S);
+int bf3_split_input(const float* x, void* ws, int N, int C, long S, hipStream_t st);
+int bf3_launch_fwd_phase(const ConvPhase& g, const void* ws, const float* wp, const float* bias, float* out, int act,
                          float slope, hipStream_t st);

@@ -29,34 +29,82 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigne
   lo = __builtin_bit_cast(unsigned, l);
 }
 
-template <int BM, int BN>
-__global__ void __launch_bounds__(256)
-conv_bf3_kernel(const ConvPhase g, const float* __restrict__ in, const uint4* __restrict__ wp,
-                const float* __restrict__ bias, float* __restrict__ out, int act, float slope) {
-  constexpr int BK = 32;
-  constexpr int TM = BM / 64, TN = BN / 64;       // 2x2 waves, 32x32 MFMA tiles per wave
-  constexpr int NA = 8 * BM / 256;                // uint4 copies of the A tile per thread (2 planes x 4 chunks x BM rows)
-  constexpr int KG = 256 / BN;                    // k groups of the gather (2 for BN = 128)
-  constexpr int CPT = 4 / KG;                     // 8-wide k chunks per thread per tile
-  constexpr int STAGE = 8 * (BM + BN);            // uint4 per stage
-  extern __shared__ uint4 smem[];                 // 2 stages + the tap table (64 KB + 256 B: dynamic LDS)
-  int* s_tap = (int*)(smem + 2 * STAGE);
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+// one wave-wide LDS-DMA: lane l copies 16 bytes from its own global address to (wave-uniform lds) + 16*l
+__device__ __forceinline__ void dma16(const uint4* g, uint4* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
+}
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  if (tid < MAX_TAPS) s_tap[tid] = g.tap_d[tid < g.T ? tid : 0];
+// Activation operand: xs = bf16 hi plane, xs + plane_u4 = lo plane, each [N][ID][IH][IW][Cp] (channels-last, written by
+// nchw_split_nhwc_kernel), so 8 consecutive k of one pixel are 16 contiguous bytes and both operands are staged by
+// LDS-DMA with no register round trip and no conversion work in this kernel.
+//
+// Workgroup = WM x WN waves, each owning a 64x64 output tile (2x2 MFMA tiles of 32x32).  K loop: BK = 32 per step,
+// three LDS stages; the DMA of steps k+1 and k+2 stays in flight across the (raw) barrier of step k — each wave waits
+// only for its own copies of step k with a counted vmcnt before the barrier.
+template <int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(64 * WM * WN)
+conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, const uint4* __restrict__ wp,
+                const float* __restrict__ bias, float* __restrict__ out, int act, float slope,
+                const uint4* __restrict__ zero16) {
+  constexpr int BK = 32, NW = WM * WN;
+  constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+  static_assert(TM == 2 && TN == 2, "each wave owns 64x64");
+  constexpr int STAGE = 8 * (BM + BN);            // uint4 per stage: [plane][chunk][BM] then [plane][chunk][BN]
+  constexpr int RG = BM / 64, NG = BN / 64;       // 64-row groups of A, 64-pixel groups of B
+  constexpr int APW = 8 * RG / NW;                // A copies (wave instructions) per wave per step
+  constexpr int CPW = 8 * NG / NW;                // B (plane,chunk) combos per wave per step
+  static_assert(APW * NW == 8 * RG && CPW * NW == 8 * NG && NW % NG == 0, "DMA roles must tile");
+  constexpr int DMA_PER_STEP = APW + CPW;
+  extern __shared__ uint4 smem[];                 // 3 stages
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
 
-  const int pl = tid % BN;
-  const int kg = __builtin_amdgcn_readfirstlane(tid / BN);
-  const int p = blockIdx.x * BN + pl;
+  // ---- B (activation) DMA role of this wave: pixel group (wave % NG), combos [(wave / NG) * CPW, +CPW)
+  const int bgroup = wave % NG, bcombo0 = (wave / NG) * CPW;
+  const int p = blockIdx.x * BN + bgroup * 64 + lane;
   const bool pvalid = p < g.npix;
   int n, iz, iy, ix;
   decode_pix(g, pvalid ? p : 0, n, iz, iy, ix);
   const int z0 = iz * g.is[0] + g.ib[0], y0 = iy * g.is[1] + g.ib[1], x0 = ix * g.is[2] + g.ib[2];
-  const float* inb = in + (size_t)n * g.in_sN;
+  const int cp8 = g.Cp >> 3;
+  const uint4* xn = xs + (size_t)n * g.ID * g.IH * g.IW * cp8;
   const int m_tile = blockIdx.y * BM;
   const uint4* wpb = wp + g.wp_off / 4 + m_tile;   // wp_off is in floats; one uint4 = 8 bf16 = 4 floats
   const int nk = g.Kp / BK;
+
+  auto issue = [&](int kt, int stage) {
+    uint4* S = smem + stage * STAGE;
+#pragma unroll
+    for (int q = 0; q < APW; ++q) {
+      const int a = wave * APW + q;
+      const int pc = a / RG, rg = a % RG;
+      dma16(wpb + (size_t)(kt * 8 + pc) * g.Mp + rg * 64 + lane, S + pc * BM + rg * 64);
+    }
+    int t_prev = -1;
+    const uint4* src_tap = zero16;   // lane's source for chunk 0 of the current tap (zero16 when out of bounds)
+    bool ok = false;
+#pragma unroll
+    for (int q = 0; q < CPW; ++q) {
+      const int combo = bcombo0 + q;               // plane * 4 + chunk
+      const int plane = combo >> 2, ch = combo & 3;
+      const int k0 = kt * BK + ch * 8;             // wave-uniform
+      const int t = (int)(((unsigned long long)(unsigned)k0 * g.cp_magic) >> 32);
+      const int c8 = (k0 - t * g.Cp) >> 3;
+      if (t != t_prev) {                           // uniform: tap geometry only when the tap changes
+        t_prev = t;
+        const int d = g.tap_d[t < g.T ? t : 0];
+        const int z = z0 + ((d >> 16) & 255) - 128, y = y0 + ((d >> 8) & 255) - 128, x = x0 + (d & 255) - 128;
+        ok = pvalid && t < g.T && (unsigned)z < (unsigned)g.ID && (unsigned)y < (unsigned)g.IH &&
+             (unsigned)x < (unsigned)g.IW;
+        src_tap = xn + (size_t)((z * g.IH + y) * g.IW + x) * cp8;
+      }
+      const uint4* src = ok ? src_tap + (size_t)plane * plane_u4 + c8 : zero16;
+      dma16(src, S + 8 * BM + combo * BN + bgroup * 64);
+    }
+  };
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -66,66 +114,24 @@ conv_bf3_kernel(const ConvPhase g, const float* __restrict__ in, const uint4* __
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  uint4 areg[NA];
-  float breg[CPT][8];
+  // s_waitcnt immediates (gfx9 encoding): vmcnt in bits [3:0] and [15:14], expcnt [6:4] = 7, lgkmcnt [11:8] = 15
+  constexpr int WAIT_ONE_STEP_IN_FLIGHT = (DMA_PER_STEP & 15) | ((DMA_PER_STEP >> 4) << 14) | (7 << 4) | (15 << 8);
+  constexpr int WAIT_ALL = (7 << 4) | (15 << 8);
 
-  auto load_tile = [&](int kt) {
-#pragma unroll
-    for (int r = 0; r < NA; ++r) {
-      const int idx = tid + r * 256;
-      const int pc = idx / BM, m = idx % BM;         // pc = plane*4 + chunk
-      areg[r] = wpb[(size_t)(kt * 8 + pc) * g.Mp + m];
-    }
-#pragma unroll
-    for (int cc = 0; cc < CPT; ++cc) {
-      const int k0 = kt * BK + (kg * CPT + cc) * 8;  // wave-uniform
-      const int t = (int)(((unsigned long long)(unsigned)k0 * g.cp_magic) >> 32);
-      const int c0 = k0 - t * g.Cp;
-      const int d = s_tap[t < g.T ? t : 0];
-      const int z = z0 + ((d >> 16) & 255) - 128, y = y0 + ((d >> 8) & 255) - 128, x = x0 + (d & 255) - 128;
-      const bool ok = pvalid && t < g.T && (unsigned)z < (unsigned)g.ID && (unsigned)y < (unsigned)g.IH &&
-                      (unsigned)x < (unsigned)g.IW;
-      const int off = (z * g.IH + y) * g.IW + x;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float v = 0.f;
-        if (ok && c0 + e < g.C) v = inb[(size_t)(c0 + e) * g.in_sC + off];
-        breg[cc][e] = v;
-      }
-    }
-  };
-  auto store_tile = [&](int buf) {
-    uint4* S = smem + buf * STAGE;
-#pragma unroll
-    for (int r = 0; r < NA; ++r) S[tid + r * 256] = areg[r];   // [plane][chunk][BM]
-    uint4* Bh = S + 8 * BM;                                     // [chunk][BN] hi, then lo
-    uint4* Bl = Bh + 4 * BN;
-#pragma unroll
-    for (int cc = 0; cc < CPT; ++cc) {
-      uint4 h, l;
-      split2(breg[cc][0], breg[cc][1], h.x, l.x);
-      split2(breg[cc][2], breg[cc][3], h.y, l.y);
-      split2(breg[cc][4], breg[cc][5], h.z, l.z);
-      split2(breg[cc][6], breg[cc][7], h.w, l.w);
-      const int chunk = kg * CPT + cc;
-      Bh[chunk * BN + pl] = h;
-      Bl[chunk * BN + pl] = l;
-    }
-  };
-
-  __syncthreads();  // s_tap
-  if (nk > 0) {
-    load_tile(0);
-    store_tile(0);
-  }
-  __syncthreads();
+  if (nk > 0) issue(0, 0);
+  if (nk > 1) issue(1, 1);
+  int stage = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);
-    const uint4* S = smem + buf * STAGE;
-    const uint4* Ah = S + wm * (TM * 32) + (lane & 31);
+    // this wave's copies of step kt have landed (those of step kt+1 may still be in flight) ...
+    if (kt + 1 < nk) __builtin_amdgcn_s_waitcnt(WAIT_ONE_STEP_IN_FLIGHT);
+    else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
+    // ... and after the barrier everybody's have, and everybody finished reading the stage step kt+2 goes into
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) issue(kt + 2, stage == 0 ? 2 : stage - 1);
+    const uint4* S = smem + stage * STAGE;
+    const uint4* Ah = S + wm * 64 + (lane & 31);
     const uint4* Al = Ah + 4 * BM;
-    const uint4* Bh = S + 8 * BM + wn * (TN * 32) + (lane & 31);
+    const uint4* Bh = S + 8 * BM + wn * 64 + (lane & 31);
     const uint4* Bl = Bh + 4 * BN;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -150,14 +156,13 @@ conv_bf3_kernel(const ConvPhase g, const float* __restrict__ in, const uint4* __
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
-    if (kt + 1 < nk) store_tile(buf ^ 1);
-    __syncthreads();
+    stage = stage == 2 ? 0 : stage + 1;
   }
 
   // epilogue: bias + activation, coalesced along pixels (MFMA column = lane & 31)
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int pj = blockIdx.x * BN + wn * (TN * 32) + j * 32 + (lane & 31);
+    const int pj = blockIdx.x * BN + wn * 64 + j * 32 + (lane & 31);
     if (pj >= g.npix) continue;
     int nn, jz, jy, jx;
     decode_pix(g, pj, nn, jz, jy, jx);
@@ -168,7 +173,7 @@ conv_bf3_kernel(const ConvPhase g, const float* __restrict__ in, const uint4* __
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m_tile + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int m = m_tile + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (m < g.M) {
           float v = acc[i][j][r];
           if (bias) v += bias[m];
@@ -178,6 +183,43 @@ conv_bf3_kernel(const ConvPhase g, const float* __restrict__ in, const uint4* __
     }
   }
 }
+
+// fp32 NCHW [N][C][S] -> bf16 hi / lo planes, channels-last [N][S][Cp] (Cp = roundup(C, 8), zero padded)
+__global__ void __launch_bounds__(256)
+nchw_split_nhwc_kernel(const float* __restrict__ in, uint4* __restrict__ out_hi, uint4* __restrict__ out_lo, int C, int Cp,
+                       long S) {
+  __shared__ __attribute__((aligned(16))) unsigned short th[64][72], tl[64][72];
+  const int tid = threadIdx.x;
+  const long s0 = (long)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64, n = blockIdx.z;
+  const int pl = tid & 63;
+#pragma unroll 4
+  for (int r = 0; r < 16; ++r) {
+    const int cl = (tid >> 6) + 4 * r, c = c0 + cl;
+    const long s = s0 + pl;
+    float v = 0.f;
+    if (c < C && s < S) v = in[((size_t)n * C + c) * S + s];
+    unsigned hi, lo;
+    split2(v, 0.f, hi, lo);
+    th[pl][cl] = (unsigned short)hi;
+    tl[pl][cl] = (unsigned short)lo;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int item = tid + 256 * r;
+    const int pix = item >> 3, ch = item & 7;
+    const long s = s0 + pix;
+    const int c = c0 + ch * 8;
+    if (s < S && c < Cp) {
+      const size_t o = (((size_t)n * S + s) * Cp + c) >> 3;
+      out_hi[o] = *(const uint4*)&th[pix][ch * 8];
+      out_lo[o] = *(const uint4*)&tl[pix][ch * 8];
+    }
+  }
+}
+
+__device__ uint4 g_zero16 = {0u, 0u, 0u, 0u};
 
 // wp16[(((kt*2 + plane)*4 + chunk)*Mp + m)*8 + k%8] = split(W[m][c][tap_w[t]]),  k = t*Cp + c = kt*32 + chunk*8 + k%8
 __global__ void __launch_bounds__(256) bf3_pack_kernel(const ConvPhase g, const float* __restrict__ w,
@@ -203,7 +245,7 @@ __global__ void __launch_bounds__(256) bf3_pack_kernel(const ConvPhase g, const 
 
 void bf3_finish_phase(ConvPhase& g) {
   g.Cp = roundup(g.C, 8);
-  g.Mp = g.M > 64 ? roundup(g.M, 128) : 64;
+  g.Mp = g.M > 128 ? roundup(g.M, 256) : (g.M > 64 ? 128 : 64);
   g.Kp = roundup(g.T * g.Cp, 32);
   g.cp_magic = (unsigned)((0x100000000ull / (unsigned)g.Cp) + 1ull);
   g.npix = g.N * g.SD * g.SH * g.SW;
@@ -217,28 +259,45 @@ int bf3_pack_phase(const ConvPhase& g, const float* w, float* wp, hipStream_t st
   return MUVO_OK;
 }
 
-template <int BM, int BN>
-static int bf3_launch(const ConvPhase& g, const float* in, const float* wp, const float* bias, float* out, int act,
+long bf3_workspace_bytes(int N, int C, long S) { return (long)N * S * roundup(C, 8) * 4; }
+
+int bf3_split_input(const float* x, void* ws, int N, int C, long S, hipStream_t st) {
+  const int Cp = roundup(C, 8);
+  uint4* hi = (uint4*)ws;
+  uint4* lo = hi + (size_t)N * S * Cp / 8;
+  dim3 grid(cdiv(S, 64), cdiv(Cp, 64), N);
+  hipLaunchKernelGGL(nchw_split_nhwc_kernel, grid, dim3(256), 0, st, x, hi, lo, C, Cp, S);
+  MUVO_CHECK_LAUNCH("nchw_split_nhwc_kernel");
+  return MUVO_OK;
+}
+
+template <int BM, int BN, int WM, int WN>
+static int bf3_launch(const ConvPhase& g, const void* ws, const float* wp, const float* bias, float* out, int act,
                       float slope, hipStream_t st) {
-  constexpr size_t lds = (size_t)2 * 8 * (BM + BN) * 16 + MAX_TAPS * sizeof(int);
+  constexpr size_t lds = (size_t)3 * 8 * (BM + BN) * 16;
   static bool attr_set = false;
+  static const uint4* zero16 = nullptr;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv_bf3_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-        hipSuccess) {
-      muvo_set_error("conv_bf3: cannot raise the dynamic LDS limit to %zu bytes", lds);
+    if (hipFuncSetAttribute((const void*)conv_bf3_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess ||
+        hipGetSymbolAddress((void**)&zero16, HIP_SYMBOL(g_zero16)) != hipSuccess) {
+      muvo_set_error("conv_bf3: kernel attribute / symbol setup failed");
       return MUVO_ERR_HIP;
     }
     attr_set = true;
   }
+  const long plane_u4 = (long)g.N * g.ID * g.IH * g.IW * (g.Cp / 8);
   dim3 grid(cdiv(g.npix, BN), cdiv(g.M, BM), 1);
-  hipLaunchKernelGGL((conv_bf3_kernel<BM, BN>), grid, dim3(256), lds, st, g, in, (const uint4*)wp, bias, out, act, slope);
+  hipLaunchKernelGGL((conv_bf3_kernel<BM, BN, WM, WN>), grid, dim3(64 * WM * WN), lds, st, g, (const uint4*)ws, plane_u4,
+                     (const uint4*)wp, bias, out, act, slope, zero16);
   MUVO_CHECK_LAUNCH("conv_bf3_kernel");
   return MUVO_OK;
 }
 
-int bf3_launch_fwd_phase(const ConvPhase& g, const float* in, const float* wp, const float* bias, float* out, int act,
+int bf3_launch_fwd_phase(const ConvPhase& g, const void* ws, const float* wp, const float* bias, float* out, int act,
                          float slope, hipStream_t st) {
   if (g.npix <= 0) return MUVO_OK;
-  if (g.M > 64) return bf3_launch<128, 128>(g, in, wp, bias, out, act, slope, st);
-  return bf3_launch<64, 128>(g, in, wp, bias, out, act, slope, st);
+  if (g.M > 128) return bf3_launch<256, 128, 4, 2>(g, ws, wp, bias, out, act, slope, st);
+  if (g.M > 64) return bf3_launch<128, 256, 2, 4>(g, ws, wp, bias, out, act, slope, st);
+  return bf3_launch<64, 256, 1, 4>(g, ws, wp, bias, out, act, slope, st);
 }

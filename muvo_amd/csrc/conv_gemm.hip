@@ -396,8 +396,9 @@ static int conv_mode() {
   return g_conv_mode;
 }
 
+static double g_bf3_min_gflop = -1.0;
 static double bf3_min_gflop() {
-  static double v = -1.0;
+  double& v = g_bf3_min_gflop;
   if (v < 0.0) {
     const char* e = getenv("MUVO_BF16X3_MIN_GFLOP");
     v = e ? atof(e) : 2.0;
@@ -564,9 +565,9 @@ static void launch_fwd_run(const ConvPhase& g, const float* in, const float* wp,
 }
 
 static int launch_fwd_phase(const ConvPhase& g, const float* in, const float* wp, const float* bias, float* out,
-                            int act, float slope, hipStream_t st) {
+                            int act, float slope, hipStream_t st, const void* ws) {
   if (g.npix <= 0) return MUVO_OK;
-  if (g.bf3) return bf3_launch_fwd_phase(g, in, wp, bias, out, act, slope, st);
+  if (g.bf3) return bf3_launch_fwd_phase(g, ws, wp, bias, out, act, slope, st);
   if (g.M > 64) launch_fwd_run<128, 128, 2, 2>(g, in, wp, bias, out, act, slope, st);
   else if (g.M > 32) launch_fwd_run<64, 128, 2, 2>(g, in, wp, bias, out, act, slope, st);
   else launch_fwd_run<32, 128, 1, 4>(g, in, wp, bias, out, act, slope, st);
@@ -604,6 +605,11 @@ int muvo_conv_set_mode(int mode) {
   return MUVO_OK;
 }
 int muvo_conv_get_mode(void) { return conv_mode(); }
+int muvo_conv_set_bf16x3_min_gflop(double gflop_per_item) {
+  MUVO_CHECK_ARG(gflop_per_item >= 0.0, "conv_set_bf16x3_min_gflop: negative threshold");
+  g_bf3_min_gflop = gflop_per_item;
+  return MUVO_OK;
+}
 
 int muvo_conv_pack_sizes(const muvo_conv_desc* d, int64_t* fwd_floats, int64_t* dgrad_floats) {
   ConvPlan pl;
@@ -665,31 +671,52 @@ int muvo_conv_pack_weights(const muvo_conv_desc* d, const float* w, float* wp_fw
   return MUVO_OK;
 }
 
-int muvo_conv_forward(const muvo_conv_desc* d, const float* x, const float* wp_fwd, const float* bias, float* y,
-                      int act, float slope, void* stream) {
+// bytes of caller-provided workspace needed by forward (op 0) / dgrad (op 1): the channels-last bf16 hi/lo copy of the
+// activation operand when a phase of that direction runs on the bf16x3 kernel, else 0
+int64_t muvo_conv_workspace_bytes(const muvo_conv_desc* d, int op) {
   ConvPlan pl;
-  int rc = build_plan(d, &pl);
-  if (rc) return rc;
-  MUVO_CHECK_ARG(x && wp_fwd && y, "conv_forward: null pointer");
-  if (vox_fwd_applicable(d)) return vox_forward(d, x, wp_fwd, bias, y, act, slope, (hipStream_t)stream);
-  for (int i = 0; i < pl.nfwd; ++i) {
-    rc = launch_fwd_phase(pl.fwd[i], x, wp_fwd, bias, y, act, slope, (hipStream_t)stream);
+  if (build_plan(d, &pl)) return -1;
+  const ConvPhase* ph = op == 0 ? pl.fwd : pl.dgr;
+  const int nph = op == 0 ? pl.nfwd : pl.ndgr;
+  if (op == 0 ? vox_fwd_applicable(d) : vox_dgrad_applicable(d)) return 0;
+  for (int i = 0; i < nph; ++i)
+    if (ph[i].bf3) return bf3_workspace_bytes(ph[i].N, ph[i].C, (long)ph[i].ID * ph[i].IH * ph[i].IW);
+  return 0;
+}
+
+static int run_phases(const ConvPhase* ph, int nph, const float* in, const float* wp, const float* bias, float* out, int act,
+                      float slope, void* ws, hipStream_t st) {
+  bool split_done = false;
+  for (int i = 0; i < nph; ++i) {
+    if (ph[i].bf3 && !split_done) {
+      MUVO_CHECK_ARG(ws != nullptr, "conv: this shape runs on the bf16x3 kernel and needs muvo_conv_workspace_bytes() of workspace");
+      int rc = bf3_split_input(in, ws, ph[i].N, ph[i].C, (long)ph[i].ID * ph[i].IH * ph[i].IW, st);
+      if (rc) return rc;
+      split_done = true;
+    }
+    int rc = launch_fwd_phase(ph[i], in, wp, bias, out, act, slope, st, ws);
     if (rc) return rc;
   }
   return MUVO_OK;
 }
 
-int muvo_conv_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp_dgrad, float* dx, void* stream) {
+int muvo_conv_forward(const muvo_conv_desc* d, const float* x, const float* wp_fwd, const float* bias, float* y,
+                      int act, float slope, void* ws, void* stream) {
+  ConvPlan pl;
+  int rc = build_plan(d, &pl);
+  if (rc) return rc;
+  MUVO_CHECK_ARG(x && wp_fwd && y, "conv_forward: null pointer");
+  if (vox_fwd_applicable(d)) return vox_forward(d, x, wp_fwd, bias, y, act, slope, (hipStream_t)stream);
+  return run_phases(pl.fwd, pl.nfwd, x, wp_fwd, bias, y, act, slope, ws, (hipStream_t)stream);
+}
+
+int muvo_conv_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp_dgrad, float* dx, void* ws, void* stream) {
   ConvPlan pl;
   int rc = build_plan(d, &pl);
   if (rc) return rc;
   MUVO_CHECK_ARG(dy && wp_dgrad && dx, "conv_dgrad: null pointer");
   if (vox_dgrad_applicable(d)) return vox_dgrad(d, dy, wp_dgrad, dx, (hipStream_t)stream);
-  for (int i = 0; i < pl.ndgr; ++i) {
-    rc = launch_fwd_phase(pl.dgr[i], dy, wp_dgrad, nullptr, dx, MUVO_ACT_NONE, 0.f, (hipStream_t)stream);
-    if (rc) return rc;
-  }
-  return MUVO_OK;
+  return run_phases(pl.dgr, pl.ndgr, dy, wp_dgrad, nullptr, dx, MUVO_ACT_NONE, 0.f, ws, (hipStream_t)stream);
 }
 
 // dw (PyTorch layout) += grad;  dbias += sum(dy).  dwp_scratch: fwd_floats floats of workspace.

@@ -42,7 +42,7 @@ class GemmDesc(C.Structure):
 # every exported symbol of include/muvo_hip.h (tests/test_abi.py checks this list against the header)
 EXPORTS = [
     'muvo_last_error', 'muvo_abi_version', 'muvo_selftest_mfma',
-    'muvo_conv_set_mode', 'muvo_conv_get_mode', 'muvo_conv_pack_sizes', 'muvo_conv_pack_weights', 'muvo_conv_forward', 'muvo_conv_dgrad', 'muvo_conv_wgrad', 'muvo_bias_grad_nchw',
+    'muvo_conv_set_mode', 'muvo_conv_get_mode', 'muvo_conv_set_bf16x3_min_gflop', 'muvo_conv_pack_sizes', 'muvo_conv_workspace_bytes', 'muvo_conv_pack_weights', 'muvo_conv_forward', 'muvo_conv_dgrad', 'muvo_conv_wgrad', 'muvo_bias_grad_nchw',
     'muvo_gemm',
     'muvo_bn_train_fwd', 'muvo_bn_train_bwd', 'muvo_adain_fwd', 'muvo_adain_bwd',
     'muvo_add_dropout_layernorm_fwd', 'muvo_add_dropout_layernorm_bwd',
@@ -69,6 +69,7 @@ def lib():
                                        '(there is no fallback path)')
                 L = C.CDLL(_LIB_PATH)
                 L.muvo_last_error.restype = C.c_char_p
+                L.muvo_conv_workspace_bytes.restype = C.c_int64
                 for name in EXPORTS:
                     getattr(L, name)  # AttributeError if a declared symbol is missing
                 _lib = L
@@ -115,10 +116,13 @@ def bump_weight_epoch():
 CONV_F32, CONV_BF16X3 = 0, 1
 
 
-def set_conv_mode(mode):
-    """Select the matrix-pipe arithmetic of the large convolutions (CONV_F32 exact / CONV_BF16X3 split products).
-    Packed weights and plans depend on it, so both caches are invalidated."""
+def set_conv_mode(mode, min_gflop=None):
+    """Select the matrix-pipe arithmetic of the large convolutions (CONV_F32 exact / CONV_BF16X3 split products;
+    min_gflop = per-item work below which a phase stays on fp32 MFMA).  Packed weights and plans depend on it, so both
+    caches are invalidated."""
     _ck(lib().muvo_conv_set_mode(int(mode)))
+    if min_gflop is not None:
+        _ck(lib().muvo_conv_set_bf16x3_min_gflop(C.c_double(min_gflop)))
     bump_weight_epoch()
     _plan_epoch[0] += 1
 
@@ -286,6 +290,7 @@ class ConvGeom:
             self.dil = (1,) + self.dil[1:]
         self.pad, self.out_pad = p, op
         self._plans = {}
+        self.ws_bytes = {}
 
     def out_size(self, in_sz):
         o = []
@@ -307,6 +312,10 @@ class ConvGeom:
                          (C.c_int32 * 3)(*self.pad), (C.c_int32 * 3)(*self.dil))
             ff, df = C.c_int64(0), C.c_int64(0)
             _ck(lib().muvo_conv_pack_sizes(C.byref(d), C.byref(ff), C.byref(df)))
+            wsf, wsd = (lib().muvo_conv_workspace_bytes(C.byref(d), op) for op in (0, 1))
+            if wsf < 0 or wsd < 0:
+                raise RuntimeError(f'muvo_hip error: {lib().muvo_last_error().decode()}')
+            self.ws_bytes[(n, in_sz, _plan_epoch[0])] = (wsf, wsd)
             pl = (d, out_sz, ff.value, df.value)
             self._plans[key] = pl
         return pl
@@ -347,7 +356,9 @@ class ConvFn(torch.autograd.Function):
             e0, e1 = kt.bracket('conv_fwd_kernel(fwd)', _conv_flops(geom, n, in_sz, out_sz),
                                 math.prod(geom.stride) if geom.transposed else 1, _conv_tag(geom, n, in_sz))
             e0.record()
-        _ck(L.muvo_conv_forward(C.byref(d), _f(x), _f(packed.fwd), _f(bias), _f(y), act, _fl(slope), _st()))
+        wsb = geom.ws_bytes[(n, in_sz, _plan_epoch[0])][0]
+        ws = scratch('conv_ws', (wsb + 3) // 4, x.device) if wsb else None
+        _ck(L.muvo_conv_forward(C.byref(d), _f(x), _f(packed.fwd), _f(bias), _f(y), act, _fl(slope), _p(ws), _st()))
         if kt is not None:
             e1.record()
         ctx.geom, ctx.packed, ctx.act, ctx.slope = geom, packed, act, slope
@@ -383,7 +394,9 @@ class ConvFn(torch.autograd.Function):
                 e0, e1 = kt.bracket('conv_fwd_kernel(dgrad)', _conv_flops(geom, x.shape[0], ctx.in_sz, out_sz),
                                     1 if geom.transposed else math.prod(geom.stride), _conv_tag(geom, x.shape[0], ctx.in_sz))
                 e0.record()
-            _ck(L.muvo_conv_dgrad(C.byref(d), _f(dz), _f(packed.dgr), _f(dx), _st()))
+            wsb = geom.ws_bytes[(x.shape[0], ctx.in_sz, _plan_epoch[0])][1]
+            ws = scratch('conv_ws', (wsb + 3) // 4, x.device) if wsb else None
+            _ck(L.muvo_conv_dgrad(C.byref(d), _f(dz), _f(packed.dgr), _f(dx), _p(ws), _st()))
             if kt is not None:
                 e1.record()
         if weight.requires_grad:

@@ -53,9 +53,9 @@ def conv_mode(request):
     """Both matrix-pipe arithmetics of the conv family: exact fp32 MFMA and the bf16x3 split-product kernel."""
     from muvo_amd import ops
     old = ops.get_conv_mode()
-    ops.set_conv_mode(ops.CONV_BF16X3 if request.param == 'bf16x3' else ops.CONV_F32)
+    ops.set_conv_mode(ops.CONV_BF16X3 if request.param == 'bf16x3' else ops.CONV_F32, min_gflop=0.0)
     yield request.param
-    ops.set_conv_mode(old)
+    ops.set_conv_mode(old, min_gflop=2.0)
 
 
 @pytest.mark.parametrize('case', CONV_CASES, ids=[str(i) for i in range(len(CONV_CASES))])

@@ -78,10 +78,13 @@ def main():
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) / args.iters
         xd, gd = x.detach(), g
+        wb = geom.ws_bytes[(args.n, in_sz, ops._plan_epoch[0])]
+        wsf = torch.empty(wb[0] // 4 + 1, device=dev) if wb[0] else None
+        wsd = torch.empty(wb[1] // 4 + 1, device=dev) if wb[1] else None
         dx = torch.empty_like(xd)
         fns = {
-            'fwd': lambda: ops._ck(L.muvo_conv_forward(C.byref(d), ops._f(xd), ops._f(packed.fwd), ops._f(m.bias), ops._f(y.detach()), 0, ops._fl(0.0), ops._st())),
-            'dgrad': lambda: ops._ck(L.muvo_conv_dgrad(C.byref(d), ops._f(gd), ops._f(packed.dgr), ops._f(dx), ops._st())),
+            'fwd': lambda: ops._ck(L.muvo_conv_forward(C.byref(d), ops._f(xd), ops._f(packed.fwd), ops._f(m.bias), ops._f(y.detach()), 0, ops._fl(0.0), ops._p(wsf), ops._st())),
+            'dgrad': lambda: ops._ck(L.muvo_conv_dgrad(C.byref(d), ops._f(gd), ops._f(packed.dgr), ops._f(dx), ops._p(wsd), ops._st())),
             'wgrad': lambda: ops._ck(L.muvo_conv_wgrad(C.byref(d), ops._f(xd), ops._f(gd), ops._f(ws), ops._f(m.weight.grad), ops._f(m.bias.grad), ops._st())),
         }
         for w in what:
