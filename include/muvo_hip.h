@@ -61,8 +61,9 @@ int muvo_conv_set_bf16x3_min_gflop(double gflop_per_item);
 int muvo_conv_pack_sizes(const muvo_conv_desc* d, int64_t* fwd_floats, int64_t* dgrad_floats);
 /* repack w into wp_fwd and/or wp_dgrad (either may be NULL) */
 int muvo_conv_pack_weights(const muvo_conv_desc* d, const float* w, float* wp_fwd, float* wp_dgrad, void* stream);
-/* bytes of workspace `ws` that forward (op 0) / dgrad (op 1) need for this shape in the current mode (0 = none; the
- * bf16x3 kernel reads a channels-last bf16 hi/lo copy of its activation operand that it writes there first) */
+/* bytes of workspace that forward (op 0: ws), dgrad (op 1: ws) and wgrad (op 2: ws_x, op 3: ws_dy) need for this shape
+ * in the current mode (0 = none; the bf16x3 kernels read channels-last bf16 hi/lo copies of their activation operands,
+ * which the call writes there first).  The copy of x is the same for op 0 and op 2, the copy of dy for op 1 and op 3. */
 int64_t muvo_conv_workspace_bytes(const muvo_conv_desc* d, int op);
 /* y = act(conv(x, w) + bias); bias may be NULL; ws may be NULL when muvo_conv_workspace_bytes(d, 0) == 0 */
 int muvo_conv_forward(const muvo_conv_desc* d, const float* x, const float* wp_fwd, const float* bias, float* y, int act,
@@ -70,9 +71,11 @@ int muvo_conv_forward(const muvo_conv_desc* d, const float* x, const float* wp_f
 /* dx = conv_data_grad(dy, w) (dy already multiplied by act'(y) by the caller) */
 int muvo_conv_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp_dgrad, float* dx, void* ws, void* stream);
 /* dw += conv_weight_grad(x, dy) (PyTorch layout); dbias += sum(dy) if non-NULL.
- * dwp_scratch: fwd_floats floats of workspace (overwritten). */
+ * dwp_scratch: fwd_floats floats of workspace (overwritten).  ws_x / ws_dy: see muvo_conv_workspace_bytes (may be NULL
+ * when 0 bytes); flags bit 0 / bit 1: ws_x / ws_dy already hold the copies written by muvo_conv_forward(x) /
+ * muvo_conv_dgrad(dy) for the same tensors, so wgrad does not rewrite them. */
 int muvo_conv_wgrad(const muvo_conv_desc* d, const float* x, const float* dy, float* dwp_scratch, float* dw, float* dbias,
-                    void* stream);
+                    void* ws_x, void* ws_dy, int flags, void* stream);
 
 /* db[m] += sum_{n,s} dy[n][m][s] (bias gradient of any NCHW-like tensor) */
 int muvo_bias_grad_nchw(const float* dy, float* db, int N, int M, int64_t S, void* stream);

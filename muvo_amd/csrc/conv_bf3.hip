@@ -63,6 +63,7 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
   const int wm = wave / WN, wn = wave % WN;
 
   // ---- B (activation) DMA role of this wave: pixel group (wave % NG), combos [(wave / NG) * CPW, +CPW)
+  // All sources are xs (uniform) + a 32-bit uint4 offset per lane; out-of-bounds taps read the zero page at zero_off.
   const int bgroup = wave % NG, bcombo0 = (wave / NG) * CPW;
   const int p = blockIdx.x * BN + bgroup * 64 + lane;
   const bool pvalid = p < g.npix;
@@ -70,7 +71,15 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
   decode_pix(g, pvalid ? p : 0, n, iz, iy, ix);
   const int z0 = iz * g.is[0] + g.ib[0], y0 = iy * g.is[1] + g.ib[1], x0 = ix * g.is[2] + g.ib[2];
   const int cp8 = g.Cp >> 3;
-  const uint4* xn = xs + (size_t)n * g.ID * g.IH * g.IW * cp8;
+  const int pixoff = (((n * g.ID + z0) * g.IH + y0) * g.IW + x0) * cp8;   // may be "negative" at borders: only used when valid
+  unsigned long long vmask = 0ull;                                          // bit t: tap t of this pixel is inside the input
+  for (int tt = 0; tt < g.T; ++tt) {
+    const int d = g.tap_d[tt];
+    const int z = z0 + ((d >> 16) & 255) - 128, y = y0 + ((d >> 8) & 255) - 128, x = x0 + (d & 255) - 128;
+    const bool ok = pvalid && (unsigned)z < (unsigned)g.ID && (unsigned)y < (unsigned)g.IH && (unsigned)x < (unsigned)g.IW;
+    vmask |= (unsigned long long)ok << tt;
+  }
+  const int zero_off = (int)(2 * plane_u4);
   const int m_tile = blockIdx.y * BM;
   const uint4* wpb = wp + g.wp_off / 4 + m_tile;   // wp_off is in floats; one uint4 = 8 bf16 = 4 floats
   const int nk = g.Kp / BK;
@@ -83,9 +92,6 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
       const int pc = a / RG, rg = a % RG;
       dma16(wpb + (size_t)(kt * 8 + pc) * g.Mp + rg * 64 + lane, S + pc * BM + rg * 64);
     }
-    int t_prev = -1;
-    const uint4* src_tap = zero16;   // lane's source for chunk 0 of the current tap (zero16 when out of bounds)
-    bool ok = false;
 #pragma unroll
     for (int q = 0; q < CPW; ++q) {
       const int combo = bcombo0 + q;               // plane * 4 + chunk
@@ -93,16 +99,12 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
       const int k0 = kt * BK + ch * 8;             // wave-uniform
       const int t = (int)(((unsigned long long)(unsigned)k0 * g.cp_magic) >> 32);
       const int c8 = (k0 - t * g.Cp) >> 3;
-      if (t != t_prev) {                           // uniform: tap geometry only when the tap changes
-        t_prev = t;
-        const int d = g.tap_d[t < g.T ? t : 0];
-        const int z = z0 + ((d >> 16) & 255) - 128, y = y0 + ((d >> 8) & 255) - 128, x = x0 + (d & 255) - 128;
-        ok = pvalid && t < g.T && (unsigned)z < (unsigned)g.ID && (unsigned)y < (unsigned)g.IH &&
-             (unsigned)x < (unsigned)g.IW;
-        src_tap = xn + (size_t)((z * g.IH + y) * g.IW + x) * cp8;
-      }
-      const uint4* src = ok ? src_tap + (size_t)plane * plane_u4 + c8 : zero16;
-      dma16(src, S + 8 * BM + combo * BN + bgroup * 64);
+      const int d = g.tap_d[t < g.T ? t : 0];
+      const int tapoff = (((((d >> 16) & 255) - 128) * g.IH + ((d >> 8) & 255) - 128) * g.IW + (d & 255) - 128) * cp8;
+      const int uoff = tapoff + c8 + plane * (int)plane_u4;            // scalar part
+      const bool ok = t < g.T && ((vmask >> t) & 1ull);
+      const int off = ok ? pixoff + uoff : zero_off;
+      dma16(xs + (unsigned)off, S + 8 * BM + combo * BN + bgroup * 64);
     }
   };
 
@@ -184,6 +186,200 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient on the same split planes:  Wg[t][m][c] += sum_pix dz[opix][m] * x[ipix(pix, t)][c]
+// GEMM rows = m (A from the channels-last dz planes), cols = c (B from the channels-last x planes), reduction over
+// the pixels of the phase, one tap per workgroup column, split-K over pixel ranges with coalesced float atomics into
+// a [tap][m][c] scratch (lanes along c), which bf3_unpack_wgrad_kernel adds into the PyTorch weight layout.
+// Both operands are channel-contiguous in memory but the MFMA wants 8 consecutive k (= pixels) per lane, so the LDS
+// image is [plane][chunk of 8 channels][32 pixels] and the fragments come from ds_read_b64_tr_b16 (hardware
+// transpose read, 4 pixels x 16 channels per 16-lane group).  pos = pixel ^ ((chunk & 3) << 2) spreads the four pixel
+// rows of a transpose block over the four 64-byte bank windows (applied on the DMA source side and on the read side).
+// ------------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+__device__ __forceinline__ bf16x8 tr_read8(const char* lds_addr0, const char* lds_addr1) {
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)lds_addr0);
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)lds_addr1);
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(64 * WM * WN)
+conv_bf3_wgrad_kernel(const ConvPhase g, const uint4* __restrict__ xs, long xplane_u4, int xc8, const uint4* __restrict__ dzs,
+                      long dzplane_u4, int dzc8, float* __restrict__ wg, int steps_per_split,
+                      const uint4* __restrict__ zero16) {
+  constexpr int BK = 32, NW = WM * WN;
+  constexpr int CA = BM / 8, CB = BN / 8;           // 8-channel chunks per pixel row
+  constexpr int STAGE = 2 * 32 * (CA + CB);         // uint4 per stage: A [plane][CA][32] then B [plane][CB][32]
+  constexpr int NA = CA, NB = CB;                   // DMA wave-instructions per stage (2 planes x chunks/2)
+  constexpr int APW = NA / NW, BPW = NB / NW;
+  static_assert(APW * NW == NA && BPW * NW == NB, "DMA roles must tile");
+  constexpr int DMA_PER_STEP = APW + BPW;
+  extern __shared__ uint4 smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int ctiles = (g.C + BN - 1) / BN;
+  const int t = blockIdx.x / ctiles, c_tile = (blockIdx.x % ctiles) * BN, m_tile = blockIdx.y * BM;
+  const int td = g.tap_d[t];
+  const int dz_ = ((td >> 16) & 255) - 128, dy_ = ((td >> 8) & 255) - 128, dx_ = (td & 255) - 128;
+  const int nsteps = (g.npix + BK - 1) / BK;
+  const int s_begin = blockIdx.z * steps_per_split;
+  int s_end = s_begin + steps_per_split;
+  if (s_end > nsteps) s_end = nsteps;
+  const int ns = s_end - s_begin;
+
+  // The two pixel variants of this lane (DMA instruction parity, see the header comment).  Coordinates are decoded
+  // once and then advanced by 32 pixels per step with small exact magic divisions; all DMA sources are a uniform base
+  // + a 32-bit uint4 offset, out-of-range rows read the zero page that follows the planes.
+  const int pos = lane & 31, hi5 = lane >> 5;
+  const unsigned sw_magic = (unsigned)(0x100000000ull / (unsigned)g.SW) + 1u, sh_magic = (unsigned)(0x100000000ull / (unsigned)g.SH) + 1u,
+                 sd_magic = (unsigned)(0x100000000ull / (unsigned)g.SD) + 1u;
+  int cpix[2], cn[2], cz[2], cy[2], cx_[2];
+#pragma unroll
+  for (int v = 0; v < 2; ++v) {
+    cpix[v] = s_begin * BK + (pos ^ ((((2 * v) + hi5) & 3) << 2));
+    decode_pix(g, cpix[v] < g.npix ? cpix[v] : 0, cn[v], cz[v], cy[v], cx_[v]);
+  }
+  const int zeroA = (int)(2 * dzplane_u4), zeroB = (int)(2 * xplane_u4);
+  const int mt8 = m_tile >> 3, ct8 = c_tile >> 3;
+  auto issue = [&](int stage) {     // stages the step the coordinates currently point at, then advances them
+    uint4* S = smem + stage * STAGE;
+    int offA[2], offB[2];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const bool pv = cpix[v] < g.npix;
+      const int o = ((cn[v] * g.OD + (cz[v] * g.os[0] + g.op[0])) * g.OH + (cy[v] * g.os[1] + g.op[1])) * g.OW +
+                    (cx_[v] * g.os[2] + g.op[2]);
+      offA[v] = pv ? o * dzc8 + mt8 : -1;
+      const int z = cz[v] * g.is[0] + g.ib[0] + dz_, y = cy[v] * g.is[1] + g.ib[1] + dy_, x = cx_[v] * g.is[2] + g.ib[2] + dx_;
+      const bool ok = pv && (unsigned)z < (unsigned)g.ID && (unsigned)y < (unsigned)g.IH && (unsigned)x < (unsigned)g.IW;
+      offB[v] = ok ? (((cn[v] * g.ID + z) * g.IH + y) * g.IW + x) * xc8 + ct8 : -1;
+      // advance by BK pixels
+      cpix[v] += BK;
+      int xx = cx_[v] + BK;
+      int q = g.SW == 1 ? xx : (int)(((unsigned long long)(unsigned)xx * sw_magic) >> 32);
+      cx_[v] = xx - q * g.SW;
+      int yy = cy[v] + q;
+      q = g.SH == 1 ? yy : (int)(((unsigned long long)(unsigned)yy * sh_magic) >> 32);
+      cy[v] = yy - q * g.SH;
+      int zz = cz[v] + q;
+      q = g.SD == 1 ? zz : (int)(((unsigned long long)(unsigned)zz * sd_magic) >> 32);
+      cz[v] = zz - q * g.SD;
+      cn[v] += q;
+    }
+#pragma unroll
+    for (int q = 0; q < APW; ++q) {
+      const int a = wave * APW + q;                 // plane * (CA/2) + e
+      const int plane = a / (CA / 2), e = a % (CA / 2);
+      const int chunk = 2 * e + hi5;
+      const int base = offA[e & 1];
+      const bool inb = m_tile + chunk * 8 < g.Mp;   // Mp = channel extent of the dz planes (see launcher)
+      const int off = (base >= 0 && inb) ? base + plane * (int)dzplane_u4 + chunk : zeroA;
+      dma16(dzs + (unsigned)off, S + (plane * CA + 2 * e) * 32);
+    }
+#pragma unroll
+    for (int q = 0; q < BPW; ++q) {
+      const int b = wave * BPW + q;
+      const int plane = b / (CB / 2), e = b % (CB / 2);
+      const int chunk = 2 * e + hi5;
+      const int base = offB[e & 1];
+      const bool inb = c_tile + chunk * 8 < g.Cp;
+      const int off = (base >= 0 && inb) ? base + plane * (int)xplane_u4 + chunk : zeroB;
+      dma16(xs + (unsigned)off, S + 2 * CA * 32 + (plane * CB + 2 * e) * 32);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // transpose-read lane geometry: group g4 = lane>>4: channel half (g4&1), k half (g4>>1); q = pixel row, p = 4-channel slot
+  const int g4 = lane >> 4, rhalf = g4 & 1, kh = g4 >> 1, tq = (lane >> 2) & 3, tp = lane & 3;
+  const int cx = 2 * rhalf + (tp >> 1);             // chunk index within a 32-channel tile (== chunk & 3)
+  const int pos0 = (8 * kh + tq) ^ (cx << 2);       // pixel position for j = 0; j = 1 flips bit 2
+  const int lane_off0 = (cx * 32 + pos0) * 16 + 8 * (tp & 1);
+  const int lane_off1 = (cx * 32 + (pos0 ^ 4)) * 16 + 8 * (tp & 1);
+
+  constexpr int WAIT_ONE_STEP_IN_FLIGHT = (DMA_PER_STEP & 15) | ((DMA_PER_STEP >> 4) << 14) | (7 << 4) | (15 << 8);
+  constexpr int WAIT_ALL = (7 << 4) | (15 << 8);
+  if (ns > 0) issue(0);
+  if (ns > 1) issue(1);
+  int stage = 0;
+  for (int st = 0; st < ns; ++st) {
+    if (st + 1 < ns) __builtin_amdgcn_s_waitcnt(WAIT_ONE_STEP_IN_FLIGHT);
+    else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
+    __builtin_amdgcn_s_barrier();
+    if (st + 2 < ns) issue(stage == 0 ? 2 : stage - 1);
+    const char* S = (const char*)(smem + stage * STAGE);
+    const char* Ah = S + (size_t)(wm * 8) * 512;                     // chunk base of this wave's 64 rows
+    const char* Al = Ah + (size_t)CA * 512;
+    const char* Bh = S + (size_t)2 * CA * 512 + (size_t)(wn * 8) * 512;
+    const char* Bl = Bh + (size_t)CB * 512;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int o = i * 4 * 512 + ks * 256;
+        ah[i] = tr_read8(Ah + o + lane_off0, Ah + o + lane_off1);
+        al[i] = tr_read8(Al + o + lane_off0, Al + o + lane_off1);
+        bh[i] = tr_read8(Bh + o + lane_off0, Bh + o + lane_off1);
+        bl[i] = tr_read8(Bl + o + lane_off0, Bl + o + lane_off1);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    stage = stage == 2 ? 0 : stage + 1;
+  }
+  if (ns <= 0) return;
+
+  float* wt = wg + g.wp_off + (size_t)t * g.M * g.C;   // [m][c] slab of this tap
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = c_tile + wn * 64 + j * 32 + (lane & 31);
+    if (c >= g.C) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m_tile + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < g.M) atomicAdd(wt + (size_t)m * g.C + c, acc[i][j][r]);
+      }
+  }
+}
+
+// dw[m*wsm + c*wsc + tap_w[t]] += Wg[t][m][c]   (thread order follows the PyTorch weight layout)
+__global__ void __launch_bounds__(256) bf3_unpack_wgrad_kernel(const ConvPhase g, const float* __restrict__ wg,
+                                                               float* __restrict__ dw) {
+  __shared__ int s_tw[MAX_TAPS];
+  if (threadIdx.x < MAX_TAPS) s_tw[threadIdx.x] = g.tap_w[threadIdx.x];
+  __syncthreads();
+  const long total = (long)g.M * g.C * g.T;
+  const float* base = wg + g.wp_off;
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int t = (int)(idx % g.T);
+    const long r = idx / g.T;
+    int m, c;
+    if (g.wsm > g.wsc) { c = (int)(r % g.C); m = (int)(r / g.C); }
+    else { m = (int)(r % g.M); c = (int)(r / g.M); }
+    dw[(size_t)m * g.wsm + (size_t)c * g.wsc + s_tw[t]] += base[((size_t)t * g.M + m) * g.C + c];
+  }
+}
+
 // fp32 NCHW [N][C][S] -> bf16 hi / lo planes, channels-last [N][S][Cp] (Cp = roundup(C, 8), zero padded)
 __global__ void __launch_bounds__(256)
 nchw_split_nhwc_kernel(const float* __restrict__ in, uint4* __restrict__ out_hi, uint4* __restrict__ out_lo, int C, int Cp,
@@ -217,6 +413,9 @@ nchw_split_nhwc_kernel(const float* __restrict__ in, uint4* __restrict__ out_hi,
       out_lo[o] = *(const uint4*)&tl[pix][ch * 8];
     }
   }
+  // zero page right after the two planes (source of out-of-bounds DMA reads)
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0)
+    out_hi[2 * ((size_t)gridDim.z * S * Cp >> 3)] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 __device__ uint4 g_zero16 = {0u, 0u, 0u, 0u};
@@ -259,7 +458,7 @@ int bf3_pack_phase(const ConvPhase& g, const float* w, float* wp, hipStream_t st
   return MUVO_OK;
 }
 
-long bf3_workspace_bytes(int N, int C, long S) { return (long)N * S * roundup(C, 8) * 4; }
+long bf3_workspace_bytes(int N, int C, long S) { return (long)N * S * roundup(C, 8) * 4 + 16; }
 
 int bf3_split_input(const float* x, void* ws, int N, int C, long S, hipStream_t st) {
   const int Cp = roundup(C, 8);
@@ -300,4 +499,55 @@ int bf3_launch_fwd_phase(const ConvPhase& g, const void* ws, const float* wp, co
   if (g.M > 128) return bf3_launch<256, 128, 4, 2>(g, ws, wp, bias, out, act, slope, st);
   if (g.M > 64) return bf3_launch<128, 256, 2, 4>(g, ws, wp, bias, out, act, slope, st);
   return bf3_launch<64, 256, 1, 4>(g, ws, wp, bias, out, act, slope, st);
+}
+
+template <int BM, int BN, int WM, int WN>
+static int bf3_wgrad_launch(const ConvPhase& g, const void* ws_x, int Cin_total, const void* ws_dz, int Cout_total,
+                            float* wg, hipStream_t st) {
+  constexpr size_t lds = (size_t)3 * 2 * 32 * (BM / 8 + BN / 8) * 16;
+  static bool attr_set = false;
+  static const uint4* zero16 = nullptr;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)conv_bf3_wgrad_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess ||
+        hipGetSymbolAddress((void**)&zero16, HIP_SYMBOL(g_zero16)) != hipSuccess) {
+      muvo_set_error("conv_bf3_wgrad: kernel attribute / symbol setup failed");
+      return MUVO_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  ConvPhase p = g;
+  const int xc8 = roundup(Cin_total, 8) / 8, dzc8 = roundup(Cout_total, 8) / 8;
+  p.Cp = xc8 * 8;     // channel extents of the split planes: DMA beyond them reads the zero page
+  p.Mp = dzc8 * 8;
+  const long xplane = (long)g.N * g.ID * g.IH * g.IW * xc8, dzplane = (long)g.N * g.OD * g.OH * g.OW * dzc8;
+  const int ctiles = cdiv(g.C, BN), mtiles = cdiv(g.M, BM);
+  const int nsteps = cdiv(g.npix, 32);
+  int ksplit = cdiv(1536, (long)ctiles * g.T * mtiles);
+  if (ksplit > cdiv(nsteps, 16)) ksplit = cdiv(nsteps, 16);
+  if (ksplit < 1) ksplit = 1;
+  const int sps = cdiv(nsteps, ksplit);
+  ksplit = cdiv(nsteps, sps);
+  dim3 grid(ctiles * g.T, mtiles, ksplit);
+  hipLaunchKernelGGL((conv_bf3_wgrad_kernel<BM, BN, WM, WN>), grid, dim3(64 * WM * WN), lds, st, p, (const uint4*)ws_x, xplane,
+                     xc8, (const uint4*)ws_dz, dzplane, dzc8, wg, sps, zero16);
+  MUVO_CHECK_LAUNCH("conv_bf3_wgrad_kernel");
+  return MUVO_OK;
+}
+
+// g: a forward-form phase with the fp32-plan wp_off replaced by the float offset of its [T][M][C] slab in wg
+int bf3_wgrad_phase(const ConvPhase& g, const void* ws_x, int Cin_total, const void* ws_dz, int Cout_total, float* wg,
+                    float* dw, hipStream_t st) {
+  if (g.npix <= 0 || g.T == 0) return MUVO_OK;
+  int rc;
+  if (g.M > 128) rc = bf3_wgrad_launch<256, 128, 4, 2>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st);
+  else if (g.M > 64) rc = g.C > 128 ? bf3_wgrad_launch<128, 256, 2, 4>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st)
+                                    : bf3_wgrad_launch<128, 128, 2, 2>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st);
+  else rc = g.C > 128 ? bf3_wgrad_launch<64, 256, 1, 4>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st)
+                      : bf3_wgrad_launch<64, 128, 1, 2>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st);
+  if (rc) return rc;
+  const long total = (long)g.M * g.C * g.T;
+  hipLaunchKernelGGL(bf3_unpack_wgrad_kernel, dim3(ew_grid(total)), dim3(256), 0, st, g, wg, dw);
+  MUVO_CHECK_LAUNCH("bf3_unpack_wgrad_kernel");
+  return MUVO_OK;
 }

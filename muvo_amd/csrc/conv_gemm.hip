@@ -673,8 +673,15 @@ int muvo_conv_pack_weights(const muvo_conv_desc* d, const float* w, float* wp_fw
 
 // bytes of caller-provided workspace needed by forward (op 0) / dgrad (op 1): the channels-last bf16 hi/lo copy of the
 // activation operand when a phase of that direction runs on the bf16x3 kernel, else 0
+static bool wgrad_uses_bf3(const ConvPlan& pf);
 int64_t muvo_conv_workspace_bytes(const muvo_conv_desc* d, int op) {
   ConvPlan pl;
+  if (op >= 2) {  // weight gradient: split planes of x (op 2) and of dy (op 3)
+    if (build_plan(d, &pl, 0)) return -1;
+    if (vox_wgrad_applicable(d) || !wgrad_uses_bf3(pl)) return 0;
+    return op == 2 ? bf3_workspace_bytes(d->N, d->Cin, (long)d->in_sz[0] * d->in_sz[1] * d->in_sz[2])
+                   : bf3_workspace_bytes(d->N, d->Cout, (long)d->out_sz[0] * d->out_sz[1] * d->out_sz[2]);
+  }
   if (build_plan(d, &pl)) return -1;
   const ConvPhase* ph = op == 0 ? pl.fwd : pl.dgr;
   const int nph = op == 0 ? pl.nfwd : pl.ndgr;
@@ -719,34 +726,70 @@ int muvo_conv_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp_dg
   return run_phases(pl.dgr, pl.ndgr, dy, wp_dgrad, nullptr, dx, MUVO_ACT_NONE, 0.f, ws, (hipStream_t)stream);
 }
 
-// dw (PyTorch layout) += grad;  dbias += sum(dy).  dwp_scratch: fwd_floats floats of workspace.
-int muvo_conv_wgrad(const muvo_conv_desc* d, const float* x, const float* dy, float* dwp_scratch, float* dw,
-                    float* dbias, void* stream) {
+// does the weight gradient of this conv run on the bf16x3 kernel (conv_bf3.hip)?  Same per-item work threshold as
+// forward/dgrad, every phase must have > 32 output and >= 32 input channels.
+static bool wgrad_uses_bf3(const ConvPlan& pf) {
+  if (conv_mode() != 1) return false;
+  for (int i = 0; i < pf.nfwd; ++i) {
+    const ConvPhase& g = pf.fwd[i];
+    const double gflop = 2.0 * g.M * g.T * g.C * (double)g.SD * g.SH * g.SW * 1e-9;
+    if (g.M <= 32 || g.C < 32 || gflop < bf3_min_gflop()) return false;
+  }
+  return pf.nfwd > 0;
+}
+
+// dw (PyTorch layout) += grad;  dbias += sum(dy).  dwp_scratch: fwd_floats floats of workspace (overwritten).
+// ws_x / ws_dy: muvo_conv_workspace_bytes(d, 2) / (d, 3) bytes (NULL when 0); flags bit 0 / bit 1: ws_x / ws_dy already
+// hold the split planes of x / dy (left there by muvo_conv_forward / muvo_conv_dgrad of the same tensors).
+int muvo_conv_wgrad(const muvo_conv_desc* d, const float* x, const float* dy, float* dwp_scratch, float* dw, float* dbias,
+                    void* ws_x, void* ws_dy, int flags, void* stream) {
   ConvPlan pl;
-  int rc = build_plan(d, &pl);
+  int rc = build_plan(d, &pl, 0);
   if (rc) return rc;
   MUVO_CHECK_ARG(x && dy && dwp_scratch && dw, "conv_wgrad: null pointer");
   hipStream_t st = (hipStream_t)stream;
   if (vox_wgrad_applicable(d)) return vox_wgrad(d, x, dy, dw, dbias, st);
-  if (hipMemsetAsync(dwp_scratch, 0, sizeof(float) * pl.fwd_floats, st) != hipSuccess) {
-    muvo_set_error("conv_wgrad: memset failed");
-    return MUVO_ERR_HIP;
+  const long S_out = (long)d->out_sz[0] * d->out_sz[1] * d->out_sz[2];
+  if (wgrad_uses_bf3(pl)) {
+    MUVO_CHECK_ARG(ws_x && ws_dy, "conv_wgrad: this shape runs on the bf16x3 kernel and needs both workspaces");
+    const long S_in = (long)d->in_sz[0] * d->in_sz[1] * d->in_sz[2];
+    if (!(flags & 1)) { rc = bf3_split_input(x, ws_x, d->N, d->Cin, S_in, st); if (rc) return rc; }
+    if (!(flags & 2)) { rc = bf3_split_input(dy, ws_dy, d->N, d->Cout, S_out, st); if (rc) return rc; }
+    long off = 0;
+    for (int i = 0; i < pl.nfwd; ++i) off += (long)pl.fwd[i].T * pl.fwd[i].M * pl.fwd[i].C;
+    if (hipMemsetAsync(dwp_scratch, 0, sizeof(float) * off, st) != hipSuccess) {
+      muvo_set_error("conv_wgrad: memset failed");
+      return MUVO_ERR_HIP;
+    }
+    off = 0;
+    for (int i = 0; i < pl.nfwd; ++i) {
+      ConvPhase g = pl.fwd[i];
+      g.wp_off = off;
+      off += (long)g.T * g.M * g.C;
+      // in a forward-form phase "C" channels come from x (Cin) and "M" from dy (Cout)
+      rc = bf3_wgrad_phase(g, ws_x, d->Cin, ws_dy, d->Cout, dwp_scratch, dw, st);
+      if (rc) return rc;
+    }
+  } else {
+    if (hipMemsetAsync(dwp_scratch, 0, sizeof(float) * pl.fwd_floats, st) != hipSuccess) {
+      muvo_set_error("conv_wgrad: memset failed");
+      return MUVO_ERR_HIP;
+    }
+    for (int i = 0; i < pl.nfwd; ++i) {
+      rc = launch_wgrad_phase(pl.fwd[i], x, dy, dwp_scratch, st);
+      if (rc) return rc;
+    }
+    for (int i = 0; i < pl.nfwd; ++i) {
+      const long total = (long)pl.fwd[i].M * pl.fwd[i].C * pl.fwd[i].T;
+      if (total == 0) continue;
+      hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(ew_grid(total)), dim3(256), 0, st, pl.fwd[i], dwp_scratch, dw);
+    }
+    MUVO_CHECK_LAUNCH("unpack_wgrad_kernel");
   }
-  for (int i = 0; i < pl.nfwd; ++i) {
-    rc = launch_wgrad_phase(pl.fwd[i], x, dy, dwp_scratch, st);
-    if (rc) return rc;
-  }
-  for (int i = 0; i < pl.nfwd; ++i) {
-    const long total = (long)pl.fwd[i].M * pl.fwd[i].C * pl.fwd[i].T;
-    if (total == 0) continue;
-    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(ew_grid(total)), dim3(256), 0, st, pl.fwd[i], dwp_scratch, dw);
-  }
-  MUVO_CHECK_LAUNCH("unpack_wgrad_kernel");
   if (dbias) {
-    const long S = (long)d->out_sz[0] * d->out_sz[1] * d->out_sz[2];
-    int chunks = cdiv((long)d->N * S, 65536);
+    int chunks = cdiv((long)d->N * S_out, 65536);
     if (chunks > 64) chunks = 64;
-    hipLaunchKernelGGL(bias_grad_kernel, dim3(d->Cout, chunks), dim3(256), 0, st, dy, dbias, d->N, d->Cout, S);
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(d->Cout, chunks), dim3(256), 0, st, dy, dbias, d->N, d->Cout, S_out);
     MUVO_CHECK_LAUNCH("bias_grad_kernel");
   }
   return MUVO_OK;

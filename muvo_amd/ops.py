@@ -312,10 +312,10 @@ class ConvGeom:
                          (C.c_int32 * 3)(*self.pad), (C.c_int32 * 3)(*self.dil))
             ff, df = C.c_int64(0), C.c_int64(0)
             _ck(lib().muvo_conv_pack_sizes(C.byref(d), C.byref(ff), C.byref(df)))
-            wsf, wsd = (lib().muvo_conv_workspace_bytes(C.byref(d), op) for op in (0, 1))
-            if wsf < 0 or wsd < 0:
+            wsf, wsd, wsx, wsy = (lib().muvo_conv_workspace_bytes(C.byref(d), op) for op in (0, 1, 2, 3))
+            if min(wsf, wsd, wsx, wsy) < 0:
                 raise RuntimeError(f'muvo_hip error: {lib().muvo_last_error().decode()}')
-            self.ws_bytes[(n, in_sz, _plan_epoch[0])] = (wsf, wsd)
+            self.ws_bytes[(n, in_sz, _plan_epoch[0])] = (wsf, wsd, wsx, wsy)
             pl = (d, out_sz, ff.value, df.value)
             self._plans[key] = pl
         return pl
@@ -356,8 +356,13 @@ class ConvFn(torch.autograd.Function):
             e0, e1 = kt.bracket('conv_fwd_kernel(fwd)', _conv_flops(geom, n, in_sz, out_sz),
                                 math.prod(geom.stride) if geom.transposed else 1, _conv_tag(geom, n, in_sz))
             e0.record()
-        wsb = geom.ws_bytes[(n, in_sz, _plan_epoch[0])][0]
-        ws = scratch('conv_ws', (wsb + 3) // 4, x.device) if wsb else None
+        wsb = geom.ws_bytes[(n, in_sz, _plan_epoch[0])]
+        keep_ws = wsb[0] > 0 and wsb[2] > 0 and weight.requires_grad  # wgrad reuses the split copy of x
+        if keep_ws:
+            ws = torch.empty((wsb[0] + 3) // 4, device=x.device, dtype=torch.float32)
+        else:
+            ws = scratch('conv_ws', (wsb[0] + 3) // 4, x.device) if wsb[0] else None
+        ctx.ws_x = ws if keep_ws else None
         _ck(L.muvo_conv_forward(C.byref(d), _f(x), _f(packed.fwd), _f(bias), _f(y), act, _fl(slope), _p(ws), _st()))
         if kt is not None:
             e1.record()
@@ -379,6 +384,7 @@ class ConvFn(torch.autograd.Function):
         else:
             dz = dy
         dx = None
+        ws_dy, dy_split = None, False
         if ctx.needs_input_grad[0]:
             if packed.dgr is None or packed.dgr.numel() < df:
                 packed.dgr = torch.empty(df, device=x.device, dtype=torch.float32)
@@ -394,9 +400,11 @@ class ConvFn(torch.autograd.Function):
                 e0, e1 = kt.bracket('conv_fwd_kernel(dgrad)', _conv_flops(geom, x.shape[0], ctx.in_sz, out_sz),
                                     1 if geom.transposed else math.prod(geom.stride), _conv_tag(geom, x.shape[0], ctx.in_sz))
                 e0.record()
-            wsb = geom.ws_bytes[(x.shape[0], ctx.in_sz, _plan_epoch[0])][1]
-            ws = scratch('conv_ws', (wsb + 3) // 4, x.device) if wsb else None
-            _ck(L.muvo_conv_dgrad(C.byref(d), _f(dz), _f(packed.dgr), _f(dx), _p(ws), _st()))
+            wsb = geom.ws_bytes[(x.shape[0], ctx.in_sz, _plan_epoch[0])]
+            nb = max(wsb[1], wsb[3])
+            ws_dy = scratch('conv_ws_dy', (nb + 3) // 4, x.device) if nb else None
+            dy_split = wsb[1] > 0
+            _ck(L.muvo_conv_dgrad(C.byref(d), _f(dz), _f(packed.dgr), _f(dx), _p(ws_dy), _st()))
             if kt is not None:
                 e1.record()
         if weight.requires_grad:
@@ -408,7 +416,15 @@ class ConvFn(torch.autograd.Function):
                 e0, e1 = kt.bracket('conv_wgrad_kernel(+unpack,bias)', _conv_flops(geom, x.shape[0], ctx.in_sz, out_sz),
                                     math.prod(geom.stride) if geom.transposed else 1, _conv_tag(geom, x.shape[0], ctx.in_sz))
                 e0.record()
-            _ck(L.muvo_conv_wgrad(C.byref(d), _f(x), _f(dz), _f(ws), _f(grad_of(weight)), _f(db), _st()))
+            wsb = geom.ws_bytes[(x.shape[0], ctx.in_sz, _plan_epoch[0])]
+            ws_x = ctx.ws_x
+            flags = (1 if ws_x is not None else 0) | (2 if (dy_split and wsb[3] > 0) else 0)
+            if ws_x is None and wsb[2]:
+                ws_x = scratch('conv_ws', (wsb[2] + 3) // 4, x.device)
+            if wsb[3] and ws_dy is None:
+                ws_dy = scratch('conv_ws_dy', (wsb[3] + 3) // 4, x.device)
+            _ck(L.muvo_conv_wgrad(C.byref(d), _f(x), _f(dz), _f(ws), _f(grad_of(weight)), _f(db), _p(ws_x), _p(ws_dy),
+                                  flags, _st()))
             if kt is not None:
                 e1.record()
         return dx, None, None, None, None, None, None

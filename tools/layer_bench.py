@@ -81,11 +81,13 @@ def main():
         wb = geom.ws_bytes[(args.n, in_sz, ops._plan_epoch[0])]
         wsf = torch.empty(wb[0] // 4 + 1, device=dev) if wb[0] else None
         wsd = torch.empty(wb[1] // 4 + 1, device=dev) if wb[1] else None
+        wsx = torch.empty(wb[2] // 4 + 1, device=dev) if wb[2] else None
+        wsy = torch.empty(wb[3] // 4 + 1, device=dev) if wb[3] else None
         dx = torch.empty_like(xd)
         fns = {
             'fwd': lambda: ops._ck(L.muvo_conv_forward(C.byref(d), ops._f(xd), ops._f(packed.fwd), ops._f(m.bias), ops._f(y.detach()), 0, ops._fl(0.0), ops._p(wsf), ops._st())),
             'dgrad': lambda: ops._ck(L.muvo_conv_dgrad(C.byref(d), ops._f(gd), ops._f(packed.dgr), ops._f(dx), ops._p(wsd), ops._st())),
-            'wgrad': lambda: ops._ck(L.muvo_conv_wgrad(C.byref(d), ops._f(xd), ops._f(gd), ops._f(ws), ops._f(m.weight.grad), ops._f(m.bias.grad), ops._st())),
+            'wgrad': lambda: ops._ck(L.muvo_conv_wgrad(C.byref(d), ops._f(xd), ops._f(gd), ops._f(ws), ops._f(m.weight.grad), ops._f(m.bias.grad), ops._p(wsx), ops._p(wsy), 0, ops._st())),
         }
         for w in what:
             ms = run(fns[w])
