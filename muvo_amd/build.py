@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libmuvo_hip.so')
-SOURCES = ['abi.hip', 'conv_gemm.hip', 'conv_vox.hip', 'conv_bf3.hip', 'gemm.hip', 'norm.hip', 'elementwise.hip', 'losses.hip']
+SOURCES = ['abi.hip', 'conv_gemm.hip', 'conv_vox.hip', 'conv_pw.hip', 'conv_bf3.hip', 'gemm.hip', 'norm.hip', 'elementwise.hip', 'losses.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-munsafe-fp-atomics', '-Wno-unused-result', '-Wno-unused-value',
          '-ffp-contract=off']
 
@@ -21,7 +21,7 @@ def _stale(out, deps):
 
 def build(force=False, verbose=True):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    hdrs = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_vox.h'), os.path.join(CSRC, 'conv_plan.h'), os.path.join(CSRC, 'conv_bf3.h'), os.path.join(HERE, '..', 'include', 'muvo_hip.h')]
+    hdrs = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_vox.h'), os.path.join(CSRC, 'conv_pw.h'), os.path.join(CSRC, 'conv_plan.h'), os.path.join(CSRC, 'conv_bf3.h'), os.path.join(HERE, '..', 'include', 'muvo_hip.h')]
     objdir = os.path.join(HERE, 'build')
     os.makedirs(objdir, exist_ok=True)
     objs, jobs = [], []

@@ -16,6 +16,7 @@
 // (voxel decoder), timm ResNet-18 (mile.py:24,81; common.py:15), layers.py:9-66, common.py:102-130.
 #include "common.h"
 #include "conv_vox.h"
+#include "conv_pw.h"
 #include "conv_plan.h"
 #include "conv_bf3.h"
 
@@ -635,6 +636,15 @@ int muvo_conv_pack_weights(const muvo_conv_desc* d, const float* w, float* wp_fw
   if (rc) return rc;
   MUVO_CHECK_ARG(w != nullptr, "conv_pack_weights: w is null");
   hipStream_t st = (hipStream_t)stream;
+  if (pw_applicable(d)) {  // heads: the kernels read the PyTorch layout directly
+    const size_t bytes = sizeof(float) * d->Cout * d->Cin;
+    if ((wp_fwd && hipMemcpyAsync(wp_fwd, w, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) ||
+        (wp_dgrad && hipMemcpyAsync(wp_dgrad, w, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess)) {
+      muvo_set_error("conv_pack_weights: copy failed");
+      return MUVO_ERR_HIP;
+    }
+    return MUVO_OK;
+  }
   if (wp_fwd && vox_fwd_applicable(d)) {
     rc = vox_pack(d, w, wp_fwd, 0, st);
     if (rc) return rc;
@@ -678,13 +688,14 @@ int64_t muvo_conv_workspace_bytes(const muvo_conv_desc* d, int op) {
   ConvPlan pl;
   if (op >= 2) {  // weight gradient: split planes of x (op 2) and of dy (op 3)
     if (build_plan(d, &pl, 0)) return -1;
-    if (vox_wgrad_applicable(d) || !wgrad_uses_bf3(pl)) return 0;
+    if (pw_applicable(d) || vox_wgrad_applicable(d) || !wgrad_uses_bf3(pl)) return 0;
     return op == 2 ? bf3_workspace_bytes(d->N, d->Cin, (long)d->in_sz[0] * d->in_sz[1] * d->in_sz[2])
                    : bf3_workspace_bytes(d->N, d->Cout, (long)d->out_sz[0] * d->out_sz[1] * d->out_sz[2]);
   }
   if (build_plan(d, &pl)) return -1;
   const ConvPhase* ph = op == 0 ? pl.fwd : pl.dgr;
   const int nph = op == 0 ? pl.nfwd : pl.ndgr;
+  if (pw_applicable(d)) return 0;
   if (op == 0 ? vox_fwd_applicable(d) : vox_dgrad_applicable(d)) return 0;
   for (int i = 0; i < nph; ++i)
     if (ph[i].bf3) return bf3_workspace_bytes(ph[i].N, ph[i].C, (long)ph[i].ID * ph[i].IH * ph[i].IW);
@@ -713,6 +724,7 @@ int muvo_conv_forward(const muvo_conv_desc* d, const float* x, const float* wp_f
   int rc = build_plan(d, &pl);
   if (rc) return rc;
   MUVO_CHECK_ARG(x && wp_fwd && y, "conv_forward: null pointer");
+  if (pw_applicable(d)) return pw_forward(d, x, wp_fwd, bias, y, act, slope, (hipStream_t)stream);
   if (vox_fwd_applicable(d)) return vox_forward(d, x, wp_fwd, bias, y, act, slope, (hipStream_t)stream);
   return run_phases(pl.fwd, pl.nfwd, x, wp_fwd, bias, y, act, slope, ws, (hipStream_t)stream);
 }
@@ -722,6 +734,7 @@ int muvo_conv_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp_dg
   int rc = build_plan(d, &pl);
   if (rc) return rc;
   MUVO_CHECK_ARG(dy && wp_dgrad && dx, "conv_dgrad: null pointer");
+  if (pw_applicable(d)) return pw_dgrad(d, dy, wp_dgrad, dx, (hipStream_t)stream);
   if (vox_dgrad_applicable(d)) return vox_dgrad(d, dy, wp_dgrad, dx, (hipStream_t)stream);
   return run_phases(pl.dgr, pl.ndgr, dy, wp_dgrad, nullptr, dx, MUVO_ACT_NONE, 0.f, ws, (hipStream_t)stream);
 }
@@ -748,6 +761,7 @@ int muvo_conv_wgrad(const muvo_conv_desc* d, const float* x, const float* dy, fl
   if (rc) return rc;
   MUVO_CHECK_ARG(x && dy && dwp_scratch && dw, "conv_wgrad: null pointer");
   hipStream_t st = (hipStream_t)stream;
+  if (pw_applicable(d)) return pw_wgrad(d, x, dy, dw, dbias, st);
   if (vox_wgrad_applicable(d)) return vox_wgrad(d, x, dy, dw, dbias, st);
   const long S_out = (long)d->out_sz[0] * d->out_sz[1] * d->out_sz[2];
   if (wgrad_uses_bf3(pl)) {

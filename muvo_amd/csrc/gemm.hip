@@ -164,6 +164,88 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g, const float
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Skinny GEMM (M <= 32 rows, store mode): the per-timestep Linear / GRU products of the RSSM (batch rows only,
+// transition.py:108-127) and the small MLPs.  These are weight-bandwidth bound: B (the weight) is streamed exactly once
+// by as many workgroups as possible; A (a few rows) is re-read from L1/L2.  Two variants by the contiguous axis of B.
+// ------------------------------------------------------------------------------------------------
+// B k-contiguous (nn.Linear forward: B(k,n) = W[n][k]).  One wave per pair of output columns, lanes stride over k.
+template <int RM>
+__global__ void __launch_bounds__(256) gemm_skinny_kcontig_kernel(const GemmArgs g, const float* __restrict__ A,
+                                                                  const float* __restrict__ B, float* __restrict__ C) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = (blockIdx.x * 4 + wave) * 2;
+  if (n0 >= g.N) return;
+  const bool two = n0 + 1 < g.N;
+  const float* b0 = B + (long)n0 * g.sbn;
+  const float* b1 = B + (long)(two ? n0 + 1 : n0) * g.sbn;
+  for (int r0 = 0; r0 < g.M; r0 += RM) {
+    float acc0[RM], acc1[RM];
+#pragma unroll
+    for (int r = 0; r < RM; ++r) acc0[r] = acc1[r] = 0.f;
+    for (int k = lane; k < g.K; k += 64) {
+      const float w0 = b0[(long)k * g.sbk], w1 = b1[(long)k * g.sbk];
+#pragma unroll
+      for (int r = 0; r < RM; ++r) {
+        const float a = (r0 + r < g.M) ? A[(long)(r0 + r) * g.sam + (long)k * g.sak] : 0.f;
+        acc0[r] += a * w0;
+        acc1[r] += a * w1;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+      const float s0 = wave_sum(acc0[r]), s1 = wave_sum(acc1[r]);
+      if (lane == 0 && r0 + r < g.M) {
+        const float bv0 = g.bias ? g.bias[n0 / g.bias_div] : 0.f;
+        C[(long)(r0 + r) * g.scm + n0] = act_apply(g.alpha * s0 + bv0, g.act, g.slope);
+        if (two) {
+          const float bv1 = g.bias ? g.bias[(n0 + 1) / g.bias_div] : 0.f;
+          C[(long)(r0 + r) * g.scm + n0 + 1] = act_apply(g.alpha * s1 + bv1, g.act, g.slope);
+        }
+      }
+    }
+  }
+}
+
+// B n-contiguous (data gradient of nn.Linear: B(k,n) = W[k][n]).  Lanes along n (coalesced weight rows), the 16 waves of
+// a workgroup split k and are reduced through LDS.
+template <int RM>
+__global__ void __launch_bounds__(1024) gemm_skinny_ncontig_kernel(const GemmArgs g, const float* __restrict__ A,
+                                                                   const float* __restrict__ B, float* __restrict__ C) {
+  __shared__ float red[16][RM][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + lane;
+  const bool nok = n < g.N;
+  const int kper = (g.K + 15) / 16;
+  const int k0 = wave * kper;
+  int k1 = k0 + kper;
+  if (k1 > g.K) k1 = g.K;
+  for (int r0 = 0; r0 < g.M; r0 += RM) {
+    float acc[RM];
+#pragma unroll
+    for (int r = 0; r < RM; ++r) acc[r] = 0.f;
+    for (int k = k0; k < k1; ++k) {
+      const float w = nok ? B[(long)k * g.sbk + (long)n * g.sbn] : 0.f;
+#pragma unroll
+      for (int r = 0; r < RM; ++r) {
+        const float a = (r0 + r < g.M) ? A[(long)(r0 + r) * g.sam + (long)k * g.sak] : 0.f;  // wave-uniform address
+        acc[r] += a * w;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RM; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    if (wave < RM && r0 + wave < g.M && nok) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) s += red[w][wave][lane];
+      const float bv = g.bias ? g.bias[n / g.bias_div] : 0.f;
+      C[(long)(r0 + wave) * g.scm + n] = act_apply(g.alpha * s + bv, g.act, g.slope);
+    }
+  }
+}
+
 template <int BM, int BN, int WM, int WN>
 static void launch_gemm_lay(const GemmArgs& g, const float* A, const float* B, float* C, dim3 grid, hipStream_t st) {
   const int al = (g.sam == 1 && g.sak != 1) ? 0 : (g.sak == 1 ? 1 : 0);
@@ -190,6 +272,20 @@ extern "C" int muvo_gemm(const muvo_gemm_desc* d, const float* A, const float* B
   g.act = d->act; g.slope = d->slope; g.mode = d->mode;
   const int nb = d->B1 * d->B2;
   hipStream_t st = (hipStream_t)stream;
+  if (d->M <= 32 && d->mode == 0 && nb == 1 && d->N >= 64 && d->K >= 16) {
+    g.ksplit = 1;
+    if (d->sbk == 1) {
+      const int blocks = cdiv(d->N, 8);
+      if (d->M <= 4) hipLaunchKernelGGL((gemm_skinny_kcontig_kernel<4>), dim3(blocks), dim3(256), 0, st, g, A, B, C);
+      else hipLaunchKernelGGL((gemm_skinny_kcontig_kernel<8>), dim3(blocks), dim3(256), 0, st, g, A, B, C);
+    } else {
+      const int blocks = cdiv(d->N, 64);
+      if (d->M <= 4) hipLaunchKernelGGL((gemm_skinny_ncontig_kernel<4>), dim3(blocks), dim3(1024), 0, st, g, A, B, C);
+      else hipLaunchKernelGGL((gemm_skinny_ncontig_kernel<8>), dim3(blocks), dim3(1024), 0, st, g, A, B, C);
+    }
+    MUVO_CHECK_LAUNCH("gemm_skinny_kernel");
+    return MUVO_OK;
+  }
   int bm, bn;
   if (d->M <= 32) { bm = 32; bn = 128; }
   else if (d->N <= 64) { bm = 128; bn = 64; }

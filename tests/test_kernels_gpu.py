@@ -45,6 +45,11 @@ CONV_CASES = [
     (3, False, 16, 16, 3, 1, 1, 0, (6, 5, 64), False, 0),
     (3, False, 8, 8, 3, 1, 1, 0, (1, 1, 64), True, 0),
     (3, False, 16, 8, 3, 1, 1, 0, (19, 12, 32), True, 2),
+    # decoder heads (conv_pw.hip: float4 VALU kernels), Cout <= 4, spatial size % 4 == 0 and >= 1024
+    (3, False, 8, 2, 1, 1, 0, 0, (16, 16, 8), True, 0),
+    (3, False, 32, 2, 1, 1, 0, 0, (12, 12, 8), True, 0),
+    (2, False, 64, 3, 1, 1, 0, 0, (40, 52), True, 0),
+    (2, False, 130, 4, 1, 1, 0, 0, (32, 64), True, 0),
 ]
 
 
@@ -106,7 +111,8 @@ def test_conv_family(dev, case, conv_mode):
     _close(m.weight.grad, 2 * w.grad, rtol=5e-4, name='wgrad accumulate')
 
 
-GEMM_SHAPES = [(7, 33, 5), (130, 257, 70), (324, 48, 324), (2, 1600, 1088), (300, 1, 16), (64, 64, 1)]
+GEMM_SHAPES = [(7, 33, 5), (130, 257, 70), (324, 48, 324), (2, 1600, 1088), (300, 1, 16), (64, 64, 1),
+               (20, 1536, 1536), (3, 100, 70), (9, 64, 16)]  # skinny (M <= 32) kernels incl. row chunking
 
 
 @pytest.mark.parametrize('shape', GEMM_SHAPES)
