@@ -28,7 +28,7 @@
 template <int BM, int BN, int WM, int WN, int RUN>
 __global__ void __launch_bounds__(256)
 conv_fwd_kernel(const ConvPhase g, const float* __restrict__ in, const float* __restrict__ wp,
-                const float* __restrict__ bias, float* __restrict__ out, int act, float slope) {
+                const float* __restrict__ bias, float* __restrict__ out, int act, float slope, int ksplit) {
   constexpr int BK = 16;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   constexpr int KG = 256 / BN;   // thread groups along k for the gather
@@ -69,7 +69,12 @@ conv_fwd_kernel(const ConvPhase g, const float* __restrict__ in, const float* __
 
   float4 areg[NA4];
   float breg[KPT];
-  const int nk = g.Kp / BK;
+  // split-K (ksplit > 1, tiny pixel grids with a long reduction): blockIdx.z takes a contiguous range of k tiles and
+  // adds its partial tile into the pre-zeroed output with float atomics; bias/activation are applied afterwards
+  const int nk_all = g.Kp / BK;
+  const int kper = (nk_all + ksplit - 1) / ksplit;
+  const int kt0 = blockIdx.z * kper;
+  const int nk = kt0 + kper < nk_all ? kt0 + kper : nk_all;
 
   auto load_tile = [&](int kt) {
     const int k0 = kt * BK;
@@ -115,13 +120,13 @@ conv_fwd_kernel(const ConvPhase g, const float* __restrict__ in, const float* __
   };
 
   __syncthreads();  // s_tap visible
-  if (nk > 0) {
-    load_tile(0);
+  if (kt0 < nk) {
+    load_tile(kt0);
     store_tile(0);
   }
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
+  for (int kt = kt0; kt < nk; ++kt) {
+    const int buf = (kt - kt0) & 1;
     if (kt + 1 < nk) load_tile(kt + 1);
     const float* As = As0 + buf * BK * LDA + wm * (TM * 32) + (lane & 31);
     const float* Bs = Bs0 + buf * BK * LDB + wn * (TN * 32) + (lane & 31);
@@ -142,6 +147,7 @@ conv_fwd_kernel(const ConvPhase g, const float* __restrict__ in, const float* __
     if (kt + 1 < nk) store_tile(buf ^ 1);
     __syncthreads();
   }
+  if (ksplit > 1 && kt0 >= nk) return;
 
   // ---- epilogue: bias + activation, coalesced along pixels (MFMA column = lane&31)
 #pragma unroll
@@ -160,11 +166,25 @@ conv_fwd_kernel(const ConvPhase g, const float* __restrict__ in, const float* __
         const int m = m_tile + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (m < g.M) {
           float v = acc[i][j][r];
-          if (bias) v += bias[m];
-          out[obase + (size_t)m * g.out_sC] = act_apply(v, act, slope);
+          if (ksplit > 1) {
+            atomicAdd(out + obase + (size_t)m * g.out_sC, v);
+          } else {
+            if (bias) v += bias[m];
+            out[obase + (size_t)m * g.out_sC] = act_apply(v, act, slope);
+          }
         }
       }
     }
+  }
+}
+
+// y[n][m][s] = act(y + bias[m]) in place (finishing pass of split-K launches)
+__global__ void __launch_bounds__(256) bias_act_kernel(float* __restrict__ y, const float* __restrict__ bias, int M, long S,
+                                                       long total, int act, float slope) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    float v = y[i];
+    if (bias) v += bias[(i / S) % M];
+    y[i] = act_apply(v, act, slope);
   }
 }
 
@@ -554,24 +574,36 @@ static int build_plan(const muvo_conv_desc* d, ConvPlan* pl, int mode = -1) {
 
 template <int BM, int BN, int WM, int WN>
 static void launch_fwd_run(const ConvPhase& g, const float* in, const float* wp, const float* bias, float* out,
-                           int act, float slope, hipStream_t st) {
-  dim3 grid(cdiv(g.npix, BN), cdiv(g.M, BM), 1);
+                           int act, float slope, hipStream_t st, int ksplit) {
+  dim3 grid(cdiv(g.npix, BN), cdiv(g.M, BM), ksplit);
   constexpr int KPT = 16 / (256 / BN);
   if (g.Cp == 4)
-    hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 4>), grid, dim3(256), 0, st, g, in, wp, bias, out, act, slope);
+    hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 4>), grid, dim3(256), 0, st, g, in, wp, bias, out, act, slope, ksplit);
   else if (g.Cp == 8 || KPT == 8)
-    hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 8>), grid, dim3(256), 0, st, g, in, wp, bias, out, act, slope);
+    hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, 8>), grid, dim3(256), 0, st, g, in, wp, bias, out, act, slope, ksplit);
   else
-    hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, KPT>), grid, dim3(256), 0, st, g, in, wp, bias, out, act, slope);
+    hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, KPT>), grid, dim3(256), 0, st, g, in, wp, bias, out, act, slope, ksplit);
+}
+
+// split-K factor of a fp32 phase: only for small grids with a long reduction
+static int phase_ksplit(const ConvPhase& g) {
+  if (g.bf3 || g.npix <= 0) return 1;
+  const int bm = g.M > 64 ? 128 : (g.M > 32 ? 64 : 32);
+  const long blocks = (long)cdiv(g.npix, 128) * cdiv(g.M, bm);
+  const int nk = g.Kp / 16;
+  if (blocks >= 192 || nk < 32) return 1;
+  int ks = cdiv(768, blocks);
+  if (ks > nk / 8) ks = nk / 8;
+  return ks < 1 ? 1 : ks;
 }
 
 static int launch_fwd_phase(const ConvPhase& g, const float* in, const float* wp, const float* bias, float* out,
-                            int act, float slope, hipStream_t st, const void* ws) {
+                            int act, float slope, hipStream_t st, const void* ws, int ksplit) {
   if (g.npix <= 0) return MUVO_OK;
   if (g.bf3) return bf3_launch_fwd_phase(g, ws, wp, bias, out, act, slope, st);
-  if (g.M > 64) launch_fwd_run<128, 128, 2, 2>(g, in, wp, bias, out, act, slope, st);
-  else if (g.M > 32) launch_fwd_run<64, 128, 2, 2>(g, in, wp, bias, out, act, slope, st);
-  else launch_fwd_run<32, 128, 1, 4>(g, in, wp, bias, out, act, slope, st);
+  if (g.M > 64) launch_fwd_run<128, 128, 2, 2>(g, in, wp, bias, out, act, slope, st, ksplit);
+  else if (g.M > 32) launch_fwd_run<64, 128, 2, 2>(g, in, wp, bias, out, act, slope, st, ksplit);
+  else launch_fwd_run<32, 128, 1, 4>(g, in, wp, bias, out, act, slope, st, ksplit);
   MUVO_CHECK_LAUNCH("conv_fwd_kernel");
   return MUVO_OK;
 }
@@ -705,6 +737,14 @@ int64_t muvo_conv_workspace_bytes(const muvo_conv_desc* d, int op) {
 static int run_phases(const ConvPhase* ph, int nph, const float* in, const float* wp, const float* bias, float* out, int act,
                       float slope, void* ws, hipStream_t st) {
   bool split_done = false;
+  // split-K needs a zeroed output and a finishing bias/activation pass; use it only when every phase wants it
+  bool use_ksplit = nph > 0;
+  for (int i = 0; i < nph; ++i) use_ksplit = use_ksplit && phase_ksplit(ph[i]) > 1;
+  const long out_total = nph > 0 ? (long)ph[0].N * ph[0].out_sN : 0;
+  if (use_ksplit && hipMemsetAsync(out, 0, sizeof(float) * out_total, st) != hipSuccess) {
+    muvo_set_error("conv: memset of the split-K output failed");
+    return MUVO_ERR_HIP;
+  }
   for (int i = 0; i < nph; ++i) {
     if (ph[i].bf3 && !split_done) {
       MUVO_CHECK_ARG(ws != nullptr, "conv: this shape runs on the bf16x3 kernel and needs muvo_conv_workspace_bytes() of workspace");
@@ -712,8 +752,13 @@ static int run_phases(const ConvPhase* ph, int nph, const float* in, const float
       if (rc) return rc;
       split_done = true;
     }
-    int rc = launch_fwd_phase(ph[i], in, wp, bias, out, act, slope, st, ws);
+    int rc = launch_fwd_phase(ph[i], in, wp, bias, out, act, slope, st, ws, use_ksplit ? phase_ksplit(ph[i]) : 1);
     if (rc) return rc;
+  }
+  if (use_ksplit && (bias != nullptr || act != MUVO_ACT_NONE)) {
+    hipLaunchKernelGGL(bias_act_kernel, dim3(ew_grid(out_total)), dim3(256), 0, st, out, bias, ph[0].M, (long)ph[0].out_sC,
+                       out_total, act, slope);
+    MUVO_CHECK_LAUNCH("bias_act_kernel");
   }
   return MUVO_OK;
 }

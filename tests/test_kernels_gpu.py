@@ -45,6 +45,9 @@ CONV_CASES = [
     (3, False, 16, 16, 3, 1, 1, 0, (6, 5, 64), False, 0),
     (3, False, 8, 8, 3, 1, 1, 0, (1, 1, 64), True, 0),
     (3, False, 16, 8, 3, 1, 1, 0, (19, 12, 32), True, 2),
+    # split-K path of the fp32 kernel (tiny pixel grid, long reduction) incl. the finishing bias+activation pass
+    (2, False, 256, 64, 3, 1, 1, 0, (6, 7), True, 3),
+    (2, True, 160, 96, 6, 2, 2, 0, (3, 4), True, 3),
     # decoder heads (conv_pw.hip: float4 VALU kernels), Cout <= 4, spatial size % 4 == 0 and >= 1024
     (3, False, 8, 2, 1, 1, 0, 0, (16, 16, 8), True, 0),
     (3, False, 32, 2, 1, 1, 0, 0, (12, 12, 8), True, 0),
