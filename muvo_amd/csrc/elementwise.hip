@@ -236,6 +236,97 @@ __global__ void upsample3d_x2_bwd_kernel(const float* __restrict__ dy, float* __
   }
 }
 
+// Vectorised variants (W even resp. W % 4 == 0): one float4 of outputs per lane, 3-D grid instead of 64-bit index
+// decomposition.  grid = (ceil(OH*OW/4 / 256), OD, NC) forward; (ceil(H*W/4 / 256), D, NC) backward.
+__global__ void __launch_bounds__(256) upsample3d_x2_fwd_vec_kernel(const float* __restrict__ x, float* __restrict__ y, int D,
+                                                                    int H, int W) {
+  const int OH = 2 * H, OW = 2 * W, Q = OW / 4;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= OH * Q) return;
+  const int oh = idx / Q, j = idx - oh * Q;
+  const int od = blockIdx.y;
+  const long nc = blockIdx.z;
+  int d0, d1, h0, h1;
+  float fd, fh;
+  lin_src(od, D, d0, d1, fd);
+  lin_src(oh, H, h0, h1, fh);
+  const float* xp = x + nc * D * H * W;
+  // input columns 2j-1 .. 2j+2 (clamped): the four outputs 4j+e read slots (0,1) (1,2) (1,2) (2,3)
+  int wi[4];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {
+    int w = 2 * j - 1 + s4;
+    wi[s4] = w < 0 ? 0 : (w > W - 1 ? W - 1 : w);
+  }
+  float r[4][4];  // [corner row][slot]
+  const float* rows[4] = {xp + (d0 * H + h0) * W, xp + (d0 * H + h1) * W, xp + (d1 * H + h0) * W, xp + (d1 * H + h1) * W};
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) r[q][s4] = rows[q][wi[s4]];
+  float o[4];
+  const float a = 1.f - fd, b = 1.f - fh;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    int i0, i1;
+    float fw;
+    lin_src(4 * j + e, W, i0, i1, fw);   // only the weight is used; the slots hold x[i0], x[i1]
+    const int s0 = (e + 1) >> 1, s1 = s0 + 1;
+    const float c = 1.f - fw;
+    o[e] = a * (b * (c * r[0][s0] + fw * r[0][s1]) + fh * (c * r[1][s0] + fw * r[1][s1])) +
+           fd * (b * (c * r[2][s0] + fw * r[2][s1]) + fh * (c * r[3][s0] + fw * r[3][s1]));
+  }
+  float4* yp = (float4*)(y + ((nc * (2 * D) + od) * OH + oh) * (long)OW) + j;
+  *yp = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// weights with which input index i (of n) receives output indices 2i-1 .. 2i+2 (out-of-range outputs get 0)
+__device__ __forceinline__ void up2_bwd_weights(int i, int n, float (&w)[4]) {
+  w[0] = i > 0 ? 0.25f : 0.f;
+  w[1] = i > 0 ? 0.75f : 1.f;
+  w[2] = i < n - 1 ? 0.75f : 1.f;
+  w[3] = i < n - 1 ? 0.25f : 0.f;
+}
+__global__ void __launch_bounds__(256) upsample3d_x2_bwd_vec_kernel(const float* __restrict__ dy, float* __restrict__ dx, int D,
+                                                                    int H, int W) {
+  const int OH = 2 * H, OW = 2 * W, Q = W / 4;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= H * Q) return;
+  const int h = idx / Q, j = idx - h * Q;
+  const int d = blockIdx.y;
+  const long nc = blockIdx.z;
+  float wa[4], wb[4];
+  up2_bwd_weights(d, D, wa);
+  up2_bwd_weights(h, H, wb);
+  const float* gp = dy + nc * (2 * D) * (long)OH * OW;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool left = j > 0, right = 8 * j + 8 < OW;
+#pragma unroll
+  for (int ia = 0; ia < 4; ++ia) {
+    const int a = 2 * d - 1 + ia;
+    if (wa[ia] == 0.f) continue;
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib) {
+      const int b = 2 * h - 1 + ib;
+      if (wb[ib] == 0.f) continue;
+      const float* row = gp + ((long)a * OH + b) * OW + 8 * j;
+      const float4 m0 = *(const float4*)row, m1 = *(const float4*)(row + 4);
+      const float gl = left ? row[-1] : 0.f, gr = right ? row[8] : 0.f;
+      const float g[10] = {gl, m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, gr};
+      const float wab = wa[ia] * wb[ib];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // input column w = 4j+e receives outputs 2w-1 .. 2w+2 = g[2e .. 2e+3]
+        const int w = 4 * j + e;
+        const float w1 = w > 0 ? 0.75f : 1.f, w2 = w < W - 1 ? 0.75f : 1.f;
+        acc[e] += wab * ((0.25f * g[2 * e] + w1 * g[2 * e + 1]) + (w2 * g[2 * e + 2] + 0.25f * g[2 * e + 3]));
+      }
+    }
+  }
+  float4* xp = (float4*)(dx + ((nc * D + d) * H + h) * (long)W) + j;
+  *xp = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
 // ------------------------------------------------------------------------------------ preprocess
 // u8 (NC, H, W) -> crop (top,left,CH,CW) -> /255 -> label ; (label-mean[c])/std[c] -> normalised
 __global__ void preprocess_image_kernel(const uint8_t* __restrict__ img, float* __restrict__ label,
@@ -552,12 +643,24 @@ int muvo_avgpool_bwd(const float* dy, float* dx, int64_t G, int64_t S, void* str
 }
 int muvo_upsample3d_x2_fwd(const float* x, float* y, int64_t NC, int D, int H, int W, void* stream) {
   MUVO_CHECK_ARG(x && y && NC > 0 && D > 0 && H > 0 && W > 0, "upsample3d_fwd: bad args");
+  if (W % 2 == 0 && 2 * D <= 65535 && NC <= 65535) {
+    dim3 grid(cdiv((long)2 * H * (2 * W / 4), 256), 2 * D, (unsigned)NC);
+    hipLaunchKernelGGL(upsample3d_x2_fwd_vec_kernel, grid, dim3(256), 0, ST, x, y, D, H, W);
+    MUVO_CHECK_LAUNCH("upsample3d_fwd_vec");
+    return MUVO_OK;
+  }
   hipLaunchKernelGGL(upsample3d_x2_fwd_kernel, dim3(ew_grid(NC * D * H * W * 8)), dim3(256), 0, ST, x, y, (long)NC, D, H, W);
   MUVO_CHECK_LAUNCH("upsample3d_fwd");
   return MUVO_OK;
 }
 int muvo_upsample3d_x2_bwd(const float* dy, float* dx, int64_t NC, int D, int H, int W, void* stream) {
   MUVO_CHECK_ARG(dy && dx && NC > 0 && D > 0 && H > 0 && W > 0, "upsample3d_bwd: bad args");
+  if (W % 4 == 0 && D <= 65535 && NC <= 65535) {
+    dim3 grid(cdiv((long)H * (W / 4), 256), D, (unsigned)NC);
+    hipLaunchKernelGGL(upsample3d_x2_bwd_vec_kernel, grid, dim3(256), 0, ST, dy, dx, D, H, W);
+    MUVO_CHECK_LAUNCH("upsample3d_bwd_vec");
+    return MUVO_OK;
+  }
   hipLaunchKernelGGL(upsample3d_x2_bwd_kernel, dim3(ew_grid(NC * D * H * W)), dim3(256), 0, ST, dy, dx, (long)NC, D, H, W);
   MUVO_CHECK_LAUNCH("upsample3d_bwd");
   return MUVO_OK;

@@ -113,6 +113,7 @@ def main():
     ap.add_argument('--tag', default=None)
     ap.add_argument('--steps', type=int, default=2)
     ap.add_argument('--skip-oracle', action='store_true')
+    ap.add_argument('--no-fp64', action='store_true', help='skip the float64 run of the reference (gradient noise floor)')
     args = ap.parse_args()
     tag = args.tag or f'b{args.b}s{args.s}'
     torch.manual_seed(0)
@@ -226,6 +227,54 @@ def main():
                                  'voxel_decoder.conv3.conv2.conv_act.0.weight']:
                 _, smp = tensor_stats(dict(model.named_parameters())[n].grad)
                 samples['grad.' + n] = smp
+            if not args.no_fp64:
+                # The same step of the REAL reference in float64: the truth the fp32 gradients are measured against.
+                # tests compare |hip - ref64| with the reference's own fp32 rounding error |ref32 - ref64| per tensor.
+                t0 = time.time()
+                torch.set_default_dtype(torch.float64)
+                _tensor_float = torch.Tensor.float
+                torch.Tensor.float = lambda self, *a, **k: self.double()   # the reference calls .float() on inputs
+                try:
+                    tr64 = ref_trainer.WorldModelTrainer(cfg_dict)
+                    tr64.train()
+                    tr64.preprocess.eval()
+                    tr64.model.load_state_dict(model.state_dict())
+                    tr64.double()
+                    for m in tr64.model.modules():
+                        if isinstance(m, torch.nn.Dropout):
+                            m.p = 0.0
+                        if isinstance(m, torch.nn.MultiheadAttention):
+                            m.dropout = 0.0
+                    b64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in raw.items()}
+                    with NoisePatch(eps.double(), coin):
+                        out64, _ = tr64.forward(b64)
+                    l64 = tr64.compute_loss(b64, out64)
+                    tot64 = tr64.loss_reducing(l64)
+                    tot64.backward()
+                finally:
+                    torch.set_default_dtype(torch.float32)
+                    torch.Tensor.float = _tensor_float
+                p64 = dict(tr64.model.named_parameters())
+                rec['total_fp64'] = float(tot64.item())
+                rec['losses_fp64'] = {k: float(v.item()) for k, v in l64.items()}
+                gn64, noise = {}, {}
+                for n, p in model.named_parameters():
+                    if p.grad is None:
+                        gn64[n] = None
+                        continue
+                    g64 = p64[n].grad
+                    gn64[n] = float(g64.pow(2).sum().sqrt())
+                    noise[n] = float((p.grad.double() - g64).pow(2).sum().sqrt())   # L2 of the fp32 reference's own error
+                rec['grad_l2_fp64'] = gn64
+                rec['grad_l2_ref32_err'] = noise
+                for key in [k for k in samples if k.startswith('grad.')]:
+                    n = key[5:]
+                    g64 = p64[n].grad.detach().contiguous().view(-1)
+                    stride = max(1, g64.numel() // 1024)
+                    samples['grad64.' + n] = g64[::stride][:1024].clone().numpy()
+                print(f'  fp64 reference fwd+bwd {time.time() - t0:.1f}s total={tot64.item():.9f} '
+                      f'(fp32 total {total.item():.9f})')
+                del tr64, out64, p64
 
         if oracle_model is not None:
             from oracle import muvo_ref

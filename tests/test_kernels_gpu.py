@@ -323,15 +323,16 @@ def test_pooling_and_upsample(dev):
     yr.backward(g)
     y.backward(g.to(dev))
     _close(xg.grad, xc.grad, name='avgpool bwd')
-    v = torch.randn(2, 3, 3, 5, 2)
-    vg, vc = v.to(dev).requires_grad_(True), v.clone().requires_grad_(True)
-    y = ops.upsample3d_x2(vg)
-    yr = F.interpolate(vc, scale_factor=2.0, mode='trilinear', align_corners=False)
-    _close(y, yr, name='upsample3d fwd')
-    g = torch.randn_like(yr)
-    yr.backward(g)
-    y.backward(g.to(dev))
-    _close(vg.grad, vc.grad, name='upsample3d bwd')
+    for shape in ((2, 3, 3, 5, 2), (2, 3, 3, 5, 8), (1, 2, 4, 6, 4), (1, 1, 2, 3, 5)):  # vectorised (W%4==0 / even) + scalar
+        v = torch.randn(*shape)
+        vg, vc = v.to(dev).requires_grad_(True), v.clone().requires_grad_(True)
+        y = ops.upsample3d_x2(vg)
+        yr = F.interpolate(vc, scale_factor=2.0, mode='trilinear', align_corners=False)
+        _close(y, yr, name=f'upsample3d fwd {shape}')
+        g = torch.randn_like(yr)
+        yr.backward(g)
+        y.backward(g.to(dev))
+        _close(vg.grad, vc.grad, name=f'upsample3d bwd {shape}')
     v1 = torch.randn(1, 2, 3, 3, 1)  # degenerate depth 1 (VoxelDecoder1 first levels)
     _close(ops.upsample3d_x2(v1.to(dev)), F.interpolate(v1, scale_factor=2.0, mode='trilinear', align_corners=False),
            name='upsample3d depth1')
