@@ -110,26 +110,33 @@ def test_voxel_argmax_bit_exact(run):
 
 
 def test_gradients_match_reference(run):
+    """Gradients against the float64 run of the REAL reference (fixture keys grad_l2_fp64 / grad64.*).  Several tensors
+    at the end of the backward chain are ill-conditioned: the reference's own fp32 gradients deviate from its fp64
+    gradients by up to 2e-3 of the tensor maximum (grad_l2_ref32_err, grad.* vs grad64.*).  Bar: within 2e-3 relative
+    of the truth, or within 4x the reference's own fp32 rounding error where that is larger."""
     fx, smp, recs = run
-    g = fx['steps'][0]['grad_l2']
+    st = fx['steps'][0]
     bad = []
-    for n, ref in g.items():
+    for n, ref in st['grad_l2_fp64'].items():
         got = recs[0]['grad_l2'][n]
         if ref is None:
             assert got is None or got == 0.0, n  # never-used encoder_layer.* (SURVEY App. B 2)
             continue
-        # abs escape: bias grads that are sums of ~1e7 cancelling terms carry ~1e-5 of fp32 summation noise
-        if _rel(got, ref) > 2e-3 and abs(got - ref) > 1e-5:
-            bad.append((n, got, ref))
+        tol = max(2e-3 * abs(ref), 4.0 * st['grad_l2_ref32_err'][n], 1e-5)
+        if abs(got - ref) > tol:
+            bad.append((n, got, ref, tol))
     assert not bad, f'{len(bad)} gradient norms off, first: {bad[:5]}'
     for key in smp.files:
-        if key.startswith('grad.'):
-            n = key[5:]
-            ref = torch.from_numpy(smp[key])
-            t = recs[0]['grads'][n].float().contiguous().view(-1)
+        if key.startswith('grad64.'):
+            n = key[7:]
+            ref = torch.from_numpy(smp[key]).double()
+            noise = (torch.from_numpy(smp['grad.' + n]).double() - ref).abs().max().item()
+            t = recs[0]['grads'][n].double().contiguous().view(-1)
             stride = max(1, t.numel() // 1024)
             got = t[::stride][:ref.numel()].cpu()
-            assert (got - ref).abs().max().item() < 2e-3 * max(ref.abs().max().item(), 1e-8), n
+            err = (got - ref).abs().max().item()
+            tol = max(2e-3 * ref.abs().max().item(), 4.0 * noise, 1e-12)
+            assert err <= tol, f'{n}: max err {err:.3e} > tol {tol:.3e} (reference fp32 noise {noise:.3e})'
 
 
 def test_adamw_steps_match_reference(run):

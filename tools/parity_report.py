@@ -33,17 +33,19 @@ def main():
         print(f'  {r[0]:.2e} {r[1]:.2e} {r[2]} {r[3]:.3e}')
     rows = []
     for key in smp.files:
-        if key.startswith('grad.'):
-            n = key[5:]
-            ref = torch.from_numpy(smp[key])
-            t = recs[0]['grads'][n].float().contiguous().view(-1)
+        if key.startswith('grad64.'):
+            n = key[7:]
+            ref = torch.from_numpy(smp[key]).double()
+            ref32 = torch.from_numpy(smp['grad.' + n]).double()
+            t = recs[0]['grads'][n].double().contiguous().view(-1)
             stride = max(1, t.numel() // 1024)
             got = t[::stride][:ref.numel()].cpu()
-            rows.append(((got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12), n))
+            mx = max(ref.abs().max().item(), 1e-30)
+            rows.append(((got - ref).abs().max().item() / mx, (ref32 - ref).abs().max().item() / mx, n))
     rows.sort(reverse=True)
-    print('grad samples, max|err| / max|ref|:')
+    print('grad samples vs the fp64 reference, max|err|/max|ref|:  ours   reference-fp32   name')
     for r in rows:
-        print(f'  {r[0]:.2e} {r[1]}')
+        print(f'  {r[0]:.2e} {r[1]:.2e} {r[2]}')
     for step, (rec, gg) in enumerate(zip(recs, fx['steps'])):
         bad = []
         for n, (s_ref, a_ref) in gg['param_checksums_after_step'].items():
