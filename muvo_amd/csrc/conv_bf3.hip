@@ -161,22 +161,26 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
     stage = stage == 2 ? 0 : stage + 1;
   }
 
-  // epilogue: bias + activation, coalesced along pixels (MFMA column = lane & 31)
+  // epilogue: bias + activation, coalesced along pixels (MFMA column = lane & 31); merged phases: row group -> residue
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int pj = blockIdx.x * BN + wn * 64 + j * 32 + (lane & 31);
     if (pj >= g.npix) continue;
     int nn, jz, jy, jx;
     decode_pix(g, pj, nn, jz, jy, jx);
-    const size_t obase = (size_t)nn * g.out_sN +
-                         ((size_t)(jz * g.os[0] + g.op[0]) * g.OH + (jy * g.os[1] + g.op[1])) * g.OW +
-                         (jx * g.os[2] + g.op[2]);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      const int mb = m_tile + wm * 64 + i * 32;
+      const int grp = g.nmerge > 1 ? mb / g.Msub : 0;
+      const int mo = mb - grp * g.Msub;
+      const size_t obase = (size_t)nn * g.out_sN +
+                           ((size_t)(jz * g.os[0] + g.mop[grp][0]) * g.OH + (jy * g.os[1] + g.mop[grp][1])) * g.OW +
+                           (jx * g.os[2] + g.mop[grp][2]);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m_tile + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m < g.M) {
+        const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int m = mo + rr;
+        if (mb + rr < g.M && m < g.Msub) {
           float v = acc[i][j][r];
           if (bias) v += bias[m];
           out[obase + (size_t)m * g.out_sC] = act_apply(v, act, slope);
@@ -432,7 +436,10 @@ __global__ void __launch_bounds__(256) bf3_pack_kernel(const ConvPhase g, const 
     const int m = (int)(idx % g.Mp), k = (int)(idx / g.Mp);
     const int t = k / g.Cp, c = k - t * g.Cp;
     float v = 0.f;
-    if (t < g.T && c < g.C && m < g.M) v = w[(size_t)m * g.wsm + (size_t)c * g.wsc + s_tw[t]];
+    if (t < g.T && c < g.C && m < g.M) {
+      const int grp = m / g.Msub, co = m - grp * g.Msub;
+      v = w[(size_t)co * g.wsm + (size_t)c * g.wsc + (g.nmerge > 1 ? g.tap_wm[grp][t] : s_tw[t])];
+    }
     unsigned hi, lo;
     split2(v, 0.f, hi, lo);
     const int kt = k >> 5, chunk = (k >> 3) & 3, e = k & 7;

@@ -156,15 +156,19 @@ conv_fwd_kernel(const ConvPhase g, const float* __restrict__ in, const float* __
     if (pj >= g.npix) continue;
     int nn, jz, jy, jx;
     decode_pix(g, pj, nn, jz, jy, jx);
-    const size_t obase = (size_t)nn * g.out_sN +
-                         ((size_t)(jz * g.os[0] + g.op[0]) * g.OH + (jy * g.os[1] + g.op[1])) * g.OW +
-                         (jx * g.os[2] + g.op[2]);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      const int mb = m_tile + wm * (TM * 32) + i * 32;   // 32-row tile: inside one merged group (Msub % 32 == 0)
+      const int grp = g.nmerge > 1 ? mb / g.Msub : 0;
+      const int mo = mb - grp * g.Msub;
+      const size_t obase = (size_t)nn * g.out_sN +
+                           ((size_t)(jz * g.os[0] + g.mop[grp][0]) * g.OH + (jy * g.os[1] + g.mop[grp][1])) * g.OW +
+                           (jx * g.os[2] + g.mop[grp][2]);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m_tile + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m < g.M) {
+        const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int m = mo + rr;
+        if (mb + rr < g.M && m < g.Msub) {
           float v = acc[i][j][r];
           if (ksplit > 1) {
             atomicAdd(out + obase + (size_t)m * g.out_sC, v);
@@ -336,7 +340,10 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const ConvPhase g, co
     const int k = (int)(idx / g.Mp), m = (int)(idx - (long)k * g.Mp);
     const int t = k / g.Cp, c = k - t * g.Cp;
     float v = 0.f;
-    if (t < g.T && c < g.C && m < g.M) v = w[(size_t)m * g.wsm + (size_t)c * g.wsc + s_tw[t]];
+    if (t < g.T && c < g.C && m < g.M) {
+      const int grp = m / g.Msub, co = m - grp * g.Msub;
+      v = w[(size_t)co * g.wsm + (size_t)c * g.wsc + (g.nmerge > 1 ? g.tap_wm[grp][t] : s_tw[t])];
+    }
     wp[g.wp_off + idx] = v;
   }
 }
@@ -409,6 +416,7 @@ static int choose_cp(int C) { return C <= 4 ? 4 : (C <= 8 ? 8 : roundup(C, 16));
 // 0: exact fp32 MFMA everywhere; 1: bf16x3 split-product MFMA for phases with more than 32 output channels
 static int g_conv_mode = -1;
 static thread_local int t_plan_mode = 0;
+static thread_local bool t_allow_merge = true;
 static int conv_mode() {
   if (g_conv_mode < 0) {
     const char* e = getenv("MUVO_CONV_MFMA");
@@ -429,9 +437,14 @@ static double bf3_min_gflop() {
 
 static void finish_phase(ConvPhase& g) {
   g.bf3 = 0;
+  if (g.nmerge <= 1) {
+    g.nmerge = 1;
+    g.Msub = g.M;
+    for (int a = 0; a < 3; ++a) g.mop[0][a] = g.op[a];
+  }
   // bf16x3 only where it pays: phases with >= MUVO_BF16X3_MIN_GFLOP (default 2) GFLOP of work per batch item, i.e.
   // the ConvDecoder stacks and the widest DecoderDS conv; the rest (encoders, voxel trunk) stays on exact fp32 MFMA.
-  const double gflop = 2.0 * g.M * g.T * g.C * (double)g.SD * g.SH * g.SW * 1e-9;
+  const double gflop = 2.0 * g.Msub * g.T * g.C * (double)g.SD * g.SH * g.SW * 1e-9;   // per original phase
   if (t_plan_mode == 1 && g.M > 32 && (long)g.T * g.C >= 32 && gflop >= bf3_min_gflop()) {
     g.bf3 = 1;
     bf3_finish_phase(g);
@@ -533,6 +546,27 @@ static int build_transposed_form(const muvo_conv_desc* d, const int* in_dims, co
         finish_phase(g);
         phs[count++] = g;
       }
+  // merge the phases into one GEMM when they all read the same input offsets (see conv_plan.h)
+  if (t_allow_merge && count > 1 && count <= 8 && M % 32 == 0 && (long)count * M <= 1024) {
+    bool same = true;
+    for (int i = 1; i < count && same; ++i) {
+      same = phs[i].T == phs[0].T && phs[i].SD == phs[0].SD && phs[i].SH == phs[0].SH && phs[i].SW == phs[0].SW;
+      for (int t = 0; t < phs[0].T && same; ++t) same = phs[i].tap_d[t] == phs[0].tap_d[t];
+    }
+    if (same) {
+      ConvPhase g = phs[0];
+      g.nmerge = count;
+      g.Msub = M;
+      g.M = count * M;
+      for (int i = 0; i < count; ++i) {
+        for (int a = 0; a < 3; ++a) g.mop[i][a] = phs[i].op[a];
+        for (int t = 0; t < g.T; ++t) g.tap_wm[i][t] = phs[i].tap_w[t];
+      }
+      finish_phase(g);
+      phs[0] = g;
+      count = 1;
+    }
+  }
   *nph = count;
   return MUVO_OK;
 }
@@ -543,10 +577,11 @@ struct ConvPlan {
   long fwd_floats, dgr_floats;
 };
 
-static int build_plan(const muvo_conv_desc* d, ConvPlan* pl, int mode = -1) {
+static int build_plan(const muvo_conv_desc* d, ConvPlan* pl, int mode = -1, bool allow_merge = true) {
   int rc = check_desc(d);
   if (rc) return rc;
   t_plan_mode = mode < 0 ? conv_mode() : mode;
+  t_allow_merge = allow_merge;
   const long taps = (long)d->ksz[0] * d->ksz[1] * d->ksz[2];
   if (!d->transposed) {
     // weight [Cout][Cin][taps]
@@ -650,7 +685,7 @@ int muvo_conv_pack_sizes(const muvo_conv_desc* d, int64_t* fwd_floats, int64_t* 
   if (rc) return rc;
   {  // wgrad always runs on the fp32-layout plan and uses fwd_floats of scratch
     ConvPlan pf;
-    rc = build_plan(d, &pf, 0);
+    rc = build_plan(d, &pf, 0, false);
     if (rc) return rc;
     if (pf.fwd_floats > pl.fwd_floats) pl.fwd_floats = pf.fwd_floats;
   }
@@ -719,7 +754,7 @@ static bool wgrad_uses_bf3(const ConvPlan& pf);
 int64_t muvo_conv_workspace_bytes(const muvo_conv_desc* d, int op) {
   ConvPlan pl;
   if (op >= 2) {  // weight gradient: split planes of x (op 2) and of dy (op 3)
-    if (build_plan(d, &pl, 0)) return -1;
+    if (build_plan(d, &pl, 0, false)) return -1;
     if (pw_applicable(d) || vox_wgrad_applicable(d) || !wgrad_uses_bf3(pl)) return 0;
     return op == 2 ? bf3_workspace_bytes(d->N, d->Cin, (long)d->in_sz[0] * d->in_sz[1] * d->in_sz[2])
                    : bf3_workspace_bytes(d->N, d->Cout, (long)d->out_sz[0] * d->out_sz[1] * d->out_sz[2]);
@@ -756,7 +791,7 @@ static int run_phases(const ConvPhase* ph, int nph, const float* in, const float
     if (rc) return rc;
   }
   if (use_ksplit && (bias != nullptr || act != MUVO_ACT_NONE)) {
-    hipLaunchKernelGGL(bias_act_kernel, dim3(ew_grid(out_total)), dim3(256), 0, st, out, bias, ph[0].M, (long)ph[0].out_sC,
+    hipLaunchKernelGGL(bias_act_kernel, dim3(ew_grid(out_total)), dim3(256), 0, st, out, bias, ph[0].Msub, (long)ph[0].out_sC,
                        out_total, act, slope);
     MUVO_CHECK_LAUNCH("bias_act_kernel");
   }
@@ -802,7 +837,7 @@ static bool wgrad_uses_bf3(const ConvPlan& pf) {
 int muvo_conv_wgrad(const muvo_conv_desc* d, const float* x, const float* dy, float* dwp_scratch, float* dw, float* dbias,
                     void* ws_x, void* ws_dy, int flags, void* stream) {
   ConvPlan pl;
-  int rc = build_plan(d, &pl, 0);
+  int rc = build_plan(d, &pl, 0, false);
   if (rc) return rc;
   MUVO_CHECK_ARG(x && dy && dwp_scratch && dw, "conv_wgrad: null pointer");
   hipStream_t st = (hipStream_t)stream;

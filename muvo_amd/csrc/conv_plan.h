@@ -21,6 +21,12 @@ struct ConvPhase {
   long wp_off;         // float offset of this phase inside the packed weight buffer
   long wsm, wsc;       // PyTorch-weight strides of (m, c)
   int bf3;             // 1: packed for / launched on the bf16x3 kernel (conv_bf3.hip), 0: exact fp32 MFMA
+  // Merged sub-pixel phases of a transposed conv: when all stride^nd phases read the same input offsets (k6 s2 p2:
+  // every phase is a 3x3 window at offsets -1..1) they are ONE GEMM with M = nmerge * Msub rows; row group m / Msub
+  // writes output residue mop[group] and takes its weights at kernel taps tap_wm[group][t].  nmerge == 1: plain phase.
+  int nmerge, Msub;
+  int mop[8][3];
+  int tap_wm[8][MAX_TAPS];
 };
 
 __device__ __forceinline__ void decode_pix(const ConvPhase& g, int p, int& n, int& iz, int& iy, int& ix) {

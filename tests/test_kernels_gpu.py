@@ -45,6 +45,9 @@ CONV_CASES = [
     (3, False, 16, 16, 3, 1, 1, 0, (6, 5, 64), False, 0),
     (3, False, 8, 8, 3, 1, 1, 0, (1, 1, 64), True, 0),
     (3, False, 16, 8, 3, 1, 1, 0, (19, 12, 32), True, 2),
+    # merged sub-pixel phases (ConvTranspose k6 s2 p2 with Cout % 32 == 0: the four phases run as one GEMM)
+    (2, True, 48, 64, 6, 2, 2, 0, (7, 9), True, 3),
+    (2, True, 64, 32, 6, 2, 2, 0, (5, 13), True, 3),
     # split-K path of the fp32 kernel (tiny pixel grid, long reduction) incl. the finishing bias+activation pass
     (2, False, 256, 64, 3, 1, 1, 0, (6, 7), True, 3),
     (2, True, 160, 96, 6, 2, 2, 0, (3, 4), True, 3),
