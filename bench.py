@@ -66,6 +66,8 @@ def main():
     ap.add_argument('--seq-len', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--conv-mfma', default=os.environ.get('MUVO_CONV_MFMA', 'bf16x3'), choices=['f32', 'bf16x3'],
+                    help='matrix-pipe arithmetic of the large convolutions (DESIGN.md section 5)')
     ap.add_argument('--layer-table', default='', help='write the per-layer conv timing table to this file')
     args = ap.parse_args()
 
@@ -80,6 +82,7 @@ def main():
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     from muvo_amd import ops
+    ops.set_conv_mode(ops.CONV_BF16X3 if args.conv_mfma == 'bf16x3' else ops.CONV_F32)
     from muvo_amd.config import base_1d_cfg
     from muvo_amd.data.synthetic import make_batch
     from muvo_amd.parallel import SegmentedGradReducer
@@ -139,11 +142,14 @@ def main():
         out = {
             'metric': 'world-model training samples/sec (seq_len=10)', 'value': samples / dt, 'unit': 'samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if args.conv_mfma == 'f32' else 'f32 storage/accumulate; decoder contractions as bf16x3 split products',
+            'data': 'synthetic',
             'config': {'workload': f'base_1d (resnet18 + range-view + transformer fusion + 1D latent), batch={args.batch} '
                                    f'per GPU, seq_len={s}, 600x960 RGB (crop 320x832) + 64x1024 range-view + '
                                    f'192x192x64 voxels, full step incl. 21 losses, backward, AdamW',
-                       'global_batch': args.batch * world, 'seq_len': s, 'parallelism': f'dp{world}'},
+                       'global_batch': args.batch * world, 'seq_len': s, 'parallelism': f'dp{world}',
+                       'conv_mfma': args.conv_mfma},
             'frames_per_s': samples * s / dt,
             'step_tflops_per_gpu': GFLOP_PER_FRAME * frames_per_gpu_step / (ms * 1e-3) / 1e3,
             'step_frac_of_fp32_mfma_peak': GFLOP_PER_FRAME * frames_per_gpu_step / (ms * 1e-3) / 1e3 / PEAK_FP32_MFMA_TFLOPS,
@@ -153,7 +159,7 @@ def main():
             with open(args.layer_table, 'w') as f:
                 f.write(timing.layer_table() + '\n')
         if timing is not None:
-            out['roofline'], out['kernel_classes'] = timing.summary(PEAK_FP32_MFMA_TFLOPS)
+            out['roofline'], out['kernel_classes'] = timing.summary()
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(usable_cores())
         print(json.dumps(out), flush=True)

@@ -51,7 +51,7 @@ typedef struct muvo_conv_desc {
  * (3/16 of the fp32-MFMA cost, per-product relative error <= ~1e-5).  Initial value: env MUVO_CONV_MFMA=f32|bf16x3. */
 #define MUVO_CONV_F32 0
 #define MUVO_CONV_BF16X3 1
-#define MUVO_CONV_MODE_DEFAULT MUVO_CONV_F32
+#define MUVO_CONV_MODE_DEFAULT MUVO_CONV_BF16X3
 int muvo_conv_set_mode(int mode);
 int muvo_conv_get_mode(void);
 /* In MUVO_CONV_BF16X3 mode only phases with at least this much work per batch item (GFLOP, 2*MAC) use the split-product
@@ -65,6 +65,9 @@ int muvo_conv_pack_weights(const muvo_conv_desc* d, const float* w, float* wp_fw
  * in the current mode (0 = none; the bf16x3 kernels read channels-last bf16 hi/lo copies of their activation operands,
  * which the call writes there first).  The copy of x is the same for op 0 and op 2, the copy of dy for op 1 and op 3. */
 int64_t muvo_conv_workspace_bytes(const muvo_conv_desc* d, int op);
+/* kernel family that serves this shape in the current mode (for profiling/roofline attribution): 0 exact-fp32 implicit
+ * GEMM, 1 bf16x3 implicit GEMM, 2 4x4x1-MFMA small-channel Conv3d, 3 float4 VALU heads; op 0 fwd, 1 dgrad, 2 wgrad */
+int muvo_conv_kernel_family(const muvo_conv_desc* d, int op);
 /* y = act(conv(x, w) + bias); bias may be NULL; ws may be NULL when muvo_conv_workspace_bytes(d, 0) == 0 */
 int muvo_conv_forward(const muvo_conv_desc* d, const float* x, const float* wp_fwd, const float* bias, float* y, int act,
                       float slope, void* ws, void* stream);

@@ -210,12 +210,12 @@ __device__ __forceinline__ bf16x8 tr_read8(const char* lds_addr0, const char* ld
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int BM, int BN, int WM, int WN>
-__global__ void __launch_bounds__(64 * WM * WN)
+template <int BM, int BN, int WM, int WN, int WK>
+__global__ void __launch_bounds__(64 * WM * WN * WK)
 conv_bf3_wgrad_kernel(const ConvPhase g, const uint4* __restrict__ xs, long xplane_u4, int xc8, const uint4* __restrict__ dzs,
                       long dzplane_u4, int dzc8, float* __restrict__ wg, int steps_per_split,
                       const uint4* __restrict__ zero16) {
-  constexpr int BK = 32, NW = WM * WN;
+  constexpr int BK = 32, NW = WM * WN * WK;         // WK = 2: two wave groups split the 32 pixels of a step
   constexpr int CA = BM / 8, CB = BN / 8;           // 8-channel chunks per pixel row
   constexpr int STAGE = 2 * 32 * (CA + CB);         // uint4 per stage: A [plane][CA][32] then B [plane][CB][32]
   constexpr int NA = CA, NB = CB;                   // DMA wave-instructions per stage (2 planes x chunks/2)
@@ -225,7 +225,7 @@ conv_bf3_wgrad_kernel(const ConvPhase g, const uint4* __restrict__ xs, long xpla
   extern __shared__ uint4 smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
+  const int wk = wave / (WM * WN), wm = (wave / WN) % WM, wn = wave % WN;
   const int ctiles = (g.C + BN - 1) / BN;
   const int t = blockIdx.x / ctiles, c_tile = (blockIdx.x % ctiles) * BN, m_tile = blockIdx.y * BM;
   const int td = g.tap_d[t];
@@ -328,7 +328,8 @@ conv_bf3_wgrad_kernel(const ConvPhase g, const uint4* __restrict__ xs, long xpla
     const char* Bh = S + (size_t)2 * CA * 512 + (size_t)(wn * 8) * 512;
     const char* Bl = Bh + (size_t)CB * 512;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks0 = 0; ks0 < 2 / WK; ++ks0) {
+      const int ks = WK == 2 ? wk : ks0;
       bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -508,14 +509,14 @@ int bf3_launch_fwd_phase(const ConvPhase& g, const void* ws, const float* wp, co
   return bf3_launch<64, 256, 1, 4>(g, ws, wp, bias, out, act, slope, st);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int WK>
 static int bf3_wgrad_launch(const ConvPhase& g, const void* ws_x, int Cin_total, const void* ws_dz, int Cout_total,
                             float* wg, hipStream_t st) {
   constexpr size_t lds = (size_t)3 * 2 * 32 * (BM / 8 + BN / 8) * 16;
   static bool attr_set = false;
   static const uint4* zero16 = nullptr;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv_bf3_wgrad_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)conv_bf3_wgrad_kernel<BM, BN, WM, WN, WK>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess ||
         hipGetSymbolAddress((void**)&zero16, HIP_SYMBOL(g_zero16)) != hipSuccess) {
       muvo_set_error("conv_bf3_wgrad: kernel attribute / symbol setup failed");
@@ -536,7 +537,7 @@ static int bf3_wgrad_launch(const ConvPhase& g, const void* ws_x, int Cin_total,
   const int sps = cdiv(nsteps, ksplit);
   ksplit = cdiv(nsteps, sps);
   dim3 grid(ctiles * g.T, mtiles, ksplit);
-  hipLaunchKernelGGL((conv_bf3_wgrad_kernel<BM, BN, WM, WN>), grid, dim3(64 * WM * WN), lds, st, p, (const uint4*)ws_x, xplane,
+  hipLaunchKernelGGL((conv_bf3_wgrad_kernel<BM, BN, WM, WN, WK>), grid, dim3(64 * WM * WN * WK), lds, st, p, (const uint4*)ws_x, xplane,
                      xc8, (const uint4*)ws_dz, dzplane, dzc8, wg, sps, zero16);
   MUVO_CHECK_LAUNCH("conv_bf3_wgrad_kernel");
   return MUVO_OK;
@@ -547,11 +548,11 @@ int bf3_wgrad_phase(const ConvPhase& g, const void* ws_x, int Cin_total, const v
                     float* dw, hipStream_t st) {
   if (g.npix <= 0 || g.T == 0) return MUVO_OK;
   int rc;
-  if (g.M > 128) rc = bf3_wgrad_launch<256, 128, 4, 2>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st);
-  else if (g.M > 64) rc = g.C > 128 ? bf3_wgrad_launch<128, 256, 2, 4>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st)
-                                    : bf3_wgrad_launch<128, 128, 2, 2>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st);
-  else rc = g.C > 128 ? bf3_wgrad_launch<64, 256, 1, 4>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st)
-                      : bf3_wgrad_launch<64, 128, 1, 2>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st);
+  if (g.M > 128) rc = bf3_wgrad_launch<256, 128, 4, 2, 1>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st);
+  else if (g.M > 64) rc = g.C > 128 ? bf3_wgrad_launch<128, 256, 2, 4, 1>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st)
+                                    : bf3_wgrad_launch<128, 128, 2, 2, 2>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st);
+  else rc = g.C > 128 ? bf3_wgrad_launch<64, 256, 1, 4, 2>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st)
+                      : bf3_wgrad_launch<64, 128, 1, 2, 2>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st);
   if (rc) return rc;
   const long total = (long)g.M * g.C * g.T;
   hipLaunchKernelGGL(bf3_unpack_wgrad_kernel, dim3(ew_grid(total)), dim3(256), 0, st, g, wg, dw);

@@ -769,6 +769,25 @@ int64_t muvo_conv_workspace_bytes(const muvo_conv_desc* d, int op) {
   return 0;
 }
 
+// which kernel family serves this shape: 0 fp32 implicit GEMM (conv_gemm.hip), 1 bf16x3 (conv_bf3.hip),
+// 2 small-channel Conv3d on the 4x4x1 MFMA (conv_vox.hip), 3 decoder heads (conv_pw.hip); op 0 fwd, 1 dgrad, 2 wgrad
+int muvo_conv_kernel_family(const muvo_conv_desc* d, int op) {
+  ConvPlan pl;
+  if (pw_applicable(d)) return 3;
+  if (op == 2) {
+    if (build_plan(d, &pl, 0, false)) return -1;
+    if (vox_wgrad_applicable(d)) return 2;
+    return wgrad_uses_bf3(pl) ? 1 : 0;
+  }
+  if (build_plan(d, &pl)) return -1;
+  if (op == 0 ? vox_fwd_applicable(d) : vox_dgrad_applicable(d)) return 2;
+  const ConvPhase* ph = op == 0 ? pl.fwd : pl.dgr;
+  const int nph = op == 0 ? pl.nfwd : pl.ndgr;
+  for (int i = 0; i < nph; ++i)
+    if (ph[i].bf3) return 1;
+  return 0;
+}
+
 static int run_phases(const ConvPhase* ph, int nph, const float* in, const float* wp, const float* bias, float* out, int act,
                       float slope, void* ws, hipStream_t st) {
   bool split_done = false;

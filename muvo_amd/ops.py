@@ -42,7 +42,7 @@ class GemmDesc(C.Structure):
 # every exported symbol of include/muvo_hip.h (tests/test_abi.py checks this list against the header)
 EXPORTS = [
     'muvo_last_error', 'muvo_abi_version', 'muvo_selftest_mfma',
-    'muvo_conv_set_mode', 'muvo_conv_get_mode', 'muvo_conv_set_bf16x3_min_gflop', 'muvo_conv_pack_sizes', 'muvo_conv_workspace_bytes', 'muvo_conv_pack_weights', 'muvo_conv_forward', 'muvo_conv_dgrad', 'muvo_conv_wgrad', 'muvo_bias_grad_nchw',
+    'muvo_conv_set_mode', 'muvo_conv_get_mode', 'muvo_conv_set_bf16x3_min_gflop', 'muvo_conv_pack_sizes', 'muvo_conv_workspace_bytes', 'muvo_conv_kernel_family', 'muvo_conv_pack_weights', 'muvo_conv_forward', 'muvo_conv_dgrad', 'muvo_conv_wgrad', 'muvo_bias_grad_nchw',
     'muvo_gemm',
     'muvo_bn_train_fwd', 'muvo_bn_train_bwd', 'muvo_adain_fwd', 'muvo_adain_bwd',
     'muvo_add_dropout_layernorm_fwd', 'muvo_add_dropout_layernorm_bwd',
@@ -181,7 +181,9 @@ class KernelTiming:
             out.append(f'{sec / n * 1e3:9.3f} {n:5d} {fl / max(sec, 1e-12) / 1e12:8.1f} {fl / n / 1e9:9.2f}  {cls} | {tag}')
         return '\n'.join(out)
 
-    def summary(self, peak_tflops):
+    def summary(self):
+        """(roofline object of the dominant conv kernel family, per-class table).  Times are HIP-event brackets on the
+        launch stream around the C-ABI call (they include the small pack/split/unpack helper launches of that call)."""
         torch.cuda.synchronize()
         agg = {}
         for cls, flops, launches, e0, e1, _tag in self.rec:
@@ -192,16 +194,34 @@ class KernelTiming:
         classes = {k: dict(seconds=v[0], tflop=v[1] / 1e12, launches=v[2],
                            avg_launch_us=v[0] / max(v[2], 1) * 1e6, tflops=v[1] / max(v[0], 1e-12) / 1e12)
                    for k, v in agg.items()}
-        dom = max((k for k in classes if k.startswith('conv_fwd_kernel')), key=lambda k: classes[k]['seconds'],
-                  default=None)
+        fam = {}
+        for k, c in classes.items():
+            f = fam.setdefault(k.split(':')[0], dict(seconds=0.0, tflop=0.0, launches=0))
+            f['seconds'] += c['seconds']
+            f['tflop'] += c['tflop']
+            f['launches'] += c['launches']
+        mfma = {k: v for k, v in fam.items() if k in PEAK_TFLOPS}
         roof = None
-        if dom is not None:
-            c = classes[dom]
-            roof = dict(bound='mfma', kernel=dom, achieved=c['tflops'], peak=peak_tflops, unit='TFLOP/s',
-                        frac=c['tflops'] / peak_tflops, traffic=None, launches=c['launches'],
-                        avg_launch_us=c['avg_launch_us'],
-                        flop_per_launch=c['tflop'] * 1e12 / max(c['launches'], 1))
+        if mfma:
+            dom = max(mfma, key=lambda k: mfma[k]['seconds'])
+            f = mfma[dom]
+            alg = f['tflop'] / max(f['seconds'], 1e-12)
+            mult = MFMA_FLOPS_PER_ALGORITHMIC_FLOP[dom]
+            roof = dict(bound='mfma', kernel=KERNEL_NAMES[dom], achieved=alg * mult, peak=PEAK_TFLOPS[dom], unit='TFLOP/s',
+                        frac=alg * mult / PEAK_TFLOPS[dom], traffic=None, algorithmic_tflops=alg,
+                        mfma_flops_per_algorithmic_flop=mult, launches=f['launches'],
+                        avg_launch_us=f['seconds'] / max(f['launches'], 1) * 1e6,
+                        share_of_conv_time=f['seconds'] / max(sum(v['seconds'] for v in fam.values()), 1e-12))
         return roof, classes
+
+
+FAMILY = {0: 'f32_implicit_gemm', 1: 'bf16x3_implicit_gemm', 2: 'vox_4x4x1', 3: 'heads_valu', -1: 'unknown'}
+KERNEL_NAMES = {'f32_implicit_gemm': 'conv_fwd_kernel / conv_wgrad_kernel (v_mfma_f32_32x32x2_f32)',
+                'bf16x3_implicit_gemm': 'conv_bf3_kernel / conv_bf3_wgrad_kernel (v_mfma_f32_32x32x16_bf16, 3 products)',
+                'vox_4x4x1': 'vox_conv_kernel / vox_wgrad_kernel (v_mfma_f32_4x4x1_16b_f32)'}
+# dense MFMA peaks from /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_TFLOPS = {'f32_implicit_gemm': 157.3, 'bf16x3_implicit_gemm': 2500.0, 'vox_4x4x1': 157.3}
+MFMA_FLOPS_PER_ALGORITHMIC_FLOP = {'f32_implicit_gemm': 1.0, 'bf16x3_implicit_gemm': 3.0, 'vox_4x4x1': 1.0}
 
 
 def _conv_tag(geom, n, in_sz):
@@ -291,6 +311,7 @@ class ConvGeom:
         self.pad, self.out_pad = p, op
         self._plans = {}
         self.ws_bytes = {}
+        self.family = {}
 
     def out_size(self, in_sz):
         o = []
@@ -316,6 +337,7 @@ class ConvGeom:
             if min(wsf, wsd, wsx, wsy) < 0:
                 raise RuntimeError(f'muvo_hip error: {lib().muvo_last_error().decode()}')
             self.ws_bytes[(n, in_sz, _plan_epoch[0])] = (wsf, wsd, wsx, wsy)
+            self.family[(n, in_sz, _plan_epoch[0])] = tuple(lib().muvo_conv_kernel_family(C.byref(d), op) for op in (0, 1, 2))
             pl = (d, out_sz, ff.value, df.value)
             self._plans[key] = pl
         return pl
@@ -353,7 +375,7 @@ class ConvFn(torch.autograd.Function):
         kt = KERNEL_TIMING
         if kt is not None:
             import math
-            e0, e1 = kt.bracket('conv_fwd_kernel(fwd)', _conv_flops(geom, n, in_sz, out_sz),
+            e0, e1 = kt.bracket(FAMILY[geom.family[(n, in_sz, _plan_epoch[0])][0]] + ':fwd', _conv_flops(geom, n, in_sz, out_sz),
                                 math.prod(geom.stride) if geom.transposed else 1, _conv_tag(geom, n, in_sz))
             e0.record()
         wsb = geom.ws_bytes[(n, in_sz, _plan_epoch[0])]
@@ -397,7 +419,8 @@ class ConvFn(torch.autograd.Function):
             kt = KERNEL_TIMING
             if kt is not None:
                 import math
-                e0, e1 = kt.bracket('conv_fwd_kernel(dgrad)', _conv_flops(geom, x.shape[0], ctx.in_sz, out_sz),
+                e0, e1 = kt.bracket(FAMILY[geom.family[(x.shape[0], ctx.in_sz, _plan_epoch[0])][1]] + ':dgrad',
+                                    _conv_flops(geom, x.shape[0], ctx.in_sz, out_sz),
                                     1 if geom.transposed else math.prod(geom.stride), _conv_tag(geom, x.shape[0], ctx.in_sz))
                 e0.record()
             wsb = geom.ws_bytes[(x.shape[0], ctx.in_sz, _plan_epoch[0])]
@@ -413,7 +436,8 @@ class ConvFn(torch.autograd.Function):
             kt = KERNEL_TIMING
             if kt is not None:
                 import math
-                e0, e1 = kt.bracket('conv_wgrad_kernel(+unpack,bias)', _conv_flops(geom, x.shape[0], ctx.in_sz, out_sz),
+                e0, e1 = kt.bracket(FAMILY[geom.family[(x.shape[0], ctx.in_sz, _plan_epoch[0])][2]] + ':wgrad',
+                                    _conv_flops(geom, x.shape[0], ctx.in_sz, out_sz),
                                     math.prod(geom.stride) if geom.transposed else 1, _conv_tag(geom, x.shape[0], ctx.in_sz))
                 e0.record()
             wsb = geom.ws_bytes[(x.shape[0], ctx.in_sz, _plan_epoch[0])]
