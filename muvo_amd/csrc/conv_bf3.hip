@@ -43,21 +43,21 @@ __device__ __forceinline__ void dma16(const uint4* g, uint4* lds_wave_base) {
 // Workgroup = WM x WN waves, each owning a 64x64 output tile (2x2 MFMA tiles of 32x32).  K loop: BK = 32 per step,
 // three LDS stages; the DMA of steps k+1 and k+2 stays in flight across the (raw) barrier of step k — each wave waits
 // only for its own copies of step k with a counted vmcnt before the barrier.
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BKC, int NST>
 __global__ void __launch_bounds__(64 * WM * WN)
 conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, const uint4* __restrict__ wp,
                 const float* __restrict__ bias, float* __restrict__ out, int act, float slope,
                 const uint4* __restrict__ zero16) {
-  constexpr int BK = 32, NW = WM * WN;
+  constexpr int BK = 8 * BKC, NW = WM * WN;       // BKC = 8-channel chunks per K step (4: BK = 32, 2: BK = 16)
+  constexpr bool SETPRIO = NST == 6;              // tuning experiment: raise priority around the MFMA cluster
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-  static_assert(TM == 2 && TN == 2, "each wave owns 64x64");
-  constexpr int STAGE = 8 * (BM + BN);            // uint4 per stage: [plane][chunk][BM] then [plane][chunk][BN]
+  constexpr int STAGE = 2 * BKC * (BM + BN);      // uint4 per stage: [plane][chunk][BM] then [plane][chunk][BN]
   constexpr int RG = BM / 64, NG = BN / 64;       // 64-row groups of A, 64-pixel groups of B
-  constexpr int APW = 8 * RG / NW;                // A copies (wave instructions) per wave per step
-  constexpr int CPW = 8 * NG / NW;                // B (plane,chunk) combos per wave per step
-  static_assert(APW * NW == 8 * RG && CPW * NW == 8 * NG && NW % NG == 0, "DMA roles must tile");
+  constexpr int APW = 2 * BKC * RG / NW;          // A copies (wave instructions) per wave per step
+  constexpr int CPW = 2 * BKC * NG / NW;          // B (plane,chunk) combos per wave per step
+  static_assert(APW * NW == 2 * BKC * RG && CPW * NW == 2 * BKC * NG && NW % NG == 0, "DMA roles must tile");
   constexpr int DMA_PER_STEP = APW + CPW;
-  extern __shared__ uint4 smem[];                 // 3 stages
+  extern __shared__ uint4 smem[];                 // NST stages
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
@@ -86,16 +86,18 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
 
   auto issue = [&](int kt, int stage) {
     uint4* S = smem + stage * STAGE;
+    const int k32 = (kt * BK) >> 5, c4 = ((kt * BK) >> 3) & 3;   // position of this step inside the 32-deep packed tiles
 #pragma unroll
     for (int q = 0; q < APW; ++q) {
       const int a = wave * APW + q;
-      const int pc = a / RG, rg = a % RG;
-      dma16(wpb + (size_t)(kt * 8 + pc) * g.Mp + rg * 64 + lane, S + pc * BM + rg * 64);
+      const int pc = a / RG, rg = a % RG;           // pc = plane * BKC + chunk
+      const int plane = pc / BKC, ch = pc % BKC;
+      dma16(wpb + (size_t)(k32 * 8 + plane * 4 + c4 + ch) * g.Mp + rg * 64 + lane, S + pc * BM + rg * 64);
     }
 #pragma unroll
     for (int q = 0; q < CPW; ++q) {
-      const int combo = bcombo0 + q;               // plane * 4 + chunk
-      const int plane = combo >> 2, ch = combo & 3;
+      const int combo = bcombo0 + q;               // plane * BKC + chunk
+      const int plane = combo / BKC, ch = combo % BKC;
       const int k0 = kt * BK + ch * 8;             // wave-uniform
       const int t = (int)(((unsigned long long)(unsigned)k0 * g.cp_magic) >> 32);
       const int c8 = (k0 - t * g.Cp) >> 3;
@@ -104,7 +106,7 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
       const int uoff = tapoff + c8 + plane * (int)plane_u4;            // scalar part
       const bool ok = t < g.T && ((vmask >> t) & 1ull);
       const int off = ok ? pixoff + uoff : zero_off;
-      dma16(xs + (unsigned)off, S + 8 * BM + combo * BN + bgroup * 64);
+      dma16(xs + (unsigned)off, S + 2 * BKC * BM + combo * BN + bgroup * 64);
     }
   };
 
@@ -116,27 +118,32 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // s_waitcnt immediates (gfx9 encoding): vmcnt in bits [3:0] and [15:14], expcnt [6:4] = 7, lgkmcnt [11:8] = 15
-  constexpr int WAIT_ONE_STEP_IN_FLIGHT = (DMA_PER_STEP & 15) | ((DMA_PER_STEP >> 4) << 14) | (7 << 4) | (15 << 8);
-  constexpr int WAIT_ALL = (7 << 4) | (15 << 8);
-
-  if (nk > 0) issue(0, 0);
-  if (nk > 1) issue(1, 1);
+  // NST-stage ring: steps kt+1 .. kt+NST-2 stay in flight across the barrier of step kt.  s_waitcnt immediates (gfx9
+  // encoding): vmcnt in bits [3:0] and [15:14], expcnt [6:4] = 7, lgkmcnt [11:8] = 15.
+#define BF3_WAITCNT(n) ((((n) * DMA_PER_STEP) & 15) | ((((n) * DMA_PER_STEP) >> 4) << 14) | (7 << 4) | (15 << 8))
+  static_assert((NST - 2) * DMA_PER_STEP < 64, "vmcnt is 6 bits");
+#pragma unroll
+  for (int pre = 0; pre < NST - 1; ++pre)
+    if (pre < nk) issue(pre, pre);
   int stage = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    // this wave's copies of step kt have landed (those of step kt+1 may still be in flight) ...
-    if (kt + 1 < nk) __builtin_amdgcn_s_waitcnt(WAIT_ONE_STEP_IN_FLIGHT);
-    else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
-    // ... and after the barrier everybody's have, and everybody finished reading the stage step kt+2 goes into
+    // this wave's copies of step kt have landed (later steps may still be in flight) ...
+    const int ahead = nk - 1 - kt < NST - 2 ? nk - 1 - kt : NST - 2;   // steps issued after kt
+    if (NST >= 6 && ahead == 4) __builtin_amdgcn_s_waitcnt(BF3_WAITCNT(4));
+    else if (NST >= 5 && ahead == 3) __builtin_amdgcn_s_waitcnt(BF3_WAITCNT(3));
+    else if (NST >= 4 && ahead == 2) __builtin_amdgcn_s_waitcnt(BF3_WAITCNT(2));
+    else if (ahead == 1) __builtin_amdgcn_s_waitcnt(BF3_WAITCNT(1));
+    else __builtin_amdgcn_s_waitcnt(BF3_WAITCNT(0));
+    // ... and after the barrier everybody's have, and everybody finished reading the stage step kt+NST-1 goes into
     __builtin_amdgcn_s_barrier();
-    if (kt + 2 < nk) issue(kt + 2, stage == 0 ? 2 : stage - 1);
+    if (kt + NST - 1 < nk) issue(kt + NST - 1, stage == 0 ? NST - 1 : stage - 1);
     const uint4* S = smem + stage * STAGE;
-    const uint4* Ah = S + wm * 64 + (lane & 31);
-    const uint4* Al = Ah + 4 * BM;
-    const uint4* Bh = S + 8 * BM + wn * 64 + (lane & 31);
-    const uint4* Bl = Bh + 4 * BN;
+    const uint4* Ah = S + wm * (TM * 32) + (lane & 31);
+    const uint4* Al = Ah + BKC * BM;
+    const uint4* Bh = S + 2 * BKC * BM + wn * (TN * 32) + (lane & 31);
+    const uint4* Bl = Bh + BKC * BN;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < BKC / 2; ++ks) {
       const int chunk = ks * 2 + (lane >> 5);
       bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
@@ -149,6 +156,7 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
         bh[j] = __builtin_bit_cast(bf16x8, Bh[chunk * BN + j * 32]);
         bl[j] = __builtin_bit_cast(bf16x8, Bl[chunk * BN + j * 32]);
       }
+      if (SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -157,20 +165,22 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
+      if (SETPRIO) __builtin_amdgcn_s_setprio(0);
     }
-    stage = stage == 2 ? 0 : stage + 1;
+    stage = stage == NST - 1 ? 0 : stage + 1;
   }
+#undef BF3_WAITCNT
 
   // epilogue: bias + activation, coalesced along pixels (MFMA column = lane & 31); merged phases: row group -> residue
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int pj = blockIdx.x * BN + wn * 64 + j * 32 + (lane & 31);
+    const int pj = blockIdx.x * BN + wn * (TN * 32) + j * 32 + (lane & 31);
     if (pj >= g.npix) continue;
     int nn, jz, jy, jx;
     decode_pix(g, pj, nn, jz, jy, jx);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const int mb = m_tile + wm * 64 + i * 32;
+      const int mb = m_tile + wm * (TM * 32) + i * 32;
       const int grp = g.nmerge > 1 ? mb / g.Msub : 0;
       const int mo = mb - grp * g.Msub;
       const size_t obase = (size_t)nn * g.out_sN +
@@ -478,14 +488,15 @@ int bf3_split_input(const float* x, void* ws, int N, int C, long S, hipStream_t 
   return MUVO_OK;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BKC, int NST>
 static int bf3_launch(const ConvPhase& g, const void* ws, const float* wp, const float* bias, float* out, int act,
                       float slope, hipStream_t st) {
-  constexpr size_t lds = (size_t)3 * 8 * (BM + BN) * 16;
+  constexpr size_t lds = (size_t)NST * 2 * BKC * (BM + BN) * 16;
+  static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   static const uint4* zero16 = nullptr;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv_bf3_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)conv_bf3_kernel<BM, BN, WM, WN, BKC, NST>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess ||
         hipGetSymbolAddress((void**)&zero16, HIP_SYMBOL(g_zero16)) != hipSuccess) {
       muvo_set_error("conv_bf3: kernel attribute / symbol setup failed");
@@ -495,7 +506,7 @@ static int bf3_launch(const ConvPhase& g, const void* ws, const float* wp, const
   }
   const long plane_u4 = (long)g.N * g.ID * g.IH * g.IW * (g.Cp / 8);
   dim3 grid(cdiv(g.npix, BN), cdiv(g.M, BM), 1);
-  hipLaunchKernelGGL((conv_bf3_kernel<BM, BN, WM, WN>), grid, dim3(64 * WM * WN), lds, st, g, (const uint4*)ws, plane_u4,
+  hipLaunchKernelGGL((conv_bf3_kernel<BM, BN, WM, WN, BKC, NST>), grid, dim3(64 * WM * WN), lds, st, g, (const uint4*)ws, plane_u4,
                      (const uint4*)wp, bias, out, act, slope, zero16);
   MUVO_CHECK_LAUNCH("conv_bf3_kernel");
   return MUVO_OK;
@@ -504,9 +515,15 @@ static int bf3_launch(const ConvPhase& g, const void* ws, const float* wp, const
 int bf3_launch_fwd_phase(const ConvPhase& g, const void* ws, const float* wp, const float* bias, float* out, int act,
                          float slope, hipStream_t st) {
   if (g.npix <= 0) return MUVO_OK;
-  if (g.M > 128) return bf3_launch<256, 128, 4, 2>(g, ws, wp, bias, out, act, slope, st);
-  if (g.M > 64) return bf3_launch<128, 256, 2, 4>(g, ws, wp, bias, out, act, slope, st);
-  return bf3_launch<64, 256, 1, 4>(g, ws, wp, bias, out, act, slope, st);
+  // 256x256 tiles (K step 16, wave tile 64x128) halve the LDS-DMA bytes per flop: the big layers are bound by the
+  // L2->LDS copy rate, not by the matrix pipe
+  static const int variant = getenv("MUVO_BF3_VARIANT") ? atoi(getenv("MUVO_BF3_VARIANT")) : 0;   // tuning switch
+  if (g.M > 128 && g.npix >= 256 * 256 && variant == 1) return bf3_launch<256, 256, 4, 2, 2, 4>(g, ws, wp, bias, out, act, slope, st);
+  if (g.M > 128 && variant == 2) return bf3_launch<256, 128, 4, 2, 2, 6>(g, ws, wp, bias, out, act, slope, st);
+  if (g.M > 128 && g.npix >= 256 * 256 && variant == 3) return bf3_launch<256, 256, 4, 2, 2, 3>(g, ws, wp, bias, out, act, slope, st);
+  if (g.M > 128) return bf3_launch<256, 128, 4, 2, 4, 3>(g, ws, wp, bias, out, act, slope, st);
+  if (g.M > 64) return bf3_launch<128, 256, 2, 4, 4, 3>(g, ws, wp, bias, out, act, slope, st);
+  return bf3_launch<64, 256, 1, 4, 4, 3>(g, ws, wp, bias, out, act, slope, st);
 }
 
 template <int BM, int BN, int WM, int WN, int WK>
