@@ -29,6 +29,14 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigne
   lo = __builtin_bit_cast(unsigned, l);
 }
 
+// XCD-aware workgroup order (guide T1, bijective form): workgroups are dealt round-robin over the 8 XCDs, so give each
+// XCD a contiguous chunk of the tile space — the 32 workgroups resident on one XCD then share weight / pixel tiles in
+// that XCD's L2 instead of every L2 streaming every operand.
+__device__ __forceinline__ int xcd_swizzle(int orig, int nwg) {
+  const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 // one wave-wide LDS-DMA: lane l copies 16 bytes from its own global address to (wave-uniform lds) + 16*l
@@ -62,10 +70,15 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
 
+  // 1-D grid, pixel tiles fastest, XCD-swizzled: one XCD works through consecutive pixel tiles of one m-tile
+  const int gx = (g.npix + BN - 1) / BN;
+  const int wg = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int bx = wg % gx, by = wg / gx;
+
   // ---- B (activation) DMA role of this wave: pixel group (wave % NG), combos [(wave / NG) * CPW, +CPW)
   // All sources are xs (uniform) + a 32-bit uint4 offset per lane; out-of-bounds taps read the zero page at zero_off.
   const int bgroup = wave % NG, bcombo0 = (wave / NG) * CPW;
-  const int p = blockIdx.x * BN + bgroup * 64 + lane;
+  const int p = bx * BN + bgroup * 64 + lane;
   const bool pvalid = p < g.npix;
   int n, iz, iy, ix;
   decode_pix(g, pvalid ? p : 0, n, iz, iy, ix);
@@ -80,7 +93,7 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
     vmask |= (unsigned long long)ok << tt;
   }
   const int zero_off = (int)(2 * plane_u4);
-  const int m_tile = blockIdx.y * BM;
+  const int m_tile = by * BM;
   const uint4* wpb = wp + g.wp_off / 4 + m_tile;   // wp_off is in floats; one uint4 = 8 bf16 = 4 floats
   const int nk = g.Kp / BK;
 
@@ -174,7 +187,7 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
   // epilogue: bias + activation, coalesced along pixels (MFMA column = lane & 31); merged phases: row group -> residue
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int pj = blockIdx.x * BN + wn * (TN * 32) + j * 32 + (lane & 31);
+    const int pj = bx * BN + wn * (TN * 32) + j * 32 + (lane & 31);
     if (pj >= g.npix) continue;
     int nn, jz, jy, jx;
     decode_pix(g, pj, nn, jz, jy, jx);
@@ -505,7 +518,7 @@ static int bf3_launch(const ConvPhase& g, const void* ws, const float* wp, const
     attr_set = true;
   }
   const long plane_u4 = (long)g.N * g.ID * g.IH * g.IW * (g.Cp / 8);
-  dim3 grid(cdiv(g.npix, BN), cdiv(g.M, BM), 1);
+  dim3 grid(cdiv(g.npix, BN) * cdiv(g.M, BM), 1, 1);
   hipLaunchKernelGGL((conv_bf3_kernel<BM, BN, WM, WN, BKC, NST>), grid, dim3(64 * WM * WN), lds, st, g, (const uint4*)ws, plane_u4,
                      (const uint4*)wp, bias, out, act, slope, zero16);
   MUVO_CHECK_LAUNCH("conv_bf3_kernel");
