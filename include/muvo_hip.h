@@ -117,8 +117,11 @@ int muvo_bn_train_bwd(const float* x, const float* y, const float* dy, const flo
  * x_batch_stride = 0 broadcasts one (C,S) tensor over the batch (VoxelDecoder1.constant_tensor). ws: 2*N*C doubles. */
 int muvo_adain_fwd(const float* x, const float* style, float* y, float* save_mean, float* save_rstd, double* ws, int N,
                    int C, int64_t S, int64_t x_batch_stride, float eps, void* stream);
+/* act/slope: when x is the output of an activation (conv + LeakyReLU in ConvInstanceNorm3d, common.py:190-202) the
+ * returned dx is already multiplied by that activation's derivative (MUVO_ACT_NONE: plain AdaIN gradient) */
 int muvo_adain_bwd(const float* x, const float* style, const float* dy, const float* save_mean, const float* save_rstd,
-                   float* dx, float* dstyle, double* ws, int N, int C, int64_t S, int64_t x_batch_stride, void* stream);
+                   float* dx, float* dstyle, double* ws, int N, int C, int64_t S, int64_t x_batch_stride, int act,
+                   float slope, void* stream);
 /* post-LN transformer sub-layer tail: z = x + dropout(a); y = LayerNorm(z) (nn.TransformerEncoderLayer, mile.py:96-101) */
 int muvo_add_dropout_layernorm_fwd(const float* x, const float* a, const float* gamma, const float* beta, float* y,
                                    float* z, float* mean, float* rstd, int rows, int E, float eps, float p, uint64_t seed,

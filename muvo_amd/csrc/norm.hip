@@ -259,16 +259,18 @@ __global__ void __launch_bounds__(256) adain_bwd_apply_kernel(const float* __res
                                                               const float* __restrict__ rstd,
                                                               const float* __restrict__ style,
                                                               const double* __restrict__ sums, float* __restrict__ dx,
-                                                              int C, long S, long x_bs, long total) {
+                                                              int C, long S, long x_bs, long total, int act, float slope) {
   for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const long g = e / S;
     const long n = g / C;
     const int c = (int)(g - n * C);
     const long s = e - g * S;
     const float rs = rstd[g];
-    const float xh = (x[n * x_bs + (long)c * S + s] - mean[g]) * rs;
+    const float xv = x[n * x_bs + (long)c * S + s];
+    const float xh = (xv - mean[g]) * rs;
     const float m1 = (float)(sums[2 * g] / (double)S), m2 = (float)(sums[2 * g + 1] / (double)S);
-    dx[e] = style[n * 2 * C + c] * rs * (dy[e] - m1 - xh * m2);
+    // act != NONE: x is the output of that activation (conv + LeakyReLU feeding the norm): chain its derivative here
+    dx[e] = style[n * 2 * C + c] * rs * (dy[e] - m1 - xh * m2) * act_grad_from_out(xv, act, slope);
   }
 }
 
@@ -300,7 +302,7 @@ extern "C" int muvo_adain_fwd(const float* x, const float* style, float* y, floa
 // dx: (N,C,S) always dense (caller reduces over batch when the input was broadcast); dstyle: (N, 2C) overwritten
 extern "C" int muvo_adain_bwd(const float* x, const float* style, const float* dy, const float* save_mean,
                               const float* save_rstd, float* dx, float* dstyle, double* ws, int N, int C, int64_t S,
-                              int64_t x_batch_stride, void* stream) {
+                              int64_t x_batch_stride, int act, float slope, void* stream) {
   MUVO_CHECK_ARG(x && style && dy && save_mean && save_rstd && dx && dstyle && ws, "adain_bwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
   const int G = N * C;
@@ -321,7 +323,7 @@ extern "C" int muvo_adain_bwd(const float* x, const float* style, const float* d
   hipLaunchKernelGGL(adain_bwd_finalize_kernel, dim3(cdiv(G, 64)), dim3(64), 0, st, ws, dstyle, N, C);
   const long total = (long)G * S;
   hipLaunchKernelGGL(adain_bwd_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, st, x, dy, save_mean, save_rstd, style,
-                     ws, dx, C, (long)S, (long)x_batch_stride, total);
+                     ws, dx, C, (long)S, (long)x_batch_stride, total, act, slope);
   MUVO_CHECK_LAUNCH("adain_bwd");
   return MUVO_OK;
 }

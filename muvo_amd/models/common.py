@@ -71,8 +71,8 @@ class AdaptiveInstanceNorm3d(nn.Module):
         self.epsilon = epsilon
         self.latent_affine = hnn.Linear(latent_n_channels, 2 * out_channels)
 
-    def forward(self, x, style):
-        return ops.adain(x, self.latent_affine(style), self.epsilon, style.shape[0])
+    def forward(self, x, style, pre_act=ops.ACT_NONE, pre_slope=0.0):
+        return ops.adain(x, self.latent_affine(style), self.epsilon, style.shape[0], pre_act, pre_slope)
 
 
 class ConvInstanceNorm3d(nn.Module):
@@ -82,8 +82,9 @@ class ConvInstanceNorm3d(nn.Module):
         self.adaptive_norm = AdaptiveInstanceNorm3d(latent_n_channels, out_channels)
 
     def forward(self, x, w):
-        x = self.conv_act[0](x, act=ops.ACT_LEAKY, slope=0.2)
-        return self.adaptive_norm(x, w)
+        # LeakyReLU is fused into the conv epilogue; its derivative is chained inside the AdaIN backward kernel
+        x = self.conv_act[0](x, act=ops.ACT_LEAKY, slope=0.2, act_bwd_fused=True)
+        return self.adaptive_norm(x, w, pre_act=ops.ACT_LEAKY, pre_slope=0.2)
 
 
 class DecoderBlock3d(nn.Module):

@@ -357,8 +357,9 @@ def _wkey(w):
 
 class ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, geom, packed, act, slope):
+    def forward(ctx, x, weight, bias, geom, packed, act, slope, act_bwd_fused=False):
         x = x.contiguous()
+        ctx.act_bwd_fused = act_bwd_fused
         n = x.shape[0]
         in_sz = tuple(x.shape[2:]) if geom.nd == 3 else (1,) + tuple(x.shape[2:])
         d, out_sz, ff, df = geom.plan(n, in_sz)
@@ -390,7 +391,7 @@ class ConvFn(torch.autograd.Function):
             e1.record()
         ctx.geom, ctx.packed, ctx.act, ctx.slope = geom, packed, act, slope
         ctx.weight, ctx.bias, ctx.in_sz = weight, bias, in_sz
-        ctx.save_for_backward(x, y if act != ACT_NONE else None)
+        ctx.save_for_backward(x, y if (act != ACT_NONE and not act_bwd_fused) else None)
         return y
 
     @staticmethod
@@ -400,11 +401,11 @@ class ConvFn(torch.autograd.Function):
         d, out_sz, ff, df = geom.plan(x.shape[0], ctx.in_sz)
         L = lib()
         dy = dy.contiguous()
-        if ctx.act != ACT_NONE:
+        if ctx.act != ACT_NONE and not ctx.act_bwd_fused:
             dz = torch.empty_like(dy)
             _ck(L.muvo_act_bwd(_f(y), _f(dy), _f(dz), _i64(dy.numel()), ctx.act, _fl(ctx.slope), _st()))
         else:
-            dz = dy
+            dz = dy   # no activation, or its derivative was already chained by the consumer's backward
         dx = None
         ws_dy, dy_split = None, False
         if ctx.needs_input_grad[0]:
@@ -451,11 +452,11 @@ class ConvFn(torch.autograd.Function):
                                   flags, _st()))
             if kt is not None:
                 e1.record()
-        return dx, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None
 
 
-def conv(x, weight, bias, geom, packed, act=ACT_NONE, slope=0.0):
-    return ConvFn.apply(x, weight, bias, geom, packed, act, slope)
+def conv(x, weight, bias, geom, packed, act=ACT_NONE, slope=0.0, act_bwd_fused=False):
+    return ConvFn.apply(x, weight, bias, geom, packed, act, slope, act_bwd_fused)
 
 
 # ================================================================================================ norms
@@ -512,10 +513,11 @@ class AdaINFn(torch.autograd.Function):
     """AdaptiveInstanceNorm3d. x: (N,C,D,H,W) or a broadcast (C,D,H,W) parameter; style: (N, 2C)."""
 
     @staticmethod
-    def forward(ctx, x, style, eps, n_batch):
+    def forward(ctx, x, style, eps, n_batch, pre_act=ACT_NONE, pre_slope=0.0):
         x = x.contiguous()
         style = style.contiguous()
         bcast = x.dim() == 4
+        ctx.pre_act, ctx.pre_slope = pre_act, pre_slope
         c = x.shape[0] if bcast else x.shape[1]
         s = x.numel() // c if bcast else x.numel() // (x.shape[0] * c)
         n = n_batch
@@ -538,17 +540,19 @@ class AdaINFn(torch.autograd.Function):
         dstyle = torch.empty_like(style)
         ws = torch.empty(2 * n * c, device=x.device, dtype=torch.float64)
         _ck(lib().muvo_adain_bwd(_f(x), _f(style), _f(dy), _f(mean), _f(rstd), _f(dxf), _f(dstyle), _p(ws), n, c,
-                                 _i64(s), _i64(0 if bcast else c * s), _st()))
+                                 _i64(s), _i64(0 if bcast else c * s), ctx.pre_act, _fl(ctx.pre_slope), _st()))
         if bcast:
             dx = torch.empty_like(x)
             _ck(lib().muvo_batchsum(_f(dxf), _f(dx), n, _i64(c * s), 0, _st()))
         else:
             dx = dxf
-        return dx, dstyle, None, None
+        return dx, dstyle, None, None, None, None
 
 
-def adain(x, style, eps, n_batch):
-    return AdaINFn.apply(x, style, eps, n_batch)
+def adain(x, style, eps, n_batch, pre_act=ACT_NONE, pre_slope=0.0):
+    """pre_act: x is the output of that activation and the producer's backward does NOT apply its derivative (the
+    AdaIN backward kernel chains it); pair with conv(..., act_bwd_fused=True)."""
+    return AdaINFn.apply(x, style, eps, n_batch, pre_act, pre_slope)
 
 
 class AddDropoutLNFn(torch.autograd.Function):

@@ -238,6 +238,36 @@ def test_adain(dev):
         _close(sg.grad, sc.grad, rtol=5e-4, name='adain dstyle')
 
 
+def test_conv_lrelu_adain_fused_backward(dev):
+    """ConvInstanceNorm3d (common.py:190-202): conv + LeakyReLU(0.2) + AdaIN with the LeakyReLU derivative chained inside
+    the AdaIN backward kernel (no separate activation-gradient pass) against the plain PyTorch composition."""
+    from muvo_amd import nn as hnn
+    from muvo_amd import ops
+    torch.manual_seed(11)
+    n, cin, cout = 2, 16, 8
+    with torch.device(dev):
+        m = hnn.Conv3d(cin, cout, 3, 1, 1)
+    x = torch.randn(n, cin, 4, 6, 32)
+    style = torch.randn(n, 2 * cout)
+    xg, sg = x.to(dev).requires_grad_(True), style.to(dev).requires_grad_(True)
+    m.weight.grad, m.bias.grad = torch.zeros_like(m.weight), torch.zeros_like(m.bias)
+    y = ops.adain(m(xg, act=ops.ACT_LEAKY, slope=0.2, act_bwd_fused=True), sg, 1e-8, n, ops.ACT_LEAKY, 0.2)
+    w, b = m.weight.detach().cpu().requires_grad_(True), m.bias.detach().cpu().requires_grad_(True)
+    xc, sc = x.clone().requires_grad_(True), style.clone().requires_grad_(True)
+    h = F.leaky_relu(F.conv3d(xc, w, b, 1, 1), 0.2)
+    hm = h - h.mean(dim=(-1, -2, -3), keepdim=True)
+    yr = sc[:, :cout, None, None, None] * (hm / torch.sqrt((hm ** 2).mean(dim=(-1, -2, -3), keepdim=True) + 1e-8)) + \
+        sc[:, cout:, None, None, None]
+    _close(y, yr, name='fwd')
+    g = torch.randn_like(yr)
+    yr.backward(g)
+    y.backward(g.to(dev))
+    _close(xg.grad, xc.grad, rtol=5e-4, name='dx')
+    _close(m.weight.grad, w.grad, rtol=5e-4, name='dW')
+    _close(m.bias.grad, b.grad, rtol=5e-4, atol=1e-4, name='db')
+    _close(sg.grad, sc.grad, rtol=5e-4, name='dstyle')
+
+
 def test_transformer_layer(dev):
     from muvo_amd import nn as hnn
     torch.manual_seed(5)
