@@ -12,10 +12,11 @@
 //     shifts of the same registers, and each loaded row feeds 9 taps x TY rows x Cout/4 MFMAs.  Weights sit in LDS
 //     in the order the lanes read them ([tap][ci][co%4][co/4]).
 //   weight-gradient (vox_wgrad_kernel): i <-> 4 output channels, j <-> 4 input channels, block b <-> 16 consecutive
-//     voxels; nine waves per workgroup take the nine (tx,ty) tap pairs, the workgroup walks along x with a 3-plane
-//     LDS ring of the input tile (transposed to [y][z][ci%4][ci/4] so one ds_read_b128 feeds four MFMAs) and the
-//     per-wave accumulators are reduced over the 16 blocks once at the end and added to dW (PyTorch layout) with
-//     float atomics; the bias gradient is accumulated by the centre-tap wave from the same registers.
+//     voxels; twelve waves per workgroup (three per SIMD) take (tx, input quad, output quad group) roles; the
+//     workgroup walks along x with a 3-plane LDS ring of the input tile ([ci/4][y][z][ci%4]: conflict-free b32 reads
+//     with lane = (voxel, ci%4)), each role keeps its 9 (ty,tz) taps in registers, the per-wave accumulators are
+//     reduced over the 16 blocks once at the end and added to dW (PyTorch layout) with float atomics; the bias
+//     gradient is accumulated by the tx = 1 waves from the same registers.
 #include "common.h"
 #include "conv_vox.h"
 
@@ -145,24 +146,32 @@ vox_conv_kernel(const VoxArgs a, const float* __restrict__ in, const float* __re
 // ------------------------------------------------------------------------------------------------
 // weight-gradient kernel
 // ------------------------------------------------------------------------------------------------
-template <int CQB, int RQB, int Z, int TYB>
-__global__ void __launch_bounds__(576)
+// Twelve waves per workgroup (three per SIMD, balanced): wave role = (tx, input-channel quad r, output quad group qg).
+// A role keeps the 9 (ty,tz) taps x CQR output quads of its (tx, r) in registers (<= 18 accumulators of 4 regs); the
+// workgroup covers RQB input quads x 2 output quads, other channel ranges go to blockIdx.y.
+template <int RQB, int CQR, int Z, int TYB>
+__global__ void __launch_bounds__(768)
 vox_wgrad_kernel(const VoxArgs a, const float* __restrict__ in, const float* __restrict__ dz, float* __restrict__ dw,
                  float* __restrict__ dbias, int xsplit, int nqc) {
+  constexpr int CQB = 2;                          // output quads per workgroup
+  constexpr int NQG = CQB / CQR;                  // output quad groups (roles along q)
+  static_assert(3 * RQB * NQG == 12, "twelve roles");
   constexpr int ZP = Z + 2;
-  constexpr int SLOT = (TYB + 2) * ZP * 4 * RQB;  // floats per ring slot
-  constexpr int DBUF = TYB * Z * 4 * CQB;         // floats per dz buffer
-  constexpr int NIN = ((TYB + 2) * Z * 4 + 575) / 576;  // staging items per thread (input plane)
-  constexpr int NDZ = (TYB * Z * 4 + 575) / 576;
+  constexpr int PLANE = (TYB + 2) * ZP * 4;       // floats per (slot, r) plane: [row][z+1][j]
+  constexpr int SLOT = RQB * PLANE;
+  constexpr int DPL = TYB * Z * 4;                // floats per (buffer, q) plane: [row][z][i]
+  constexpr int DBUF = CQB * DPL;
+  constexpr int NT = 768;
+  constexpr int NIN = ((TYB + 2) * Z * 4 + NT - 1) / NT;  // staging items per thread (input plane)
+  constexpr int NDZ = (TYB * Z * 4 + NT - 1) / NT;
   constexpr int ZS = Z / 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* P = smem;              // [3][TYB+2][ZP][4][RQB]
-  float* D = smem + 3 * SLOT;   // [2][TYB][Z][4][CQB]
+  float* P = smem;              // [3][RQB][TYB+2][ZP][4]
+  float* D = smem + 3 * SLOT;   // [2][CQB][TYB][Z][4]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tx = wave / 3, ty = wave - 3 * tx;
+  const int tx = wave % 3, rr = (wave / 3) % RQB, qg = wave / (3 * RQB);
   const int qc = blockIdx.y % nqc, rc = blockIdx.y / nqc;
-  // block -> (n, ytile, xpart)
   int bid = blockIdx.x;
   const int xp = bid % xsplit; bid /= xsplit;
   const int yt = bid % a.ytiles;
@@ -176,7 +185,7 @@ vox_wgrad_kernel(const VoxArgs a, const float* __restrict__ in, const float* __r
   const float* inn = in + (size_t)n * a.sN_in + (size_t)(rc * RQB * 4) * a.XYZ;
   const float* dzn = dz + (size_t)n * a.sN_out + (size_t)(qc * CQB * 4) * a.XYZ;
 
-  for (int i = tid; i < 3 * SLOT; i += 576) P[i] = 0.f;  // z halos stay zero for the whole kernel
+  for (int i = tid; i < 3 * SLOT; i += NT) P[i] = 0.f;  // z halos stay zero for the whole kernel
   __syncthreads();
 
   float pin[NIN][RQB], pdz[NDZ][CQB];
@@ -184,7 +193,7 @@ vox_wgrad_kernel(const VoxArgs a, const float* __restrict__ in, const float* __r
     const bool xok = (unsigned)xin < (unsigned)a.X;
 #pragma unroll
     for (int k = 0; k < NIN; ++k) {
-      const int item = tid + k * 576;
+      const int item = tid + k * NT;
       const int j = item & 3, zz = (item >> 2) % Z, r = (item >> 2) / Z;
       const int y = y0 - 1 + r;
       const bool ok = xok && r < TYB + 2 && (unsigned)y < (unsigned)a.Y;
@@ -197,19 +206,18 @@ vox_wgrad_kernel(const VoxArgs a, const float* __restrict__ in, const float* __r
     float* S = P + slot * SLOT;
 #pragma unroll
     for (int k = 0; k < NIN; ++k) {
-      const int item = tid + k * 576;
+      const int item = tid + k * NT;
       const int j = item & 3, zz = (item >> 2) % Z, r = (item >> 2) / Z;
       if (r < TYB + 2) {
-        float* d = S + ((r * ZP + zz + 1) * 4 + j) * RQB;
-        if constexpr (RQB == 4) *(float4*)d = make_float4(pin[k][0], pin[k][1], pin[k][2], pin[k][3]);
-        else *(float2*)d = make_float2(pin[k][0], pin[k][1]);
+#pragma unroll
+        for (int e = 0; e < RQB; ++e) S[e * PLANE + (r * ZP + zz + 1) * 4 + j] = pin[k][e];
       }
     }
   };
   auto fetch_dz = [&](int xx) {
 #pragma unroll
     for (int k = 0; k < NDZ; ++k) {
-      const int item = tid + k * 576;
+      const int item = tid + k * NT;
       const int i = item & 3, zz = (item >> 2) % Z, r = (item >> 2) / Z;
       const int y = y0 + r;
       const bool ok = xx < xb && r < TYB && y < a.Y;
@@ -222,29 +230,25 @@ vox_wgrad_kernel(const VoxArgs a, const float* __restrict__ in, const float* __r
     float* S = D + buf * DBUF;
 #pragma unroll
     for (int k = 0; k < NDZ; ++k) {
-      const int item = tid + k * 576;
+      const int item = tid + k * NT;
       const int i = item & 3, zz = (item >> 2) % Z, r = (item >> 2) / Z;
       if (r < TYB) {
-        float* d = S + ((r * Z + zz) * 4 + i) * CQB;
-        if constexpr (CQB == 4) *(float4*)d = make_float4(pdz[k][0], pdz[k][1], pdz[k][2], pdz[k][3]);
-        else *(float2*)d = make_float2(pdz[k][0], pdz[k][1]);
+#pragma unroll
+        for (int e = 0; e < CQB; ++e) S[e * DPL + (r * Z + zz) * 4 + i] = pdz[k][e];
       }
     }
   };
   auto slot_of = [](int xx) { return (xx + 3) % 3; };
 
-  f32x4 acc[CQB][RQB][3];
+  f32x4 acc[CQR][9];
 #pragma unroll
-  for (int q = 0; q < CQB; ++q)
+  for (int q = 0; q < CQR; ++q)
 #pragma unroll
-    for (int r = 0; r < RQB; ++r)
+    for (int t = 0; t < 9; ++t) acc[q][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float db[CQR];
 #pragma unroll
-      for (int t = 0; t < 3; ++t) acc[q][r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float db[CQB];
-#pragma unroll
-  for (int q = 0; q < CQB; ++q) db[q] = 0.f;
+  for (int q = 0; q < CQR; ++q) db[q] = 0.f;
 
-  // prologue: planes xa-1, xa, xa+1 and dz(xa)
   fetch_in(xa - 1); store_in(slot_of(xa - 1));
   fetch_in(xa);     store_in(slot_of(xa));
   fetch_in(xa + 1); store_in(slot_of(xa + 1));
@@ -252,39 +256,32 @@ vox_wgrad_kernel(const VoxArgs a, const float* __restrict__ in, const float* __r
   __syncthreads();
 
   const int b = lane >> 2, lj = lane & 3;
+  const bool bias_role = tx == 1 && rr == 0;
   for (int x = xa; x < xb; ++x) {
     const bool more = x + 1 < xb;
     if (more) { fetch_in(x + 2); fetch_dz(x + 1); }   // global loads in flight during the MFMA phase
-    const float* S = P + slot_of(x + tx - 1) * SLOT;
-    const float* Dz = D + (x & 1) * DBUF;
+    const float* S = P + slot_of(x + tx - 1) * SLOT + rr * PLANE;
+    const float* Dz = D + (x & 1) * DBUF + (qg * CQR) * DPL;
 #pragma unroll 1
     for (int row = 0; row < TYB; ++row) {
 #pragma unroll
       for (int zs = 0; zs < ZS; ++zs) {
         const int zz = zs * 16 + b;
-        float av[CQB];
-        {
-          const float* pa = Dz + ((row * Z + zz) * 4 + lj) * CQB;
-          if constexpr (CQB == 4) { const float4 t = *(const float4*)pa; av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w; }
-          else { const float2 t = *(const float2*)pa; av[0] = t.x; av[1] = t.y; }
-        }
-        float bv[3][RQB];
+        float av[CQR];
 #pragma unroll
-        for (int tz = 0; tz < 3; ++tz) {
-          const float* pb = S + (((row + ty) * ZP + zz + tz) * 4 + lj) * RQB;
-          if constexpr (RQB == 4) { const float4 t = *(const float4*)pb; bv[tz][0] = t.x; bv[tz][1] = t.y; bv[tz][2] = t.z; bv[tz][3] = t.w; }
-          else { const float2 t = *(const float2*)pb; bv[tz][0] = t.x; bv[tz][1] = t.y; }
-        }
+        for (int q = 0; q < CQR; ++q) av[q] = Dz[q * DPL + (row * Z + zz) * 4 + lj];
+        float bv[9];
 #pragma unroll
-        for (int tz = 0; tz < 3; ++tz)
+        for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
-          for (int q = 0; q < CQB; ++q)
+          for (int tz = 0; tz < 3; ++tz) bv[ty * 3 + tz] = S[((row + ty) * ZP + zz + tz) * 4 + lj];
 #pragma unroll
-            for (int r = 0; r < RQB; ++r)
-              acc[q][r][tz] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q], bv[tz][r], acc[q][r][tz], 0, 0, 0);
-        if (wave == 4) {
+        for (int t = 0; t < 9; ++t)
 #pragma unroll
-          for (int q = 0; q < CQB; ++q) db[q] += av[q];
+          for (int q = 0; q < CQR; ++q) acc[q][t] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[q], bv[t], acc[q][t], 0, 0, 0);
+        if (bias_role) {
+#pragma unroll
+          for (int q = 0; q < CQR; ++q) db[q] += av[q];
         }
       }
     }
@@ -295,32 +292,30 @@ vox_wgrad_kernel(const VoxArgs a, const float* __restrict__ in, const float* __r
 
   // reduce over the 16 blocks (lane bits 2..5), then lanes 0..3 publish
 #pragma unroll
-  for (int q = 0; q < CQB; ++q)
+  for (int q = 0; q < CQR; ++q)
 #pragma unroll
-    for (int r = 0; r < RQB; ++r)
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
-      for (int tz = 0; tz < 3; ++tz)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float v = acc[q][r][tz][i];
-          v += __shfl_xor(v, 4, 64);
-          v += __shfl_xor(v, 8, 64);
-          v += __shfl_xor(v, 16, 64);
-          v += __shfl_xor(v, 32, 64);
-          if (lane < 4) {
-            const int co = (qc * CQB + q) * 4 + i, ci = (rc * RQB + r) * 4 + lane;
-            atomicAdd(dw + ((size_t)co * a.Cin + ci) * 27 + (tx * 3 + ty) * 3 + tz, v);
-          }
+      for (int i = 0; i < 4; ++i) {
+        float v = acc[q][t][i];
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (lane < 4) {
+          const int co = (qc * CQB + qg * CQR + q) * 4 + i, ci = (rc * RQB + rr) * 4 + lane;
+          atomicAdd(dw + ((size_t)co * a.Cin + ci) * 27 + tx * 9 + t, v);   // t = ty*3 + tz
         }
-  if (wave == 4 && rc == 0 && dbias != nullptr) {
+      }
+  if (bias_role && rc == 0 && dbias != nullptr) {
 #pragma unroll
-    for (int q = 0; q < CQB; ++q) {
+    for (int q = 0; q < CQR; ++q) {
       float v = db[q];
       v += __shfl_xor(v, 4, 64);
       v += __shfl_xor(v, 8, 64);
       v += __shfl_xor(v, 16, 64);
       v += __shfl_xor(v, 32, 64);
-      if (lane < 4) atomicAdd(dbias + (qc * CQB + q) * 4 + lane, v);
+      if (lane < 4) atomicAdd(dbias + (qc * CQB + qg * CQR + q) * 4 + lane, v);
     }
   }
 }
@@ -412,9 +407,10 @@ int vox_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp, float* 
   return vox_conv_dispatch(d, d->Cout, d->Cin, dy, wp, nullptr, dx, MUVO_ACT_NONE, 0.f, st);
 }
 
-template <int CQB, int RQB, int Z, int TYB>
+template <int RQB, int CQR, int Z, int TYB>
 static int launch_vox_wgrad(const muvo_conv_desc* d, const float* x, const float* dz, float* dw, float* dbias,
                             hipStream_t st) {
+  constexpr int CQB = 2;
   VoxArgs a;
   a.N = d->N; a.Cin = d->Cin; a.Cout = d->Cout; a.X = d->in_sz[0]; a.Y = d->in_sz[1];
   a.ytiles = cdiv(a.Y, TYB);
@@ -424,10 +420,10 @@ static int launch_vox_wgrad(const muvo_conv_desc* d, const float* x, const float
   const int nqc = d->Cout / (4 * CQB), nrc = d->Cin / (4 * RQB);
   int xsplit = 1;
   while ((long)a.N * a.ytiles * xsplit * nqc * nrc < 1536 && a.X / (xsplit * 2) >= 8) xsplit *= 2;
-  constexpr size_t lds = sizeof(float) * (3 * (TYB + 2) * (Z + 2) * 4 * RQB + 2 * TYB * Z * 4 * CQB);
+  constexpr size_t lds = sizeof(float) * (3 * RQB * (TYB + 2) * (Z + 2) * 4 + 2 * CQB * TYB * Z * 4);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)vox_wgrad_kernel<CQB, RQB, Z, TYB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)vox_wgrad_kernel<RQB, CQR, Z, TYB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) {
       muvo_set_error("vox_wgrad: cannot raise the dynamic LDS limit to %zu bytes", lds);
       return MUVO_ERR_HIP;
@@ -435,7 +431,7 @@ static int launch_vox_wgrad(const muvo_conv_desc* d, const float* x, const float
     attr_set = true;
   }
   dim3 grid(a.N * a.ytiles * xsplit, nqc * nrc);
-  hipLaunchKernelGGL((vox_wgrad_kernel<CQB, RQB, Z, TYB>), grid, dim3(576), lds, st, a, x, dz, dw, dbias, xsplit, nqc);
+  hipLaunchKernelGGL((vox_wgrad_kernel<RQB, CQR, Z, TYB>), grid, dim3(768), lds, st, a, x, dz, dw, dbias, xsplit, nqc);
   MUVO_CHECK_LAUNCH("vox_wgrad_kernel");
   return MUVO_OK;
 }
@@ -443,6 +439,7 @@ static int launch_vox_wgrad(const muvo_conv_desc* d, const float* x, const float
 int vox_wgrad(const muvo_conv_desc* d, const float* x, const float* dz, float* dw, float* dbias, hipStream_t st) {
   const int Z = d->in_sz[2];
   const bool r4 = d->Cin % 16 == 0;
-  if (Z == 64) return r4 ? launch_vox_wgrad<2, 4, 64, 4>(d, x, dz, dw, dbias, st) : launch_vox_wgrad<2, 2, 64, 4>(d, x, dz, dw, dbias, st);
-  return r4 ? launch_vox_wgrad<2, 4, 32, 8>(d, x, dz, dw, dbias, st) : launch_vox_wgrad<2, 2, 32, 8>(d, x, dz, dw, dbias, st);
+  // 16 input channels per workgroup with 2 output quads per role, or 8 input channels with 1 output quad per role
+  if (Z == 64) return r4 ? launch_vox_wgrad<4, 2, 64, 4>(d, x, dz, dw, dbias, st) : launch_vox_wgrad<2, 1, 64, 4>(d, x, dz, dw, dbias, st);
+  return r4 ? launch_vox_wgrad<4, 2, 32, 8>(d, x, dz, dw, dbias, st) : launch_vox_wgrad<2, 1, 32, 8>(d, x, dz, dw, dbias, st);
 }
