@@ -71,8 +71,14 @@ int muvo_conv_kernel_family(const muvo_conv_desc* d, int op);
 /* y = act(conv(x, w) + bias); bias may be NULL; ws may be NULL when muvo_conv_workspace_bytes(d, 0) == 0 */
 int muvo_conv_forward(const muvo_conv_desc* d, const float* x, const float* wp_fwd, const float* bias, float* y, int act,
                       float slope, void* ws, void* stream);
-/* dx = conv_data_grad(dy, w) (dy already multiplied by act'(y) by the caller) */
-int muvo_conv_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp_dgrad, float* dx, void* ws, void* stream);
+/* dx = conv_data_grad(dy, w) (dy already multiplied by act'(y) by the caller); ws_valid != 0: ws already holds the split
+ * planes of dy (written by muvo_conv_prepare_dy), dy itself is then not read by the bf16x3 path */
+int muvo_conv_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp_dgrad, float* dx, void* ws, int ws_valid,
+                    void* stream);
+/* backward preamble when muvo_conv_kernel_family(d, 1) == muvo_conv_kernel_family(d, 2) == 1: ws_dy <- split planes of
+ * dy * act'(y) (y may be NULL with MUVO_ACT_NONE), dbias += its per-channel sums (dbias may be NULL) */
+int muvo_conv_prepare_dy(const muvo_conv_desc* d, const float* y, const float* dy, int act, float slope, void* ws_dy,
+                         float* dbias, void* stream);
 /* dw += conv_weight_grad(x, dy) (PyTorch layout); dbias += sum(dy) if non-NULL.
  * dwp_scratch: fwd_floats floats of workspace (overwritten).  ws_x / ws_dy: see muvo_conv_workspace_bytes (may be NULL
  * when 0 bytes); flags bit 0 / bit 1: ws_x / ws_dy already hold the copies written by muvo_conv_forward(x) /

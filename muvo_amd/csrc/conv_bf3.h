@@ -7,7 +7,9 @@ void bf3_finish_phase(ConvPhase& g);
 int bf3_pack_phase(const ConvPhase& g, const float* w, float* wp, hipStream_t st);
 // workspace = channels-last bf16 hi/lo copy of the activation operand (N*S*roundup(C,8)*4 bytes)
 long bf3_workspace_bytes(int N, int C, long S);
-int bf3_split_input(const float* x, void* ws, int N, int C, long S, hipStream_t st);
+// yact/act/slope/dbias (optional): write the planes of x * act'(yact) and add its per-channel sums to dbias
+int bf3_split_input(const float* x, void* ws, int N, int C, long S, hipStream_t st, const float* yact = nullptr, int act = 0,
+                    float slope = 0.f, float* dbias = nullptr);
 int bf3_launch_fwd_phase(const ConvPhase& g, const void* ws, const float* wp, const float* bias, float* out, int act,
                          float slope, hipStream_t st);
 // weight gradient of one forward-form phase on the split planes (ws_x: planes of x with Cin_total channels, ws_dz: planes

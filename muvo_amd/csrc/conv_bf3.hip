@@ -408,42 +408,90 @@ __global__ void __launch_bounds__(256) bf3_unpack_wgrad_kernel(const ConvPhase g
   }
 }
 
-// fp32 NCHW [N][C][S] -> bf16 hi / lo planes, channels-last [N][S][Cp] (Cp = roundup(C, 8), zero padded)
+// fp32 NCHW [N][C][S] -> bf16 hi / lo planes, channels-last [N][S][Cp] (Cp = roundup(C, 8), zero padded).
+// Tile = 64 pixels x 64 channels through LDS: reads coalesced along pixels (each lane takes two adjacent channels of its
+// pixel so it stores one packed dword), writes one full 128-byte line per pixel and plane.  LDS rows are 33 dwords, which
+// makes both the dword stores (lane = pixel) and the 4-dword reads (lane = (pixel, chunk)) bank-conflict free.
+// Optional fusion for the backward pass: in = dy, yact = the activation output y -> the planes hold dy * act'(y) and
+// dbias[c] += sum of it (the separate activation-gradient and bias-gradient passes disappear).
+// grid = (ceil(S / 64 / SPLIT_TILES), ceil(Cp / 64), N)
+#define SPLIT_TILES 1
+#define BIAS_REPLICAS 64   // the per-tile bias partial sums are spread over this many replicas to avoid atomic contention
 __global__ void __launch_bounds__(256)
 nchw_split_nhwc_kernel(const float* __restrict__ in, uint4* __restrict__ out_hi, uint4* __restrict__ out_lo, int C, int Cp,
-                       long S) {
-  __shared__ __attribute__((aligned(16))) unsigned short th[64][72], tl[64][72];
-  const int tid = threadIdx.x;
-  const long s0 = (long)blockIdx.x * 64;
+                       long S, const float* __restrict__ yact, int act, float slope, float* __restrict__ dbias) {
+  constexpr int RS = 33;
+  __shared__ unsigned th[64 * RS], tl[64 * RS];
+  const int tid = threadIdx.x, pl = tid & 63, w = tid >> 6;
   const int c0 = blockIdx.y * 64, n = blockIdx.z;
-  const int pl = tid & 63;
-#pragma unroll 4
-  for (int r = 0; r < 16; ++r) {
-    const int cl = (tid >> 6) + 4 * r, c = c0 + cl;
-    const long s = s0 + pl;
-    float v = 0.f;
-    if (c < C && s < S) v = in[((size_t)n * C + c) * S + s];
-    unsigned hi, lo;
-    split2(v, 0.f, hi, lo);
-    th[pl][cl] = (unsigned short)hi;
-    tl[pl][cl] = (unsigned short)lo;
-  }
-  __syncthreads();
+  const float* inn = in + (size_t)n * C * S;
+  const float* yn = yact ? yact + (size_t)n * C * S : nullptr;
+  float bsum[16];
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int item = tid + 256 * r;
-    const int pix = item >> 3, ch = item & 7;
-    const long s = s0 + pix;
-    const int c = c0 + ch * 8;
-    if (s < S && c < Cp) {
-      const size_t o = (((size_t)n * S + s) * Cp + c) >> 3;
-      out_hi[o] = *(const uint4*)&th[pix][ch * 8];
-      out_lo[o] = *(const uint4*)&tl[pix][ch * 8];
+  for (int r = 0; r < 16; ++r) bsum[r] = 0.f;
+  for (int it = 0; it < SPLIT_TILES; ++it) {
+    const long s0 = ((long)blockIdx.x * SPLIT_TILES + it) * 64;
+    if (s0 >= S) break;
+    const long s = s0 + pl;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int k = w + 4 * r;              // channel pair index inside the tile
+      float v[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int c = c0 + 2 * k + e;
+        float t = 0.f;
+        if (c < C && s < S) {
+          t = inn[(size_t)c * S + s];
+          if (yn) t *= act_grad_from_out(yn[(size_t)c * S + s], act, slope);
+        }
+        v[e] = t;
+        bsum[2 * r + e] += t;
+      }
+      unsigned hi, lo;
+      split2(v[0], v[1], hi, lo);
+      th[pl * RS + k] = hi;
+      tl[pl * RS + k] = lo;
     }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int item = tid + 256 * r;
+      const int pix = item >> 3, ch = item & 7;
+      const long so = s0 + pix;
+      const int c = c0 + ch * 8;
+      if (so < S && c < Cp) {
+        const unsigned* ph = th + pix * RS + ch * 4;
+        const unsigned* pq = tl + pix * RS + ch * 4;
+        const size_t o = (((size_t)n * S + so) * Cp + c) >> 3;
+        out_hi[o] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+        out_lo[o] = make_uint4(pq[0], pq[1], pq[2], pq[3]);
+      }
+    }
+    __syncthreads();
+  }
+  if (dbias) {   // lanes of a wave = 64 pixels of the same channels
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int c = c0 + 2 * (w + 4 * r) + e;
+        const float sum = wave_sum(bsum[2 * r + e]);
+        if (pl == 0 && c < C) atomicAdd(dbias + (size_t)(blockIdx.x % BIAS_REPLICAS) * Cp + c, sum);
+      }
   }
   // zero page right after the two planes (source of out-of-bounds DMA reads)
   if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0)
     out_hi[2 * ((size_t)gridDim.z * S * Cp >> 3)] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+// dbias[c] += sum over replicas
+__global__ void bias_replica_reduce_kernel(const float* __restrict__ rep, float* __restrict__ dbias, int C, int Cp) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int r = 0; r < BIAS_REPLICAS; ++r) s += rep[(size_t)r * Cp + c];
+  dbias[c] += s;
 }
 
 __device__ uint4 g_zero16 = {0u, 0u, 0u, 0u};
@@ -489,14 +537,27 @@ int bf3_pack_phase(const ConvPhase& g, const float* w, float* wp, hipStream_t st
   return MUVO_OK;
 }
 
-long bf3_workspace_bytes(int N, int C, long S) { return (long)N * S * roundup(C, 8) * 4 + 16; }
+// split planes + zero page + BIAS_REPLICAS x Cp floats of bias partial sums
+long bf3_workspace_bytes(int N, int C, long S) {
+  return (long)N * S * roundup(C, 8) * 4 + 16 + (long)BIAS_REPLICAS * roundup(C, 8) * 4;
+}
 
-int bf3_split_input(const float* x, void* ws, int N, int C, long S, hipStream_t st) {
+int bf3_split_input(const float* x, void* ws, int N, int C, long S, hipStream_t st, const float* yact, int act, float slope,
+                    float* dbias) {
   const int Cp = roundup(C, 8);
   uint4* hi = (uint4*)ws;
   uint4* lo = hi + (size_t)N * S * Cp / 8;
-  dim3 grid(cdiv(S, 64), cdiv(Cp, 64), N);
-  hipLaunchKernelGGL(nchw_split_nhwc_kernel, grid, dim3(256), 0, st, x, hi, lo, C, Cp, S);
+  float* rep = nullptr;
+  if (dbias) {
+    rep = (float*)((char*)ws + (size_t)N * S * Cp * 4 + 16);
+    if (hipMemsetAsync(rep, 0, sizeof(float) * BIAS_REPLICAS * Cp, st) != hipSuccess) {
+      muvo_set_error("bf3_split_input: memset failed");
+      return MUVO_ERR_HIP;
+    }
+  }
+  dim3 grid(cdiv(cdiv(S, 64), SPLIT_TILES), cdiv(Cp, 64), N);
+  hipLaunchKernelGGL(nchw_split_nhwc_kernel, grid, dim3(256), 0, st, x, hi, lo, C, Cp, S, yact, act, slope, rep);
+  if (dbias) hipLaunchKernelGGL(bias_replica_reduce_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, rep, dbias, C, Cp);
   MUVO_CHECK_LAUNCH("nchw_split_nhwc_kernel");
   return MUVO_OK;
 }

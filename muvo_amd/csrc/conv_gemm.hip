@@ -789,8 +789,8 @@ int muvo_conv_kernel_family(const muvo_conv_desc* d, int op) {
 }
 
 static int run_phases(const ConvPhase* ph, int nph, const float* in, const float* wp, const float* bias, float* out, int act,
-                      float slope, void* ws, hipStream_t st) {
-  bool split_done = false;
+                      float slope, void* ws, hipStream_t st, bool ws_valid = false) {
+  bool split_done = ws_valid;
   // split-K needs a zeroed output and a finishing bias/activation pass; use it only when every phase wants it
   bool use_ksplit = nph > 0;
   for (int i = 0; i < nph; ++i) use_ksplit = use_ksplit && phase_ksplit(ph[i]) > 1;
@@ -828,14 +828,28 @@ int muvo_conv_forward(const muvo_conv_desc* d, const float* x, const float* wp_f
   return run_phases(pl.fwd, pl.nfwd, x, wp_fwd, bias, y, act, slope, ws, (hipStream_t)stream);
 }
 
-int muvo_conv_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp_dgrad, float* dx, void* ws, void* stream) {
+int muvo_conv_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp_dgrad, float* dx, void* ws, int ws_valid,
+                    void* stream) {
   ConvPlan pl;
   int rc = build_plan(d, &pl);
   if (rc) return rc;
   MUVO_CHECK_ARG(dy && wp_dgrad && dx, "conv_dgrad: null pointer");
   if (pw_applicable(d)) return pw_dgrad(d, dy, wp_dgrad, dx, (hipStream_t)stream);
   if (vox_dgrad_applicable(d)) return vox_dgrad(d, dy, wp_dgrad, dx, (hipStream_t)stream);
-  return run_phases(pl.dgr, pl.ndgr, dy, wp_dgrad, nullptr, dx, MUVO_ACT_NONE, 0.f, ws, (hipStream_t)stream);
+  return run_phases(pl.dgr, pl.ndgr, dy, wp_dgrad, nullptr, dx, MUVO_ACT_NONE, 0.f, ws, (hipStream_t)stream, ws_valid != 0);
+}
+
+// Backward preamble for layers whose dgrad AND wgrad run on the bf16x3 kernels: one pass over (y, dy) writes the
+// channels-last split planes of dz = dy * act'(y) into ws_dy (muvo_conv_workspace_bytes(d, 1) bytes) and adds the bias
+// gradient sum(dz) to dbias — instead of an activation-gradient pass, a split pass and a bias-gradient pass.
+int muvo_conv_prepare_dy(const muvo_conv_desc* d, const float* y, const float* dy, int act, float slope, void* ws_dy,
+                         float* dbias, void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  MUVO_CHECK_ARG(dy && ws_dy && (y || act == MUVO_ACT_NONE), "conv_prepare_dy: null pointer");
+  const long S_out = (long)d->out_sz[0] * d->out_sz[1] * d->out_sz[2];
+  return bf3_split_input(dy, ws_dy, d->N, d->Cout, S_out, (hipStream_t)stream, act == MUVO_ACT_NONE ? nullptr : y, act, slope,
+                         dbias);
 }
 
 // does the weight gradient of this conv run on the bf16x3 kernel (conv_bf3.hip)?  Same per-item work threshold as

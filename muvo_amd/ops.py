@@ -42,7 +42,7 @@ class GemmDesc(C.Structure):
 # every exported symbol of include/muvo_hip.h (tests/test_abi.py checks this list against the header)
 EXPORTS = [
     'muvo_last_error', 'muvo_abi_version', 'muvo_selftest_mfma',
-    'muvo_conv_set_mode', 'muvo_conv_get_mode', 'muvo_conv_set_bf16x3_min_gflop', 'muvo_conv_pack_sizes', 'muvo_conv_workspace_bytes', 'muvo_conv_kernel_family', 'muvo_conv_pack_weights', 'muvo_conv_forward', 'muvo_conv_dgrad', 'muvo_conv_wgrad', 'muvo_bias_grad_nchw',
+    'muvo_conv_set_mode', 'muvo_conv_get_mode', 'muvo_conv_set_bf16x3_min_gflop', 'muvo_conv_pack_sizes', 'muvo_conv_workspace_bytes', 'muvo_conv_kernel_family', 'muvo_conv_pack_weights', 'muvo_conv_forward', 'muvo_conv_dgrad', 'muvo_conv_prepare_dy', 'muvo_conv_wgrad', 'muvo_bias_grad_nchw',
     'muvo_gemm',
     'muvo_bn_train_fwd', 'muvo_bn_train_bwd', 'muvo_adain_fwd', 'muvo_adain_bwd',
     'muvo_add_dropout_layernorm_fwd', 'muvo_add_dropout_layernorm_bwd',
@@ -401,7 +401,21 @@ class ConvFn(torch.autograd.Function):
         d, out_sz, ff, df = geom.plan(x.shape[0], ctx.in_sz)
         L = lib()
         dy = dy.contiguous()
-        if ctx.act != ACT_NONE and not ctx.act_bwd_fused:
+        key = (x.shape[0], ctx.in_sz, _plan_epoch[0])
+        fam, wsb = geom.family[key], geom.ws_bytes[key]
+        # both gradient kernels read dy through the channels-last split planes: one fused pass makes them from (y, dy)
+        # together with the activation derivative and the bias gradient
+        fused_dy = (fam[1] == 1 and fam[2] == 1 and ctx.needs_input_grad[0] and weight.requires_grad and wsb[1] > 0
+                    and wsb[3] > 0)
+        ws_dy_fused = None
+        if fused_dy:
+            ws_dy_fused = scratch('conv_ws_dy', (max(wsb[1], wsb[3]) + 3) // 4, x.device)
+            use_act = ctx.act != ACT_NONE and not ctx.act_bwd_fused
+            _ck(L.muvo_conv_prepare_dy(C.byref(d), _f(y) if use_act else None, _f(dy), ctx.act if use_act else ACT_NONE,
+                                       _fl(ctx.slope), _p(ws_dy_fused), _f(grad_of(bias)) if bias is not None else None,
+                                       _st()))
+            dz = dy   # not read by the bf16x3 kernels
+        elif ctx.act != ACT_NONE and not ctx.act_bwd_fused:
             dz = torch.empty_like(dy)
             _ck(L.muvo_act_bwd(_f(y), _f(dy), _f(dz), _i64(dy.numel()), ctx.act, _fl(ctx.slope), _st()))
         else:
@@ -424,16 +438,15 @@ class ConvFn(torch.autograd.Function):
                                     _conv_flops(geom, x.shape[0], ctx.in_sz, out_sz),
                                     1 if geom.transposed else math.prod(geom.stride), _conv_tag(geom, x.shape[0], ctx.in_sz))
                 e0.record()
-            wsb = geom.ws_bytes[(x.shape[0], ctx.in_sz, _plan_epoch[0])]
             nb = max(wsb[1], wsb[3])
             ws_dy = scratch('conv_ws_dy', (nb + 3) // 4, x.device) if nb else None
             dy_split = wsb[1] > 0
-            _ck(L.muvo_conv_dgrad(C.byref(d), _f(dz), _f(packed.dgr), _f(dx), _p(ws_dy), _st()))
+            _ck(L.muvo_conv_dgrad(C.byref(d), _f(dz), _f(packed.dgr), _f(dx), _p(ws_dy), 1 if fused_dy else 0, _st()))
             if kt is not None:
                 e1.record()
         if weight.requires_grad:
             ws = scratch('wgrad', ff, x.device)
-            db = grad_of(bias) if bias is not None else None
+            db = grad_of(bias) if (bias is not None and not fused_dy) else None   # fused_dy: already accumulated
             kt = KERNEL_TIMING
             if kt is not None:
                 import math
@@ -441,7 +454,6 @@ class ConvFn(torch.autograd.Function):
                                     _conv_flops(geom, x.shape[0], ctx.in_sz, out_sz),
                                     math.prod(geom.stride) if geom.transposed else 1, _conv_tag(geom, x.shape[0], ctx.in_sz))
                 e0.record()
-            wsb = geom.ws_bytes[(x.shape[0], ctx.in_sz, _plan_epoch[0])]
             ws_x = ctx.ws_x
             flags = (1 if ws_x is not None else 0) | (2 if (dy_split and wsb[3] > 0) else 0)
             if ws_x is None and wsb[2]:

@@ -86,7 +86,7 @@ def main():
         dx = torch.empty_like(xd)
         fns = {
             'fwd': lambda: ops._ck(L.muvo_conv_forward(C.byref(d), ops._f(xd), ops._f(packed.fwd), ops._f(m.bias), ops._f(y.detach()), 0, ops._fl(0.0), ops._p(wsf), ops._st())),
-            'dgrad': lambda: ops._ck(L.muvo_conv_dgrad(C.byref(d), ops._f(gd), ops._f(packed.dgr), ops._f(dx), ops._p(wsd), ops._st())),
+            'dgrad': lambda: ops._ck(L.muvo_conv_dgrad(C.byref(d), ops._f(gd), ops._f(packed.dgr), ops._f(dx), ops._p(wsd), 0, ops._st())),
             'wgrad': lambda: ops._ck(L.muvo_conv_wgrad(C.byref(d), ops._f(xd), ops._f(gd), ops._f(ws), ops._f(m.weight.grad), ops._f(m.bias.grad), ops._p(wsx), ops._p(wsy), 0, ops._st())),
         }
         for w in what:
