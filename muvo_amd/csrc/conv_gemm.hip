@@ -852,6 +852,17 @@ int muvo_conv_prepare_dy(const muvo_conv_desc* d, const float* y, const float* d
                          dbias);
 }
 
+// Weight gradients are leaves of the backward graph (their rounding error does not propagate into other gradients), so
+// they can go to bf16x3 at a lower work threshold than forward / data-gradient.
+static double bf3_wgrad_min_gflop() {
+  static double v = -1.0;
+  if (v < 0.0) {
+    const char* e = getenv("MUVO_BF16X3_WGRAD_MIN_GFLOP");
+    v = e ? atof(e) : (bf3_min_gflop() < 0.5 ? bf3_min_gflop() : 0.5);
+  }
+  return v;
+}
+
 // does the weight gradient of this conv run on the bf16x3 kernel (conv_bf3.hip)?  Same per-item work threshold as
 // forward/dgrad, every phase must have > 32 output and >= 32 input channels.
 static bool wgrad_uses_bf3(const ConvPlan& pf) {
@@ -859,7 +870,7 @@ static bool wgrad_uses_bf3(const ConvPlan& pf) {
   for (int i = 0; i < pf.nfwd; ++i) {
     const ConvPhase& g = pf.fwd[i];
     const double gflop = 2.0 * g.M * g.T * g.C * (double)g.SD * g.SH * g.SW * 1e-9;
-    if (g.M <= 32 || g.C < 32 || gflop < bf3_min_gflop()) return false;
+    if (g.M <= 32 || g.C < 32 || gflop < bf3_wgrad_min_gflop()) return false;
   }
   return pf.nfwd > 0;
 }
