@@ -207,23 +207,25 @@ __global__ void __launch_bounds__(256) gemm_skinny_kcontig_kernel(const GemmArgs
   }
 }
 
-// B n-contiguous (data gradient of nn.Linear: B(k,n) = W[k][n]).  Lanes along n (coalesced weight rows), the 16 waves of
-// a workgroup split k and are reduced through LDS.
+// B n-contiguous (data gradient of nn.Linear: B(k,n) = W[k][n]).  Lanes along n (coalesced weight rows); the four waves of
+// a workgroup and the KS workgroups of grid.y split k.  KS > 1: partial sums are added into the pre-zeroed C with float
+// atomics (only offered without bias/activation).
 template <int RM>
-__global__ void __launch_bounds__(1024) gemm_skinny_ncontig_kernel(const GemmArgs g, const float* __restrict__ A,
-                                                                   const float* __restrict__ B, float* __restrict__ C) {
-  __shared__ float red[16][RM][64];
+__global__ void __launch_bounds__(256) gemm_skinny_ncontig_kernel(const GemmArgs g, const float* __restrict__ A,
+                                                                  const float* __restrict__ B, float* __restrict__ C, int KS) {
+  __shared__ float red[4][RM][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + lane;
   const bool nok = n < g.N;
-  const int kper = (g.K + 15) / 16;
-  const int k0 = wave * kper;
+  const int kper = (g.K + 4 * KS - 1) / (4 * KS);
+  const int k0 = (blockIdx.y * 4 + wave) * kper;
   int k1 = k0 + kper;
   if (k1 > g.K) k1 = g.K;
   for (int r0 = 0; r0 < g.M; r0 += RM) {
     float acc[RM];
 #pragma unroll
     for (int r = 0; r < RM; ++r) acc[r] = 0.f;
+#pragma unroll 4
     for (int k = k0; k < k1; ++k) {
       const float w = nok ? B[(long)k * g.sbk + (long)n * g.sbn] : 0.f;
 #pragma unroll
@@ -236,12 +238,17 @@ __global__ void __launch_bounds__(1024) gemm_skinny_ncontig_kernel(const GemmArg
 #pragma unroll
     for (int r = 0; r < RM; ++r) red[wave][r][lane] = acc[r];
     __syncthreads();
-    if (wave < RM && r0 + wave < g.M && nok) {
-      float s = 0.f;
-#pragma unroll
-      for (int w = 0; w < 16; ++w) s += red[w][wave][lane];
-      const float bv = g.bias ? g.bias[n / g.bias_div] : 0.f;
-      C[(long)(r0 + wave) * g.scm + n] = act_apply(g.alpha * s + bv, g.act, g.slope);
+    for (int r = wave; r < RM; r += 4) {
+      if (r0 + r < g.M && nok) {
+        const float s = red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + red[3][r][lane];
+        float* dst = C + (long)(r0 + r) * g.scm + n;
+        if (KS > 1) {
+          atomicAdd(dst, g.alpha * s);
+        } else {
+          const float bv = g.bias ? g.bias[n / g.bias_div] : 0.f;
+          *dst = act_apply(g.alpha * s + bv, g.act, g.slope);
+        }
+      }
     }
   }
 }
@@ -280,8 +287,18 @@ extern "C" int muvo_gemm(const muvo_gemm_desc* d, const float* A, const float* B
       else hipLaunchKernelGGL((gemm_skinny_kcontig_kernel<8>), dim3(blocks), dim3(256), 0, st, g, A, B, C);
     } else {
       const int blocks = cdiv(d->N, 64);
-      if (d->M <= 4) hipLaunchKernelGGL((gemm_skinny_ncontig_kernel<4>), dim3(blocks), dim3(1024), 0, st, g, A, B, C);
-      else hipLaunchKernelGGL((gemm_skinny_ncontig_kernel<8>), dim3(blocks), dim3(1024), 0, st, g, A, B, C);
+      int ks = 1;
+      if (!bias && d->act == MUVO_ACT_NONE && d->scm == d->N) {   // dense C: zero it, then split k over workgroups
+        ks = cdiv(512, blocks);
+        if (ks > d->K / 64) ks = d->K / 64;
+        if (ks < 1) ks = 1;
+      }
+      if (ks > 1 && hipMemsetAsync(C, 0, sizeof(float) * (size_t)d->M * d->N, st) != hipSuccess) {
+        muvo_set_error("gemm_skinny: memset failed");
+        return MUVO_ERR_HIP;
+      }
+      if (d->M <= 4) hipLaunchKernelGGL((gemm_skinny_ncontig_kernel<4>), dim3(blocks, ks), dim3(256), 0, st, g, A, B, C, ks);
+      else hipLaunchKernelGGL((gemm_skinny_ncontig_kernel<8>), dim3(blocks, ks), dim3(256), 0, st, g, A, B, C, ks);
     }
     MUVO_CHECK_LAUNCH("gemm_skinny_kernel");
     return MUVO_OK;
