@@ -272,16 +272,16 @@ conv_bf3_wgrad_kernel(const ConvPhase g, const uint4* __restrict__ xs, long xpla
     decode_pix(g, cpix[v] < g.npix ? cpix[v] : 0, cn[v], cz[v], cy[v], cx_[v]);
   }
   const int zeroA = (int)(2 * dzplane_u4), zeroB = (int)(2 * xplane_u4);
-  const int mt8 = m_tile >> 3, ct8 = c_tile >> 3;
+  const int ct8 = c_tile >> 3;
   auto issue = [&](int stage) {     // stages the step the coordinates currently point at, then advances them
     uint4* S = smem + stage * STAGE;
     int offA[2], offB[2];
 #pragma unroll
     for (int v = 0; v < 2; ++v) {
       const bool pv = cpix[v] < g.npix;
-      const int o = ((cn[v] * g.OD + (cz[v] * g.os[0] + g.op[0])) * g.OH + (cy[v] * g.os[1] + g.op[1])) * g.OW +
-                    (cx_[v] * g.os[2] + g.op[2]);
-      offA[v] = pv ? o * dzc8 + mt8 : -1;
+      // output pixel of residue (0,0,0); the residue of the row group is added per DMA instruction (merged phases)
+      const int o = ((cn[v] * g.OD + cz[v] * g.os[0]) * g.OH + cy[v] * g.os[1]) * g.OW + cx_[v] * g.os[2];
+      offA[v] = pv ? o : -1;
       const int z = cz[v] * g.is[0] + g.ib[0] + dz_, y = cy[v] * g.is[1] + g.ib[1] + dy_, x = cx_[v] * g.is[2] + g.ib[2] + dx_;
       const bool ok = pv && (unsigned)z < (unsigned)g.ID && (unsigned)y < (unsigned)g.IH && (unsigned)x < (unsigned)g.IW;
       offB[v] = ok ? (((cn[v] * g.ID + z) * g.IH + y) * g.IW + x) * xc8 + ct8 : -1;
@@ -304,8 +304,14 @@ conv_bf3_wgrad_kernel(const ConvPhase g, const uint4* __restrict__ xs, long xpla
       const int plane = a / (CA / 2), e = a % (CA / 2);
       const int chunk = 2 * e + hi5;
       const int base = offA[e & 1];
-      const bool inb = m_tile + chunk * 8 < g.Mp;   // Mp = channel extent of the dz planes (see launcher)
-      const int off = (base >= 0 && inb) ? base + plane * (int)dzplane_u4 + chunk : zeroA;
+      // rows [m_tile + 16e, +16) belong to one row group (Msub % 16 == 0): its output residue and local channel chunk
+      const int row0 = m_tile + 16 * e;
+      const int grp = row0 / g.Msub;
+      const int lc8 = ((row0 - grp * g.Msub) >> 3) + hi5;
+      const int resid = (g.mop[grp < g.nmerge ? grp : 0][0] * g.OH + g.mop[grp < g.nmerge ? grp : 0][1]) * g.OW +
+                        g.mop[grp < g.nmerge ? grp : 0][2];
+      const bool inb = m_tile + chunk * 8 < g.M && lc8 < dzc8;
+      const int off = (base >= 0 && inb) ? (base + resid) * dzc8 + lc8 + plane * (int)dzplane_u4 : zeroA;
       dma16(dzs + (unsigned)off, S + (plane * CA + 2 * e) * 32);
     }
 #pragma unroll
@@ -404,7 +410,9 @@ __global__ void __launch_bounds__(256) bf3_unpack_wgrad_kernel(const ConvPhase g
     int m, c;
     if (g.wsm > g.wsc) { c = (int)(r % g.C); m = (int)(r / g.C); }
     else { m = (int)(r % g.M); c = (int)(r / g.M); }
-    dw[(size_t)m * g.wsm + (size_t)c * g.wsc + s_tw[t]] += base[((size_t)t * g.M + m) * g.C + c];
+    const int grp = m / g.Msub, co = m - grp * g.Msub;
+    dw[(size_t)co * g.wsm + (size_t)c * g.wsc + (g.nmerge > 1 ? g.tap_wm[grp][t] : s_tw[t])] +=
+        base[((size_t)t * g.M + m) * g.C + c];
   }
 }
 
@@ -617,8 +625,7 @@ static int bf3_wgrad_launch(const ConvPhase& g, const void* ws_x, int Cin_total,
   }
   ConvPhase p = g;
   const int xc8 = roundup(Cin_total, 8) / 8, dzc8 = roundup(Cout_total, 8) / 8;
-  p.Cp = xc8 * 8;     // channel extents of the split planes: DMA beyond them reads the zero page
-  p.Mp = dzc8 * 8;
+  p.Cp = xc8 * 8;     // channel extent of the x planes: DMA beyond it reads the zero page (dz: dzc8 in the kernel)
   const long xplane = (long)g.N * g.ID * g.IH * g.IW * xc8, dzplane = (long)g.N * g.OD * g.OH * g.OW * dzc8;
   const int ctiles = cdiv(g.C, BN), mtiles = cdiv(g.M, BM);
   const int nsteps = cdiv(g.npix, 32);

@@ -855,12 +855,10 @@ int muvo_conv_prepare_dy(const muvo_conv_desc* d, const float* y, const float* d
 // Weight gradients are leaves of the backward graph (their rounding error does not propagate into other gradients), so
 // they can go to bf16x3 at a lower work threshold than forward / data-gradient.
 static double bf3_wgrad_min_gflop() {
-  static double v = -1.0;
-  if (v < 0.0) {
-    const char* e = getenv("MUVO_BF16X3_WGRAD_MIN_GFLOP");
-    v = e ? atof(e) : (bf3_min_gflop() < 0.5 ? bf3_min_gflop() : 0.5);
-  }
-  return v;
+  static const char* e = getenv("MUVO_BF16X3_WGRAD_MIN_GFLOP");
+  static const double env_v = e ? atof(e) : -1.0;
+  if (env_v >= 0.0) return env_v;
+  return bf3_min_gflop() < 0.5 ? bf3_min_gflop() : 0.5;   // follows muvo_conv_set_bf16x3_min_gflop
 }
 
 // does the weight gradient of this conv run on the bf16x3 kernel (conv_bf3.hip)?  Same per-item work threshold as
@@ -869,8 +867,8 @@ static bool wgrad_uses_bf3(const ConvPlan& pf) {
   if (conv_mode() != 1) return false;
   for (int i = 0; i < pf.nfwd; ++i) {
     const ConvPhase& g = pf.fwd[i];
-    const double gflop = 2.0 * g.M * g.T * g.C * (double)g.SD * g.SH * g.SW * 1e-9;
-    if (g.M <= 32 || g.C < 32 || gflop < bf3_wgrad_min_gflop()) return false;
+    const double gflop = 2.0 * g.Msub * g.T * g.C * (double)g.SD * g.SH * g.SW * 1e-9;   // per original phase
+    if (g.Msub <= 32 || g.C < 32 || g.Msub % 16 != 0 && g.nmerge > 1 || gflop < bf3_wgrad_min_gflop()) return false;
   }
   return pf.nfwd > 0;
 }
@@ -889,6 +887,9 @@ int muvo_conv_wgrad(const muvo_conv_desc* d, const float* x, const float* dy, fl
   if (vox_wgrad_applicable(d)) return vox_wgrad(d, x, dy, dw, dbias, st);
   const long S_out = (long)d->out_sz[0] * d->out_sz[1] * d->out_sz[2];
   if (wgrad_uses_bf3(pl)) {
+    // the bf16x3 kernel understands merged sub-pixel phases (one GEMM with nmerge * Cout rows): use them when they exist
+    ConvPlan pm;
+    if (build_plan(d, &pm, 0, true) == MUVO_OK && wgrad_uses_bf3(pm)) pl = pm;
     MUVO_CHECK_ARG(ws_x && ws_dy, "conv_wgrad: this shape runs on the bf16x3 kernel and needs both workspaces");
     const long S_in = (long)d->in_sz[0] * d->in_sz[1] * d->in_sz[2];
     if (!(flags & 1)) { rc = bf3_split_input(x, ws_x, d->N, d->Cin, S_in, st); if (rc) return rc; }

@@ -31,6 +31,18 @@ def main():
     print('grad L2 norms, worst 12 (rel, abs, name, ref):')
     for r in rows[:12]:
         print(f'  {r[0]:.2e} {r[1]:.2e} {r[2]} {r[3]:.3e}')
+    if 'grad_l2_fp64' in g:
+        rows = []
+        for n, ref in g['grad_l2_fp64'].items():
+            if ref is None:
+                continue
+            got = recs[0]['grad_l2'][n]
+            tol = max(2e-3 * abs(ref), 6.0 * g['grad_l2_ref32_err'][n], 1e-5)
+            rows.append((abs(got - ref) / tol, abs(got - ref), ref, g['grad_l2_ref32_err'][n], n))
+        rows.sort(reverse=True)
+        print('grad L2 norms vs fp64 reference, worst 10 (|err|/tol of the test, |err|, ref norm, reference fp32 err, name):')
+        for r in rows[:10]:
+            print(f'  {r[0]:.2f} {r[1]:.2e} {r[2]:.3e} {r[3]:.2e} {r[4]}')
     rows = []
     for key in smp.files:
         if key.startswith('grad64.'):
