@@ -265,45 +265,44 @@ conv_bf3_wgrad_kernel(const ConvPhase g, const uint4* __restrict__ xs, long xpla
   const int pos = lane & 31, hi5 = lane >> 5;
   const unsigned sw_magic = (unsigned)(0x100000000ull / (unsigned)g.SW) + 1u, sh_magic = (unsigned)(0x100000000ull / (unsigned)g.SH) + 1u,
                  sd_magic = (unsigned)(0x100000000ull / (unsigned)g.SD) + 1u;
-  int cpix[2], cn[2], cz[2], cy[2], cx_[2];
-#pragma unroll
-  for (int v = 0; v < 2; ++v) {
-    cpix[v] = s_begin * BK + (pos ^ ((((2 * v) + hi5) & 3) << 2));
-    decode_pix(g, cpix[v] < g.npix ? cpix[v] : 0, cn[v], cz[v], cy[v], cx_[v]);
-  }
+  // Each wave only issues DMA instructions of ONE parity (e & 1 == wave & 1), i.e. one pixel variant: a single
+  // coordinate set per lane.
+  static_assert(NW % 2 == 0 && (CA / 4) * 4 == CA && (CB / 4) * 4 == CB, "parity split of the DMA roles");
+  const int v = wave & 1;
+  int cpix = s_begin * BK + (pos ^ ((((2 * v) + hi5) & 3) << 2));
+  int cn, cz, cy, cx_;
+  decode_pix(g, cpix < g.npix ? cpix : 0, cn, cz, cy, cx_);
   const int zeroA = (int)(2 * dzplane_u4), zeroB = (int)(2 * xplane_u4);
   const int ct8 = c_tile >> 3;
   auto issue = [&](int stage) {     // stages the step the coordinates currently point at, then advances them
     uint4* S = smem + stage * STAGE;
-    int offA[2], offB[2];
-#pragma unroll
-    for (int v = 0; v < 2; ++v) {
-      const bool pv = cpix[v] < g.npix;
+    int offA, offB;
+    {
+      const bool pv = cpix < g.npix;
       // output pixel of residue (0,0,0); the residue of the row group is added per DMA instruction (merged phases)
-      const int o = ((cn[v] * g.OD + cz[v] * g.os[0]) * g.OH + cy[v] * g.os[1]) * g.OW + cx_[v] * g.os[2];
-      offA[v] = pv ? o : -1;
-      const int z = cz[v] * g.is[0] + g.ib[0] + dz_, y = cy[v] * g.is[1] + g.ib[1] + dy_, x = cx_[v] * g.is[2] + g.ib[2] + dx_;
+      const int o = ((cn * g.OD + cz * g.os[0]) * g.OH + cy * g.os[1]) * g.OW + cx_ * g.os[2];
+      offA = pv ? o : -1;
+      const int z = cz * g.is[0] + g.ib[0] + dz_, y = cy * g.is[1] + g.ib[1] + dy_, x = cx_ * g.is[2] + g.ib[2] + dx_;
       const bool ok = pv && (unsigned)z < (unsigned)g.ID && (unsigned)y < (unsigned)g.IH && (unsigned)x < (unsigned)g.IW;
-      offB[v] = ok ? (((cn[v] * g.ID + z) * g.IH + y) * g.IW + x) * xc8 + ct8 : -1;
+      offB = ok ? (((cn * g.ID + z) * g.IH + y) * g.IW + x) * xc8 + ct8 : -1;
       // advance by BK pixels
-      cpix[v] += BK;
-      int xx = cx_[v] + BK;
+      cpix += BK;
+      int xx = cx_ + BK;
       int q = g.SW == 1 ? xx : (int)(((unsigned long long)(unsigned)xx * sw_magic) >> 32);
-      cx_[v] = xx - q * g.SW;
-      int yy = cy[v] + q;
+      cx_ = xx - q * g.SW;
+      int yy = cy + q;
       q = g.SH == 1 ? yy : (int)(((unsigned long long)(unsigned)yy * sh_magic) >> 32);
-      cy[v] = yy - q * g.SH;
-      int zz = cz[v] + q;
+      cy = yy - q * g.SH;
+      int zz = cz + q;
       q = g.SD == 1 ? zz : (int)(((unsigned long long)(unsigned)zz * sd_magic) >> 32);
-      cz[v] = zz - q * g.SD;
-      cn[v] += q;
+      cz = zz - q * g.SD;
+      cn += q;
     }
 #pragma unroll
     for (int q = 0; q < APW; ++q) {
-      const int a = wave * APW + q;                 // plane * (CA/2) + e
-      const int plane = a / (CA / 2), e = a % (CA / 2);
+      const int k = (wave >> 1) * APW + q;          // plane * (CA/4) + j,  e = 2j + v
+      const int plane = k / (CA / 4), e = 2 * (k % (CA / 4)) + v;
       const int chunk = 2 * e + hi5;
-      const int base = offA[e & 1];
       // rows [m_tile + 16e, +16) belong to one row group (Msub % 16 == 0): its output residue and local channel chunk
       const int row0 = m_tile + 16 * e;
       const int grp = row0 / g.Msub;
@@ -311,17 +310,16 @@ conv_bf3_wgrad_kernel(const ConvPhase g, const uint4* __restrict__ xs, long xpla
       const int resid = (g.mop[grp < g.nmerge ? grp : 0][0] * g.OH + g.mop[grp < g.nmerge ? grp : 0][1]) * g.OW +
                         g.mop[grp < g.nmerge ? grp : 0][2];
       const bool inb = m_tile + chunk * 8 < g.M && lc8 < dzc8;
-      const int off = (base >= 0 && inb) ? (base + resid) * dzc8 + lc8 + plane * (int)dzplane_u4 : zeroA;
+      const int off = (offA >= 0 && inb) ? (offA + resid) * dzc8 + lc8 + plane * (int)dzplane_u4 : zeroA;
       dma16(dzs + (unsigned)off, S + (plane * CA + 2 * e) * 32);
     }
 #pragma unroll
     for (int q = 0; q < BPW; ++q) {
-      const int b = wave * BPW + q;
-      const int plane = b / (CB / 2), e = b % (CB / 2);
+      const int k = (wave >> 1) * BPW + q;
+      const int plane = k / (CB / 4), e = 2 * (k % (CB / 4)) + v;
       const int chunk = 2 * e + hi5;
-      const int base = offB[e & 1];
       const bool inb = c_tile + chunk * 8 < g.Cp;
-      const int off = (base >= 0 && inb) ? base + plane * (int)xplane_u4 + chunk : zeroB;
+      const int off = (offB >= 0 && inb) ? offB + plane * (int)xplane_u4 + chunk : zeroB;
       dma16(xs + (unsigned)off, S + 2 * CA * 32 + (plane * CB + 2 * e) * 32);
     }
   };
