@@ -119,6 +119,40 @@ class Mile(nn.Module):
             output.update(unpack_sequence_dim(self.voxel_decoder(state), b, s))
         return output, state_dict
 
+    def imagine(self, batch, predict_action=False, future_horizon=None, noise=None):
+        """Mile.imagine (mile.py:771-850): roll the prior forward from (hidden_state, sample) with the recorded actions (or
+        the policy's) and decode every imagined state.  noise: optional explicit (b, fh, S) draws for parity runs."""
+        assert self.cfg.MODEL.TRANSITION.ENABLED
+        fh = self.cfg.FUTURE_HORIZON if future_horizon is None else future_horizon
+        h_t, sample_t = batch['hidden_state'].contiguous(), batch['sample'].contiguous()
+        b = h_t.shape[0]
+        tb, st = ops.unstack_time(batch['throttle_brake'].contiguous()), ops.unstack_time(batch['steering'].contiguous())
+        out = {'action': [], 'state': [], 'hidden': [], 'sample': []}
+        for t in range(fh):
+            if predict_action:
+                action_t = self.policy(ops.cat_last([h_t, sample_t]))
+            else:
+                action_t = ops.cat_last([tb[t], st[t]])
+            prior_t = self.rssm.imagine_step(h_t, sample_t, action_t, use_sample=True, policy=self.policy,
+                                             eps=None if noise is None else noise[:, t])
+            sample_t, h_t = prior_t['sample'], prior_t['hidden_state']
+            out['action'].append(action_t)
+            out['state'].append(ops.cat_last([h_t, sample_t]))
+            out['hidden'].append(h_t)
+            out['sample'].append(sample_t)
+        out = {k: ops.stack_time(v) for k, v in out.items()}
+        state = pack_sequence_dim(out['state'])
+        pol = self.policy(state)
+        out['throttle_brake'] = unpack_sequence_dim(ops.slice_last(pol, 0, 1), b, fh)
+        out['steering'] = unpack_sequence_dim(ops.slice_last(pol, 1, 2), b, fh)
+        if self.cfg.EVAL.RGB_SUPERVISION:
+            out.update(unpack_sequence_dim(self.rgb_decoder(state), b, fh))
+        if self.cfg.LIDAR_RE.ENABLED:
+            out.update(unpack_sequence_dim(self.lidar_re(state), b, fh))
+        if self.cfg.VOXEL_SEG.ENABLED:
+            out.update(unpack_sequence_dim(self.voxel_decoder(state), b, fh))
+        return out
+
     def encode(self, batch):
         b, s = batch['image'].shape[:2]
         image = pack_sequence_dim(batch['image'])

@@ -73,3 +73,14 @@ class RSSM(nn.Module):
             sample_t = p_sample if use_prior[t] else q_sample
         return {'prior': {k: ops.stack_time(v) for k, v in prior.items()},
                 'posterior': {k: ops.stack_time(v) for k, v in post.items()}}
+
+    def imagine_step(self, h_t, sample_t, action_t, use_sample=True, policy=None, eps=None):
+        """transition.py:151-173: one prior roll-out step (eps: the explicit N(0,1) draw, generated when None)."""
+        if self.active_inference:
+            action_t = policy(ops.cat_last([h_t, sample_t]))
+        h_t = self.recurrent_model(self.pre_gru_net[0](sample_t), h_t)
+        la = self.prior_action_module[0](action_t)
+        if use_sample and eps is None:
+            eps = torch.randn(h_t.shape[0], self.state_dim, device=h_t.device)
+        mu, sigma, sample = self.prior(ops.cat_last([h_t, la]), eps if use_sample else None)
+        return {'hidden_state': h_t, 'sample': sample, 'mu': mu, 'sigma': sigma}

@@ -121,15 +121,17 @@ class TransformerEncoderLayer(nn.Module):
 
     def forward(self, x, seed):
         p = self.p if self.training else 0.0
+        # validation (trainer.py:404-409) switches only the nn.Dropout MODULES off; MHA's functional dropout stays on
+        pm = 0.0 if getattr(self, 'module_dropout_off', False) else p
         sa = self.self_attn
         qkv = ops.linear(x, sa.in_proj_weight, sa.in_proj_bias)
         o = ops.attention(qkv, self.nhead, p, seed)
         a = sa.out_proj(o)
-        x = ops.add_dropout_layernorm(x, a, self.norm1, p, seed + 1)
+        x = ops.add_dropout_layernorm(x, a, self.norm1, pm, seed + 1)
         f = self.linear1(x, act=ops.ACT_RELU)
-        f = ops.dropout(f, p, seed + 2)
+        f = ops.dropout(f, pm, seed + 2)
         f = self.linear2(f)
-        return ops.add_dropout_layernorm(x, f, self.norm2, p, seed + 3)
+        return ops.add_dropout_layernorm(x, f, self.norm2, pm, seed + 3)
 
 
 class TransformerEncoder(nn.Module):

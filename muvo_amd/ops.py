@@ -380,7 +380,7 @@ class ConvFn(torch.autograd.Function):
                                 math.prod(geom.stride) if geom.transposed else 1, _conv_tag(geom, n, in_sz))
             e0.record()
         wsb = geom.ws_bytes[(n, in_sz, _plan_epoch[0])]
-        keep_ws = wsb[0] > 0 and wsb[2] > 0 and weight.requires_grad  # wgrad reuses the split copy of x
+        keep_ws = wsb[0] > 0 and wsb[2] > 0 and weight.requires_grad and torch.is_grad_enabled()  # wgrad reuses the copy of x
         if keep_ws:
             ws = torch.empty((wsb[0] + 3) // 4, device=x.device, dtype=torch.float32)
         else:

@@ -70,11 +70,52 @@ class WorldModelTrainer(_Base):
         return output, state_dict
 
     def shared_step(self, batch, mode='train', predict_action=False, noise=None, use_prior=None):
-        if mode != 'train':
-            raise NotImplementedError("only mode='train' is on the hot path (validation/imagination: next rows)")
-        output, state_dict = self.forward(batch, noise=noise, use_prior=use_prior)
-        losses = self.compute_loss(batch, output)
-        return losses, output, [], []
+        """trainer.py:223-249.  mode='train': reconstruction of the whole sequence.  Otherwise: reconstruct the first
+        RECEPTIVE_FIELD frames, then imagine FUTURE_HORIZON steps from the last posterior state and score them against the
+        remaining frames.  noise (b, rf + N_SAMPLES*fh, 2, S) / use_prior (rf,) make the RNG explicit: [:, t < rf] feed the
+        observe steps, [:, rf + k*fh + t, 0] step t of imagined sample k."""
+        if mode == 'train':
+            output, state_dict = self.forward(batch, noise=noise, use_prior=use_prior)
+            losses = self.compute_loss(batch, output)
+            return losses, output, [], []
+        rf, fh = self.rf, self.fh
+        batch = self.preprocess(batch)
+        batch_rf = {k: v[:, :rf].contiguous() for k, v in batch.items()}
+        batch_fh = {k: v[:, rf:].contiguous() for k, v in batch.items()}
+        output, state_dict = self.model.forward(batch_rf, deployment=False, noise=None if noise is None else noise[:, :rf],
+                                                use_prior=None if use_prior is None else list(use_prior[:rf]))
+        losses = self.compute_loss(batch_rf, output)
+        post = state_dict['posterior']
+        state_imagine = {'hidden_state': post['hidden_state'][:, -1], 'sample': post['sample'][:, -1],
+                         'throttle_brake': batch_fh['throttle_brake'], 'steering': batch_fh['steering']}
+        output_imagines, losses_imagines = [], []
+        for k in range(self.cfg.PREDICTION.N_SAMPLES):
+            # explicit noise layout: (b, rf + N_SAMPLES * fh, 2, S); sample k of the roll-out uses rows rf + k*fh ...
+            nz = None if noise is None else noise[:, rf + k * fh:rf + (k + 1) * fh, 0].contiguous()
+            out_i = self.model.imagine(state_imagine, predict_action=predict_action, future_horizon=fh, noise=nz)
+            output_imagines.append(out_i)
+            losses_imagines.append(self.compute_loss(batch_fh, out_i))
+        return losses, output, losses_imagines, output_imagines
+
+    def validation_step(self, batch, batch_idx=0, dataloader_idx=0, noise=None, use_prior=None):
+        """trainer.py:404-424 without the metric/visualisation side effects (SSC IoU, PSNR, ... are evaluation tooling, not
+        part of this path): train-mode BatchNorm, transformer nn.Dropout modules off (the functional attention dropout of
+        nn.MultiheadAttention stays on), no_grad."""
+        self.train()
+        layers = list(self.model.transformer_encoder.layers)
+        saved = [getattr(layer, 'module_dropout_off', False) for layer in layers]
+        for layer in layers:
+            layer.module_dropout_off = True
+        try:
+            with torch.no_grad():
+                loss, output, loss_imagines, output_imagines = self.shared_step(batch, mode='val', predict_action=False,
+                                                                                noise=noise, use_prior=use_prior)
+        finally:
+            for layer, v in zip(layers, saved):
+                layer.module_dropout_off = v
+        out = {f'val{dataloader_idx}_loss': self.loss_reducing(loss),
+               f'val{dataloader_idx}_loss_imagine': sum(self.loss_reducing(li) for li in loss_imagines) / len(loss_imagines)}
+        return out, loss, output, loss_imagines, output_imagines
 
     def compute_loss(self, batch, output):
         """The reference's 21 weighted loss terms (trainer.py:251-390), computed by fused kernels."""

@@ -231,6 +231,12 @@ class RSSM(nn.Module):
             z = pz if use_prior[t] else qz
         return ({k: torch.stack(v, 1) for k, v in pri.items()}, {k: torch.stack(v, 1) for k, v in pos.items()})
 
+    def imagine_step(self, h, z, a, eps):
+        """transition.py:151-173 (prior roll-out step; eps = the explicit N(0,1) draw of sample_from_distribution)."""
+        h = self.recurrent_model(self.pre_gru_net(z), h)
+        pm, ps = self.prior(torch.cat([h, self.prior_action_module(a)], -1))
+        return h, pm + ps * eps, pm, ps
+
 
 class Policy(nn.Module):
     """common.py:53-68."""
@@ -429,6 +435,27 @@ class MileRef(nn.Module):
         return out
 
 
+def imagine(model, state, future_horizon, noise):
+    """Mile.imagine (mile.py:771-850, predict_action=False): roll the prior forward with the recorded actions and decode
+    every imagined state.  state: hidden_state (b,H), sample (b,S), throttle_brake / steering (b,fh,1); noise (b,fh,S)."""
+    h, z = state['hidden_state'], state['sample']
+    b = h.shape[0]
+    states = []
+    for t in range(future_horizon):
+        a = torch.cat([state['throttle_brake'][:, t], state['steering'][:, t]], -1)
+        h, z, _, _ = model.rssm.imagine_step(h, z, a, noise[:, t])
+        states.append(torch.cat([h, z], -1))
+    st = torch.stack(states, 1)
+    flat = st.flatten(0, 1)
+    pol = model.policy(flat)
+    out = {'state': st, 'throttle_brake': pol[:, :1].view(b, future_horizon, 1),
+           'steering': pol[:, 1:].view(b, future_horizon, 1)}
+    for dec in (model.rgb_decoder, model.lidar_re, model.voxel_decoder):
+        for k, v in dec(flat).items():
+            out[k] = v.view(b, future_horizon, *v.shape[1:])
+    return out
+
+
 # --------------------------------------------------------------------------- losses
 def _spatial_regression(pred, target, norm):
     """losses.py:74-99 (mask = target channel 0 != 255; channel-sum; masked mean)."""
@@ -498,11 +525,12 @@ def compute_losses(batch, out, cfg) -> Dict[str, torch.Tensor]:
     L = {}
     L['throttle_brake'] = cfg['W_ACTION'] * (out['throttle_brake'] - batch['throttle_brake']).abs().sum(-1, keepdim=True).mean()
     L['steering'] = cfg['W_ACTION'] * (out['steering'] - batch['steering']).abs().sum(-1, keepdim=True).mean()
-    pr, po = out['prior'], out['posterior']
-    a = cfg['KL_ALPHA']
-    kl = a * _kl(pr['mu'], pr['sigma'], po['mu'].detach(), po['sigma'].detach()) + \
-        (1 - a) * _kl(pr['mu'].detach(), pr['sigma'].detach(), po['mu'], po['sigma'])
-    L['probabilistic'] = cfg['W_PROB'] * kl
+    if 'prior' in out and 'posterior' in out:   # absent for imagined outputs (trainer.py:261-265)
+        pr, po = out['prior'], out['posterior']
+        a = cfg['KL_ALPHA']
+        kl = a * _kl(pr['mu'], pr['sigma'], po['mu'].detach(), po['sigma'].detach()) + \
+            (1 - a) * _kl(pr['mu'].detach(), pr['sigma'].detach(), po['mu'], po['sigma'])
+        L['probabilistic'] = cfg['W_PROB'] * kl
     for f in (1, 2, 4):
         d = 1 / f
         L[f'rgb_{f}'] = cfg['W_RGB'] * d * _spatial_regression(out[f'rgb_{f}'], batch[f'rgb_label_{f}'], 1)
@@ -542,3 +570,24 @@ def training_step(model: MileRef, raw_batch, noise, use_prior):
     losses = compute_losses(batch, out, model.cfg)
     total = sum(losses.values())
     return total, losses, out, batch
+
+
+def validation_step(model: MileRef, raw_batch, rf, fh, noise, use_prior, n_samples=2):
+    """shared_step(mode='val') (trainer.py:232-249) under no_grad, train-mode BatchNorm (trainer.py:404-409): reconstruct the
+    first rf frames, then imagine fh steps (n_samples = PREDICTION.N_SAMPLES times) from the last posterior state with the
+    recorded actions.  noise: (b, rf + n_samples*fh, 2, S) — [:, t<rf] feed the observe steps, [:, rf + k*fh + t, 0] step t
+    of imagined sample k.  Returns (losses_rf, out_rf, [losses_fh per sample], [out_fh per sample])."""
+    with torch.no_grad():
+        batch = preprocess(raw_batch, model.cfg)
+        brf = {k: v[:, :rf] for k, v in batch.items()}
+        bfh = {k: v[:, rf:] for k, v in batch.items()}
+        out = model(brf, noise[:, :rf], use_prior[:rf])
+        losses = compute_losses(brf, out, model.cfg)
+        state = {'hidden_state': out['posterior']['hidden_state'][:, -1], 'sample': out['posterior']['sample'][:, -1],
+                 'throttle_brake': batch['throttle_brake'][:, rf:], 'steering': batch['steering'][:, rf:]}
+        outs_i, losses_i = [], []
+        for k in range(n_samples):
+            o = imagine(model, state, fh, noise[:, rf + k * fh:rf + (k + 1) * fh, 0])
+            outs_i.append(o)
+            losses_i.append(compute_losses(bfh, o, model.cfg))
+    return losses, out, losses_i, outs_i

@@ -1,0 +1,19 @@
+import os, sys, time, torch
+sys.path.insert(0, '/root/repo')
+from muvo_amd import ops
+from muvo_amd.config import base_1d_cfg
+from muvo_amd.data.synthetic import make_batch
+from muvo_amd.trainer import WorldModelTrainer
+dev = torch.device('cuda:0')
+cfg = base_1d_cfg(RECEPTIVE_FIELD=6, FUTURE_HORIZON=4, BATCHSIZE=2, STEPS=100000)
+torch.manual_seed(1234)
+tr = WorldModelTrainer(cfg.convert_to_dict(), device=dev); tr.train()
+opts, scheds = tr.configure_optimizers(); opt, sched = opts[0], scheds[0]['scheduler']
+batches = [make_batch(2, 10, seed=1234 + k, device=dev) for k in range(2)]
+def step(i):
+    opt.zero_grad(); loss = tr.training_step(dict(batches[i % 2]), i); loss.backward(); opt.step(); sched.step(); return loss
+for i in range(2): step(i)
+torch.cuda.synchronize()
+for i in range(4):
+    t0 = time.perf_counter(); step(2 + i); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+    print(f'host issue {1e3*(t1-t0):.1f} ms, gpu tail {1e3*(t2-t1):.1f} ms, total {1e3*(t2-t0):.1f} ms')
