@@ -15,6 +15,7 @@
 // channels of one pixel is one conflict-free ds_write_b128 per plane.  Weights are split and laid out in exactly that
 // order by bf3_pack_phase, so the A tile is staged with plain 16-byte copies.
 #include "conv_bf3.h"
+#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -40,6 +41,12 @@ __device__ __forceinline__ int xcd_swizzle(int orig, int nwg) {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 // one wave-wide LDS-DMA: lane l copies 16 bytes from its own global address to (wave-uniform lds) + 16*l
+// K order of a phase.  Default k = t * Cp + c.  When Cp is a multiple of 32 the taps run INSIDE each 32-channel group
+// (k = ((c / 32) * T + t) * 32 + c % 32): consecutive K steps then revisit the same few input rows with shifted taps, so the
+// activation re-reads of a tile hit in L2 — with taps outermost every tap re-fetched the tile's inputs through the fabric
+// (FETCH_SIZE showed ~12x the algorithmic bytes).
+__host__ __device__ static inline bool bf3_tap_inner(const ConvPhase& g) { return (g.Cp & 31) == 0 && g.T > 1; }
+
 __device__ __forceinline__ void dma16(const uint4* g, uint4* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
 }
@@ -57,9 +64,8 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
                 const float* __restrict__ bias, float* __restrict__ out, int act, float slope,
                 const uint4* __restrict__ zero16) {
   constexpr int BK = 8 * BKC, NW = WM * WN;       // BKC = 8-channel chunks per K step (4: BK = 32, 2: BK = 16)
-  constexpr bool SETPRIO = NST == 6;              // tuning experiment: raise priority around the MFMA cluster
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-  constexpr int STAGE = 2 * BKC * (BM + BN);      // uint4 per stage: [plane][chunk][BM] then [plane][chunk][BN]
+  constexpr int STAGE = 2 * BKC * (BM + BN);      // uint4 per stage: A [plane][chunk][BM] then B [plane][BN pixels][4 chunks]
   constexpr int RG = BM / 64, NG = BN / 64;       // 64-row groups of A, 64-pixel groups of B
   constexpr int APW = 2 * BKC * RG / NW;          // A copies (wave instructions) per wave per step
   constexpr int CPW = 2 * BKC * NG / NW;          // B (plane,chunk) combos per wave per step
@@ -75,51 +81,110 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
   const int wg = xcd_swizzle(blockIdx.x, gridDim.x);
   const int bx = wg % gx, by = wg / gx;
 
-  // ---- B (activation) DMA role of this wave: pixel group (wave % NG), combos [(wave / NG) * CPW, +CPW)
-  // All sources are xs (uniform) + a 32-bit uint4 offset per lane; out-of-bounds taps read the zero page at zero_off.
-  const int bgroup = wave % NG, bcombo0 = (wave / NG) * CPW;
-  const int p = bx * BN + bgroup * 64 + lane;
-  const bool pvalid = p < g.npix;
-  int n, iz, iy, ix;
-  decode_pix(g, pvalid ? p : 0, n, iz, iy, ix);
-  const int z0 = iz * g.is[0] + g.ib[0], y0 = iy * g.is[1] + g.ib[1], x0 = ix * g.is[2] + g.ib[2];
+  // ---- B (activation) loads: one wave instruction = 16 pixels x the 4 chunks (64 contiguous bytes per pixel) of one
+  // plane, lane = 4 * pixel + chunk, so a quad of lanes reads one 64-byte segment.  (With lane = pixel each lane touched
+  // its own 128-byte line for 16 useful bytes; the step time tracked the number of such gathers, not the MFMA count.)
+  // Wave w owns pixel groups [w * NPS, +NPS) of 16 pixels, both planes.  Sources are xs + a 32-bit uint4 offset per lane;
+  // out-of-bounds taps read the zero page at zero_off.
+  constexpr int NPS = CPW / 2;
+  static_assert(CPW % 2 == 0 && NPS * NW * 16 == BN, "B load roles must tile");
   const int cp8 = g.Cp >> 3;
-  const int pixoff = (((n * g.ID + z0) * g.IH + y0) * g.IW + x0) * cp8;   // may be "negative" at borders: only used when valid
-  unsigned long long vmask = 0ull;                                          // bit t: tap t of this pixel is inside the input
-  for (int tt = 0; tt < g.T; ++tt) {
-    const int d = g.tap_d[tt];
-    const int z = z0 + ((d >> 16) & 255) - 128, y = y0 + ((d >> 8) & 255) - 128, x = x0 + (d & 255) - 128;
-    const bool ok = pvalid && (unsigned)z < (unsigned)g.ID && (unsigned)y < (unsigned)g.IH && (unsigned)x < (unsigned)g.IW;
-    vmask |= (unsigned long long)ok << tt;
+  int pixoff[NPS];                       // may be "negative" at borders: only used when valid
+  unsigned long long vmask[NPS];         // bit t: tap t of this pixel is inside the input
+#pragma unroll
+  for (int sidx = 0; sidx < NPS; ++sidx) {
+    const int p = bx * BN + (wave * NPS + sidx) * 16 + (lane >> 2);
+    const bool pvalid = p < g.npix;
+    int n, iz, iy, ix;
+    decode_pix(g, pvalid ? p : 0, n, iz, iy, ix);
+    const int z0 = iz * g.is[0] + g.ib[0], y0 = iy * g.is[1] + g.ib[1], x0 = ix * g.is[2] + g.ib[2];
+    pixoff[sidx] = (((n * g.ID + z0) * g.IH + y0) * g.IW + x0) * cp8;
+    unsigned long long vm = 0ull;
+    for (int tt = 0; tt < g.T; ++tt) {
+      const int d = g.tap_d[tt];
+      const int z = z0 + ((d >> 16) & 255) - 128, y = y0 + ((d >> 8) & 255) - 128, x = x0 + (d & 255) - 128;
+      const bool ok = pvalid && (unsigned)z < (unsigned)g.ID && (unsigned)y < (unsigned)g.IH && (unsigned)x < (unsigned)g.IW;
+      vm |= (unsigned long long)ok << tt;
+    }
+    vmask[sidx] = vm;
   }
   const int zero_off = (int)(2 * plane_u4);
   const int m_tile = by * BM;
   const uint4* wpb = wp + g.wp_off / 4 + m_tile;   // wp_off is in floats; one uint4 = 8 bf16 = 4 floats
   const int nk = g.Kp / BK;
 
-  auto issue = [&](int kt, int stage) {
-    uint4* S = smem + stage * STAGE;
-    const int k32 = (kt * BK) >> 5, c4 = ((kt * BK) >> 3) & 3;   // position of this step inside the 32-deep packed tiles
-#pragma unroll
-    for (int q = 0; q < APW; ++q) {
+  // Staging: plain 16-byte global loads into registers, written to LDS one step later (ds_write_b128).  Measured on this
+  // chip (tools/microbench/mfma_lds.hip) the register round trip sustains the MFMA rate far better than LDS-DMA
+  // (global_load_lds_dwordx4): 1.6-1.76 PFLOP/s against 0.96-1.5 with the same bytes per MFMA.
+  // The per-tap input offset comes from a small LDS table so that the loop holds no scalar memory loads (their
+  // out-of-order return would force full lgkmcnt(0) waits in front of the fragment reads).
+  int* taptab = (int*)(smem + NST * STAGE);
+  for (int tt = tid; tt < g.T; tt += 64 * NW) {
+    const int d = g.tap_d[tt];
+    taptab[tt] = (((((d >> 16) & 255) - 128) * g.IH + ((d >> 8) & 255) - 128) * g.IW + (d & 255) - 128) * cp8;
+  }
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in registers (uint4 is a struct)
+  // Buffer loads (descriptor in SGPRs + 32-bit byte offset): no 64-bit address temporaries — with flat loads the
+  // compiler recycled the destination registers of in-flight loads for address math and put s_waitcnt vmcnt(0) in front
+  // of every piece — and the range check turns out-of-image taps, channel padding and steps past the end of K into
+  // zeros without touching memory.
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)wpb, 0, (int)(((long)(g.Kp >> 5) * 8 * g.Mp - m_tile) * 16), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)xs, 0, (int)(2 * plane_u4 * 16), 0x00020000);
+  constexpr int OOB = 0x7ffffff0;
+  // Two register sets: set (k & 1) carries step k from its global loads (issued during step k-3) to its LDS writes
+  // (during step k-2).  Loads and writes are cut into single-instruction pieces that the loop slots between MFMAs: a
+  // wave that issues its six loads back to back fills the address queue and then cannot issue MFMAs either
+  // (s_memtime stamps: 700 clocks per step for six loads, the matrix pipe idle meanwhile).
+  u32x4 R[2][DMA_PER_STEP];
+  // B source offset of this lane for the step the next B pieces load (kept one step ahead so that the LDS table read
+  // is never waited for where it is issued)
+  int b_uoff = 0; unsigned long long b_bit = 0ull; bool b_tval = false;
+  const bool tap_inner = bf3_tap_inner(g);
+  int ti_t = 0, ti_c8 = lane & 3;         // tap-inner order: tap and chunk of the NEXT bstate call (calls are sequential in kt)
+  auto bstate = [&](int kt) {
+    if (tap_inner) {
+      b_uoff = taptab[ti_t] + ti_c8;
+      b_bit = 1ull << ti_t;
+      b_tval = ti_c8 < cp8;                // past the last channel group: zeros (K padding never happens in this order)
+      if (++ti_t == g.T) { ti_t = 0; ti_c8 += 4; }
+      return;
+    }
+    // this lane's chunk of the step: k0 = kt * 32 + 8 * (lane & 3); tap and channel position per lane (Cp need not
+    // be a multiple of 32, so the four chunks of a step may belong to different taps)
+    const int k0 = kt * BK + (lane & 3) * 8;
+    const int t = (int)(((unsigned long long)(unsigned)k0 * g.cp_magic) >> 32);
+    const int c8 = (k0 - t * g.Cp) >> 3;
+    const int tc = t < g.T ? t : 0;
+    b_uoff = taptab[tc] + c8;
+    b_bit = 1ull << tc;
+    b_tval = t < g.T;
+  };
+  auto gload_piece = [&](auto par, int kt, int q) {
+    constexpr int P = decltype(par)::value;
+    if (q < APW) {
+      const int k32 = (kt * BK) >> 5, c4 = ((kt * BK) >> 3) & 3;   // position of this step inside the 32-deep packed tiles
       const int a = wave * APW + q;
       const int pc = a / RG, rg = a % RG;           // pc = plane * BKC + chunk
       const int plane = pc / BKC, ch = pc % BKC;
-      dma16(wpb + (size_t)(k32 * 8 + plane * 4 + c4 + ch) * g.Mp + rg * 64 + lane, S + pc * BM + rg * 64);
+      R[P][q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, lane * 16, ((k32 * 8 + plane * 4 + c4 + ch) * g.Mp + rg * 64) * 16, 0));
+    } else {
+      const int plane = (q - APW) & 1, sidx = (q - APW) >> 1;
+      const bool ok = b_tval && (vmask[sidx] & b_bit);
+      const int off = ok ? (pixoff[sidx] + b_uoff + plane * (int)plane_u4) * 16 : OOB;
+      R[P][q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
     }
-#pragma unroll
-    for (int q = 0; q < CPW; ++q) {
-      const int combo = bcombo0 + q;               // plane * BKC + chunk
-      const int plane = combo / BKC, ch = combo % BKC;
-      const int k0 = kt * BK + ch * 8;             // wave-uniform
-      const int t = (int)(((unsigned long long)(unsigned)k0 * g.cp_magic) >> 32);
-      const int c8 = (k0 - t * g.Cp) >> 3;
-      const int d = g.tap_d[t < g.T ? t : 0];
-      const int tapoff = (((((d >> 16) & 255) - 128) * g.IH + ((d >> 8) & 255) - 128) * g.IW + (d & 255) - 128) * cp8;
-      const int uoff = tapoff + c8 + plane * (int)plane_u4;            // scalar part
-      const bool ok = t < g.T && ((vmask >> t) & 1ull);
-      const int off = ok ? pixoff + uoff : zero_off;
-      dma16(xs + (unsigned)off, S + 2 * BKC * BM + combo * BN + bgroup * 64);
+  };
+  auto lstore_piece = [&](auto par, int stage, int q) {
+    constexpr int P = decltype(par)::value;
+    uint4* S = smem + stage * STAGE;
+    if (q < APW) {
+      const int a = wave * APW + q;
+      const int pc = a / RG, rg = a % RG;
+      *(u32x4*)(S + pc * BM + rg * 64 + lane) = R[P][q];
+    } else {                               // B tile: [plane][pixel][4 chunks], chunk position XOR-swizzled by pixel bits 2-3
+      const int pl = (wave * NPS + ((q - APW) >> 1)) * 16 + (lane >> 2);
+      *(u32x4*)(S + 2 * BKC * BM + ((q - APW) & 1) * BKC * BN + pl * 4 + ((lane & 3) ^ ((lane >> 4) & 3))) = R[P][q];
     }
   };
 
@@ -131,58 +196,170 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // NST-stage ring: steps kt+1 .. kt+NST-2 stay in flight across the barrier of step kt.  s_waitcnt immediates (gfx9
-  // encoding): vmcnt in bits [3:0] and [15:14], expcnt [6:4] = 7, lgkmcnt [11:8] = 15.
-#define BF3_WAITCNT(n) ((((n) * DMA_PER_STEP) & 15) | ((((n) * DMA_PER_STEP) >> 4) << 14) | (7 << 4) | (15 << 8))
-  static_assert((NST - 2) * DMA_PER_STEP < 64, "vmcnt is 6 bits");
-#pragma unroll
-  for (int pre = 0; pre < NST - 1; ++pre)
-    if (pre < nk) issue(pre, pre);
-  int stage = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    // this wave's copies of step kt have landed (later steps may still be in flight) ...
-    const int ahead = nk - 1 - kt < NST - 2 ? nk - 1 - kt : NST - 2;   // steps issued after kt
-    if (NST >= 6 && ahead == 4) __builtin_amdgcn_s_waitcnt(BF3_WAITCNT(4));
-    else if (NST >= 5 && ahead == 3) __builtin_amdgcn_s_waitcnt(BF3_WAITCNT(3));
-    else if (NST >= 4 && ahead == 2) __builtin_amdgcn_s_waitcnt(BF3_WAITCNT(2));
-    else if (ahead == 1) __builtin_amdgcn_s_waitcnt(BF3_WAITCNT(1));
-    else __builtin_amdgcn_s_waitcnt(BF3_WAITCNT(0));
-    // ... and after the barrier everybody's have, and everybody finished reading the stage step kt+NST-1 goes into
-    __builtin_amdgcn_s_barrier();
-    if (kt + NST - 1 < nk) issue(kt + NST - 1, stage == 0 ? NST - 1 : stage - 1);
+  // K loop, software-pipelined through registers.  One step = BK = 32 = two MFMA k-slices (ks 0/1) with fragment sets
+  // F0/F1, two LDS stages, one barrier per step placed BETWEEN the slices:
+  //     F1 <- LDS(kt, ks1);  MFMA(F0);  [own LDS reads of stage kt and own LDS writes of step kt+1 complete]  barrier;
+  //     F0 <- LDS(kt+1, ks0);  LDS(stage of kt) <- R (step kt+2, loaded a step ago);  R <- global(step kt+3);  MFMA(F1)
+  // Every LDS read is requested one MFMA group (12 instructions, >= 384 clocks) before its use, the global loads have a
+  // whole step to land, and the stage of step kt is free for step kt+2 as soon as everybody holds its second slice in
+  // registers — which is what the mid-step barrier certifies.  s_waitcnt 0xC07F = lgkmcnt(0) only (gfx9 encoding).
+  static_assert(BKC == 4 && (NST == 2 || NST == 3), "two k-slices per step; two LDS stages, or three for the ping-pong schedule");
+  const int fragA = wm * (TM * 32) + (lane & 31);
+  const int fragB = 2 * BKC * BM + (wn * (TN * 32) + (lane & 31)) * 4 + ((lane >> 5) ^ ((lane >> 2) & 3));   // ks 0; ks 1: ^ 2
+  auto load_frags = [&](int stage, int ks, bf16x8 (&ah)[TM], bf16x8 (&al)[TM], bf16x8 (&bh)[TN], bf16x8 (&bl)[TN]) {
     const uint4* S = smem + stage * STAGE;
-    const uint4* Ah = S + wm * (TM * 32) + (lane & 31);
-    const uint4* Al = Ah + BKC * BM;
-    const uint4* Bh = S + 2 * BKC * BM + wn * (TN * 32) + (lane & 31);
-    const uint4* Bl = Bh + BKC * BN;
+    const int chunk = ks * 2 + (lane >> 5);
 #pragma unroll
-    for (int ks = 0; ks < BKC / 2; ++ks) {
-      const int chunk = ks * 2 + (lane >> 5);
-      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        ah[i] = __builtin_bit_cast(bf16x8, Ah[chunk * BM + i * 32]);
-        al[i] = __builtin_bit_cast(bf16x8, Al[chunk * BM + i * 32]);
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        bh[j] = __builtin_bit_cast(bf16x8, Bh[chunk * BN + j * 32]);
-        bl[j] = __builtin_bit_cast(bf16x8, Bl[chunk * BN + j * 32]);
-      }
-      if (SETPRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-        }
-      if (SETPRIO) __builtin_amdgcn_s_setprio(0);
+    for (int i = 0; i < TM; ++i) {
+      ah[i] = __builtin_bit_cast(bf16x8, S[fragA + chunk * BM + i * 32]);
+      al[i] = __builtin_bit_cast(bf16x8, S[fragA + BKC * BM + chunk * BM + i * 32]);
     }
-    stage = stage == NST - 1 ? 0 : stage + 1;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      bh[j] = __builtin_bit_cast(bf16x8, S[(fragB ^ (ks * 2)) + j * 128]);
+      bl[j] = __builtin_bit_cast(bf16x8, S[(fragB ^ (ks * 2)) + BKC * BN + j * 128]);
+    }
+  };
+  auto read_piece = [&](int stage, int ks, int w, bf16x8 (&ah)[TM], bf16x8 (&al)[TM], bf16x8 (&bh)[TN], bf16x8 (&bl)[TN]) {
+    const uint4* S = smem + stage * STAGE;      // w: 0 .. 2 TM - 1 = A (i, plane), then B (j, plane)
+    const int chunk = ks * 2 + (lane >> 5);
+    if (w < 2 * TM) {
+      const int i = w >> 1;
+      if (w & 1) al[i] = __builtin_bit_cast(bf16x8, S[fragA + BKC * BM + chunk * BM + i * 32]);
+      else ah[i] = __builtin_bit_cast(bf16x8, S[fragA + chunk * BM + i * 32]);
+    } else {
+      const int j = (w - 2 * TM) >> 1;
+      if (w & 1) bl[j] = __builtin_bit_cast(bf16x8, S[(fragB ^ (ks * 2)) + BKC * BN + j * 128]);
+      else bh[j] = __builtin_bit_cast(bf16x8, S[(fragB ^ (ks * 2)) + j * 128]);
+    }
+  };
+  auto mma_row = [&](int i, const bf16x8 (&ah)[TM], const bf16x8 (&al)[TM], const bf16x8 (&bh)[TN], const bf16x8 (&bl)[TN]) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+    }
+  };
+  bf16x8 a0h[TM], a0l[TM], b0h[TN], b0l[TN], a1h[TM], a1l[TM], b1h[TN], b1l[TN];
+  using par0 = std::integral_constant<int, 0>;
+  using par1 = std::integral_constant<int, 1>;
+  __syncthreads();                       // tap table
+  bstate(0);
+#pragma unroll
+  for (int q = 0; q < DMA_PER_STEP; ++q) gload_piece(par0{}, 0, q);
+#pragma unroll
+  for (int q = 0; q < DMA_PER_STEP; ++q) lstore_piece(par0{}, 0, q);
+  bstate(1);
+#pragma unroll
+  for (int q = 0; q < DMA_PER_STEP; ++q) gload_piece(par1{}, 1, q);
+#pragma unroll
+  for (int q = 0; q < DMA_PER_STEP; ++q) lstore_piece(par1{}, 1, q);
+  bstate(2);
+#pragma unroll
+  for (int q = 0; q < DMA_PER_STEP; ++q) gload_piece(par0{}, 2, q);
+  bstate(3);
+  __syncthreads();
+  if constexpr (NST == 3) {
+    // Ping-pong schedule: the waves of a workgroup form two groups (one wave per SIMD each) that run half a step out
+    // of phase.  While one group issues nothing but its 24 MFMAs of a step, the other does all memory work of its next
+    // step (16 fragment reads, 6 stage writes, 6 buffer loads); every phase ends at a workgroup barrier.  With all
+    // waves in the same phase the LDS saw the reads of all eight waves at once right after each barrier (512 clocks in
+    // which no MFMA issued), and the two waves of a SIMD competed for the matrix pipe afterwards.
+    //   barrier index b:  group 0 MEM(k) in [2k, 2k+1], MMA(k) in [2k+1, 2k+2];  group 1 one phase later.
+    //   MEM(k): F <- stage k%3;  stage (k+2)%3 <- R (step k+2, loaded one step ago);  R <- global(step k+3)
+    // Stage k%3 was written during MEM(k-2) of both groups (complete by barrier 2k-2) and stage (k+2)%3 = (k-1)%3 was
+    // last read in MEM(k-1) (complete by barrier 2k), so three stages suffice.
+    const int grp = wave / (NW / 2);
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      // stage writes first (R is free again once they are issued), then the buffer loads of step kt+3 spread between
+      // the fragment reads so that the address path and the LDS work at the same time
+      const int wstage = stage == 0 ? 2 : stage - 1;          // (stage + 2) % 3
+#pragma unroll
+      for (int q = 0; q < DMA_PER_STEP; ++q) lstore_piece(par0{}, wstage, q);
+      __builtin_amdgcn_sched_barrier(0);
+      constexpr int NRD = 4 * (TM + TN);                       // fragment reads of a step
+      constexpr int RPL = (NRD + DMA_PER_STEP - 1) / DMA_PER_STEP;
+#pragma unroll
+      for (int q = 0; q < DMA_PER_STEP; ++q) {
+        gload_piece(par0{}, kt + 3, q);
+#pragma unroll
+        for (int u = 0; u < RPL; ++u) {
+          const int r = q * RPL + u;
+          if (r < NRD) {
+            const int ks = r / (2 * (TM + TN)), w = r % (2 * (TM + TN));
+            if (ks == 0) read_piece(stage, 0, w, a0h, a0l, b0h, b0l);
+            else read_piece(stage, 1, w, a1h, a1l, b1h, b1l);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      bstate(kt + 4);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) mma_row(i, a0h, a0l, b0h, b0l);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) mma_row(i, a1h, a1l, b1h, b1l);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      stage = stage == 2 ? 0 : stage + 1;
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+  } else {
+    load_frags(0, 0, a0h, a0l, b0h, b0l);
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // enter the loop with no LDS operation pending (see loop end)
+    constexpr int PAIRS = TM * TN;                              // MFMA groups of 3 per k-slice
+    constexpr int PPP = (DMA_PER_STEP + PAIRS - 2) / (PAIRS - 1);   // pieces per pair, the last pair carries none
+    // step kt (parity P = kt & 1, LDS stage P): loads of step kt+3 -> R[P^1] before the barrier, writes of step kt+2
+    // (R[P]) into stage P after it
+    auto step = [&](auto par, int kt) {
+      constexpr int P = decltype(par)::value;
+      using parn = std::integral_constant<int, P ^ 1>;
+      load_frags(P, 1, a1h, a1l, b1h, b1l);
+      __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+      for (int i = 0; i < TM; ++i)
+  #pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l[i], b0h[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h[i], b0l[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h[i], b0h[j], acc[i][j], 0, 0, 0);
+  #pragma unroll
+          for (int u = 0; u < PPP; ++u)      // past the end of K these read zeros (range check), nobody consumes them
+            if ((i * TN + j) * PPP + u < DMA_PER_STEP) gload_piece(parn{}, kt + 3, (i * TN + j) * PPP + u);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_s_barrier();
+      load_frags(P ^ 1, 0, a0h, a0l, b0h, b0l);
+      bstate(kt + 4);                         // for the B pieces of the next step; its table read rides with the fragment reads
+      __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+      for (int i = 0; i < TM; ++i)
+  #pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l[i], b1h[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h[i], b1l[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h[i], b1h[j], acc[i][j], 0, 0, 0);
+  #pragma unroll
+          for (int u = 0; u < PPP; ++u)      // stage P is free (mid-step barrier); past the end of K nobody reads it again
+            if ((i * TN + j) * PPP + u < DMA_PER_STEP) lstore_piece(par, P, (i * TN + j) * PPP + u);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      // F0 and the stage writes were issued at least one MFMA group ago: this wait is (nearly) free, and it keeps the
+      // compiler from putting a full lgkmcnt(0) between the F1 requests and MFMA(F0) at the top of the next step
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+      step(par0{}, kt);
+      if (kt + 1 < nk) step(par1{}, kt + 1);    // (uniform) only the last pair of an odd K loop skips it
+    }
   }
-#undef BF3_WAITCNT
 
   // epilogue: bias + activation, coalesced along pixels (MFMA column = lane & 31); merged phases: row group -> residue
 #pragma unroll
@@ -502,7 +679,7 @@ __global__ void bias_replica_reduce_kernel(const float* __restrict__ rep, float*
 
 __device__ uint4 g_zero16 = {0u, 0u, 0u, 0u};
 
-// wp16[(((kt*2 + plane)*4 + chunk)*Mp + m)*8 + k%8] = split(W[m][c][tap_w[t]]),  k = t*Cp + c = kt*32 + chunk*8 + k%8
+// wp16[(((kt*2 + plane)*4 + chunk)*Mp + m)*8 + k%8] = split(W[m][c][tap_w[t]]),  k = kt*32 + chunk*8 + k%8
 __global__ void __launch_bounds__(256) bf3_pack_kernel(const ConvPhase g, const float* __restrict__ w,
                                                        unsigned short* __restrict__ wp16) {
   __shared__ int s_tw[MAX_TAPS];
@@ -512,7 +689,11 @@ __global__ void __launch_bounds__(256) bf3_pack_kernel(const ConvPhase g, const 
   const long total = (long)g.Kp * g.Mp;
   for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const int m = (int)(idx % g.Mp), k = (int)(idx / g.Mp);
-    const int t = k / g.Cp, c = k - t * g.Cp;
+    int t = k / g.Cp, c = k - t * g.Cp;
+    if (bf3_tap_inner(g)) {              // K order (32-channel group, tap, channel in group): see conv_bf3_kernel
+      t = (k >> 5) % g.T;
+      c = ((k >> 5) / g.T) * 32 + (k & 31);
+    }
     float v = 0.f;
     if (t < g.T && c < g.C && m < g.M) {
       const int grp = m / g.Msub, co = m - grp * g.Msub;
@@ -571,7 +752,7 @@ int bf3_split_input(const float* x, void* ws, int N, int C, long S, hipStream_t 
 template <int BM, int BN, int WM, int WN, int BKC, int NST>
 static int bf3_launch(const ConvPhase& g, const void* ws, const float* wp, const float* bias, float* out, int act,
                       float slope, hipStream_t st) {
-  constexpr size_t lds = (size_t)NST * 2 * BKC * (BM + BN) * 16;
+  constexpr size_t lds = (size_t)NST * 2 * BKC * (BM + BN) * 16 + 256;   // stages + tap table
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   static const uint4* zero16 = nullptr;
@@ -595,15 +776,16 @@ static int bf3_launch(const ConvPhase& g, const void* ws, const float* wp, const
 int bf3_launch_fwd_phase(const ConvPhase& g, const void* ws, const float* wp, const float* bias, float* out, int act,
                          float slope, hipStream_t st) {
   if (g.npix <= 0) return MUVO_OK;
-  // 256x256 tiles (K step 16, wave tile 64x128) halve the LDS-DMA bytes per flop: the big layers are bound by the
-  // L2->LDS copy rate, not by the matrix pipe
+  // eight-wave tiles run the ping-pong schedule (three LDS stages); MUVO_BF3_VARIANT=2 selects the in-phase two-stage
+  // schedule for comparison.  64-row tiles have four waves (one per SIMD) and keep the two-stage schedule.
   static const int variant = getenv("MUVO_BF3_VARIANT") ? atoi(getenv("MUVO_BF3_VARIANT")) : 0;   // tuning switch
-  if (g.M > 128 && g.npix >= 256 * 256 && variant == 1) return bf3_launch<256, 256, 4, 2, 2, 4>(g, ws, wp, bias, out, act, slope, st);
-  if (g.M > 128 && variant == 2) return bf3_launch<256, 128, 4, 2, 2, 6>(g, ws, wp, bias, out, act, slope, st);
-  if (g.M > 128 && g.npix >= 256 * 256 && variant == 3) return bf3_launch<256, 256, 4, 2, 2, 3>(g, ws, wp, bias, out, act, slope, st);
+  if (variant == 2) {
+    if (g.M > 128) return bf3_launch<256, 128, 4, 2, 4, 2>(g, ws, wp, bias, out, act, slope, st);
+    if (g.M > 64) return bf3_launch<128, 256, 2, 4, 4, 2>(g, ws, wp, bias, out, act, slope, st);
+  }
   if (g.M > 128) return bf3_launch<256, 128, 4, 2, 4, 3>(g, ws, wp, bias, out, act, slope, st);
   if (g.M > 64) return bf3_launch<128, 256, 2, 4, 4, 3>(g, ws, wp, bias, out, act, slope, st);
-  return bf3_launch<64, 256, 1, 4, 4, 3>(g, ws, wp, bias, out, act, slope, st);
+  return bf3_launch<64, 256, 1, 4, 4, 2>(g, ws, wp, bias, out, act, slope, st);
 }
 
 template <int BM, int BN, int WM, int WN, int WK>

@@ -82,7 +82,8 @@ def _ck(rc):
 
 
 def _st():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # raw handle of the current PyTorch stream of the current device (fast path: one C call)
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
 def _p(t):

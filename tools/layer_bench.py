@@ -37,6 +37,7 @@ def main():
     ap.add_argument('--iters', type=int, default=10)
     ap.add_argument('--what', default='fwd,dgrad,wgrad')
     ap.add_argument('--n', type=int, default=20)
+    ap.add_argument('--zeros', action='store_true', help='all-zero activations (power experiment: same instructions, no bit toggling)')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     ops.set_conv_mode(ops.CONV_BF16X3 if args.mode == 'bf16x3' else ops.CONV_F32)
@@ -52,6 +53,10 @@ def main():
             else:
                 m = hnn.Conv2d(cin, cout, k, s, p)
         x = torch.randn(args.n, cin, *sz, device=dev, requires_grad=True)
+        if args.zeros:
+            x = torch.zeros_like(x).requires_grad_(True)
+            with torch.no_grad():
+                m.weight.zero_()
         y = m(x)
         g = torch.randn_like(y)
         m.weight.grad = torch.zeros_like(m.weight)
