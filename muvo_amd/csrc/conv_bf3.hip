@@ -571,6 +571,202 @@ conv_bf3_wgrad_kernel(const ConvPhase g, const uint4* __restrict__ xs, long xpla
   }
 }
 
+// Eight-wave weight-gradient kernel on the schedule of conv_bf3_kernel: ping-pong wave groups, three LDS stages,
+// operands staged by 16-byte buffer loads through registers (lane = 4 * pixel + chunk: 64 contiguous bytes per pixel,
+// the range check supplies the zeros of out-of-image taps, channel padding and pixels past the end), fragments by
+// transpose reads from the same [plane][chunk][32 pixels ^ swizzle] image as conv_bf3_wgrad_kernel.
+// Wave w stages the pixel half (w & 1) of every step, A roles [(w >> 1) * APW, +APW), B roles likewise; a role is a
+// (plane, 32-channel group) pair, fixed for the whole kernel.
+template <int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(64 * WM * WN)
+conv_bf3_wgrad_pp_kernel(const ConvPhase g, const uint4* __restrict__ xs, long xplane_u4, int xc8, const uint4* __restrict__ dzs,
+                         long dzplane_u4, int dzc8, float* __restrict__ wg, int steps_per_split) {
+  constexpr int BK = 32, NW = WM * WN;
+  static_assert(NW == 8 && BM == WM * 64 && BN == WN * 64, "two groups of four waves, 64x64 wave tiles");
+  constexpr int CA = BM / 8, CB = BN / 8;           // 8-channel chunks per pixel row
+  constexpr int STAGE = 2 * 32 * (CA + CB);         // uint4 per stage: A [plane][CA][32] then B [plane][CB][32]
+  constexpr int APW = 2 * (BM / 32) / 4, BPW = 2 * (BN / 32) / 4;
+  constexpr int DPS = APW + BPW;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  extern __shared__ uint4 smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int ctiles = (g.C + BN - 1) / BN;
+  const int t = blockIdx.x / ctiles, c_tile = (blockIdx.x % ctiles) * BN, m_tile = blockIdx.y * BM;
+  const int td = g.tap_d[t];
+  const int dz_ = ((td >> 16) & 255) - 128, dy_ = ((td >> 8) & 255) - 128, dx_ = (td & 255) - 128;
+  const int nsteps = (g.npix + BK - 1) / BK;
+  const int s_begin = blockIdx.z * steps_per_split;
+  int s_end = s_begin + steps_per_split;
+  if (s_end > nsteps) s_end = nsteps;
+  const int ns = s_end - s_begin;
+  if (ns <= 0) return;
+
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)dzs, 0, (int)(2 * dzplane_u4 * 16), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)xs, 0, (int)(2 * xplane_u4 * 16), 0x00020000);
+  constexpr unsigned OOB = 0xfffffff0u;
+
+  // roles of this lane: pixel p of the step, chunk c4 of each 32-channel group
+  const int half = wave & 1, ridx = wave >> 1, c4 = lane & 3;
+  const int p = (lane >> 2) + 16 * half;
+  unsigned a_base[APW], b_base[BPW];                // uint4 offset without the pixel term, OOB = role outside the tensor
+  int a_lds[APW], b_lds[BPW];                       // uint4 index inside a stage
+#pragma unroll
+  for (int q = 0; q < APW; ++q) {
+    const int k = ridx * APW + q;
+    const int plane = k / (BM / 32), chunk = (k % (BM / 32)) * 4 + c4;
+    const int row = m_tile + chunk * 8;             // rows [row, row + 8) lie in one row group (Msub % 8 == 0)
+    const int grp = row / g.Msub, gi = grp < g.nmerge ? grp : 0;
+    const int lc8 = (row - grp * g.Msub) >> 3;
+    const int resid = (g.mop[gi][0] * g.OH + g.mop[gi][1]) * g.OW + g.mop[gi][2];
+    const bool inb = row < g.M && lc8 < dzc8;
+    a_base[q] = inb ? (unsigned)(resid * dzc8 + lc8) + (unsigned)plane * (unsigned)dzplane_u4 : OOB;
+    a_lds[q] = (plane * CA + chunk) * 32 + (p ^ (c4 << 2));
+  }
+  const int ct8 = c_tile >> 3;
+#pragma unroll
+  for (int q = 0; q < BPW; ++q) {
+    const int k = ridx * BPW + q;
+    const int plane = k / (BN / 32), chunk = (k % (BN / 32)) * 4 + c4;
+    const bool inb = c_tile + chunk * 8 < g.Cp;
+    b_base[q] = inb ? (unsigned)(ct8 + chunk) + (unsigned)plane * (unsigned)xplane_u4 : OOB;
+    b_lds[q] = 2 * CA * 32 + (plane * CB + chunk) * 32 + (p ^ (c4 << 2));
+  }
+  // pixel of this lane in the current load step; advanced by 32 per step with small exact magic divisions
+  const unsigned sw_magic = (unsigned)(0x100000000ull / (unsigned)g.SW) + 1u, sh_magic = (unsigned)(0x100000000ull / (unsigned)g.SH) + 1u,
+                 sd_magic = (unsigned)(0x100000000ull / (unsigned)g.SD) + 1u;
+  int cpix = s_begin * BK + p;
+  int cn, cz, cy, cx_;
+  decode_pix(g, cpix < g.npix ? cpix : 0, cn, cz, cy, cx_);
+  unsigned offA = 0, offB = 0; bool okA = false, okB = false;
+  auto pixstate = [&]() {            // offsets of the step the coordinates point at, then advance the coordinates
+    okA = cpix < g.npix;
+    offA = (unsigned)((((cn * g.OD + cz * g.os[0]) * g.OH + cy * g.os[1]) * g.OW + cx_ * g.os[2]) * dzc8);
+    const int z = cz * g.is[0] + g.ib[0] + dz_, y = cy * g.is[1] + g.ib[1] + dy_, x = cx_ * g.is[2] + g.ib[2] + dx_;
+    okB = okA && (unsigned)z < (unsigned)g.ID && (unsigned)y < (unsigned)g.IH && (unsigned)x < (unsigned)g.IW;
+    offB = (unsigned)((((cn * g.ID + z) * g.IH + y) * g.IW + x) * xc8);
+    cpix += BK;
+    int xx = cx_ + BK;
+    int q = g.SW == 1 ? xx : (int)(((unsigned long long)(unsigned)xx * sw_magic) >> 32);
+    cx_ = xx - q * g.SW;
+    int yy = cy + q;
+    q = g.SH == 1 ? yy : (int)(((unsigned long long)(unsigned)yy * sh_magic) >> 32);
+    cy = yy - q * g.SH;
+    int zz = cz + q;
+    q = g.SD == 1 ? zz : (int)(((unsigned long long)(unsigned)zz * sd_magic) >> 32);
+    cz = zz - q * g.SD;
+    cn += q;
+  };
+  u32x4 R[DPS];
+  auto gload_piece = [&](int q) {
+    if (q < APW) {
+      const unsigned off = (okA && a_base[q] != OOB) ? (offA + a_base[q]) * 16u : OOB;
+      R[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, (int)off, 0, 0));
+    } else {
+      const unsigned off = (okB && b_base[q - APW] != OOB) ? (offB + b_base[q - APW]) * 16u : OOB;
+      R[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, (int)off, 0, 0));
+    }
+  };
+  auto lstore_piece = [&](int stage, int q) {
+    uint4* S = smem + stage * STAGE;
+    *(u32x4*)(S + (q < APW ? a_lds[q] : b_lds[q - APW])) = R[q];
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // transpose-read lane geometry: group g4 = lane>>4: channel half (g4&1), k half (g4>>1); q = pixel row, p = 4-channel slot
+  const int g4 = lane >> 4, rhalf = g4 & 1, kh = g4 >> 1, tq = (lane >> 2) & 3, tp = lane & 3;
+  const int cx = 2 * rhalf + (tp >> 1);             // chunk index within a 32-channel tile (== chunk & 3)
+  const int pos0 = (8 * kh + tq) ^ (cx << 2);       // pixel position for j = 0; j = 1 flips bit 2
+  const int lane_off0 = (cx * 32 + pos0) * 16 + 8 * (tp & 1);
+  const int lane_off1 = (cx * 32 + (pos0 ^ 4)) * 16 + 8 * (tp & 1);
+  bf16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2];    // [ks][i]
+  auto read_piece = [&](int stage, int r) {         // r: ks * 8 + operand (0 ah, 1 al, 2 bh, 3 bl) * 2 + i
+    const char* S = (const char*)(smem + stage * STAGE);
+    const int ks = r >> 3, op = (r >> 1) & 3, i = r & 1;
+    const char* base = S + (op >= 2 ? (size_t)2 * CA * 512 + (size_t)(wn * 8) * 512 : (size_t)(wm * 8) * 512) +
+                       ((op & 1) ? (size_t)(op >= 2 ? CB : CA) * 512 : 0) + i * 4 * 512 + ks * 256;
+    const bf16x8 v = tr_read8(base + lane_off0, base + lane_off1);
+    if (op == 0) ah[ks][i] = v;
+    else if (op == 1) al[ks][i] = v;
+    else if (op == 2) bh[ks][i] = v;
+    else bl[ks][i] = v;
+  };
+
+  // prologue: steps 0 and 1 into stages 0 and 1, step 2 into R
+#pragma unroll
+  for (int pre = 0; pre < 2; ++pre) {
+    pixstate();
+#pragma unroll
+    for (int q = 0; q < DPS; ++q) gload_piece(q);
+#pragma unroll
+    for (int q = 0; q < DPS; ++q) lstore_piece(pre, q);
+  }
+  pixstate();
+#pragma unroll
+  for (int q = 0; q < DPS; ++q) gload_piece(q);
+  pixstate();                                       // offsets of step 3
+  __syncthreads();
+  const int grp = wave / (NW / 2);
+  if (grp == 1) __builtin_amdgcn_s_barrier();
+  int stage = 0;
+  for (int st = 0; st < ns; ++st) {
+    const int wstage = stage == 0 ? 2 : stage - 1;  // (stage + 2) % 3
+#pragma unroll
+    for (int q = 0; q < DPS; ++q) lstore_piece(wstage, q);
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int RPL = (16 + DPS - 1) / DPS;
+#pragma unroll
+    for (int q = 0; q < DPS; ++q) {
+      gload_piece(q);                               // step st + 3
+#pragma unroll
+      for (int u = 0; u < RPL; ++u)
+        if (q * RPL + u < 16) read_piece(stage, q * RPL + u);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    pixstate();                                     // step st + 4
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bl[ks][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+        }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    stage = stage == 2 ? 0 : stage + 1;
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();
+
+  float* wt = wg + g.wp_off + (size_t)t * g.M * g.C;   // [m][c] slab of this tap
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = c_tile + wn * 64 + j * 32 + (lane & 31);
+    if (c >= g.C) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m_tile + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < g.M) atomicAdd(wt + (size_t)m * g.C + c, acc[i][j][r]);
+      }
+  }
+}
+
 // dw[m*wsm + c*wsc + tap_w[t]] += Wg[t][m][c]   (thread order follows the PyTorch weight layout)
 __global__ void __launch_bounds__(256) bf3_unpack_wgrad_kernel(const ConvPhase g, const float* __restrict__ wg,
                                                                float* __restrict__ dw) {
@@ -788,6 +984,37 @@ int bf3_launch_fwd_phase(const ConvPhase& g, const void* ws, const float* wp, co
   return bf3_launch<64, 256, 1, 4, 4, 2>(g, ws, wp, bias, out, act, slope, st);
 }
 
+template <int BM, int BN, int WM, int WN>
+static int bf3_wgrad_pp_launch(const ConvPhase& g, const void* ws_x, int Cin_total, const void* ws_dz, int Cout_total,
+                               float* wg, hipStream_t st) {
+  constexpr size_t lds = (size_t)3 * 2 * 32 * (BM / 8 + BN / 8) * 16;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)conv_bf3_wgrad_pp_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess) {
+      muvo_set_error("conv_bf3_wgrad_pp: kernel attribute setup failed");
+      return MUVO_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  ConvPhase p = g;
+  const int xc8 = roundup(Cin_total, 8) / 8, dzc8 = roundup(Cout_total, 8) / 8;
+  p.Cp = xc8 * 8;     // channel extent of the x planes
+  const long xplane = (long)g.N * g.ID * g.IH * g.IW * xc8, dzplane = (long)g.N * g.OD * g.OH * g.OW * dzc8;
+  const int ctiles = cdiv(g.C, BN), mtiles = cdiv(g.M, BM);
+  const int nsteps = cdiv(g.npix, 32);
+  int ksplit = cdiv(1536, (long)ctiles * g.T * mtiles);
+  if (ksplit > cdiv(nsteps, 16)) ksplit = cdiv(nsteps, 16);
+  if (ksplit < 1) ksplit = 1;
+  const int sps = cdiv(nsteps, ksplit);
+  ksplit = cdiv(nsteps, sps);
+  dim3 grid(ctiles * g.T, mtiles, ksplit);
+  hipLaunchKernelGGL((conv_bf3_wgrad_pp_kernel<BM, BN, WM, WN>), grid, dim3(64 * WM * WN), lds, st, p, (const uint4*)ws_x, xplane,
+                     xc8, (const uint4*)ws_dz, dzplane, dzc8, wg, sps);
+  MUVO_CHECK_LAUNCH("conv_bf3_wgrad_pp_kernel");
+  return MUVO_OK;
+}
+
 template <int BM, int BN, int WM, int WN, int WK>
 static int bf3_wgrad_launch(const ConvPhase& g, const void* ws_x, int Cin_total, const void* ws_dz, int Cout_total,
                             float* wg, hipStream_t st) {
@@ -826,8 +1053,11 @@ int bf3_wgrad_phase(const ConvPhase& g, const void* ws_x, int Cin_total, const v
                     float* dw, hipStream_t st) {
   if (g.npix <= 0 || g.T == 0) return MUVO_OK;
   int rc;
-  if (g.M > 128) rc = bf3_wgrad_launch<256, 128, 4, 2, 1>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st);
-  else if (g.M > 64) rc = g.C > 128 ? bf3_wgrad_launch<128, 256, 2, 4, 1>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st)
+  static const int wvariant = getenv("MUVO_BF3_WGRAD_VARIANT") ? atoi(getenv("MUVO_BF3_WGRAD_VARIANT")) : 0;   // 1: in-phase DMA kernels
+  if (g.M > 128) rc = wvariant == 1 ? bf3_wgrad_launch<256, 128, 4, 2, 1>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st)
+                                    : bf3_wgrad_pp_launch<256, 128, 4, 2>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st);
+  else if (g.M > 64) rc = g.C > 128 ? (wvariant == 1 ? bf3_wgrad_launch<128, 256, 2, 4, 1>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st)
+                                                     : bf3_wgrad_pp_launch<128, 256, 2, 4>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st))
                                     : bf3_wgrad_launch<128, 128, 2, 2, 2>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st);
   else rc = g.C > 128 ? bf3_wgrad_launch<64, 256, 1, 4, 2>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st)
                       : bf3_wgrad_launch<64, 128, 1, 2, 2>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st);
