@@ -1,3 +1,5 @@
+"""Host issue time of one training step: time until the Python side has queued everything vs. time until the GPU is done.
+    python tools/host_issue_time.py [batch] [seq]   (batch 1, seq 1 makes the GPU work tiny: the total is then the host cost)"""
 import os, sys, time, torch
 sys.path.insert(0, '/root/repo')
 from muvo_amd import ops
@@ -5,11 +7,13 @@ from muvo_amd.config import base_1d_cfg
 from muvo_amd.data.synthetic import make_batch
 from muvo_amd.trainer import WorldModelTrainer
 dev = torch.device('cuda:0')
-cfg = base_1d_cfg(RECEPTIVE_FIELD=6, FUTURE_HORIZON=4, BATCHSIZE=2, STEPS=100000)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+cfg = base_1d_cfg(RECEPTIVE_FIELD=max(S - 4, 1), FUTURE_HORIZON=S - max(S - 4, 1), BATCHSIZE=B, STEPS=100000)
 torch.manual_seed(1234)
 tr = WorldModelTrainer(cfg.convert_to_dict(), device=dev); tr.train()
 opts, scheds = tr.configure_optimizers(); opt, sched = opts[0], scheds[0]['scheduler']
-batches = [make_batch(2, 10, seed=1234 + k, device=dev) for k in range(2)]
+batches = [make_batch(B, S, seed=1234 + k, device=dev) for k in range(2)]
 def step(i):
     opt.zero_grad(); loss = tr.training_step(dict(batches[i % 2]), i); loss.backward(); opt.step(); sched.step(); return loss
 for i in range(2): step(i)
