@@ -129,15 +129,26 @@ def test_gradients_match_reference(run):
     assert not bad, f'{len(bad)} gradient norms off, first: {bad[:5]}'
     for key in smp.files:
         if key.startswith('grad64.'):
+            # strided samples.  The rgb L1 losses make the gradient a discontinuous function of the forward pass (sign
+            # flips where prediction ~ target), so single elements of the decoder gradients move by up to 3e-3 of the
+            # tensor maximum between two identical runs of this very code (tools/grad_repeat.py: float-atomic
+            # summation order -> 3e-6 forward noise -> a few flipped signs).  Bars: the sample as a vector within
+            # 5e-3 relative L2 of the float64 truth, every element within 2e-2 of the maximum — or 6x the reference's
+            # own fp32 error where that is larger.  A wrong tap, stride or missing term moves both by O(1).
             n = key[7:]
             ref = torch.from_numpy(smp[key]).double()
-            noise = (torch.from_numpy(smp['grad.' + n]).double() - ref).abs().max().item()
+            ref32 = torch.from_numpy(smp['grad.' + n]).double()
+            noise = (ref32 - ref).abs().max().item()
+            noise_l2 = (ref32 - ref).norm().item()
             t = recs[0]['grads'][n].double().contiguous().view(-1)
             stride = max(1, t.numel() // 1024)
             got = t[::stride][:ref.numel()].cpu()
             err = (got - ref).abs().max().item()
-            tol = max(2e-3 * ref.abs().max().item(), 6.0 * noise, 1e-12)
+            err_l2 = (got - ref).norm().item()
+            tol = max(2e-2 * ref.abs().max().item(), 6.0 * noise, 1e-12)
+            tol_l2 = max(5e-3 * ref.norm().item(), 6.0 * noise_l2, 1e-12)
             assert err <= tol, f'{n}: max err {err:.3e} > tol {tol:.3e} (reference fp32 noise {noise:.3e})'
+            assert err_l2 <= tol_l2, f'{n}: L2 err {err_l2:.3e} > tol {tol_l2:.3e} (reference fp32 noise {noise_l2:.3e})'
 
 
 def test_adamw_steps_match_reference(run):
