@@ -206,6 +206,21 @@ int muvo_kl_loss_bwd(const float* prior_mu, const float* prior_sigma, const floa
 int muvo_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                     float weight_decay, int step, float grad_scale, void* stream);
 
+/* ---- evaluation metrics of the validation path (muvo/metrics.py via muvo/trainer.py:426-490) ----------------------------
+ * All accumulators are caller-zeroed device buffers the kernels ADD into (several batches may share them).
+ * muvo_ssim_frames: sums[n] += sum over (c, y, x) of the SSIM map of frame n (valid 11x11 Gaussian window given as 121
+ *   floats, losses.py:304-314); mean = sums / (C (H-10) (W-10)).  Replaces SSIMLoss._ssim, losses.py:316-339.
+ * muvo_sqdiff_frames: sums[n] += sum (pred - target)^2 over the L elements of frame n (PSNRMetric.psnr, metrics.py:305-309).
+ * muvo_chamfer_sums: sums[2n] += sum_i min_j |a_i - b_j|, sums[2n+1] += sum_j min_i |a_i - b_j| for point sets a (N,P,3),
+ *   b (N,Q,3) (CDMetric.add_batch, metrics.py:243-249).
+ * muvo_ssc_counts: prediction = argmax over the C logits (N,C,V); counts[0..2] += completion tp/fp/fn, counts[3+3j..] +=
+ *   tp/fp/fn of class j over voxels with label != 255 (trainer.py:482-490, SSCMetrics.add_batch, metrics.py:77-100). */
+int muvo_ssim_frames(const float* pred, const float* target, const float* window, double* sums, int N, int C, int H, int W,
+                     float c1, float c2, void* stream);
+int muvo_sqdiff_frames(const float* pred, const float* target, double* sums, int N, int64_t L, void* stream);
+int muvo_chamfer_sums(const float* a, const float* b, double* sums, int N, int P, int Q, void* stream);
+int muvo_ssc_counts(const float* logits, const uint8_t* label, uint64_t* counts, int64_t F, int C, int64_t V, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

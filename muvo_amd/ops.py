@@ -55,6 +55,7 @@ EXPORTS = [
     'muvo_spatial_loss_fwd', 'muvo_spatial_loss_bwd', 'muvo_voxel_loss_stats_doubles', 'muvo_voxel_loss_coef_floats',
     'muvo_voxel_loss_fwd', 'muvo_voxel_loss_bwd', 'muvo_l1_rows_fwd', 'muvo_l1_rows_bwd', 'muvo_kl_loss_fwd',
     'muvo_kl_loss_bwd', 'muvo_adamw_step',
+    'muvo_ssim_frames', 'muvo_sqdiff_frames', 'muvo_chamfer_sums', 'muvo_ssc_counts',
 ]
 
 

@@ -8,6 +8,7 @@ the same hooks so the build's own loop (bench.py / train.py) can drive it.  Vali
 (trainer.py:404-1020) are outside the training hot path."""
 import os
 
+import numpy as np
 import torch
 
 from muvo_amd import ops
@@ -50,6 +51,12 @@ class WorldModelTrainer(_Base):
         self.store = None
         self._optimizer = None
         self._reducer = None
+        # evaluation metrics per validation / test dataloader (trainer.py:51-55,100-129,191-197); created on first use
+        # because they hold device accumulators
+        self.metrics_vals = [{}, {}, {}]
+        self.metrics_vals_imagine = [{}, {}, {}]
+        self.metrics_tests = [{}, {}, {}]
+        self.metrics_tests_imagine = [{}, {}, {}]
 
     # ------------------------------------------------------------------ weights
     def load_pretrained_weights(self):
@@ -97,10 +104,48 @@ class WorldModelTrainer(_Base):
             losses_imagines.append(self.compute_loss(batch_fh, out_i))
         return losses, output, losses_imagines, output_imagines
 
-    def validation_step(self, batch, batch_idx=0, dataloader_idx=0, noise=None, use_prior=None):
-        """trainer.py:404-424 without the metric/visualisation side effects (SSC IoU, PSNR, ... are evaluation tooling, not
-        part of this path): train-mode BatchNorm, transformer nn.Dropout modules off (the functional attention dropout of
-        nn.MultiheadAttention stays on), no_grad."""
+    def _metric_set(self, metrics):
+        """trainer.py:100-129,191-197: the metrics base_1d enables (ssim, psnr, cd, ssc)."""
+        if not metrics:
+            from .metrics import CDMetric, PSNRMetric, SSCMetrics, SSIMMetric
+            if self.cfg.EVAL.RGB_SUPERVISION:
+                metrics['ssim'], metrics['psnr'] = SSIMMetric(channel=3), PSNRMetric(max_pixel_val=1.0)
+            if self.cfg.LIDAR_RE.ENABLED:
+                metrics['cd'] = CDMetric()
+            if self.cfg.VOXEL_SEG.ENABLED:
+                metrics['ssc'] = SSCMetrics(self.cfg.VOXEL_SEG.N_CLASSES)
+        return metrics
+
+    def add_metrics(self, metrics, batch, output, cd_index=None):
+        """trainer.py:426-480 for the heads of base_1d.  cd_index: the 10000-point subset of the Chamfer metric; the
+        reference draws it with np.random.randint (trainer.py:455), pass it explicitly for reproducible numbers."""
+        metrics = self._metric_set(metrics)
+        if self.cfg.EVAL.RGB_SUPERVISION:
+            metrics['ssim'].add_batch(prediction=output['rgb_1'].detach(), target=batch['rgb_label_1'])
+            metrics['psnr'].add_batch(prediction=output['rgb_1'].detach(), target=batch['rgb_label_1'])
+        if self.cfg.LIDAR_RE.ENABLED:
+            lidar_target = batch['range_view_label_1']
+            lidar_pred = output['lidar_reconstruction_1'].detach()
+            pcd_target = lidar_target.detach().permute(0, 1, 3, 4, 2).flatten(2, 3).flatten(0, 1) * self.cfg.LIDAR_RE.SCALE
+            pcd_pred = lidar_pred.permute(0, 1, 3, 4, 2).flatten(2, 3).flatten(0, 1) * self.cfg.LIDAR_RE.SCALE
+            if cd_index is None:
+                cd_index = np.random.randint(0, pcd_target.size(-2), 10000)
+            index = torch.as_tensor(cd_index, device=pcd_pred.device).long()
+            metrics['cd'].add_batch(pcd_pred[:, index, :-1], pcd_target[:, index, :-1])
+        if self.cfg.VOXEL_SEG.ENABLED:
+            self.compute_ssc_metrics(batch, output, metrics['ssc'])
+
+    def compute_ssc_metrics(self, batch, output, metric):
+        """trainer.py:482-490; the argmax over the class logits happens inside the counting kernel."""
+        y_true = batch['voxel_label_1']
+        y_pred = output['voxel_1'].detach()
+        b, s, c, x, y, z = y_pred.shape
+        metric.add_batch(y_pred.reshape(b * s, c, x, y, z), y_true.reshape(b * s, x, y, z))
+
+    def validation_step(self, batch, batch_idx=0, dataloader_idx=0, noise=None, use_prior=None, cd_index=None):
+        """trainer.py:404-424 (visualisation/logging hooks excepted): train-mode BatchNorm, transformer nn.Dropout modules
+        off (the functional attention dropout of nn.MultiheadAttention stays on), no_grad; then the
+        reconstruction metrics on the observed frames and the imagination metrics on the future frames."""
         self.train()
         layers = list(self.model.transformer_encoder.layers)
         saved = [getattr(layer, 'module_dropout_off', False) for layer in layers]
@@ -113,6 +158,11 @@ class WorldModelTrainer(_Base):
         finally:
             for layer, v in zip(layers, saved):
                 layer.module_dropout_off = v
+        batch_rf = {key: value[:, :self.rf] for key, value in batch.items() if torch.is_tensor(value)}
+        batch_fh = {key: value[:, self.rf:] for key, value in batch.items() if torch.is_tensor(value)}
+        self.add_metrics(self.metrics_vals[dataloader_idx], batch_rf, output, cd_index)
+        for output_imagine in output_imagines:
+            self.add_metrics(self.metrics_vals_imagine[dataloader_idx], batch_fh, output_imagine, cd_index)
         out = {f'val{dataloader_idx}_loss': self.loss_reducing(loss),
                f'val{dataloader_idx}_loss_imagine': sum(self.loss_reducing(li) for li in loss_imagines) / len(loss_imagines)}
         return out, loss, output, loss_imagines, output_imagines

@@ -591,3 +591,88 @@ def validation_step(model: MileRef, raw_batch, rf, fh, noise, use_prior, n_sampl
             outs_i.append(o)
             losses_i.append(compute_losses(bfh, o, model.cfg))
     return losses, out, losses_i, outs_i
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Evaluation metrics: CPU restatement of muvo/metrics.py as driven by trainer.py:426-490.
+# Pinned against the real reference classes by tests/golden/metrics.json (oracle/refimport/make_golden_metrics.py).
+# ------------------------------------------------------------------------------------------------------------------
+def ssim_frames(prediction, target, window_size=11, sigma=1.5, L=1.0):
+    """losses.py:292-339 (SSIMLoss._ssim): Gaussian window, 'valid' depthwise conv, per-frame mean of the SSIM map.
+    prediction/target: (b, s, c, h, w) -> (b*s,) float32."""
+    b, s, c, h, w = prediction.shape
+    x = torch.arange(window_size)
+    g = torch.exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2))
+    g = (g / g.sum()).unsqueeze(1)
+    win = g.mm(g.t()).float()[None, None].expand(c, 1, window_size, window_size).contiguous()
+    p, t = prediction.reshape(b * s, c, h, w), target.reshape(b * s, c, h, w)
+    c1, c2 = (0.01 * L) ** 2, (0.03 * L) ** 2
+    mu1, mu2 = F.conv2d(t, win, groups=c), F.conv2d(p, win, groups=c)
+    s1 = F.conv2d(t * t, win, groups=c) - mu1 * mu1
+    s2 = F.conv2d(p * p, win, groups=c) - mu2 * mu2
+    s12 = F.conv2d(t * p, win, groups=c) - mu1 * mu2
+    m = ((2 * mu1 * mu2 + c1) * (2 * s12 + c2)) / ((mu1 * mu1 + mu2 * mu2 + c1) * (s1 + s2 + c2))
+    return m.mean([1, 2, 3])
+
+
+def psnr_frames(prediction, target, max_pixel_val=1.0):
+    """metrics.py:305-309: per-frame MSE over (c, h, w) -> 20 log10(max / sqrt(mse)); (b, s, c, h, w) -> (b, s)."""
+    mse = torch.mean((prediction - target) ** 2, dim=(2, 3, 4))
+    return 20 * torch.log10(max_pixel_val / torch.sqrt(mse))
+
+
+def chamfer_frames(prediction, target):
+    """metrics.py:243-249 (CDMetric.add_batch, reducer = mean): Euclidean nearest-neighbour distances both ways;
+    (n, P, 3) x (n, Q, 3) -> (n,)."""
+    d = torch.cdist(prediction.float(), target.float(), 2)
+    return (d.min(1)[0].mean(dim=1) + d.min(2)[0].mean(dim=1)) / 2
+
+
+def ssc_counts(y_pred, y_true, n_classes):
+    """metrics.py:77-100,143-214: with nonempty = (y_true != 255): completion tp/fp/fn on occupied-vs-empty and per-class
+    tp/fp/fn over the non-ignored voxels.  Returns (completion[3], tps[C], fps[C], fns[C]) int64."""
+    m = y_true != 255
+    p, t = y_pred[m].long(), y_true[m].long()
+    comp = torch.stack([((t > 0) & (p > 0)).sum(), ((t == 0) & (p > 0)).sum(), ((t > 0) & (p == 0)).sum()])
+    tps = torch.stack([((t == j) & (p == j)).sum() for j in range(n_classes)])
+    fps = torch.stack([((t != j) & (p == j)).sum() for j in range(n_classes)])
+    fns = torch.stack([((t == j) & (p != j)).sum() for j in range(n_classes)])
+    return comp, tps, fps, fns
+
+
+class EvalMetrics:
+    """The running statistics the reference keeps per dataloader (trainer.py:426-490; metrics.py SSIMMetric :219-235,
+    PSNRMetric :295-317, CDMetric :238-258, SSCMetrics :47-141), including its count = 1e-8 start value."""
+
+    def __init__(self, n_classes=2, scale=50.0):
+        self.n_classes, self.scale = n_classes, scale
+        self.reset()
+
+    def reset(self):
+        self.count = 1e-8
+        self.ssim_sum = self.psnr_sum = self.cd_sum = 0.0
+        self.comp = torch.zeros(3, dtype=torch.int64)
+        self.tps, self.fps, self.fns = (torch.zeros(self.n_classes, dtype=torch.int64) for _ in range(3))
+
+    def add_batch(self, rgb_pred, rgb_target, rv_pred, rv_target, cd_index, voxel_logits, voxel_label):
+        self.count += 1
+        self.ssim_sum += float(ssim_frames(rgb_pred, rgb_target).mean())
+        self.psnr_sum += float(psnr_frames(rgb_pred, rgb_target).mean())
+        pt = rv_target.permute(0, 1, 3, 4, 2).flatten(2, 3).flatten(0, 1) * self.scale
+        pp = rv_pred.permute(0, 1, 3, 4, 2).flatten(2, 3).flatten(0, 1) * self.scale
+        self.cd_sum += float(chamfer_frames(pp[:, cd_index, :-1], pt[:, cd_index, :-1]).mean())
+        b, s, c, x, y, z = voxel_logits.shape
+        comp, tps, fps, fns = ssc_counts(torch.argmax(voxel_logits.reshape(b * s, c, x, y, z), dim=1),
+                                         voxel_label.reshape(b * s, x, y, z), self.n_classes)
+        self.comp += comp
+        self.tps += tps
+        self.fps += fps
+        self.fns += fns
+
+    def stats(self):
+        tp, fp, fn = (float(v) for v in self.comp)
+        iou_ssc = self.tps.float() / (self.tps + self.fps + self.fns + 1e-5).float()
+        return dict(ssim=self.ssim_sum / self.count, psnr=self.psnr_sum / self.count, cd=self.cd_sum / self.count,
+                    precision=tp / (tp + fp) if tp else 0.0, recall=tp / (tp + fn) if tp else 0.0,
+                    iou=tp / (tp + fp + fn) if tp else 0.0, iou_ssc=iou_ssc, iou_ssc_mean=float(iou_ssc[1:].mean()),
+                    completion=self.comp.tolist(), tps=self.tps.tolist(), fps=self.fps.tolist(), fns=self.fns.tolist())

@@ -88,3 +88,41 @@ def test_hip_validation_path_matches_reference(dev):
     assert abs(res['val0_loss'].item() - ref_total) <= 1e-3 * ref_total
     ref_im = sum(sum(li.values()) for li in fx['losses_imagine']) / ns
     assert abs(res['val0_loss_imagine'].item() - ref_im) <= 1e-3 * ref_im
+
+
+@pytest.mark.gpu
+def test_hip_validation_metrics_match_oracle(dev):
+    """validation_step also feeds the evaluation metrics (trainer.py:415-417): reconstruction metrics on the observed frames,
+    imagination metrics on the future frames.  The HIP metric kernels are compared with the oracle restatement of
+    muvo/metrics.py evaluated on the very tensors the HIP model produced (integer counts bit-exact, statistics 1e-4)."""
+    from muvo_amd.config import base_1d_cfg
+    from muvo_amd.data.synthetic import make_batch, make_noise
+    from muvo_amd.trainer import WorldModelTrainer
+    from muvo_amd.utils import detinit
+    from oracle import muvo_ref as R
+    fx, _ = _fixture()
+    b, rf, fh, ns = fx['b'], fx['rf'], fx['fh'], fx['n_samples']
+    cfg = base_1d_cfg(RECEPTIVE_FIELD=rf, FUTURE_HORIZON=fh, STEPS=100000)
+    tr = WorldModelTrainer(cfg.convert_to_dict(), device=dev)
+    detinit.fill_state_dict_(tr.model)
+    for layer in tr.model.transformer_encoder.layers:
+        layer.p = 0.0
+    eps, use_prior = make_noise(b, rf + ns * fh, seed=fx['seed'])
+    batch = make_batch(b, rf + fh, seed=fx['seed'], device=dev)
+    cd_index = (detinit.hash_u64(detinit.name_key('cd_index'), 10000) % np.uint64(64 * 1024)).astype(np.int64)
+    _, _, out, _, outs_im = tr.validation_step(batch, noise=eps.to(dev), use_prior=use_prior, cd_index=cd_index)
+    for metrics, sl, outputs in ((tr.metrics_vals[0], slice(0, rf), [out]), (tr.metrics_vals_imagine[0], slice(rf, rf + fh), outs_im)):
+        assert set(metrics) == {'ssim', 'psnr', 'cd', 'ssc'}
+        o = R.EvalMetrics(2, cfg.LIDAR_RE.SCALE)
+        for od in outputs:
+            o.add_batch(od['rgb_1'].float().cpu(), batch['rgb_label_1'][:, sl].float().cpu(),
+                        od['lidar_reconstruction_1'].float().cpu(), batch['range_view_label_1'][:, sl].float().cpu(), cd_index,
+                        od['voxel_1'].float().cpu(), batch['voxel_label_1'][:, sl, 0].cpu())
+        so = o.stats()
+        assert abs(float(metrics['ssim'].get_stat()) - so['ssim']) <= 1e-4 * abs(so['ssim'])
+        assert abs(float(metrics['psnr'].get_stat()) - so['psnr']) <= 1e-4 * abs(so['psnr'])
+        assert abs(float(metrics['cd'].get_stat()) - so['cd']) <= 1e-4 * abs(so['cd'])
+        ssc = metrics['ssc']
+        assert [ssc.completion_tp, ssc.completion_fp, ssc.completion_fn] == so['completion']
+        assert ssc.tps.tolist() == so['tps'] and ssc.fps.tolist() == so['fps'] and ssc.fns.tolist() == so['fns']
+        assert abs(ssc.get_stats()['iou'] - so['iou']) < 1e-9
