@@ -221,6 +221,32 @@ int muvo_sqdiff_frames(const float* pred, const float* target, double* sums, int
 int muvo_chamfer_sums(const float* a, const float* b, double* sums, int N, int P, int Q, void* stream);
 int muvo_ssc_counts(const float* logits, const uint8_t* label, uint64_t* counts, int64_t F, int C, int64_t V, void* stream);
 
+/* ---- BEV lifting: FrustumPooling (muvo/models/frustum_pooling.py:67-217) as called from Mile.encode (mile.py:506-522) ----
+ * muvo_frustum_cells: cells[b][d][h][w] = (iz*ny + iy)*nx + ix of the frustum point, -1 outside the grid (get_geometry
+ *   :108-128 + the index part of voxel_pooling :139-158).  combine = R K^-1 per frame (3x3 row major), trans = camera position,
+ *   xs/ys/ds = pixel columns, rows and depth bin centres of the frustum (:92-106); sx, ox, sy, oy = BEV intrinsics
+ *   (geometry_utils.py:8-19), bz/dz = first cell centre and cell size along "up" (gen_dx_bx :10-21).
+ * muvo_frustum_pool_fwd: out[b][c*nz + iz][iy][ix] = sum over the lifted points of the cell of depth[b][d][p] * feat[b][c][p]
+ *   (outer product mile.py:519 + voxel_pooling :130-182).  mask: (B,D,HW) bytes, non-zero = lift (NULL = all, mile.py:511-518).
+ *   acc: B*ncell*C floats of scratch (channels-last accumulator).  Valid for nz = 1 or any nz (out is (B, C, ncell) with the
+ *   up index inside the cell number; the caller reorders for nz > 1).
+ * muvo_frustum_pool_bwd: gradients of the above w.r.t. feat and depth (QuickCumsum.backward :56-64 chained through the outer
+ *   product); g_cl: B*ncell*C floats of scratch.  Deterministic (no atomics).
+ * muvo_depth_expectation: e[b][p] = sum_d ds[d] depth[b][d][p] (get_depth_map :211-214). */
+int muvo_frustum_cells(const float* combine, const float* trans, const float* xs, const float* ys, const float* ds, int32_t* cells,
+                       int B, int D, int H, int W, float sx, float ox, float sy, float oy, float bz, float dz, int nx, int ny,
+                       int nz, void* stream);
+int muvo_frustum_pool_fwd(const float* feat, const float* depth, const uint8_t* mask, const int32_t* cells, float* acc, float* out,
+                          int B, int C, int D, int64_t HW, int ncell, void* stream);
+int muvo_frustum_pool_bwd(const float* feat, const float* depth, const uint8_t* mask, const int32_t* cells, const float* gout,
+                          float* g_cl, float* dfeat, float* ddepth, int B, int C, int D, int64_t HW, int ncell, void* stream);
+int muvo_depth_expectation(const float* depth, const float* ds, float* e, int B, int D, int64_t HW, void* stream);
+/* adjoint of muvo_resize_bilinear (backward of F.interpolate(..., 'bilinear', align_corners=False) in `Decoder`, common.py:96) */
+int muvo_resize_bilinear_bwd(const float* dy, float* dx, int64_t NC, int H, int W, int OH, int OW, void* stream);
+/* softmax over the channel dimension of (B, C, HW): depth distribution of the mono depth head (mile.py:509) */
+int muvo_softmax_channel_fwd(const float* x, float* y, int B, int C, int64_t HW, void* stream);
+int muvo_softmax_channel_bwd(const float* y, const float* dy, float* dx, int B, int C, int64_t HW, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

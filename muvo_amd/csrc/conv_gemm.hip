@@ -435,6 +435,7 @@ static double bf3_min_gflop() {
   return v;
 }
 
+static thread_local int t_force_family = 0;   // +1 / -1: make this phase bf16x3 / fp32 regardless of its own size (see below)
 static void finish_phase(ConvPhase& g) {
   g.bf3 = 0;
   if (g.nmerge <= 1) {
@@ -445,7 +446,8 @@ static void finish_phase(ConvPhase& g) {
   // bf16x3 only where it pays: phases with >= MUVO_BF16X3_MIN_GFLOP (default 2) GFLOP of work per batch item, i.e.
   // the ConvDecoder stacks and the widest DecoderDS conv; the rest (encoders, voxel trunk) stays on exact fp32 MFMA.
   const double gflop = 2.0 * g.Msub * g.T * g.C * (double)g.SD * g.SH * g.SW * 1e-9;   // per original phase
-  if (t_plan_mode == 1 && g.M > 32 && (long)g.T * g.C >= 32 && gflop >= bf3_min_gflop()) {
+  const bool structural = g.M > 32 && (long)g.T * g.C >= 32;
+  if (t_plan_mode == 1 && structural && t_force_family >= 0 && (gflop >= bf3_min_gflop() || t_force_family > 0)) {
     g.bf3 = 1;
     bf3_finish_phase(g);
     return;
@@ -546,6 +548,24 @@ static int build_transposed_form(const muvo_conv_desc* d, const int* in_dims, co
         finish_phase(g);
         phs[count++] = g;
       }
+  // One arithmetic per operation: the sub-pixel phases of a strided data gradient differ in tap count (5x5 stride 2:
+  // 9/6/6/4), so the per-phase work threshold could put some of them on bf16x3 and the rest on fp32.  The callers pick
+  // ONE input preparation per operation (the fused dy * act'(y) -> split planes pass feeds only the bf16x3 kernels),
+  // so a mixed plan would hand the fp32 phases a gradient without the activation derivative.  Promote all phases to
+  // bf16x3 when any qualifies and all are structurally eligible, otherwise keep all on fp32.
+  {
+    bool any = false, all_struct = true;
+    for (int i = 0; i < count; ++i) {
+      any = any || phs[i].bf3;
+      all_struct = all_struct && phs[i].M > 32 && (long)phs[i].T * phs[i].C >= 32;
+    }
+    if (any) {
+      t_force_family = all_struct ? 1 : -1;
+      for (int i = 0; i < count; ++i)
+        if ((phs[i].bf3 != 0) != all_struct) finish_phase(phs[i]);
+      t_force_family = 0;
+    }
+  }
   // merge the phases into one GEMM when they all read the same input offsets (see conv_plan.h)
   if (t_allow_merge && count > 1 && count <= 8 && M % 32 == 0 && (long)count * M <= 1024) {
     bool same = true;

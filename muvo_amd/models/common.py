@@ -64,6 +64,26 @@ class DecoderDS(nn.Module):
         return x
 
 
+class Decoder(nn.Module):
+    """common.py:71-99: coarse-to-fine skip decoder with bilinear upsampling (BEV lifting variant)."""
+
+    def __init__(self, feature_info, out_channels):
+        super().__init__()
+        n_upsample_skip_convs = len(feature_info) - 1
+        self.conv1 = _conv_bn_relu(feature_info[-1]['num_chs'], out_channels)
+        self.upsample_skip_convs = nn.ModuleList(
+            _conv_bn_relu(feature_info[-i]['num_chs'], out_channels) for i in range(2, n_upsample_skip_convs + 2))
+        self.out_channels = out_channels
+
+    def forward(self, xs):
+        x = self.conv1[1](self.conv1[0](xs[-1]), relu=True)
+        for i, conv in enumerate(self.upsample_skip_convs):
+            up = ops.interpolate_bilinear(x, xs[-(i + 2)].shape[-2:])
+            # relu(bn(conv(skip))) + upsample(x): residual added AFTER the ReLU (common.py:96)
+            x = conv[1](conv[0](xs[-(i + 2)]), residual=up, res_mode=2, relu=True)
+        return x
+
+
 class AdaptiveInstanceNorm3d(nn.Module):
     def __init__(self, latent_n_channels, out_channels, epsilon=1e-8):
         super().__init__()

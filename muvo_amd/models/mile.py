@@ -7,7 +7,8 @@ import torch.nn as nn
 from muvo_amd import nn as hnn
 from muvo_amd import ops
 from muvo_amd.layers.layers import BasicBlock
-from muvo_amd.models.common import (ConvDecoder, DecoderDS, Policy, RouteEncode, VoxelDecoder1,
+from muvo_amd.bev import FrustumPooling
+from muvo_amd.models.common import (ConvDecoder, Decoder, DecoderDS, Policy, RouteEncode, VoxelDecoder1,
                                     position_embedding_sine)
 from muvo_amd.models.resnet import ResNet18Features
 from muvo_amd.models.transition import RSSM
@@ -34,8 +35,8 @@ class Mile(nn.Module):
         unsupported = []
         if m.ENCODER.NAME != 'resnet18' or m.LIDAR.ENCODER != 'resnet18':
             unsupported.append('non-resnet18 encoders')
-        if not m.TRANSFORMER.ENABLED or m.TRANSFORMER.BEV or m.TRANSFORMER.LARGE:
-            unsupported.append('TRANSFORMER.{ENABLED=False,BEV,LARGE}')
+        if not m.TRANSFORMER.ENABLED or m.TRANSFORMER.LARGE:
+            unsupported.append('TRANSFORMER.{ENABLED=False,LARGE}')
         if not m.LIDAR.ENABLED or m.LIDAR.POINT_PILLAR.ENABLED:
             unsupported.append('LIDAR off / POINT_PILLAR')
         if m.MEASUREMENTS.ENABLED or m.REWARD.ENABLED or not m.TRANSITION.ENABLED or not m.ROUTE.ENABLED:
@@ -49,6 +50,20 @@ class Mile(nn.Module):
         self.encoder = ResNet18Features(3, (2, 3, 4))
         feature_info = self.encoder.feature_info.get_dicts(keys=['num_chs', 'reduction'])
         self.feat_decoder = DecoderDS(feature_info, tc)
+        self.bev = bool(m.TRANSFORMER.BEV)
+        if self.bev:
+            # BEV lifting of the image features (mile.py:33-59)
+            self.feat_decoder = Decoder(feature_info, tc)
+            bev_downsample = cfg.BEV.FEATURE_DOWNSAMPLE
+            self.frustum_pooling = FrustumPooling(
+                size=(cfg.BEV.SIZE[0] // bev_downsample, cfg.BEV.SIZE[1] // bev_downsample),
+                scale=cfg.BEV.RESOLUTION * bev_downsample, offsetx=cfg.BEV.OFFSET_FORWARD / bev_downsample,
+                dbound=cfg.BEV.FRUSTUM_POOL.D_BOUND, downsample=8)
+            self.depth_decoder = Decoder(feature_info, tc)
+            self.depth = hnn.Conv2d(self.depth_decoder.out_channels, self.frustum_pooling.D, 1)
+            self.sparse_depth = cfg.BEV.FRUSTUM_POOL.SPARSE
+            self.sparse_depth_count = cfg.BEV.FRUSTUM_POOL.SPARSE_COUNT
+            self.bev_down_sample_4 = nn.Sequential(hnn.Conv2d(tc, 512, 5, 2, 2), hnn.Placeholder(), hnn.Conv2d(512, tc, 5, 2, 2))
         self.range_view_encoder = ResNet18Features(4, (2, 3, 4))
         self.range_view_decoder = DecoderDS(self.range_view_encoder.feature_info.get_dicts(keys=['num_chs', 'reduction']), tc)
         self.type_embedding = nn.Parameter(torch.zeros(1, 1, tc, 2))
@@ -157,7 +172,18 @@ class Mile(nn.Module):
         b, s = batch['image'].shape[:2]
         image = pack_sequence_dim(batch['image'])
         speed = pack_sequence_dim(batch['speed'])
-        x = self.feat_decoder(self.encoder(image))
+        xs = self.encoder(image)
+        x = self.feat_decoder(xs)
+        if self.bev:                                                     # mile.py:506-524
+            depth = ops.softmax_channel(self.depth(self.depth_decoder(xs)))
+            depth_mask = None
+            if self.sparse_depth:                                        # only the top-k most likely bins are lifted
+                topk_bins = depth.detach().topk(self.sparse_depth_count, dim=1)[1]
+                depth_mask = torch.zeros(depth.shape, device=depth.device, dtype=torch.bool)
+                depth_mask.scatter_(1, topk_bins, 1)
+            x = self.frustum_pooling.lift(x, depth, pack_sequence_dim(batch['intrinsics']).float(),
+                                          pack_sequence_dim(batch['extrinsics']).float(), depth_mask)
+            x = self.bev_down_sample_4[2](self.bev_down_sample_4[0](x, act=ops.ACT_RELU))
         lidar_features = self.range_view_decoder(self.range_view_encoder(pack_sequence_dim(batch['range_view_pcd_xyzd'])))
         hi, wi = x.shape[-2:]
         hl, wl = lidar_features.shape[-2:]

@@ -56,6 +56,8 @@ EXPORTS = [
     'muvo_voxel_loss_fwd', 'muvo_voxel_loss_bwd', 'muvo_l1_rows_fwd', 'muvo_l1_rows_bwd', 'muvo_kl_loss_fwd',
     'muvo_kl_loss_bwd', 'muvo_adamw_step',
     'muvo_ssim_frames', 'muvo_sqdiff_frames', 'muvo_chamfer_sums', 'muvo_ssc_counts',
+    'muvo_frustum_cells', 'muvo_frustum_pool_fwd', 'muvo_frustum_pool_bwd', 'muvo_depth_expectation',
+    'muvo_resize_bilinear_bwd', 'muvo_softmax_channel_fwd', 'muvo_softmax_channel_bwd',
 ]
 
 
@@ -1040,6 +1042,51 @@ def resize_bilinear(x, oh, ow):
     y = torch.empty(*x.shape[:-2], oh, ow, device=x.device, dtype=torch.float32)
     _ck(lib().muvo_resize_bilinear(_f(x), _f(y), _i64(x.numel() // (h * w)), h, w, oh, ow, _st()))
     return y
+
+
+class _ResizeBilinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, oh, ow):
+        ctx.in_hw = tuple(x.shape[-2:])
+        return resize_bilinear(x, oh, ow)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        h, w = ctx.in_hw
+        oh, ow = g.shape[-2:]
+        dx = torch.empty(*g.shape[:-2], h, w, device=g.device, dtype=torch.float32)
+        _ck(lib().muvo_resize_bilinear_bwd(_f(g), _f(dx), _i64(g.numel() // (oh * ow)), h, w, oh, ow, _st()))
+        return dx, None, None
+
+
+def interpolate_bilinear(x, size):
+    """F.interpolate(x, size, mode='bilinear', align_corners=False) with autograd (common.py:96)."""
+    return _ResizeBilinearFn.apply(x, int(size[0]), int(size[1]))
+
+
+class _SoftmaxChannelFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        B, C = x.shape[:2]
+        y = torch.empty_like(x)
+        _ck(lib().muvo_softmax_channel_fwd(_f(x), _f(y), B, C, _i64(x[0, 0].numel()), _st()))
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        y, = ctx.saved_tensors
+        B, C = y.shape[:2]
+        dx = torch.empty_like(y)
+        _ck(lib().muvo_softmax_channel_bwd(_f(y), _f(g.contiguous()), _f(dx), B, C, _i64(y[0, 0].numel()), _st()))
+        return dx
+
+
+def softmax_channel(x):
+    """x.softmax(dim=1) of an (B, C, ...) tensor (mile.py:509)."""
+    return _SoftmaxChannelFn.apply(x)
 
 
 def resize_nearest(x, out_sz):

@@ -364,16 +364,54 @@ class VoxelDecoder1(nn.Module):
         return {'voxel_4': o4, 'voxel_2': o2, 'voxel_1': o1}
 
 
-class MileRef(nn.Module):
-    """muvo/models/mile.py:16-161,284-402 (construction), :404-593 (forward/encode), base_1d branch."""
+class DecoderUp(nn.Module):
+    """common.py:71-99 (`Decoder`): coarse-to-fine skip decoder with bilinear upsampling (align_corners=False)."""
 
-    def __init__(self, cfg: dict = None):
+    def __init__(self, chans, cout):
+        super().__init__()
+        self.conv1 = _cbr(chans[-1], cout)
+        self.upsample_skip_convs = nn.ModuleList(_cbr(c, cout) for c in reversed(chans[:-1]))
+        self.out_channels = cout
+
+    def forward(self, xs):
+        x = self.conv1(xs[-1])
+        for i, conv in enumerate(self.upsample_skip_convs):
+            size = xs[-(i + 2)].shape[-2:]
+            x = conv(xs[-(i + 2)]) + F.interpolate(x, size=size, mode='bilinear', align_corners=False)
+        return x
+
+
+BEV_DEFAULTS = dict(SIZE=(192, 192), RESOLUTION=0.2, OFFSET_FORWARD=-64, FEATURE_DOWNSAMPLE=4, D_BOUND=(1.0, 38.0, 1.0),
+                    SPARSE=True, SPARSE_COUNT=10)   # config.py:135-144
+
+
+class MileRef(nn.Module):
+    """muvo/models/mile.py:16-161,284-402 (construction), :404-593 (forward/encode), base_1d branch; bev=True adds the
+    MODEL.TRANSFORMER.BEV branch (mile.py:33-59,506-524): Decoder instead of DecoderDS, mono depth head, frustum pooling
+    and the two-conv BEV down-sampling."""
+
+    def __init__(self, cfg: dict = None, bev: bool = False):
         super().__init__()
         cfg = cfg or base_1d_cfg()
         self.cfg = cfg
+        self.bev = bev
         tc, emb = cfg['TRANSFORMER_CHANNELS'], cfg['EMBEDDING_DIM']
         self.encoder = ResNet18(3)
-        self.feat_decoder = DecoderDS((128, 256, 512), tc)
+        self.feat_decoder = DecoderUp((128, 256, 512), tc) if bev else DecoderDS((128, 256, 512), tc)
+        if bev:
+            bc = {**BEV_DEFAULTS, **cfg.get('BEV', {})}
+            ds_ = bc['FEATURE_DOWNSAMPLE']
+            self.bev_args = dict(size=(bc['SIZE'][0] // ds_, bc['SIZE'][1] // ds_), scale=bc['RESOLUTION'] * ds_,
+                                 offsetx=bc['OFFSET_FORWARD'] / ds_, dbound=list(bc['D_BOUND']), downsample=8)
+            self.sparse_depth, self.sparse_depth_count = bc['SPARSE'], bc['SPARSE_COUNT']
+            self.frustum_pooling = nn.Module()          # state-dict compatibility: the one persistent buffer (:80)
+            self.frustum_pooling.register_buffer(
+                'bev_intrinsics', frustum_grid(self.bev_args['size'], self.bev_args['scale'], self.bev_args['offsetx'])[3])
+            n_bins = len(torch.arange(*bc['D_BOUND']))
+            self.depth_decoder = DecoderUp((128, 256, 512), tc)
+            self.depth = nn.Conv2d(tc, n_bins, kernel_size=1)
+            self.bev_down_sample_4 = nn.Sequential(nn.Conv2d(tc, 512, kernel_size=5, stride=2, padding=2), nn.ReLU(),
+                                                   nn.Conv2d(512, tc, kernel_size=5, stride=2, padding=2))
         self.range_view_encoder = ResNet18(4)
         self.range_view_decoder = DecoderDS((128, 256, 512), tc)
         self.type_embedding = nn.Parameter(torch.zeros(1, 1, tc, 2))
@@ -403,7 +441,17 @@ class MileRef(nn.Module):
     def encode(self, batch):
         b, s = batch['image'].shape[:2]
         image = batch['image'].flatten(0, 1)
-        x = self.feat_decoder(self.encoder(image))
+        xs = self.encoder(image)
+        x = self.feat_decoder(xs)
+        if self.bev:                                                               # mile.py:506-524
+            depth = self.depth(self.depth_decoder(xs)).softmax(dim=1)
+            if self.sparse_depth:
+                mask = torch.zeros(depth.shape, dtype=torch.bool)
+                mask.scatter_(1, depth.topk(self.sparse_depth_count, dim=1)[1], 1)
+            else:
+                mask = torch.zeros(0)
+            x = frustum_pool(x, depth, mask, batch['intrinsics'].flatten(0, 1), batch['extrinsics'].flatten(0, 1), **self.bev_args)
+            x = self.bev_down_sample_4(x)
         lf = self.range_view_decoder(self.range_view_encoder(batch['range_view_pcd_xyzd'].flatten(0, 1)))
         nf = self.cfg['TRANSFORMER_CHANNELS'] // 2
         it = x + position_embedding_sine(x.shape[2], x.shape[3], nf)
@@ -676,3 +724,68 @@ class EvalMetrics:
                     precision=tp / (tp + fp) if tp else 0.0, recall=tp / (tp + fn) if tp else 0.0,
                     iou=tp / (tp + fp + fn) if tp else 0.0, iou_ssc=iou_ssc, iou_ssc_mean=float(iou_ssc[1:].mean()),
                     completion=self.comp.tolist(), tps=self.tps.tolist(), fps=self.fps.tolist(), fns=self.fns.tolist())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BEV lifting: CPU restatement of FrustumPooling (muvo/models/frustum_pooling.py:67-217) as called from
+# Mile.encode (mile.py:506-522).  Pinned against the real module by tests/golden/frustum_pool.* (make_golden_frustum.py).
+# ------------------------------------------------------------------------------------------------------------------
+def frustum_grid(size, scale, offsetx):
+    """gen_dx_bx (frustum_pooling.py:10-21) + bev_params_to_intrinsics (geometry_utils.py:8-19): cell size dx, first cell
+    centre bx, cell counts nx of the (forward, left, up) grid and the metric -> BEV pixel map."""
+    bounds = [[-size[0] * scale / 2 - offsetx * scale, size[0] * scale / 2 - offsetx * scale, scale],
+              [-size[1] * scale / 2, size[1] * scale / 2, scale], [-10.0, 10.0, 20.0]]
+    dx = torch.tensor([r[2] for r in bounds], dtype=torch.float32)
+    bx = torch.tensor([r[0] + r[2] / 2.0 for r in bounds], dtype=torch.float32)
+    nx = [int(round((r[1] - r[0]) / r[2])) for r in bounds]
+    bev = torch.tensor([[1 / scale, 0, size[0] / 2 + offsetx], [0, -1 / scale, size[1] / 2], [0, 0, 1]], dtype=torch.float32)
+    return dx, bx, nx, bev
+
+
+def frustum_cells(intrinsics, extrinsics, H, W, size, scale, offsetx, dbound, downsample):
+    """Cell of every frustum point (initialize_frustum :92-106, get_geometry :108-128, voxel_pooling :139-158): returns
+    (ix, iy, iz, inside) of shape (B, D, H, W).  The float -> long cast truncates toward zero, so coordinates in (-1, 0)
+    land in cell 0 like in the reference."""
+    dt = intrinsics.dtype
+    dx, bx, nx, bev = frustum_grid(size, scale, offsetx)
+    ds = torch.arange(dbound[0], dbound[1], dbound[2], dtype=torch.float32).to(dt)
+    D = len(ds)
+    xs = torch.linspace(0, W * downsample - 1, W, dtype=torch.float).to(dt).view(1, 1, W).expand(D, H, W)
+    ys = torch.linspace(0, H * downsample - 1, H, dtype=torch.float).to(dt).view(1, H, 1).expand(D, H, W)
+    dd = ds.view(-1, 1, 1).expand(D, H, W)
+    pts = torch.stack((xs * dd, ys * dd, dd), -1).unsqueeze(-1)                      # (D, H, W, 3, 1)
+    fx, fy, cx, cy = intrinsics[:, 0, 0], intrinsics[:, 1, 1], intrinsics[:, 0, 2], intrinsics[:, 1, 2]
+    one, zero = torch.ones_like(fx), torch.zeros_like(fx)
+    kinv = torch.stack((torch.stack((1 / fx, zero, -cx / fx), -1), torch.stack((zero, 1 / fy, -cy / fy), -1),
+                        torch.stack((zero, zero, one), -1)), -2)
+    combine = extrinsics[:, :3, :3].matmul(kinv)
+    g = combine.view(-1, 1, 1, 1, 3, 3).matmul(pts.unsqueeze(0)).squeeze(-1) + extrinsics[:, :3, 3].view(-1, 1, 1, 1, 3)
+    bev, dx, bx = bev.to(dt), dx.to(dt), bx.to(dt)
+    g0 = (g[..., 0] * bev[0, 0] + bev[0, 2]).long()
+    g1 = (g[..., 1] * bev[1, 1] + bev[1, 2]).long()
+    g2 = ((g[..., 2] - bx[2] + dx[2] / 2.) / dx[2]).long()
+    inside = (g0 >= 0) & (g0 < nx[0]) & (g1 >= 0) & (g1 < nx[1]) & (g2 >= 0) & (g2 < nx[2])
+    return g0, g1, g2, inside, nx
+
+
+def frustum_pool(feat, depth, mask, intrinsics, extrinsics, size, scale, offsetx, dbound, downsample):
+    """out[b, c * nz + iz, iy, ix] = sum over the lifted points of the cell of depth[b, d, h, w] * feat[b, c, h, w]
+    (outer product mile.py:519, voxel_pooling frustum_pooling.py:130-182, its sort + cumsum + difference being a per-cell
+    sum).  mask: (B, D, H, W) bool of the points to lift, or an empty tensor for all (mile.py:511-518)."""
+    B, C, H, W = feat.shape
+    g0, g1, g2, inside, nx = frustum_cells(intrinsics, extrinsics, H, W, size, scale, offsetx, dbound, downsample)
+    if mask.numel():
+        inside = inside & mask
+    out = torch.zeros(B, C, nx[2], nx[1], nx[0], dtype=feat.dtype)
+    b_, d_, h_, w_ = torch.nonzero(inside, as_tuple=True)
+    vals = depth[b_, d_, h_, w_].unsqueeze(1) * feat[b_, :, h_, w_]                   # (P, C)
+    flat = ((b_ * nx[2] + g2[b_, d_, h_, w_]) * nx[1] + g1[b_, d_, h_, w_]) * nx[0] + g0[b_, d_, h_, w_]
+    acc = torch.zeros(B * nx[2] * nx[1] * nx[0], C, dtype=feat.dtype).index_add_(0, flat, vals)
+    out = acc.view(B, nx[2], nx[1], nx[0], C).permute(0, 4, 1, 2, 3)
+    return torch.cat(out.unbind(dim=2), 1).contiguous()
+
+
+def frustum_depth_map(depth, dbound, downsample):
+    """get_depth_map (frustum_pooling.py:211-217): expected depth, bilinear x downsample (align_corners=False)."""
+    ds = torch.arange(dbound[0], dbound[1], dbound[2], dtype=torch.float32).view(1, -1, 1, 1)
+    return F.interpolate((ds * depth).sum(1, keepdim=True), scale_factor=float(downsample), mode='bilinear', align_corners=False)

@@ -1,0 +1,98 @@
+"""Golden fixture of the BEV-lifting model variant (MODEL.TRANSFORMER.BEV=True, the "BEV-mapped
+image features" configuration): one training step of the REAL reference (forward, 21 losses, backward) at b=1, s=2 with
+deterministic weights, the seeded synthetic batch plus a forward-looking camera pose, and explicit RSSM noise; checks the
+oracle restatement against it and writes tests/golden/bev_b1s2.{json,npz}.
+
+Usage: python oracle/refimport/make_golden_bev.py
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.abspath(os.path.join(HERE, '..', '..'))
+sys.path.insert(0, REPO)
+sys.path.insert(0, HERE)
+
+import make_golden as G  # noqa: E402
+from muvo_amd.data.frustum_inputs import camera_pose  # noqa: E402
+from muvo_amd.data.synthetic import make_batch, make_noise  # noqa: E402
+from muvo_amd.utils import detinit  # noqa: E402
+
+BEV_PREFIXES = ('feat_decoder.', 'depth_decoder.', 'depth.', 'bev_down_sample_4.')
+
+
+def main():
+    b, s, seed = 1, 2, 2468
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    ref_trainer, ref_config = G.import_reference()
+    cfg = G.effective_cfg_dict(ref_config)
+    cfg['RECEPTIVE_FIELD'], cfg['FUTURE_HORIZON'], cfg['STEPS'] = s, 0, 100000
+    cfg['MODEL']['TRANSFORMER']['BEV'] = True
+    trainer = ref_trainer.WorldModelTrainer(cfg)
+    trainer.train()
+    trainer.preprocess.eval()
+    model = trainer.model
+    bev_intr = model.frustum_pooling.bev_intrinsics.clone()      # a geometric constant, not a weight: keep it
+    detinit.fill_state_dict_(model)
+    model.frustum_pooling.bev_intrinsics.copy_(bev_intr)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if isinstance(m, torch.nn.MultiheadAttention):
+            m.dropout = 0.0
+    spec = {k: list(v.shape) for k, v in model.state_dict().items()}
+    eps, use_prior = make_noise(b, s, seed=seed)
+    coin = detinit.uniform_01(detinit.name_key(f'noise:{seed}') + 7, s)
+    batch = make_batch(b, s, seed=seed)
+    batch['extrinsics'] = camera_pose(b, s)
+    raw = {k: v.clone() for k, v in batch.items()}
+    t0 = time.time()
+    with G.NoisePatch(eps, coin):
+        output, _ = trainer.forward(batch)
+    losses = trainer.compute_loss(batch, output)
+    total = trainer.loss_reducing(losses)
+    total.backward()
+    print(f'reference BEV step {time.time() - t0:.1f}s total={total.item():.6f}')
+    fx = dict(b=b, s=s, seed=seed, use_prior=use_prior, total=float(total), losses={k: float(v) for k, v in losses.items()},
+              state_dict=spec, outputs={}, grad_l2={})
+    samples = {}
+    for k in ['rgb_1', 'lidar_reconstruction_1', 'voxel_1', 'throttle_brake', 'steering']:
+        st, smp = G.tensor_stats(output[k])
+        st['shape'] = list(output[k].shape)
+        fx['outputs'][k] = st
+        samples['out.' + k] = smp
+    st, smp = G.tensor_stats(output['posterior']['mu'])
+    fx['outputs']['posterior.mu'] = {**st, 'shape': list(output['posterior']['mu'].shape)}
+    samples['out.posterior.mu'] = smp
+    for n, p in model.named_parameters():
+        if p.grad is not None and (n.startswith(BEV_PREFIXES) or n in ('encoder.conv1.weight', 'type_embedding', 'features_combine.weight')):
+            fx['grad_l2'][n] = float(p.grad.double().pow(2).sum().sqrt())
+    # oracle restatement on the same inputs
+    from oracle import muvo_ref
+    om = muvo_ref.MileRef(bev=True)
+    om.load_state_dict(model.state_dict(), strict=True)
+    om.train()
+    om.set_dropout(0.0)
+    o_total, o_losses, o_out, _ = muvo_ref.training_step(om, raw, eps, use_prior)
+    o_total.backward()
+    dev = max(abs(float(o_losses[k]) - fx['losses'][k]) / max(abs(fx['losses'][k]), 1e-12) for k in fx['losses'])
+    gdev = 0.0
+    for n, p in om.named_parameters():
+        if n in fx['grad_l2'] and fx['grad_l2'][n] > 0:
+            gdev = max(gdev, abs(float(p.grad.double().pow(2).sum().sqrt()) - fx['grad_l2'][n]) / fx['grad_l2'][n])
+    print(f'oracle vs reference: max rel loss dev {dev:.3e}, max rel grad-norm dev {gdev:.3e}')
+    fx['oracle_vs_reference'] = dict(max_rel_loss_dev=dev, max_rel_grad_norm_dev=gdev)
+    with open(os.path.join(REPO, 'tests', 'golden', 'bev_b1s2.json'), 'w') as f:
+        json.dump(fx, f)
+    np.savez_compressed(os.path.join(REPO, 'tests', 'golden', 'bev_b1s2_samples.npz'), **samples)
+    print('wrote tests/golden/bev_b1s2.*')
+
+
+if __name__ == '__main__':
+    main()

@@ -28,6 +28,9 @@ CONV_CASES = [
     (2, False, 64, 128, 3, 2, 1, 0, (20, 26), False, 0),
     (2, False, 64, 128, 1, 2, 0, 0, (20, 26), False, 0),
     (2, False, 48, 160, 3, 1, 1, 0, (10, 26), False, 0),
+    # 5x5 stride-2 convs of the BEV down-sampling (mile.py:53-57): data gradient = four sub-pixel phases with 9/6/6/4 taps
+    (2, False, 48, 64, 5, 2, 2, 0, (12, 12), True, 1),
+    (2, False, 64, 48, 5, 2, 2, 0, (11, 9), True, 0),
     (2, False, 64, 3, 1, 1, 0, 0, (24, 40), True, 0),
     (2, False, 20, 4, 1, 1, 0, 0, (16, 64), True, 0),
     (2, True, 40, 24, 5, 2, 2, 1, (5, 13), True, 3),
@@ -96,7 +99,9 @@ def test_conv_family(dev, case, conv_mode):
         yr = F.conv_transpose2d(xc, w, b, stride, pad, out_pad)
     else:
         yr = F.conv2d(xc, w, b, stride, pad)
-    if act == 2:
+    if act == 1:
+        yr = F.relu(yr)
+    elif act == 2:
         yr = F.leaky_relu(yr, slope)
     elif act == 3:
         yr = F.elu(yr)
@@ -509,3 +514,33 @@ def test_adamw_matches_torch(dev):
         opt.step()
         ops.adamw_step(p, (g * step).to(dev), m, v, 3e-4, 0.95, 0.999, 1e-8, 0.01, step)
     _close(p, pr.data, rtol=1e-6, atol=1e-7, name='adamw')
+
+
+def test_conv_strided_dgrad_uses_one_arithmetic_for_all_phases(dev):
+    """Regression: the four sub-pixel phases of a 5x5 stride-2 data gradient have 9/6/6/4 taps; with a work threshold between
+    their sizes only some qualified for bf16x3, and the fp32 phases then read dy without the ReLU derivative (the fused
+    dy * act'(y) pass feeds only the bf16x3 kernels).  The plan now promotes all phases together."""
+    from muvo_amd import nn as hnn
+    from muvo_amd import ops
+    old = ops.get_conv_mode()
+    ops.set_conv_mode(ops.CONV_BF16X3, min_gflop=0.008)      # per-item phase work: 0.0106 (9 taps) ... 0.0047 (4 taps) GFLOP
+    try:
+        torch.manual_seed(0)
+        with torch.device(dev):
+            m = hnn.Conv2d(64, 64, 5, 2, 2)
+        x = torch.randn(3, 64, 24, 24)
+        xg = x.to(dev).requires_grad_(True)
+        y = m(xg, act=ops.ACT_RELU)
+        w, b = m.weight.detach().cpu().requires_grad_(True), m.bias.detach().cpu().requires_grad_(True)
+        xc = x.clone().requires_grad_(True)
+        yr = F.relu(F.conv2d(xc, w, b, 2, 2))
+        g = torch.randn_like(yr)
+        yr.backward(g)
+        m.weight.grad, m.bias.grad = torch.zeros_like(m.weight), torch.zeros_like(m.bias)
+        y.backward(g.to(dev))
+        _close(y, yr, name='fwd')
+        _close(xg.grad, xc.grad, name='dgrad')
+        _close(m.weight.grad, w.grad, rtol=5e-4, name='wgrad')
+        _close(m.bias.grad, b.grad, rtol=5e-4, name='dbias')
+    finally:
+        ops.set_conv_mode(old, min_gflop=2.0)
