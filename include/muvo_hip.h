@@ -247,6 +247,20 @@ int muvo_resize_bilinear_bwd(const float* dy, float* dx, int64_t NC, int H, int 
 int muvo_softmax_channel_fwd(const float* x, float* y, int B, int C, int64_t HW, void* stream);
 int muvo_softmax_channel_bwd(const float* y, const float* dy, float* dx, int B, int C, int64_t HW, void* stream);
 
+/* ---- input pipeline on the device: per-frame work of CarlaDataset.load_single_element_time_t (muvo/data/dataset.py:275-327) ----
+ * muvo_range_projection: raw lidar sweep (P,3) float32 in the sensor frame + CARLA object tags -> range_view_pcd_xyzd (4,H,W)
+ *   float32 (x, y, z in the ego frame, depth; empty pixels 0,0,0,-1) and optionally the label image (H,W): convert_coor_lidar
+ *   (data/data_preprocessing.py:119-122), label remap and ego-box masking (dataset.py:281-290), PointCloud.do_range_projection
+ *   (muvo/utils/geometry_utils.py:176-213; float64 geometry, the closest point of a pixel wins, exact ties: lowest index).
+ *   remap: 256-entry table; ego_dim: EGO_VEHICLE_DIMENSION (constants.py:8); scratch: 12*H*W bytes.
+ * muvo_voxel_grid: sparse voxel rows (Q,4) int64 (x, y, z, tag) -> dense uint8 grid (dataset.py:316-327: tag 255 -> 0, remap,
+ *   later rows win); scratch: 4*X*Y*Z bytes. */
+int muvo_range_projection(const float* points_xyz, const uint8_t* obj_tag, const uint8_t* remap, int64_t P, const double* lidar_pos,
+                          const double* ego_dim, double fov_down_deg, double fov_up_deg, int H, int W, void* scratch,
+                          float* xyzd, uint8_t* seg, void* stream);
+int muvo_voxel_grid(const int64_t* rows, int64_t Q, const uint8_t* remap, int X, int Y, int Z, uint32_t* scratch, uint8_t* voxels,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

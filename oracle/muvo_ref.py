@@ -789,3 +789,60 @@ def frustum_depth_map(depth, dbound, downsample):
     """get_depth_map (frustum_pooling.py:211-217): expected depth, bilinear x downsample (align_corners=False)."""
     ds = torch.arange(dbound[0], dbound[1], dbound[2], dtype=torch.float32).view(1, -1, 1, 1)
     return F.interpolate((ds * depth).sum(1, keepdim=True), scale_factor=float(downsample), mode='bilinear', align_corners=False)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Input pipeline (SURVEY 8f rank 3): CPU restatement of the lidar range projection and the voxel densification the
+# dataset does per frame (muvo/data/dataset.py:275-327, muvo/utils/geometry_utils.py:166-213,
+# data/data_preprocessing.py:119-122, constants.py:8,180-204).  Pinned by tests/golden/input_pipeline.npz.
+# ------------------------------------------------------------------------------------------------------------------
+EGO_VEHICLE_DIMENSION = (4.902, 2.128, 1.511)      # constants.py:8
+
+
+def label_remap():
+    """constants.py:180-204 + dataset.py:281-283: CARLA tag -> {0 empty/sky, 1 occupied}; unknown tags -> 1."""
+    import numpy as np
+    remap = np.full(23, 1, dtype=np.uint8)
+    remap[[0, 13]] = 0
+    return remap
+
+
+def range_projection(points_xyz, obj_tag, lidar_position=(1.0, 0.0, 2.0), fov=(-30, 10), H=64, W=1024):
+    """Raw sweep -> (range_view_pcd_xyzd (4, H, W) float32, range_view_pcd_seg (H, W) uint8).  Float64 geometry like numpy's
+    promotion in the reference; the closest point of a pixel wins (reference: sort by depth descending, then scatter with
+    last-write-wins); equal depths: the lowest point index wins (the reference's order among exact ties is unspecified)."""
+    import numpy as np
+    pts = points_xyz.astype(np.float32).copy()
+    pts += np.asarray(lidar_position)                       # convert_coor_lidar: float32 in-place add, then mirror y
+    pts[:, 1] *= -1
+    sem = label_remap()[obj_tag]
+    x, y, z = EGO_VEHICLE_DIMENSION
+    lo, hi = np.array([-x / 2, -y / 2, 0]), np.array([x / 2, y / 2, z])
+    keep = ~((lo < pts) & (pts < hi)).all(axis=1)
+    pts, sem = pts[keep], sem[keep]
+    pc = pts * np.array([1, -1, 1]) - np.asarray(lidar_position, dtype=np.float64)
+    depth = np.sqrt((pc * pc).sum(axis=1))
+    yaw, pitch = np.arctan2(-pc[:, 1], pc[:, 0]), np.arcsin(pc[:, 2] / depth)
+    fd, fu = fov[0] / 180.0 * np.pi, fov[1] / 180.0 * np.pi
+    pw = np.clip(np.floor(0.5 * (1.0 - yaw / np.pi) * W), 0, W - 1).astype(np.int64)
+    ph = np.clip(np.floor((1.0 - (pitch + abs(fd)) / (fu - fd)) * H), 0, H - 1).astype(np.int64)
+    order = np.lexsort((-np.arange(len(depth)), depth))[::-1]   # depth descending; among ties the lowest index comes last
+    xyzd = np.zeros((4, H, W), dtype=np.float32)
+    xyzd[3] = -1
+    seg = np.zeros((H, W), dtype=np.uint8)
+    xyzd[3][ph[order], pw[order]] = depth[order]
+    for a in range(3):
+        xyzd[a][ph[order], pw[order]] = pts[order, a]
+    seg[ph[order], pw[order]] = sem[order]
+    return xyzd, seg
+
+
+def voxel_grid(voxel_data, size=(192, 192, 64)):
+    """dataset.py:316-327: (Q, 4) rows of x, y, z, CARLA tag -> dense uint8 grid; tag 255 -> 0, remap, later rows win."""
+    import numpy as np
+    sem = voxel_data[:, -1].copy()
+    sem[sem == 255] = 0
+    sem = label_remap()[sem]
+    vox = np.zeros(size, dtype=np.uint8)
+    vox[voxel_data[:, 0], voxel_data[:, 1], voxel_data[:, 2]] = sem
+    return vox
