@@ -194,6 +194,13 @@ int muvo_voxel_loss_fwd(const float* logits, const uint8_t* target, int64_t F, i
                         float weight, double* stats, float* coef, float* loss3, void* stream);
 int muvo_voxel_loss_bwd(const float* logits, const uint8_t* target, float* dlogits, int64_t F, int C, int64_t V,
                         const float* class_w, float weight, const float* coef, const float* gout3, void* stream);
+/* per-pixel class-weighted cross entropy of SegmentationLoss (muvo/losses.py:22-37, F.cross_entropy(reduction='none')):
+ * logits (N,C,HW), target (N,HW) bytes, class_w C floats or NULL, loss / gloss (N,HW); the top-k / mean reduction stays with
+ * the caller (losses.py:44-50) */
+int muvo_seg_ce_fwd(const float* logits, const uint8_t* target, const float* class_w, float* loss, int64_t N, int C, int64_t HW,
+                    void* stream);
+int muvo_seg_ce_bwd(const float* logits, const uint8_t* target, const float* class_w, const float* gloss, float* dlogits, int64_t N,
+                    int C, int64_t HW, void* stream);
 int muvo_l1_rows_fwd(const float* p, const float* t, int64_t rows, int cols, float weight, float* loss, void* stream);
 int muvo_l1_rows_bwd(const float* p, const float* t, float* dp, int64_t rows, int cols, float weight, const float* gout,
                      void* stream);

@@ -325,6 +325,45 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   }
 }
 
+
+// ---- per-pixel weighted cross entropy of SegmentationLoss (muvo/losses.py:22-37: F.cross_entropy(reduction='none',
+// weight=w)); logits (N, C, HW), target (N, HW) bytes, loss (N, HW).  loss = -w[t] log_softmax(x)[t]
+__global__ void __launch_bounds__(256)
+seg_ce_fwd_kernel(const float* __restrict__ logits, const unsigned char* __restrict__ target, const float* __restrict__ w,
+                  float* __restrict__ loss, long N, int C, long HW) {
+  const long n = N * HW;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long f = i / HW, p = i - f * HW;
+    const float* x = logits + f * C * HW + p;
+    float m = x[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, x[(long)c * HW]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(x[(long)c * HW] - m);
+    const int t = target[i];
+    const float lp = (t < C ? x[(long)t * HW] : 0.f) - m - logf(s);
+    loss[i] = t < C ? -(w ? w[t] : 1.f) * lp : 0.f;
+  }
+}
+// dlogits[c] = gloss * w[t] * (softmax[c] - [c == t])
+__global__ void __launch_bounds__(256)
+seg_ce_bwd_kernel(const float* __restrict__ logits, const unsigned char* __restrict__ target, const float* __restrict__ w,
+                  const float* __restrict__ gloss, float* __restrict__ dlogits, long N, int C, long HW) {
+  const long n = N * HW;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long f = i / HW, p = i - f * HW;
+    const float* x = logits + f * C * HW + p;
+    float* d = dlogits + f * C * HW + p;
+    float m = x[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, x[(long)c * HW]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(x[(long)c * HW] - m);
+    const int t = target[i];
+    const float g = t < C ? gloss[i] * (w ? w[t] : 1.f) : 0.f;
+    const float inv = 1.f / s;
+    for (int c = 0; c < C; ++c) d[(long)c * HW] = g * (expf(x[(long)c * HW] - m) * inv - (c == t ? 1.f : 0.f));
+  }
+}
+
 #define ST ((hipStream_t)stream)
 extern "C" {
 
@@ -368,6 +407,21 @@ int muvo_voxel_loss_bwd(const float* logits, const uint8_t* target, float* dlogi
   hipLaunchKernelGGL(voxel_loss_bwd_kernel, dim3(ew_grid(F * V)), dim3(256), 0, ST, logits, target, dlogits, (long)F, C, (long)V,
                      class_w, coef, gout3, weight);
   MUVO_CHECK_LAUNCH("voxel_loss_bwd");
+  return MUVO_OK;
+}
+int muvo_seg_ce_fwd(const float* logits, const uint8_t* target, const float* class_w, float* loss, int64_t N, int C, int64_t HW,
+                    void* stream) {
+  MUVO_CHECK_ARG(logits && target && loss && N > 0 && C > 0 && C < 255 && HW > 0, "seg_ce_fwd: bad args");
+  hipLaunchKernelGGL(seg_ce_fwd_kernel, dim3(ew_grid(N * HW)), dim3(256), 0, ST, logits, target, class_w, loss, (long)N, C, (long)HW);
+  MUVO_CHECK_LAUNCH("seg_ce_fwd");
+  return MUVO_OK;
+}
+int muvo_seg_ce_bwd(const float* logits, const uint8_t* target, const float* class_w, const float* gloss, float* dlogits, int64_t N,
+                    int C, int64_t HW, void* stream) {
+  MUVO_CHECK_ARG(logits && target && gloss && dlogits && N > 0 && C > 0 && C < 255 && HW > 0, "seg_ce_bwd: bad args");
+  hipLaunchKernelGGL(seg_ce_bwd_kernel, dim3(ew_grid(N * HW)), dim3(256), 0, ST, logits, target, class_w, gloss, dlogits, (long)N, C,
+                     (long)HW);
+  MUVO_CHECK_LAUNCH("seg_ce_bwd");
   return MUVO_OK;
 }
 int muvo_l1_rows_fwd(const float* p, const float* t, int64_t rows, int cols, float weight, float* loss, void* stream) {

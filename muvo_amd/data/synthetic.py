@@ -57,3 +57,18 @@ def make_noise(b: int, s: int, state_dim: int = 512, seed: int = 1234, use_prior
     coin = detinit.uniform_01(k + 7, s)
     use_prior = [bool(t > 0 and coin[t] < use_prior_prob) for t in range(s)]
     return eps, use_prior
+
+
+def make_aux_inputs(b, s, seed, image_hw=(600, 960), range_hw=(64, 1024), n_classes=9, device='cpu'):
+    """Inputs of the config-off heads: `range_view_pcd_seg` and `semantic_image` class maps (int64,
+    values in [0, n_classes)) and a `depth` image in [0, 1) (dataset.py:300-304,331-352)."""
+    k = detinit.name_key(f'aux:{seed}')
+    n = b * s
+    out = {
+        'range_view_pcd_seg': torch.from_numpy((detinit.hash_u64(k + 1, n * range_hw[0] * range_hw[1]) % np.uint64(n_classes))
+                                               .astype(np.int64)).view(b, s, 1, *range_hw),
+        'semantic_image': torch.from_numpy((detinit.hash_u64(k + 2, n * image_hw[0] * image_hw[1]) % np.uint64(n_classes))
+                                           .astype(np.int64)).view(b, s, 1, *image_hw),
+        'depth': torch.from_numpy(detinit.uniform_01(k + 3, n * image_hw[0] * image_hw[1]).astype(np.float32)).view(b, s, 1, *image_hw),
+    }
+    return {kk: v.to(device) for kk, v in out.items()} if device != 'cpu' else out

@@ -1,6 +1,7 @@
 """Loss modules with the reference's names/signatures (muvo/losses.py:53-287) on the fused HIP loss kernels.
 `WorldModelTrainer.compute_loss` uses the fused multi-part entry points directly; these classes exist so code
 written against the reference's loss objects keeps working."""
+import torch
 import torch.nn as nn
 
 from muvo_amd import ops
@@ -66,3 +67,29 @@ class SemScalLoss(_VoxelTriple):
 
 class GeoScalLoss(_VoxelTriple):
     index = 2
+
+
+VOXEL_SEG_WEIGHTS = (1.0, 1.0, 1.0, 1.5, 2.0, 3.0, 1.0, 1.0, 1.0)      # constants.py:39
+SEMANTIC_SEG_WEIGHTS = (1.0, 1.0, 1.0, 2.0, 3.0, 1.0, 1.0, 1.0)        # constants.py:33
+
+
+class SegmentationLoss(nn.Module):
+    """muvo/losses.py:9-50: per-pixel (optionally class-weighted) cross entropy on the HIP kernel, then the mean of the
+    top-k hardest pixels of every frame (k = int(ratio * h * w)) or of all pixels.  The top-k selection itself is
+    torch.topk on the per-pixel loss (a selection, no arithmetic); its gradient flows back into the kernel's backward."""
+
+    def __init__(self, use_top_k=False, top_k_ratio=1.0, use_weights=False, poly_one=False, poly_one_coefficient=0.0, is_bev=True):
+        super().__init__()
+        if poly_one:
+            raise NotImplementedError('poly-1 is never enabled by the reference trainer (trainer.py:132-161)')
+        self.use_top_k, self.top_k_ratio, self.use_weights = use_top_k, top_k_ratio, use_weights
+        self.weights = (SEMANTIC_SEG_WEIGHTS if is_bev else VOXEL_SEG_WEIGHTS) if use_weights else None
+
+    def forward(self, prediction, target):
+        b, s, c, h, w = prediction.shape
+        cw = torch.tensor(self.weights, dtype=torch.float32, device=prediction.device) if self.weights is not None else None
+        loss = ops.seg_ce_pixel_loss(prediction.reshape(b * s, c, h, w), target.reshape(b * s, h, w), cw).view(b, s, -1)
+        if self.use_top_k:
+            k = int(self.top_k_ratio * loss.shape[2])
+            loss = loss.topk(k, dim=-1)[0]
+        return torch.mean(loss)

@@ -141,6 +141,18 @@ def LidarReHead(in_channels, n_classes, downsample_factor):
     return _Head('lidar_re_head', 'lidar_reconstruction', hnn.Conv2d(in_channels, n_classes, 1, 1, 0), downsample_factor)
 
 
+def LidarSegHead(in_channels, n_classes, downsample_factor):      # common.py:306-319
+    return _Head('seg_head', 'lidar_segmentation', hnn.Conv2d(in_channels, n_classes, 1, 1, 0), downsample_factor)
+
+
+def SemHead(in_channels, n_classes, downsample_factor):           # common.py:322-335
+    return _Head('sem_head', 'semantic_image', hnn.Conv2d(in_channels, n_classes, 1, 1, 0), downsample_factor)
+
+
+def DepthHead(in_channels, n_classes, downsample_factor):         # common.py:338-351
+    return _Head('depth_head', 'depth', hnn.Conv2d(in_channels, n_classes, 1, 1, 0), downsample_factor)
+
+
 def VoxelSemHead(in_channels, n_classes, downsample_factor):
     return _Head('segmentation_head', 'voxel', hnn.Conv3d(in_channels, n_classes, 1, 1, 0), downsample_factor)
 
@@ -224,7 +236,8 @@ class ConvDecoder(nn.Module):
             hnn.ConvTranspose2d(n_channels, n_channels, 5, 2, 2, 1), P(),
             hnn.ConvTranspose2d(n_channels, n_channels, 5, 2, 2, 1), P(),
             hnn.ConvTranspose2d(n_channels, n_channels, 6, 2, 2), P())
-        head_module = {'rgb': RGBHead, 'lidar_re': LidarReHead}[head]
+        head_module = {'rgb': RGBHead, 'lidar_re': LidarReHead, 'lidar_seg': LidarSegHead, 'sem_image': SemHead,
+                       'depth': DepthHead}[head]      # common.py:588-594
         self.trans_conv1 = nn.Sequential(hnn.ConvTranspose2d(n_channels, 256, 6, 2, 2), P())
         self.head_4 = head_module(256, out_channels, downsample_factor=4)
         self.trans_conv2 = nn.Sequential(hnn.ConvTranspose2d(256, 128, 6, 2, 2), P())

@@ -41,8 +41,8 @@ class Mile(nn.Module):
             unsupported.append('LIDAR off / POINT_PILLAR')
         if m.MEASUREMENTS.ENABLED or m.REWARD.ENABLED or not m.TRANSITION.ENABLED or not m.ROUTE.ENABLED:
             unsupported.append('MEASUREMENTS/REWARD/TRANSITION off/ROUTE off')
-        if cfg.SEMANTIC_SEG.ENABLED or cfg.LIDAR_SEG.ENABLED or cfg.SEMANTIC_IMAGE.ENABLED or cfg.DEPTH.ENABLED:
-            unsupported.append('SEMANTIC_SEG/LIDAR_SEG/SEMANTIC_IMAGE/DEPTH heads')
+        if cfg.SEMANTIC_SEG.ENABLED:
+            unsupported.append('SEMANTIC_SEG (BevDecoder) head')
         if unsupported:
             raise NotImplementedError('muvo_amd implements the base_1d hot path (SURVEY.md §8); not in scope: '
                                       + ', '.join(unsupported))
@@ -90,6 +90,13 @@ class Mile(nn.Module):
             self.rgb_decoder = ConvDecoder(state_dim, 3, constant_size=(5, 13), head='rgb')
         if cfg.LIDAR_RE.ENABLED:
             self.lidar_re = ConvDecoder(state_dim, cfg.LIDAR_RE.N_CHANNELS, constant_size=(1, 16), head='lidar_re')
+        # config-off heads of base_1d that share the ConvDecoder kernels (mile.py:337-363)
+        if cfg.LIDAR_SEG.ENABLED:
+            self.lidar_segmentation = ConvDecoder(state_dim, cfg.LIDAR_SEG.N_CLASSES, constant_size=(1, 16), head='lidar_seg')
+        if cfg.SEMANTIC_IMAGE.ENABLED:
+            self.sem_image_decoder = ConvDecoder(state_dim, cfg.SEMANTIC_IMAGE.N_CLASSES, constant_size=(5, 13), head='sem_image')
+        if cfg.DEPTH.ENABLED:
+            self.depth_image_decoder = ConvDecoder(state_dim, 1, constant_size=(5, 13), head='depth')
         if cfg.VOXEL_SEG.ENABLED:
             self.voxel_decoder = VoxelDecoder1(state_dim, cfg.VOXEL_SEG.N_CLASSES, cfg.VOXEL_SEG.DIMENSION, (3, 3, 1))
         self._pos_cache = {}
@@ -130,6 +137,7 @@ class Mile(nn.Module):
             output.update(unpack_sequence_dim(self.rgb_decoder(state), b, s))
         if self.cfg.LIDAR_RE.ENABLED:
             output.update(unpack_sequence_dim(self.lidar_re(state), b, s))
+        output.update(self._aux_heads(state, b, s))
         if self.cfg.VOXEL_SEG.ENABLED:
             output.update(unpack_sequence_dim(self.voxel_decoder(state), b, s))
         return output, state_dict
@@ -164,8 +172,19 @@ class Mile(nn.Module):
             out.update(unpack_sequence_dim(self.rgb_decoder(state), b, fh))
         if self.cfg.LIDAR_RE.ENABLED:
             out.update(unpack_sequence_dim(self.lidar_re(state), b, fh))
+        out.update(self._aux_heads(state, b, fh))
         if self.cfg.VOXEL_SEG.ENABLED:
             out.update(unpack_sequence_dim(self.voxel_decoder(state), b, fh))
+        return out
+
+    def _aux_heads(self, state, b, s):
+        out = {}
+        if self.cfg.LIDAR_SEG.ENABLED:
+            out.update(unpack_sequence_dim(self.lidar_segmentation(state), b, s))
+        if self.cfg.SEMANTIC_IMAGE.ENABLED:
+            out.update(unpack_sequence_dim(self.sem_image_decoder(state), b, s))
+        if self.cfg.DEPTH.ENABLED:
+            out.update(unpack_sequence_dim(self.depth_image_decoder(state), b, s))
         return out
 
     def encode(self, batch):

@@ -4,6 +4,7 @@ Same contract as the reference: mutates and returns the caller's batch dict, add
 range_view_label_{1,2,4}, voxel_label_{1,2,4}; `rgb_label_1` is the cropped [0,1] image (pre-normalisation) and
 `range_view_label_1` IS the range-view network input.  Pixel/route augmentation
 (preprocess.py:295-367, training only, torchvision) is not part of this round's path (next rows)."""
+import torch
 import torch.nn as nn
 
 from muvo_amd import ops
@@ -42,6 +43,29 @@ class PreProcess(nn.Module):
             h, w = rv.shape[-2:]
             for f in (2, 4):
                 batch[f'range_view_label_{f}'] = ops.resize_nearest(batch[f'range_view_label_{f // 2}'], (h // f, w // f))
+        # config-off inputs of base_1d (preprocess.py:127-149,164-175,228-241): crop like the image, then label pyramids
+        left, top, right, bottom = self.crop
+        if cfg.SEMANTIC_IMAGE.ENABLED:
+            sem = batch['semantic_image'][..., top:bottom, left:right].contiguous()
+            batch['semantic_image'] = sem
+            batch['semantic_image_label_1'] = sem
+            h, w = sem.shape[-2:]
+            for f in (2, 4):
+                batch[f'semantic_image_label_{f}'] = ops.resize_nearest(batch[f'semantic_image_label_{f // 2}'].to(torch.uint8),
+                                                                        (h // f, w // f))
+        if cfg.DEPTH.ENABLED:
+            dep = batch['depth'][..., top:bottom, left:right].float().contiguous()
+            batch['depth'] = dep
+            batch['depth_label_1'] = dep
+            h, w = dep.shape[-2:]
+            for f in (2, 4):
+                batch[f'depth_label_{f}'] = ops.resize_bilinear(batch[f'depth_label_{f // 2}'], h // f, w // f)
+        if cfg.LIDAR_SEG.ENABLED:
+            seg = batch['range_view_pcd_seg'].to(torch.uint8).contiguous()
+            batch['range_view_seg_label_1'] = seg
+            h, w = seg.shape[-2:]
+            for f in (2, 4):
+                batch[f'range_view_seg_label_{f}'] = ops.resize_nearest(batch[f'range_view_seg_label_{f // 2}'], (h // f, w // f))
         if cfg.VOXEL_SEG.ENABLED:
             batch['voxel_label_1'] = batch['voxel']
             x, y, z = batch['voxel'].shape[-3:]

@@ -58,7 +58,7 @@ EXPORTS = [
     'muvo_ssim_frames', 'muvo_sqdiff_frames', 'muvo_chamfer_sums', 'muvo_ssc_counts',
     'muvo_frustum_cells', 'muvo_frustum_pool_fwd', 'muvo_frustum_pool_bwd', 'muvo_depth_expectation',
     'muvo_resize_bilinear_bwd', 'muvo_softmax_channel_fwd', 'muvo_softmax_channel_bwd',
-    'muvo_range_projection', 'muvo_voxel_grid',
+    'muvo_range_projection', 'muvo_voxel_grid', 'muvo_seg_ce_fwd', 'muvo_seg_ce_bwd',
 ]
 
 
@@ -1197,6 +1197,33 @@ class L1RowsFn(torch.autograd.Function):
         _ck(lib().muvo_l1_rows_bwd(_f(pred), _f(target), _f(dp), _i64(rows), cols, _fl(ctx.weight), _f(g.contiguous()),
                                    _st()))
         return dp, None, None
+
+
+class _SegCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, class_w):
+        logits = logits.contiguous()
+        N, Cc = logits.shape[:2]
+        HW = logits[0, 0].numel()
+        loss = torch.empty(N, HW, device=logits.device, dtype=torch.float32)
+        _ck(lib().muvo_seg_ce_fwd(_f(logits), _p(target), _f(class_w), _f(loss), _i64(N), Cc, _i64(HW), _st()))
+        ctx.save_for_backward(logits, target, class_w)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, class_w = ctx.saved_tensors
+        N, Cc = logits.shape[:2]
+        HW = logits[0, 0].numel()
+        d = torch.empty_like(logits)
+        _ck(lib().muvo_seg_ce_bwd(_f(logits), _p(target), _f(class_w), _f(g.contiguous()), _f(d), _i64(N), Cc, _i64(HW), _st()))
+        return d, None, None
+
+
+def seg_ce_pixel_loss(logits, target, class_w=None):
+    """F.cross_entropy(logits (N, C, ...), target (N, ...), weight=class_w, reduction='none') flattened to (N, HW)."""
+    t = target.reshape(target.shape[0], -1).to(torch.uint8).contiguous()
+    return _SegCEFn.apply(logits.float(), t, class_w)
 
 
 def l1_rows_loss(pred, target, weight):

@@ -193,6 +193,21 @@ class WorldModelTrainer(_Base):
                 both = ops.spatial_losses(pred, batch[f'range_view_label_{f}'], [(0, 3, 2, w), (c - 1, c, 1, w)])
                 losses[f'lidar_re_{f}'] = both[0]
                 losses[f'lidar_depth_{f}'] = both[1]
+        # config-off heads of base_1d (trainer.py:338-365)
+        if cfg.LIDAR_SEG.ENABLED:
+            crit = self._seg_loss('lidar', cfg.LIDAR_SEG)
+            for f in (1, 2, 4):
+                losses[f'lidar_seg_{f}'] = crit(output[f'lidar_segmentation_{f}'], batch[f'range_view_seg_label_{f}']) \
+                    * ((1 / f) * cfg.LOSSES.WEIGHT_LIDAR_SEG)
+        if cfg.SEMANTIC_IMAGE.ENABLED:
+            crit = self._seg_loss('image', cfg.SEMANTIC_IMAGE)
+            for f in (1, 2, 4):
+                losses[f'semantic_image_{f}'] = crit(output[f'semantic_image_{f}'], batch[f'semantic_image_label_{f}']) \
+                    * ((1 / f) * cfg.LOSSES.WEIGHT_SEM_IMAGE)
+        if cfg.DEPTH.ENABLED:
+            for f in (1, 2, 4):
+                w = (1 / f) * cfg.LOSSES.WEIGHT_DEPTH
+                losses[f'depth_{f}'] = ops.spatial_losses(output[f'depth_{f}'], batch[f'depth_label_{f}'], [(0, 1, 1, w)])[0]
         if cfg.VOXEL_SEG.ENABLED:
             for f in (1, 2, 4):
                 w = (1 / f) * cfg.LOSSES.WEIGHT_VOXEL
@@ -201,6 +216,14 @@ class WorldModelTrainer(_Base):
                 losses[f'sem_scal_{f}'] = three[1]
                 losses[f'geo_scal_{f}'] = three[2]
         return losses
+
+    def _seg_loss(self, tag, c):
+        """trainer.py:132-161: SegmentationLoss(use_top_k, top_k_ratio, use_weights, is_bev=False)."""
+        from .losses import SegmentationLoss
+        cache = self.__dict__.setdefault('_seg_losses', {})
+        if tag not in cache:
+            cache[tag] = SegmentationLoss(use_top_k=c.USE_TOP_K, top_k_ratio=c.TOP_K_RATIO, use_weights=c.USE_WEIGHTS, is_bev=False)
+        return cache[tag]
 
     def loss_reducing(self, loss):
         vals = list(loss.values())

@@ -75,6 +75,33 @@ def preprocess(batch: Dict[str, torch.Tensor], cfg: dict) -> Dict[str, torch.Ten
         prev = F.interpolate(prev.flatten(0, 1), size=(x // f, y // f, z // f), mode='nearest').view(
             b, s, 1, x // f, y // f, z // f)
         out[f'voxel_label_{f}'] = prev
+    # inputs of the config-off heads, when present (preprocess.py:127-149,164-175,228-241): crop like the image, pyramids
+    if 'semantic_image' in batch:
+        sem = batch['semantic_image'][..., top:bottom, left:right]
+        out['semantic_image'] = sem
+        out['semantic_image_label_1'] = sem
+        h, w = sem.shape[-2:]
+        prev = sem
+        for f in (2, 4):
+            prev = F.interpolate(prev.flatten(0, 1).float(), size=(h // f, w // f), mode='nearest').to(sem.dtype).view(b, s, 1, h // f, w // f)
+            out[f'semantic_image_label_{f}'] = prev
+    if 'depth' in batch:
+        dep = batch['depth'][..., top:bottom, left:right].float()
+        out['depth'] = dep
+        out['depth_label_1'] = dep
+        h, w = dep.shape[-2:]
+        prev = dep
+        for f in (2, 4):
+            prev = F.interpolate(prev.flatten(0, 1), size=(h // f, w // f), mode='bilinear', align_corners=False).view(b, s, 1, h // f, w // f)
+            out[f'depth_label_{f}'] = prev
+    if 'range_view_pcd_seg' in batch:
+        seg = batch['range_view_pcd_seg']
+        out['range_view_seg_label_1'] = seg
+        h, w = seg.shape[-2:]
+        prev = seg
+        for f in (2, 4):
+            prev = F.interpolate(prev.flatten(0, 1).float(), size=(h // f, w // f), mode='nearest').to(seg.dtype).view(b, s, 1, h // f, w // f)
+            out[f'range_view_seg_label_{f}'] = prev
     mean = torch.tensor(cfg['MEAN']).view(3, 1, 1)
     std = torch.tensor(cfg['STD']).view(3, 1, 1)
     out['image'] = (img - mean) / std
@@ -390,11 +417,12 @@ class MileRef(nn.Module):
     MODEL.TRANSFORMER.BEV branch (mile.py:33-59,506-524): Decoder instead of DecoderDS, mono depth head, frustum pooling
     and the two-conv BEV down-sampling."""
 
-    def __init__(self, cfg: dict = None, bev: bool = False):
+    def __init__(self, cfg: dict = None, bev: bool = False, aux_heads=()):
         super().__init__()
         cfg = cfg or base_1d_cfg()
         self.cfg = cfg
         self.bev = bev
+        self.aux_heads = tuple(aux_heads)      # subset of ('lidar_seg', 'sem_image', 'depth'): mile.py:337-363
         tc, emb = cfg['TRANSFORMER_CHANNELS'], cfg['EMBEDDING_DIM']
         self.encoder = ResNet18(3)
         self.feat_decoder = DecoderUp((128, 256, 512), tc) if bev else DecoderDS((128, 256, 512), tc)
@@ -430,6 +458,12 @@ class MileRef(nn.Module):
         self.rgb_decoder = ConvDecoder(sd, 3, (5, 13), 'rgb_head', 'rgb')
         self.lidar_re = ConvDecoder(sd, cfg['LIDAR_RE_CHANNELS'], (1, 16), 'lidar_re_head', 'lidar_reconstruction')
         self.voxel_decoder = VoxelDecoder1(sd, cfg['VOXEL_N_CLASSES'], cfg['VOXEL_DIMENSION'])
+        if 'lidar_seg' in self.aux_heads:
+            self.lidar_segmentation = ConvDecoder(sd, 9, (1, 16), 'seg_head', 'lidar_segmentation')
+        if 'sem_image' in self.aux_heads:
+            self.sem_image_decoder = ConvDecoder(sd, 9, (5, 13), 'sem_head', 'semantic_image')
+        if 'depth' in self.aux_heads:
+            self.depth_image_decoder = ConvDecoder(sd, 1, (5, 13), 'depth_head', 'depth')
 
     def set_dropout(self, p: float):
         for m in self.modules():
@@ -477,10 +511,13 @@ class MileRef(nn.Module):
         pol = self.policy(state)
         out['throttle_brake'] = pol[:, :1].view(b, s, 1)
         out['steering'] = pol[:, 1:].view(b, s, 1)
-        for dec in (self.rgb_decoder, self.lidar_re, self.voxel_decoder):
+        for dec in (self.rgb_decoder, self.lidar_re, self.voxel_decoder) + self.aux_decoders():
             for k, v in dec(state).items():
                 out[k] = v.view(b, s, *v.shape[1:])
         return out
+
+    def aux_decoders(self):
+        return tuple(getattr(self, n) for n in ('lidar_segmentation', 'sem_image_decoder', 'depth_image_decoder') if hasattr(self, n))
 
 
 def imagine(model, state, future_horizon, noise):
@@ -498,7 +535,7 @@ def imagine(model, state, future_horizon, noise):
     pol = model.policy(flat)
     out = {'state': st, 'throttle_brake': pol[:, :1].view(b, future_horizon, 1),
            'steering': pol[:, 1:].view(b, future_horizon, 1)}
-    for dec in (model.rgb_decoder, model.lidar_re, model.voxel_decoder):
+    for dec in (model.rgb_decoder, model.lidar_re, model.voxel_decoder) + model.aux_decoders():
         for k, v in dec(flat).items():
             out[k] = v.view(b, future_horizon, *v.shape[1:])
     return out
@@ -594,7 +631,30 @@ def compute_losses(batch, out, cfg) -> Dict[str, torch.Tensor]:
         L[f'voxel_{f}'] = d * cfg['W_VOXEL'] * F.cross_entropy(logits, tgt.long(), reduction='none').mean()
         L[f'sem_scal_{f}'] = d * cfg['W_VOXEL'] * _sem_scal(logits, tgt)
         L[f'geo_scal_{f}'] = d * cfg['W_VOXEL'] * _geo_scal(logits, tgt)
+    # config-off heads (trainer.py:338-365), when the model produced them
+    for f in (1, 2, 4):
+        d = 1 / f
+        if f'lidar_segmentation_{f}' in out:      # LIDAR_SEG: top-k 0.5, class weights (config.py:255-260)
+            L[f'lidar_seg_{f}'] = _segmentation_loss(out[f'lidar_segmentation_{f}'], batch[f'range_view_seg_label_{f}'], True, 0.5, True) * d * 0.1
+        if f'semantic_image_{f}' in out:          # SEMANTIC_IMAGE: no top-k, class weights (config.py:263-268)
+            L[f'semantic_image_{f}'] = _segmentation_loss(out[f'semantic_image_{f}'], batch[f'semantic_image_label_{f}'], False, 0.5, True) * d * 0.1
+        if f'depth_{f}' in out:
+            L[f'depth_{f}'] = _spatial_regression(out[f'depth_{f}'], batch[f'depth_label_{f}'], 1) * d * 0.1
     return L
+
+
+VOXEL_SEG_WEIGHTS = (1.0, 1.0, 1.0, 1.5, 2.0, 3.0, 1.0, 1.0, 1.0)      # constants.py:39 (is_bev=False, trainer.py:137,161)
+
+
+def _segmentation_loss(prediction, target, use_top_k, top_k_ratio, use_weights):
+    """SegmentationLoss.forward (losses.py:22-50) without poly-1."""
+    b, s, c, h, w = prediction.shape
+    weights = torch.tensor(VOXEL_SEG_WEIGHTS, dtype=prediction.dtype) if use_weights else None
+    loss = F.cross_entropy(prediction.view(b * s, c, h, w), target.reshape(b * s, h, w).long(), reduction='none', weight=weights)
+    loss = loss.view(b, s, -1)
+    if use_top_k:
+        loss = loss.topk(int(top_k_ratio * loss.shape[2]), dim=-1)[0]
+    return torch.mean(loss)
 
 
 def make_optimizer(model: nn.Module, cfg: dict):
