@@ -436,6 +436,14 @@ static double bf3_min_gflop() {
 }
 
 static thread_local int t_force_family = 0;   // +1 / -1: make this phase bf16x3 / fp32 regardless of its own size (see below)
+// does the small-channel 3x3x3 conv of this direction run on its bf16x3 kernel (conv_vox.hip)?  Same policy as the
+// implicit-GEMM family: bf16x3 mode and at least MUVO_BF16X3_MIN_GFLOP of work per batch item.
+static bool vox_uses_bf3(const muvo_conv_desc* d, int dgrad) {
+  if (conv_mode() != 1 || !vox_bf3_shape_ok(d, dgrad)) return false;
+  const double gflop = 2.0 * d->Cin * d->Cout * 27.0 * (double)d->in_sz[0] * d->in_sz[1] * d->in_sz[2] * 1e-9;
+  return gflop >= bf3_min_gflop();
+}
+
 static void finish_phase(ConvPhase& g) {
   g.bf3 = 0;
   if (g.nmerge <= 1) {
@@ -733,12 +741,12 @@ int muvo_conv_pack_weights(const muvo_conv_desc* d, const float* w, float* wp_fw
     return MUVO_OK;
   }
   if (wp_fwd && vox_fwd_applicable(d)) {
-    rc = vox_pack(d, w, wp_fwd, 0, st);
+    rc = vox_pack(d, w, wp_fwd, 0, st, vox_uses_bf3(d, 0));
     if (rc) return rc;
     wp_fwd = nullptr;
   }
   if (wp_dgrad && vox_dgrad_applicable(d)) {
-    rc = vox_pack(d, w, wp_dgrad, 1, st);
+    rc = vox_pack(d, w, wp_dgrad, 1, st, vox_uses_bf3(d, 1));
     if (rc) return rc;
     wp_dgrad = nullptr;
   }
@@ -844,7 +852,7 @@ int muvo_conv_forward(const muvo_conv_desc* d, const float* x, const float* wp_f
   if (rc) return rc;
   MUVO_CHECK_ARG(x && wp_fwd && y, "conv_forward: null pointer");
   if (pw_applicable(d)) return pw_forward(d, x, wp_fwd, bias, y, act, slope, (hipStream_t)stream);
-  if (vox_fwd_applicable(d)) return vox_forward(d, x, wp_fwd, bias, y, act, slope, (hipStream_t)stream);
+  if (vox_fwd_applicable(d)) return vox_forward(d, x, wp_fwd, bias, y, act, slope, (hipStream_t)stream, vox_uses_bf3(d, 0));
   return run_phases(pl.fwd, pl.nfwd, x, wp_fwd, bias, y, act, slope, ws, (hipStream_t)stream);
 }
 
@@ -855,7 +863,7 @@ int muvo_conv_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp_dg
   if (rc) return rc;
   MUVO_CHECK_ARG(dy && wp_dgrad && dx, "conv_dgrad: null pointer");
   if (pw_applicable(d)) return pw_dgrad(d, dy, wp_dgrad, dx, (hipStream_t)stream);
-  if (vox_dgrad_applicable(d)) return vox_dgrad(d, dy, wp_dgrad, dx, (hipStream_t)stream);
+  if (vox_dgrad_applicable(d)) return vox_dgrad(d, dy, wp_dgrad, dx, (hipStream_t)stream, vox_uses_bf3(d, 1));
   return run_phases(pl.dgr, pl.ndgr, dy, wp_dgrad, nullptr, dx, MUVO_ACT_NONE, 0.f, ws, (hipStream_t)stream, ws_valid != 0);
 }
 

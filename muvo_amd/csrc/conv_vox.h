@@ -7,8 +7,9 @@ bool vox_fwd_applicable(const muvo_conv_desc* d);
 bool vox_dgrad_applicable(const muvo_conv_desc* d);
 bool vox_wgrad_applicable(const muvo_conv_desc* d);
 long vox_pack_floats(const muvo_conv_desc* d);
-int vox_pack(const muvo_conv_desc* d, const float* w, float* wp, int dgrad, hipStream_t st);
+bool vox_bf3_shape_ok(const muvo_conv_desc* d, int dgrad);   // bf16x3 variant (16x16x32 MFMA) available for this direction
+int vox_pack(const muvo_conv_desc* d, const float* w, float* wp, int dgrad, hipStream_t st, bool bf3);
 int vox_forward(const muvo_conv_desc* d, const float* x, const float* wp, const float* bias, float* y, int act, float slope,
-                hipStream_t st);
-int vox_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp, float* dx, hipStream_t st);
+                hipStream_t st, bool bf3);
+int vox_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp, float* dx, hipStream_t st, bool bf3);
 int vox_wgrad(const muvo_conv_desc* d, const float* x, const float* dz, float* dw, float* dbias, hipStream_t st);

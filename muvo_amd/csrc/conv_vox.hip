@@ -343,6 +343,173 @@ __global__ void __launch_bounds__(256) vox_pack_kernel(const float* __restrict__
   }
 }
 
+// ================================================================================================
+// bf16x3 variant of the small-channel 3x3x3 convolution (forward / data gradient) on v_mfma_f32_16x16x32_bf16.
+// MFMA rows = produced channels (8 or 16, padded to 16), columns = 16 consecutive z voxels, K = (tap, reduction channel)
+// in steps of 32 = TPS taps x CK channels.  The fp32 4x4x1 kernel above is bound by the fp32 matrix rate (60 % busy at
+// 157 TFLOP/s peak); here the matrix work is ~10x cheaper and the kernel is bound by LDS fragment reads and HBM.
+//   * a workgroup (8 waves) owns TY = 8 output rows (y) x the whole z line and walks along x with a ring of three input
+//     planes in LDS, each [hi/lo][8-channel group][TY + 2 rows][Z + 2 columns] x 16 bytes (bf16 split done while staging:
+//     one HBM read of the input per workgroup column, y-halo 10/8);
+//   * all weights of the layer live in registers as MFMA A fragments (hi and lo: 2 x NSTEP x 4 VGPRs);
+//   * wave w computes row w: per 16-voxel tile NSTEP x (2 fragment reads + 3 MFMAs), conflict-free 16-byte reads;
+//   * global loads of plane x+2 are issued before the MFMA work of plane x and written to LDS after it.
+// Packed weights (vox_bf3_pack_kernel): wp[(step*2 + hl)*64 + lane] = 8 bf16 of row m = lane & 15,
+// k = 8 (lane >> 4) + e -> tap = step * TPS + (lane >> 4) / CG, channel = ((lane >> 4) % CG) * 8 + e.
+// ================================================================================================
+typedef __bf16 vbf16x8 __attribute__((ext_vector_type(8)));
+typedef float vf32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned vu32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void vox_split2(float a, float b, unsigned& hi, unsigned& lo) {
+  // two fp32 -> packed bf16 pairs: hi = RNE(x), lo = RNE(x - hi)
+  auto rne = [](float x) -> unsigned {
+    unsigned u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+  };
+  const unsigned ha = rne(a), hb = rne(b);
+  const float ra = a - __uint_as_float(ha << 16), rb = b - __uint_as_float(hb << 16);
+  hi = ha | (hb << 16);
+  lo = rne(ra) | (rne(rb) << 16);
+}
+
+template <int CK, int Z, int TY>
+__global__ void __launch_bounds__(64 * TY)
+vox_bf3_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* __restrict__ wp, const float* __restrict__ bias,
+               float* __restrict__ out, int act, float slope, int xseg) {
+  constexpr int CG = CK / 8, TPS = 4 / CG, NSTEP = (27 + TPS - 1) / TPS, ZT = Z / 16;
+  constexpr int ROWS = TY + 2, COLS = Z + 2;
+  constexpr int PLANE = 2 * CG * ROWS * COLS;                   // uint4 per ring plane
+  constexpr int NTASK = CG * ROWS * Z, TPT = (NTASK + 64 * TY - 1) / (64 * TY);
+  extern __shared__ vu32x4 vsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nseg = (a.X + xseg - 1) / xseg;
+  int bid = blockIdx.x;
+  const int seg = bid % nseg; bid /= nseg;
+  const int ytile = bid % a.ytiles, n = bid / a.ytiles;
+  const int y0 = ytile * TY, xs = seg * xseg, xe = xs + xseg < a.X ? xs + xseg : a.X;
+  const long YZ = (long)a.Y * Z;
+  const float* inb = in + (long)n * a.sN_in;
+
+  // weights -> registers
+  vbf16x8 wh[NSTEP], wl[NSTEP];
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) {
+    wh[s] = __builtin_bit_cast(vbf16x8, wp[(s * 2) * 64 + lane]);
+    wl[s] = __builtin_bit_cast(vbf16x8, wp[(s * 2 + 1) * 64 + lane]);
+  }
+  // zero the whole ring once (z halo columns and out-of-range rows / planes stay zero unless overwritten)
+  for (int i = tid; i < 3 * PLANE; i += 64 * TY) vsm[i] = vu32x4{0u, 0u, 0u, 0u};
+  __syncthreads();
+
+  // staging: task t -> (cg, row r, z); loads 8 channels of one voxel, splits, writes two 16-byte entries
+  float stg[TPT][8];
+  auto stage_load = [&](int x) {
+#pragma unroll
+    for (int k = 0; k < TPT; ++k) {
+      const int t = tid + k * 64 * TY;
+      const int z = t % Z, r = (t / Z) % ROWS, cg = t / (Z * ROWS);
+      const int gy = y0 - 1 + r;
+      const bool ok = t < NTASK && x >= 0 && x < a.X && gy >= 0 && gy < a.Y;
+      const float* p = inb + (long)(cg * 8) * a.XYZ + (long)x * YZ + (long)gy * Z + z;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) stg[k][e] = ok ? p[(long)e * a.XYZ] : 0.f;
+    }
+  };
+  auto stage_store = [&](int slot) {
+    vu32x4* P = vsm + slot * PLANE;
+#pragma unroll
+    for (int k = 0; k < TPT; ++k) {
+      const int t = tid + k * 64 * TY;
+      if (t >= NTASK) continue;
+      const int z = t % Z, r = (t / Z) % ROWS, cg = t / (Z * ROWS);
+      unsigned h[4], l[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) vox_split2(stg[k][2 * q], stg[k][2 * q + 1], h[q], l[q]);
+      P[(cg * ROWS + r) * COLS + z + 1] = vu32x4{h[0], h[1], h[2], h[3]};
+      P[((CG + cg) * ROWS + r) * COLS + z + 1] = vu32x4{l[0], l[1], l[2], l[3]};
+    }
+  };
+
+  // this lane's B-fragment geometry per k-step: tap -> (dx, dy, dz), channel group
+  const int v = lane & 15, g = lane >> 4;
+  int fdx[NSTEP], foff[NSTEP];       // dx in {-1, 0, 1}; uint4 offset inside a plane (hi part) for tile 0
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) {
+    int tap = s * TPS + g / CG;
+    if (tap > 26) tap = 26;           // padded taps carry zero weights
+    const int dx = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dz = tap % 3 - 1;
+    fdx[s] = dx;
+    foff[s] = ((g % CG) * ROWS + (wave + 1 + dy)) * COLS + (v + 1 + dz);
+  }
+
+  // prologue: planes xs-1 and xs into their slots, plane xs+1 in flight
+  stage_load(xs - 1); stage_store((xs - 1 + 3) % 3);
+  stage_load(xs); stage_store(xs % 3);
+  stage_load(xs + 1);
+  __syncthreads();
+  for (int x = xs; x < xe; ++x) {
+    // plane x+1 (loaded during the previous step) -> LDS; its slot was last read while computing plane x-2
+    stage_store((x + 1) % 3);
+    __syncthreads();
+    if (x + 1 < xe) stage_load(x + 2);       // lands while this plane is computed
+    const vu32x4* P[3] = {vsm + ((x - 1 + 3) % 3) * PLANE, vsm + (x % 3) * PLANE, vsm + ((x + 1) % 3) * PLANE};
+    const vu32x4* fb[NSTEP];
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) fb[s] = (fdx[s] < 0 ? P[0] : (fdx[s] == 0 ? P[1] : P[2])) + foff[s];
+    const int gy = y0 + wave;
+#pragma unroll
+    for (int zt = 0; zt < ZT; ++zt) {
+      vf32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < NSTEP; ++s) {
+        const vbf16x8 bh = __builtin_bit_cast(vbf16x8, fb[s][zt * 16]);
+        const vbf16x8 bl = __builtin_bit_cast(vbf16x8, fb[s][zt * 16 + CG * ROWS * COLS]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[s], bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], bh, acc, 0, 0, 0);
+      }
+      if (gy < a.Y) {
+        float* ob = out + (long)n * a.sN_out + (long)x * YZ + (long)gy * Z + zt * 16 + v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int co = 4 * g + i;
+          if (co < a.Cout) {
+            float r = acc[i];
+            if (bias) r += bias[co];
+            ob[(long)co * a.XYZ] = act_apply(r, act, slope);
+          }
+        }
+      }
+    }
+    __syncthreads();     // everybody is done with plane x-1's slot before the next step overwrites it
+  }
+}
+
+// wp[(step*2 + hl)*64 + lane] (uint4 = 8 bf16) for the forward (dgrad = 0: rows = Cout, reduction = Cin, W[m][c][tap]) or
+// the data gradient (dgrad = 1: rows = Cin, reduction = Cout, W[c][m][26 - tap])
+__global__ void __launch_bounds__(256)
+vox_bf3_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int Cin, int Cout, int dgrad, int CK, int nstep) {
+  const int CG = CK / 8, TPS = 4 / CG;
+  const int rows = dgrad ? Cin : Cout;
+  const int total = nstep * 64 * 8;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    const int e = idx & 7, lane = (idx >> 3) & 63, s = idx >> 9;
+    const int m = lane & 15, g = lane >> 4;
+    const int tap = s * TPS + g / CG, c = (g % CG) * 8 + e;
+    float val = 0.f;
+    if (tap < 27 && m < rows) val = dgrad ? w[((size_t)c * Cin + m) * 27 + (26 - tap)] : w[((size_t)m * Cin + c) * 27 + tap];
+    unsigned u = __float_as_uint(val);
+    unsigned hu = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    const float rem = val - __uint_as_float(hu << 16);
+    unsigned r = __float_as_uint(rem);
+    unsigned lu = (r + 0x7fffu + ((r >> 16) & 1u)) >> 16;
+    wp[((size_t)(s * 2) * 64 + lane) * 8 + e] = (unsigned short)hu;
+    wp[((size_t)(s * 2 + 1) * 64 + lane) * 8 + e] = (unsigned short)lu;
+  }
+}
+
 // ================================================================================================ host side
 static bool vox_geometry_ok(const muvo_conv_desc* d) {
   if (d->nd != 3 || d->transposed) return false;
@@ -363,9 +530,25 @@ bool vox_dgrad_applicable(const muvo_conv_desc* d) {
 bool vox_wgrad_applicable(const muvo_conv_desc* d) {
   return vox_geometry_ok(d) && d->Cout % 8 == 0 && d->Cin % 8 == 0 && d->Cout <= 32 && d->Cin <= 64;
 }
-long vox_pack_floats(const muvo_conv_desc* d) { return 27l * d->Cin * d->Cout; }
+// bf16x3 variant: reduction and produced channels in {8, 16}
+bool vox_bf3_shape_ok(const muvo_conv_desc* d, int dgrad) {
+  if (!(dgrad ? vox_dgrad_applicable(d) : vox_fwd_applicable(d))) return false;
+  const int ck = dgrad ? d->Cout : d->Cin, cp = dgrad ? d->Cin : d->Cout;
+  return (ck == 8 || ck == 16) && (cp == 8 || cp == 16);
+}
+static int vox_bf3_steps(int ck) { return ck == 8 ? 7 : 14; }
+long vox_pack_floats(const muvo_conv_desc* d) {
+  const long plain = 27l * d->Cin * d->Cout, bf3 = 14l * 2 * 64 * 4;   // bf16x3 layout: steps x (hi, lo) x 64 lanes x 16 bytes
+  return plain > bf3 ? plain : bf3;
+}
 
-int vox_pack(const muvo_conv_desc* d, const float* w, float* wp, int dgrad, hipStream_t st) {
+int vox_pack(const muvo_conv_desc* d, const float* w, float* wp, int dgrad, hipStream_t st, bool bf3) {
+  if (bf3) {
+    const int ck = dgrad ? d->Cout : d->Cin, ns = vox_bf3_steps(ck);
+    hipLaunchKernelGGL(vox_bf3_pack_kernel, dim3(cdiv(ns * 512, 256)), dim3(256), 0, st, w, (unsigned short*)wp, d->Cin, d->Cout, dgrad, ck, ns);
+    MUVO_CHECK_LAUNCH("vox_bf3_pack_kernel");
+    return MUVO_OK;
+  }
   const int total = 27 * d->Cin * d->Cout;
   hipLaunchKernelGGL(vox_pack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, w, wp, d->Cin, d->Cout, dgrad);
   MUVO_CHECK_LAUNCH("vox_pack_kernel");
@@ -388,9 +571,44 @@ static int launch_vox_conv(const muvo_conv_desc* d, int Cin, int Cout, const flo
   return MUVO_OK;
 }
 
+template <int CK, int Z>
+static int launch_vox_bf3(const muvo_conv_desc* d, int Cin, int Cout, const float* in, const float* wp, const float* bias,
+                          float* out, int act, float slope, hipStream_t st) {
+  constexpr int TY = 8;
+  VoxArgs a;
+  a.N = d->N; a.Cin = Cin; a.Cout = Cout; a.X = d->in_sz[0]; a.Y = d->in_sz[1];
+  a.ytiles = cdiv(a.Y, TY);
+  a.xgroups = 0;
+  a.XYZ = a.X * a.Y * Z;
+  a.sN_in = (long)Cin * a.XYZ; a.sN_out = (long)Cout * a.XYZ;
+  // split x into segments until the grid fills the chip (each segment re-reads two halo planes)
+  int xseg = a.X;
+  while ((long)a.N * a.ytiles * cdiv(a.X, xseg) < 1024 && xseg > 12) xseg = cdiv(xseg, 2);
+  constexpr size_t lds = (size_t)3 * 2 * (CK / 8) * (TY + 2) * (Z + 2) * 16;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)vox_bf3_kernel<CK, Z, TY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      muvo_set_error("vox_bf3: cannot raise the dynamic LDS limit to %zu bytes", lds);
+      return MUVO_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  const long blocks = (long)a.N * a.ytiles * cdiv(a.X, xseg);
+  hipLaunchKernelGGL((vox_bf3_kernel<CK, Z, TY>), dim3((unsigned)blocks), dim3(64 * TY), lds, st, a, in, (const vu32x4*)wp, bias, out, act,
+                     slope, xseg);
+  MUVO_CHECK_LAUNCH("vox_bf3_kernel");
+  return MUVO_OK;
+}
+
 static int vox_conv_dispatch(const muvo_conv_desc* d, int Cin, int Cout, const float* in, const float* wp, const float* bias,
-                             float* out, int act, float slope, hipStream_t st) {
+                             float* out, int act, float slope, hipStream_t st, bool bf3) {
   const int Z = d->in_sz[2];
+  if (bf3) {
+    if (Cin == 16 && Z == 64) return launch_vox_bf3<16, 64>(d, Cin, Cout, in, wp, bias, out, act, slope, st);
+    if (Cin == 16 && Z == 32) return launch_vox_bf3<16, 32>(d, Cin, Cout, in, wp, bias, out, act, slope, st);
+    if (Cin == 8 && Z == 64) return launch_vox_bf3<8, 64>(d, Cin, Cout, in, wp, bias, out, act, slope, st);
+    if (Cin == 8 && Z == 32) return launch_vox_bf3<8, 32>(d, Cin, Cout, in, wp, bias, out, act, slope, st);
+  }
   if (Cout == 8 && Z == 64) return launch_vox_conv<2, 6, 64>(d, Cin, Cout, in, wp, bias, out, act, slope, st);
   if (Cout == 8 && Z == 32) return launch_vox_conv<2, 6, 32>(d, Cin, Cout, in, wp, bias, out, act, slope, st);
   if (Cout == 16 && Z == 64) return launch_vox_conv<4, 4, 64>(d, Cin, Cout, in, wp, bias, out, act, slope, st);
@@ -400,11 +618,11 @@ static int vox_conv_dispatch(const muvo_conv_desc* d, int Cin, int Cout, const f
 }
 
 int vox_forward(const muvo_conv_desc* d, const float* x, const float* wp, const float* bias, float* y, int act, float slope,
-                hipStream_t st) {
-  return vox_conv_dispatch(d, d->Cin, d->Cout, x, wp, bias, y, act, slope, st);
+                hipStream_t st, bool bf3) {
+  return vox_conv_dispatch(d, d->Cin, d->Cout, x, wp, bias, y, act, slope, st, bf3);
 }
-int vox_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp, float* dx, hipStream_t st) {
-  return vox_conv_dispatch(d, d->Cout, d->Cin, dy, wp, nullptr, dx, MUVO_ACT_NONE, 0.f, st);
+int vox_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp, float* dx, hipStream_t st, bool bf3) {
+  return vox_conv_dispatch(d, d->Cout, d->Cin, dy, wp, nullptr, dx, MUVO_ACT_NONE, 0.f, st, bf3);
 }
 
 template <int RQB, int CQR, int Z, int TYB>

@@ -26,6 +26,8 @@ LAYERS = {
     'ds128': ('conv', 128, 384, 3, 1, 1, (40, 104)),
     'res512': ('conv', 512, 512, 3, 1, 1, (10, 26)),
     'vox16': ('conv3d', 16, 8, 3, 1, 1, (192, 192, 64)),
+    'vox8': ('conv3d', 8, 8, 3, 1, 1, (192, 192, 64)),
+    'vox16b': ('conv3d', 16, 16, 3, 1, 1, (96, 96, 32)),
     'vox64': ('conv3d', 64, 64, 3, 1, 1, (24, 24, 8)),
 }
 
