@@ -444,6 +444,13 @@ static bool vox_uses_bf3(const muvo_conv_desc* d, int dgrad) {
   return gflop >= bf3_min_gflop();
 }
 
+static double bf3_wgrad_min_gflop();
+static bool vox_wgrad_uses_bf3(const muvo_conv_desc* d) {
+  if (conv_mode() != 1 || !vox_bf3_wgrad_shape_ok(d)) return false;
+  const double gflop = 2.0 * d->Cin * d->Cout * 27.0 * (double)d->in_sz[0] * d->in_sz[1] * d->in_sz[2] * 1e-9;
+  return gflop >= bf3_wgrad_min_gflop();
+}
+
 static void finish_phase(ConvPhase& g) {
   g.bf3 = 0;
   if (g.nmerge <= 1) {
@@ -798,17 +805,18 @@ int64_t muvo_conv_workspace_bytes(const muvo_conv_desc* d, int op) {
 }
 
 // which kernel family serves this shape: 0 fp32 implicit GEMM (conv_gemm.hip), 1 bf16x3 (conv_bf3.hip),
-// 2 small-channel Conv3d on the 4x4x1 MFMA (conv_vox.hip), 3 decoder heads (conv_pw.hip); op 0 fwd, 1 dgrad, 2 wgrad
+// 2 small-channel Conv3d on the 4x4x1 MFMA (conv_vox.hip), 3 decoder heads (conv_pw.hip), 4 small-channel Conv3d on the
+// bf16x3 16x16x32 kernel (conv_vox.hip); op 0 fwd, 1 dgrad, 2 wgrad
 int muvo_conv_kernel_family(const muvo_conv_desc* d, int op) {
   ConvPlan pl;
   if (pw_applicable(d)) return 3;
   if (op == 2) {
     if (build_plan(d, &pl, 0, false)) return -1;
-    if (vox_wgrad_applicable(d)) return 2;
+    if (vox_wgrad_applicable(d)) return vox_wgrad_uses_bf3(d) ? 4 : 2;
     return wgrad_uses_bf3(pl) ? 1 : 0;
   }
   if (build_plan(d, &pl)) return -1;
-  if (op == 0 ? vox_fwd_applicable(d) : vox_dgrad_applicable(d)) return 2;
+  if (op == 0 ? vox_fwd_applicable(d) : vox_dgrad_applicable(d)) return vox_uses_bf3(d, op) ? 4 : 2;
   const ConvPhase* ph = op == 0 ? pl.fwd : pl.dgr;
   const int nph = op == 0 ? pl.nfwd : pl.ndgr;
   for (int i = 0; i < nph; ++i)
@@ -912,7 +920,7 @@ int muvo_conv_wgrad(const muvo_conv_desc* d, const float* x, const float* dy, fl
   MUVO_CHECK_ARG(x && dy && dwp_scratch && dw, "conv_wgrad: null pointer");
   hipStream_t st = (hipStream_t)stream;
   if (pw_applicable(d)) return pw_wgrad(d, x, dy, dw, dbias, st);
-  if (vox_wgrad_applicable(d)) return vox_wgrad(d, x, dy, dw, dbias, st);
+  if (vox_wgrad_applicable(d)) return vox_wgrad(d, x, dy, dw, dbias, st, vox_wgrad_uses_bf3(d));
   const long S_out = (long)d->out_sz[0] * d->out_sz[1] * d->out_sz[2];
   if (wgrad_uses_bf3(pl)) {
     // the bf16x3 kernel understands merged sub-pixel phases (one GEMM with nmerge * Cout rows): use them when they exist

@@ -12,4 +12,5 @@ int vox_pack(const muvo_conv_desc* d, const float* w, float* wp, int dgrad, hipS
 int vox_forward(const muvo_conv_desc* d, const float* x, const float* wp, const float* bias, float* y, int act, float slope,
                 hipStream_t st, bool bf3);
 int vox_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp, float* dx, hipStream_t st, bool bf3);
-int vox_wgrad(const muvo_conv_desc* d, const float* x, const float* dz, float* dw, float* dbias, hipStream_t st);
+bool vox_bf3_wgrad_shape_ok(const muvo_conv_desc* d);
+int vox_wgrad(const muvo_conv_desc* d, const float* x, const float* dz, float* dw, float* dbias, hipStream_t st, bool bf3);

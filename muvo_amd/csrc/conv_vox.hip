@@ -487,6 +487,187 @@ vox_bf3_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* __re
   }
 }
 
+// ================================================================================================
+// bf16x3 weight gradient of the small-channel 3x3x3 convolution on v_mfma_f32_16x16x32_bf16:
+//   dW[co][ci][tap] += sum over voxels dz[co][v] * x[ci][v + tap],   dbias[co] += sum dz[co][v]
+// MFMA rows = output channels (padded to 16), columns = 16 input channels, K = 32 consecutive z voxels.  Both operands
+// are z-contiguous rows of one channel in NCDHW memory, so they are staged as bf16 hi/lo rows [channel][row][z] and a lane
+// reads its 8 consecutive voxels as one aligned 16-byte entry; the dz = +-1 taps are built in registers from that entry
+// and the neighbouring dword (v_alignbyte), i.e. one aligned read serves three taps.  One A fragment pair feeds all 27
+// taps (81 MFMAs per 32 voxels), which makes the kernel MFMA/HBM-bound instead of fp32-matrix-bound like vox_wgrad_kernel.
+//   * workgroup = 8 waves = WROWS output rows x ZH halves of the z line; ring of three x planes (rows + y halo) and a double
+//     buffered dz plane in LDS; channel stride padded by 16 bytes (conflict-free 16-lane reads);
+//   * each wave keeps 27 accumulator tiles (108 VGPRs) over its x range; at the end the waves of a workgroup reduce
+//     through LDS and issue one set of float atomics into dW.
+// grid.x = N * ytiles * x-segments, grid.y = Cin / 16 (column blocks).
+// ================================================================================================
+template <int Z>
+__global__ void __launch_bounds__(512)
+vox_bf3_wgrad_kernel(const VoxArgs a, const float* __restrict__ x, const float* __restrict__ dz, float* __restrict__ dw,
+                     float* __restrict__ dbias, int xseg) {
+  constexpr int ZH = Z / 32, WROWS = 8 / ZH, ROWS = WROWS + 2;
+  constexpr int XROW = (Z + 16) * 2;                    // bytes of an x row: 16-byte zero pad on both sides
+  constexpr int XCI = ROWS * XROW + 16;                 // channel stride (bytes), +16 spreads 16 channels over all banks
+  constexpr int XHL = 16 * XCI, XSLOT = 2 * XHL;
+  constexpr int DROW = Z * 2, DCO = WROWS * DROW + 16, DHL = 16 * DCO, DBUF = 2 * DHL;
+  constexpr int XT = 16 * ROWS * (Z / 8), DT = 16 * WROWS * (Z / 8);   // staging tasks (8 voxels each)
+  constexpr int XPT = (XT + 511) / 512, DPT = (DT + 511) / 512;
+  extern __shared__ char wsm[];
+  char* xring = wsm;
+  char* dzb = wsm + 3 * XSLOT;
+  float* dbsum = (float*)(dzb + 2 * DBUF);             // 16 floats
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nseg = (a.X + xseg - 1) / xseg;
+  int bid = blockIdx.x;
+  const int seg = bid % nseg; bid /= nseg;
+  const int ytile = bid % a.ytiles, n = bid / a.ytiles;
+  const int y0 = ytile * WROWS, xs = seg * xseg, xe = xs + xseg < a.X ? xs + xseg : a.X;
+  const int ci0 = blockIdx.y * 16;
+  const long YZ = (long)a.Y * Z;
+  const float* xb = x + (long)n * a.sN_in + (long)ci0 * a.XYZ;
+  const float* db = dz + (long)n * a.sN_out;
+  for (int i = tid; i < (3 * XSLOT + 2 * DBUF + 64) / 16; i += 512) ((uint4*)wsm)[i] = uint4{0u, 0u, 0u, 0u};
+  __syncthreads();
+
+  float xst[XPT][8], dst[DPT][8];
+  auto split_store = [&](const float (&v)[8], char* hi_addr, int hl_stride) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) vox_split2(v[2 * q], v[2 * q + 1], h[q], l[q]);
+    *(vu32x4*)hi_addr = vu32x4{h[0], h[1], h[2], h[3]};
+    *(vu32x4*)(hi_addr + hl_stride) = vu32x4{l[0], l[1], l[2], l[3]};
+  };
+  auto load8 = [&](const float* p, bool ok, float (&v)[8]) {
+    if (ok) {
+      const float4 u0 = *(const float4*)p, u1 = *(const float4*)(p + 4);
+      v[0] = u0.x; v[1] = u0.y; v[2] = u0.z; v[3] = u0.w; v[4] = u1.x; v[5] = u1.y; v[6] = u1.z; v[7] = u1.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    }
+  };
+  auto xload = [&](int px) {
+#pragma unroll
+    for (int k = 0; k < XPT; ++k) {
+      const int t = tid + k * 512;
+      const int z8 = t % (Z / 8), rr = (t / (Z / 8)) % ROWS, ci = t / ((Z / 8) * ROWS);
+      const int gy = y0 - 1 + rr;
+      load8(xb + (long)ci * a.XYZ + (long)px * YZ + (long)gy * Z + z8 * 8,
+            t < XT && px >= 0 && px < a.X && gy >= 0 && gy < a.Y && ci0 + ci < a.Cin, xst[k]);
+    }
+  };
+  auto xstore = [&](int slot) {
+#pragma unroll
+    for (int k = 0; k < XPT; ++k) {
+      const int t = tid + k * 512;
+      if (t >= XT) continue;
+      const int z8 = t % (Z / 8), rr = (t / (Z / 8)) % ROWS, ci = t / ((Z / 8) * ROWS);
+      split_store(xst[k], xring + slot * XSLOT + ci * XCI + rr * XROW + 16 + z8 * 16, XHL);
+    }
+  };
+  auto dload = [&](int px) {
+#pragma unroll
+    for (int k = 0; k < DPT; ++k) {
+      const int t = tid + k * 512;
+      const int z8 = t % (Z / 8), r = (t / (Z / 8)) % WROWS, co = t / ((Z / 8) * WROWS);
+      const int gy = y0 + r;
+      load8(db + (long)co * a.XYZ + (long)px * YZ + (long)gy * Z + z8 * 8, t < DT && px < xe && gy < a.Y && co < a.Cout, dst[k]);
+    }
+  };
+  auto dstore = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < DPT; ++k) {
+      const int t = tid + k * 512;
+      if (t >= DT) continue;
+      const int z8 = t % (Z / 8), r = (t / (Z / 8)) % WROWS, co = t / ((Z / 8) * WROWS);
+      split_store(dst[k], dzb + buf * DBUF + co * DCO + r * DROW + z8 * 16, DHL);
+      if (blockIdx.y == 0 && dbias) {
+        float sdz = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sdz += dst[k][e];
+        if (sdz != 0.f) atomicAdd(dbsum + co, sdz);
+      }
+    }
+  };
+
+  vf32x4 acc[27];
+#pragma unroll
+  for (int t = 0; t < 27; ++t) acc[t] = vf32x4{0.f, 0.f, 0.f, 0.f};
+  const int row = wave / ZH, z0 = (wave % ZH) * 32;     // this wave's output row and z half
+  const int j = lane & 15, kg = lane >> 4;
+  const int a_off = j * DCO + row * DROW + (z0 + kg * 8) * 2;           // A: rows = co = lane & 15
+  const int b_off = j * XCI + 16 + (z0 + kg * 8) * 2;                   // B: columns = ci = lane & 15 (+ row term below)
+
+  xload(xs - 1); xstore((xs - 1 + 3) % 3);
+  xload(xs); xstore(xs % 3);
+  xload(xs + 1);
+  dload(xs);
+  __syncthreads();
+  for (int px = xs; px < xe; ++px) {
+    xstore((px + 1) % 3);
+    dstore(px & 1);
+    __syncthreads();
+    if (px + 1 < xe) { xload(px + 2); dload(px + 1); }
+    const char* A = dzb + (px & 1) * DBUF + a_off;
+    const vbf16x8 ah = __builtin_bit_cast(vbf16x8, *(const vu32x4*)A);
+    const vbf16x8 al = __builtin_bit_cast(vbf16x8, *(const vu32x4*)(A + DHL));
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const char* S = xring + ((px + dx - 1 + 3) % 3) * XSLOT + b_off;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const char* R = S + (row + dy) * XROW;          // source row = row + 1 + (dy - 1)
+        vu32x4 w[2];
+        unsigned pw[2], nw[2];
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl) {
+          w[hl] = *(const vu32x4*)(R + hl * XHL);
+          pw[hl] = *(const unsigned*)(R + hl * XHL - 4);
+          nw[hl] = *(const unsigned*)(R + hl * XHL + 16);
+        }
+        vbf16x8 bm[2], bz[2], bp[2];                    // dz = -1, 0, +1
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl) {
+          const vu32x4 q = w[hl];
+          bz[hl] = __builtin_bit_cast(vbf16x8, q);
+          const vu32x4 m = {__builtin_amdgcn_alignbyte(q.x, pw[hl], 2), __builtin_amdgcn_alignbyte(q.y, q.x, 2),
+                            __builtin_amdgcn_alignbyte(q.z, q.y, 2), __builtin_amdgcn_alignbyte(q.w, q.z, 2)};
+          const vu32x4 pl = {__builtin_amdgcn_alignbyte(q.y, q.x, 2), __builtin_amdgcn_alignbyte(q.z, q.y, 2),
+                             __builtin_amdgcn_alignbyte(q.w, q.z, 2), __builtin_amdgcn_alignbyte(nw[hl], q.w, 2)};
+          bm[hl] = __builtin_bit_cast(vbf16x8, m);
+          bp[hl] = __builtin_bit_cast(vbf16x8, pl);
+        }
+        const int t0 = (dx * 3 + dy) * 3;
+        acc[t0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bm[0], acc[t0], 0, 0, 0);
+        acc[t0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[1], acc[t0], 0, 0, 0);
+        acc[t0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[0], acc[t0], 0, 0, 0);
+        acc[t0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bz[0], acc[t0 + 1], 0, 0, 0);
+        acc[t0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bz[1], acc[t0 + 1], 0, 0, 0);
+        acc[t0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bz[0], acc[t0 + 1], 0, 0, 0);
+        acc[t0 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bp[0], acc[t0 + 2], 0, 0, 0);
+        acc[t0 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bp[1], acc[t0 + 2], 0, 0, 0);
+        acc[t0 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bp[0], acc[t0 + 2], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // workgroup reduction of the 27 tiles through LDS (the rings are free now), then one set of atomics
+  float* red = (float*)wsm;                                             // [27][16 co][16 ci]
+  for (int i = tid; i < 27 * 256; i += 512) red[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 27; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(red + (t * 16 + 4 * kg + r) * 16 + j, acc[t][r]);
+  __syncthreads();
+  for (int i = tid; i < 27 * 256; i += 512) {
+    const int ci = i & 15, co = (i >> 4) & 15, t = i >> 8;
+    const float vsum = red[i];
+    if (co < a.Cout && ci0 + ci < a.Cin && vsum != 0.f) atomicAdd(dw + ((long)co * a.Cin + ci0 + ci) * 27 + t, vsum);
+  }
+  if (blockIdx.y == 0 && dbias && tid < a.Cout) atomicAdd(dbias + tid, dbsum[tid]);
+}
+
 // wp[(step*2 + hl)*64 + lane] (uint4 = 8 bf16) for the forward (dgrad = 0: rows = Cout, reduction = Cin, W[m][c][tap]) or
 // the data gradient (dgrad = 1: rows = Cin, reduction = Cout, W[c][m][26 - tap])
 __global__ void __launch_bounds__(256)
@@ -654,8 +835,40 @@ static int launch_vox_wgrad(const muvo_conv_desc* d, const float* x, const float
   return MUVO_OK;
 }
 
-int vox_wgrad(const muvo_conv_desc* d, const float* x, const float* dz, float* dw, float* dbias, hipStream_t st) {
+bool vox_bf3_wgrad_shape_ok(const muvo_conv_desc* d) {
+  return vox_wgrad_applicable(d) && d->Cin % 16 == 0 && d->Cin <= 64 && (d->Cout == 8 || d->Cout == 16);
+}
+
+template <int Z>
+static int launch_vox_bf3_wgrad(const muvo_conv_desc* d, const float* x, const float* dz, float* dw, float* dbias, hipStream_t st) {
+  constexpr int ZH = Z / 32, WROWS = 8 / ZH, ROWS = WROWS + 2;
+  constexpr size_t lds = (size_t)3 * 2 * 16 * (ROWS * (Z + 16) * 2 + 16) + (size_t)2 * 2 * 16 * (WROWS * Z * 2 + 16) + 64;
+  static_assert(lds >= 27 * 256 * 4, "the reduction reuses the rings");
+  VoxArgs a;
+  a.N = d->N; a.Cin = d->Cin; a.Cout = d->Cout; a.X = d->in_sz[0]; a.Y = d->in_sz[1];
+  a.ytiles = cdiv(a.Y, WROWS);
+  a.xgroups = 0;
+  a.XYZ = a.X * a.Y * Z;
+  a.sN_in = (long)a.Cin * a.XYZ; a.sN_out = (long)a.Cout * a.XYZ;
+  int xseg = a.X;
+  while ((long)a.N * a.ytiles * cdiv(a.X, xseg) * (a.Cin / 16) < 1024 && xseg > 12) xseg = cdiv(xseg, 2);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)vox_bf3_wgrad_kernel<Z>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      muvo_set_error("vox_bf3_wgrad: cannot raise the dynamic LDS limit to %zu bytes", lds);
+      return MUVO_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  dim3 grid((unsigned)((long)a.N * a.ytiles * cdiv(a.X, xseg)), a.Cin / 16);
+  hipLaunchKernelGGL((vox_bf3_wgrad_kernel<Z>), grid, dim3(512), lds, st, a, x, dz, dw, dbias, xseg);
+  MUVO_CHECK_LAUNCH("vox_bf3_wgrad_kernel");
+  return MUVO_OK;
+}
+
+int vox_wgrad(const muvo_conv_desc* d, const float* x, const float* dz, float* dw, float* dbias, hipStream_t st, bool bf3) {
   const int Z = d->in_sz[2];
+  if (bf3) return Z == 64 ? launch_vox_bf3_wgrad<64>(d, x, dz, dw, dbias, st) : launch_vox_bf3_wgrad<32>(d, x, dz, dw, dbias, st);
   const bool r4 = d->Cin % 16 == 0;
   // 16 input channels per workgroup with 2 output quads per role, or 8 input channels with 1 output quad per role
   if (Z == 64) return r4 ? launch_vox_wgrad<4, 2, 64, 4>(d, x, dz, dw, dbias, st) : launch_vox_wgrad<2, 1, 64, 4>(d, x, dz, dw, dbias, st);

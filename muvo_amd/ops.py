@@ -220,13 +220,14 @@ class KernelTiming:
         return roof, classes
 
 
-FAMILY = {0: 'f32_implicit_gemm', 1: 'bf16x3_implicit_gemm', 2: 'vox_4x4x1', 3: 'heads_valu', -1: 'unknown'}
+FAMILY = {0: 'f32_implicit_gemm', 1: 'bf16x3_implicit_gemm', 2: 'vox_4x4x1', 3: 'heads_valu', 4: 'vox_bf16x3', -1: 'unknown'}
 KERNEL_NAMES = {'f32_implicit_gemm': 'conv_fwd_kernel / conv_wgrad_kernel (v_mfma_f32_32x32x2_f32)',
                 'bf16x3_implicit_gemm': 'conv_bf3_kernel / conv_bf3_wgrad_kernel (v_mfma_f32_32x32x16_bf16, 3 products)',
-                'vox_4x4x1': 'vox_conv_kernel / vox_wgrad_kernel (v_mfma_f32_4x4x1_16b_f32)'}
+                'vox_4x4x1': 'vox_conv_kernel / vox_wgrad_kernel (v_mfma_f32_4x4x1_16b_f32)',
+                'vox_bf16x3': 'vox_bf3_kernel (v_mfma_f32_16x16x32_bf16, 3 products, rows padded to 16)'}
 # dense MFMA peaks from /opt/skills/guides/MI355X_MICROARCH.md
-PEAK_TFLOPS = {'f32_implicit_gemm': 157.3, 'bf16x3_implicit_gemm': 2500.0, 'vox_4x4x1': 157.3}
-MFMA_FLOPS_PER_ALGORITHMIC_FLOP = {'f32_implicit_gemm': 1.0, 'bf16x3_implicit_gemm': 3.0, 'vox_4x4x1': 1.0}
+PEAK_TFLOPS = {'f32_implicit_gemm': 157.3, 'bf16x3_implicit_gemm': 2500.0, 'vox_4x4x1': 157.3, 'vox_bf16x3': 2500.0}
+MFMA_FLOPS_PER_ALGORITHMIC_FLOP = {'f32_implicit_gemm': 1.0, 'bf16x3_implicit_gemm': 3.0, 'vox_4x4x1': 1.0, 'vox_bf16x3': 3.0}
 
 
 def _conv_tag(geom, n, in_sz):

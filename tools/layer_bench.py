@@ -28,6 +28,7 @@ LAYERS = {
     'vox16': ('conv3d', 16, 8, 3, 1, 1, (192, 192, 64)),
     'vox8': ('conv3d', 8, 8, 3, 1, 1, (192, 192, 64)),
     'vox16b': ('conv3d', 16, 16, 3, 1, 1, (96, 96, 32)),
+    'vox32': ('conv3d', 32, 16, 3, 1, 1, (96, 96, 32)),
     'vox64': ('conv3d', 64, 64, 3, 1, 1, (24, 24, 8)),
 }
 
