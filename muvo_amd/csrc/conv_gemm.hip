@@ -438,6 +438,11 @@ static double bf3_min_gflop() {
 static thread_local int t_force_family = 0;   // +1 / -1: make this phase bf16x3 / fp32 regardless of its own size (see below)
 // does the small-channel 3x3x3 conv of this direction run on its bf16x3 kernel (conv_vox.hip)?  Same policy as the
 // implicit-GEMM family: bf16x3 mode and at least MUVO_BF16X3_MIN_GFLOP of work per batch item.
+static bool vox_uses_bf3(const muvo_conv_desc* d, int dgrad);
+// voxel-kernel applicability per direction: the fp32 4x4x1 kernels, or (bf16x3 mode) shapes only the bf16x3 kernel covers
+// (data gradient with 32 produced channels)
+static bool vox_fwd_ok(const muvo_conv_desc* d) { return vox_fwd_applicable(d) || vox_uses_bf3(d, 0); }
+static bool vox_dgrad_ok(const muvo_conv_desc* d) { return vox_dgrad_applicable(d) || vox_uses_bf3(d, 1); }
 static bool vox_uses_bf3(const muvo_conv_desc* d, int dgrad) {
   if (conv_mode() != 1 || !vox_bf3_shape_ok(d, dgrad)) return false;
   const double gflop = 2.0 * d->Cin * d->Cout * 27.0 * (double)d->in_sz[0] * d->in_sz[1] * d->in_sz[2] * 1e-9;
@@ -725,8 +730,8 @@ int muvo_conv_pack_sizes(const muvo_conv_desc* d, int64_t* fwd_floats, int64_t* 
     if (pf.fwd_floats > pl.fwd_floats) pl.fwd_floats = pf.fwd_floats;
   }
   // the small-channel Conv3d path (conv_vox.hip) keeps its own layout in the same buffers
-  if (vox_fwd_applicable(d) && vox_pack_floats(d) > pl.fwd_floats) pl.fwd_floats = vox_pack_floats(d);
-  if (vox_dgrad_applicable(d) && vox_pack_floats(d) > pl.dgr_floats) pl.dgr_floats = vox_pack_floats(d);
+  if (vox_fwd_ok(d) && vox_pack_floats(d) > pl.fwd_floats) pl.fwd_floats = vox_pack_floats(d);
+  if (vox_dgrad_ok(d) && vox_pack_floats(d) > pl.dgr_floats) pl.dgr_floats = vox_pack_floats(d);
   if (fwd_floats) *fwd_floats = pl.fwd_floats;
   if (dgrad_floats) *dgrad_floats = pl.dgr_floats;
   return MUVO_OK;
@@ -747,12 +752,12 @@ int muvo_conv_pack_weights(const muvo_conv_desc* d, const float* w, float* wp_fw
     }
     return MUVO_OK;
   }
-  if (wp_fwd && vox_fwd_applicable(d)) {
+  if (wp_fwd && vox_fwd_ok(d)) {
     rc = vox_pack(d, w, wp_fwd, 0, st, vox_uses_bf3(d, 0));
     if (rc) return rc;
     wp_fwd = nullptr;
   }
-  if (wp_dgrad && vox_dgrad_applicable(d)) {
+  if (wp_dgrad && vox_dgrad_ok(d)) {
     rc = vox_pack(d, w, wp_dgrad, 1, st, vox_uses_bf3(d, 1));
     if (rc) return rc;
     wp_dgrad = nullptr;
@@ -798,7 +803,7 @@ int64_t muvo_conv_workspace_bytes(const muvo_conv_desc* d, int op) {
   const ConvPhase* ph = op == 0 ? pl.fwd : pl.dgr;
   const int nph = op == 0 ? pl.nfwd : pl.ndgr;
   if (pw_applicable(d)) return 0;
-  if (op == 0 ? vox_fwd_applicable(d) : vox_dgrad_applicable(d)) return 0;
+  if (op == 0 ? vox_fwd_ok(d) : vox_dgrad_ok(d)) return 0;
   for (int i = 0; i < nph; ++i)
     if (ph[i].bf3) return bf3_workspace_bytes(ph[i].N, ph[i].C, (long)ph[i].ID * ph[i].IH * ph[i].IW);
   return 0;
@@ -816,7 +821,7 @@ int muvo_conv_kernel_family(const muvo_conv_desc* d, int op) {
     return wgrad_uses_bf3(pl) ? 1 : 0;
   }
   if (build_plan(d, &pl)) return -1;
-  if (op == 0 ? vox_fwd_applicable(d) : vox_dgrad_applicable(d)) return vox_uses_bf3(d, op) ? 4 : 2;
+  if (op == 0 ? vox_fwd_ok(d) : vox_dgrad_ok(d)) return vox_uses_bf3(d, op) ? 4 : 2;
   const ConvPhase* ph = op == 0 ? pl.fwd : pl.dgr;
   const int nph = op == 0 ? pl.nfwd : pl.ndgr;
   for (int i = 0; i < nph; ++i)
@@ -860,7 +865,7 @@ int muvo_conv_forward(const muvo_conv_desc* d, const float* x, const float* wp_f
   if (rc) return rc;
   MUVO_CHECK_ARG(x && wp_fwd && y, "conv_forward: null pointer");
   if (pw_applicable(d)) return pw_forward(d, x, wp_fwd, bias, y, act, slope, (hipStream_t)stream);
-  if (vox_fwd_applicable(d)) return vox_forward(d, x, wp_fwd, bias, y, act, slope, (hipStream_t)stream, vox_uses_bf3(d, 0));
+  if (vox_fwd_ok(d)) return vox_forward(d, x, wp_fwd, bias, y, act, slope, (hipStream_t)stream, vox_uses_bf3(d, 0));
   return run_phases(pl.fwd, pl.nfwd, x, wp_fwd, bias, y, act, slope, ws, (hipStream_t)stream);
 }
 
@@ -871,7 +876,7 @@ int muvo_conv_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp_dg
   if (rc) return rc;
   MUVO_CHECK_ARG(dy && wp_dgrad && dx, "conv_dgrad: null pointer");
   if (pw_applicable(d)) return pw_dgrad(d, dy, wp_dgrad, dx, (hipStream_t)stream);
-  if (vox_dgrad_applicable(d)) return vox_dgrad(d, dy, wp_dgrad, dx, (hipStream_t)stream, vox_uses_bf3(d, 1));
+  if (vox_dgrad_ok(d)) return vox_dgrad(d, dy, wp_dgrad, dx, (hipStream_t)stream, vox_uses_bf3(d, 1));
   return run_phases(pl.dgr, pl.ndgr, dy, wp_dgrad, nullptr, dx, MUVO_ACT_NONE, 0.f, ws, (hipStream_t)stream, ws_valid != 0);
 }
 

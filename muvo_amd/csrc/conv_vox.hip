@@ -391,13 +391,15 @@ vox_bf3_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* __re
   const int y0 = ytile * TY, xs = seg * xseg, xe = xs + xseg < a.X ? xs + xseg : a.X;
   const long YZ = (long)a.Y * Z;
   const float* inb = in + (long)n * a.sN_in;
+  const int co0 = blockIdx.y * 16;                     // produced channels [co0, co0 + 16): one 16-row block per grid.y
 
   // weights -> registers
   vbf16x8 wh[NSTEP], wl[NSTEP];
+  const vu32x4* wpb = wp + (size_t)blockIdx.y * NSTEP * 2 * 64;
 #pragma unroll
   for (int s = 0; s < NSTEP; ++s) {
-    wh[s] = __builtin_bit_cast(vbf16x8, wp[(s * 2) * 64 + lane]);
-    wl[s] = __builtin_bit_cast(vbf16x8, wp[(s * 2 + 1) * 64 + lane]);
+    wh[s] = __builtin_bit_cast(vbf16x8, wpb[(s * 2) * 64 + lane]);
+    wl[s] = __builtin_bit_cast(vbf16x8, wpb[(s * 2 + 1) * 64 + lane]);
   }
   // zero the whole ring once (z halo columns and out-of-range rows / planes stay zero unless overwritten)
   for (int i = tid; i < 3 * PLANE; i += 64 * TY) vsm[i] = vu32x4{0u, 0u, 0u, 0u};
@@ -474,7 +476,7 @@ vox_bf3_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* __re
         float* ob = out + (long)n * a.sN_out + (long)x * YZ + (long)gy * Z + zt * 16 + v;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const int co = 4 * g + i;
+          const int co = co0 + 4 * g + i;
           if (co < a.Cout) {
             float r = acc[i];
             if (bias) r += bias[co];
@@ -674,10 +676,12 @@ __global__ void __launch_bounds__(256)
 vox_bf3_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int Cin, int Cout, int dgrad, int CK, int nstep) {
   const int CG = CK / 8, TPS = 4 / CG;
   const int rows = dgrad ? Cin : Cout;
-  const int total = nstep * 64 * 8;
+  const int nrb = (rows + 15) / 16;
+  const int total = nrb * nstep * 64 * 8;
   for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
-    const int e = idx & 7, lane = (idx >> 3) & 63, s = idx >> 9;
-    const int m = lane & 15, g = lane >> 4;
+    const int e = idx & 7, lane = (idx >> 3) & 63, sb = idx >> 9;
+    const int s = sb % nstep, rb = sb / nstep;
+    const int m = rb * 16 + (lane & 15), g = lane >> 4;
     const int tap = s * TPS + g / CG, c = (g % CG) * 8 + e;
     float val = 0.f;
     if (tap < 27 && m < rows) val = dgrad ? w[((size_t)c * Cin + m) * 27 + (26 - tap)] : w[((size_t)m * Cin + c) * 27 + tap];
@@ -686,8 +690,8 @@ vox_bf3_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp
     const float rem = val - __uint_as_float(hu << 16);
     unsigned r = __float_as_uint(rem);
     unsigned lu = (r + 0x7fffu + ((r >> 16) & 1u)) >> 16;
-    wp[((size_t)(s * 2) * 64 + lane) * 8 + e] = (unsigned short)hu;
-    wp[((size_t)(s * 2 + 1) * 64 + lane) * 8 + e] = (unsigned short)lu;
+    wp[((size_t)((rb * nstep + s) * 2) * 64 + lane) * 8 + e] = (unsigned short)hu;
+    wp[((size_t)((rb * nstep + s) * 2 + 1) * 64 + lane) * 8 + e] = (unsigned short)lu;
   }
 }
 
@@ -713,20 +717,22 @@ bool vox_wgrad_applicable(const muvo_conv_desc* d) {
 }
 // bf16x3 variant: reduction and produced channels in {8, 16}
 bool vox_bf3_shape_ok(const muvo_conv_desc* d, int dgrad) {
-  if (!(dgrad ? vox_dgrad_applicable(d) : vox_fwd_applicable(d))) return false;
+  if (!vox_geometry_ok(d)) return false;
   const int ck = dgrad ? d->Cout : d->Cin, cp = dgrad ? d->Cin : d->Cout;
-  return (ck == 8 || ck == 16) && (cp == 8 || cp == 16);
+  // reduction channels 8 / 16 (the weights of one 16-row block live in registers); produced channels in blocks of 16 rows
+  return (ck == 8 || ck == 16) && (cp == 8 || cp == 16 || cp == 32);
 }
 static int vox_bf3_steps(int ck) { return ck == 8 ? 7 : 14; }
 long vox_pack_floats(const muvo_conv_desc* d) {
-  const long plain = 27l * d->Cin * d->Cout, bf3 = 14l * 2 * 64 * 4;   // bf16x3 layout: steps x (hi, lo) x 64 lanes x 16 bytes
+  const long plain = 27l * d->Cin * d->Cout, bf3 = 14l * 2 * 64 * 4 * 2;   // bf16x3 layout: row blocks x steps x (hi, lo) x 64 lanes x 16 B
   return plain > bf3 ? plain : bf3;
 }
 
 int vox_pack(const muvo_conv_desc* d, const float* w, float* wp, int dgrad, hipStream_t st, bool bf3) {
   if (bf3) {
-    const int ck = dgrad ? d->Cout : d->Cin, ns = vox_bf3_steps(ck);
-    hipLaunchKernelGGL(vox_bf3_pack_kernel, dim3(cdiv(ns * 512, 256)), dim3(256), 0, st, w, (unsigned short*)wp, d->Cin, d->Cout, dgrad, ck, ns);
+    const int ck = dgrad ? d->Cout : d->Cin, cp = dgrad ? d->Cin : d->Cout, ns = vox_bf3_steps(ck);
+    hipLaunchKernelGGL(vox_bf3_pack_kernel, dim3(cdiv(cdiv(cp, 16) * ns * 512, 256)), dim3(256), 0, st, w, (unsigned short*)wp, d->Cin, d->Cout,
+                       dgrad, ck, ns);
     MUVO_CHECK_LAUNCH("vox_bf3_pack_kernel");
     return MUVO_OK;
   }
@@ -775,7 +781,7 @@ static int launch_vox_bf3(const muvo_conv_desc* d, int Cin, int Cout, const floa
     attr_set = true;
   }
   const long blocks = (long)a.N * a.ytiles * cdiv(a.X, xseg);
-  hipLaunchKernelGGL((vox_bf3_kernel<CK, Z, TY>), dim3((unsigned)blocks), dim3(64 * TY), lds, st, a, in, (const vu32x4*)wp, bias, out, act,
+  hipLaunchKernelGGL((vox_bf3_kernel<CK, Z, TY>), dim3((unsigned)blocks, cdiv(Cout, 16)), dim3(64 * TY), lds, st, a, in, (const vu32x4*)wp, bias, out, act,
                      slope, xseg);
   MUVO_CHECK_LAUNCH("vox_bf3_kernel");
   return MUVO_OK;
