@@ -503,16 +503,19 @@ vox_bf3_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* __re
 //     through LDS and issue one set of float atomics into dW.
 // grid.x = N * ytiles * x-segments, grid.y = Cin / 16 (column blocks).
 // ================================================================================================
-template <int Z>
+// CI = 16: MFMA columns = 16 input channels of one tap.  CI = 8: columns = 8 input channels x two (dx, dy) combinations
+// (column j: channel j & 7, combination 2 * pair + (j >> 3)), 5 pairs x 3 dz = 15 accumulator tiles.
+template <int Z, int CI>
 __global__ void __launch_bounds__(512)
 vox_bf3_wgrad_kernel(const VoxArgs a, const float* __restrict__ x, const float* __restrict__ dz, float* __restrict__ dw,
                      float* __restrict__ dbias, int xseg) {
   constexpr int ZH = Z / 32, WROWS = 8 / ZH, ROWS = WROWS + 2;
   constexpr int XROW = (Z + 16) * 2;                    // bytes of an x row: 16-byte zero pad on both sides
   constexpr int XCI = ROWS * XROW + 16;                 // channel stride (bytes), +16 spreads 16 channels over all banks
-  constexpr int XHL = 16 * XCI, XSLOT = 2 * XHL;
+  constexpr int XHL = CI * XCI, XSLOT = 2 * XHL;
   constexpr int DROW = Z * 2, DCO = WROWS * DROW + 16, DHL = 16 * DCO, DBUF = 2 * DHL;
-  constexpr int XT = 16 * ROWS * (Z / 8), DT = 16 * WROWS * (Z / 8);   // staging tasks (8 voxels each)
+  constexpr int XT = CI * ROWS * (Z / 8), DT = 16 * WROWS * (Z / 8);
+  constexpr int NT = CI == 16 ? 27 : 15;               // accumulator tiles   // staging tasks (8 voxels each)
   constexpr int XPT = (XT + 511) / 512, DPT = (DT + 511) / 512;
   extern __shared__ char wsm[];
   char* xring = wsm;
@@ -524,7 +527,7 @@ vox_bf3_wgrad_kernel(const VoxArgs a, const float* __restrict__ x, const float* 
   const int seg = bid % nseg; bid /= nseg;
   const int ytile = bid % a.ytiles, n = bid / a.ytiles;
   const int y0 = ytile * WROWS, xs = seg * xseg, xe = xs + xseg < a.X ? xs + xseg : a.X;
-  const int ci0 = blockIdx.y * 16;
+  const int ci0 = blockIdx.y * CI;
   const long YZ = (long)a.Y * Z;
   const float* xb = x + (long)n * a.sN_in + (long)ci0 * a.XYZ;
   const float* db = dz + (long)n * a.sN_out;
@@ -592,13 +595,14 @@ vox_bf3_wgrad_kernel(const VoxArgs a, const float* __restrict__ x, const float* 
     }
   };
 
-  vf32x4 acc[27];
+  vf32x4 acc[NT];
 #pragma unroll
-  for (int t = 0; t < 27; ++t) acc[t] = vf32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NT; ++t) acc[t] = vf32x4{0.f, 0.f, 0.f, 0.f};
   const int row = wave / ZH, z0 = (wave % ZH) * 32;     // this wave's output row and z half
   const int j = lane & 15, kg = lane >> 4;
   const int a_off = j * DCO + row * DROW + (z0 + kg * 8) * 2;           // A: rows = co = lane & 15
-  const int b_off = j * XCI + 16 + (z0 + kg * 8) * 2;                   // B: columns = ci = lane & 15 (+ row term below)
+  const int b_off = (j & (CI - 1)) * XCI + 16 + (z0 + kg * 8) * 2;      // B: columns -> channel j & (CI - 1) (+ row term below)
+  const int sel = CI == 8 ? j >> 3 : 0;                                 // CI = 8: which combination of the pair this column reads
 
   xload(xs - 1); xstore((xs - 1 + 3) % 3);
   xload(xs); xstore(xs % 3);
@@ -613,59 +617,66 @@ vox_bf3_wgrad_kernel(const VoxArgs a, const float* __restrict__ x, const float* 
     const char* A = dzb + (px & 1) * DBUF + a_off;
     const vbf16x8 ah = __builtin_bit_cast(vbf16x8, *(const vu32x4*)A);
     const vbf16x8 al = __builtin_bit_cast(vbf16x8, *(const vu32x4*)(A + DHL));
+    constexpr int NCOMB = CI == 16 ? 9 : 5;             // (dx, dy) combinations, or pairs of them
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-      const char* S = xring + ((px + dx - 1 + 3) % 3) * XSLOT + b_off;
+    for (int cb = 0; cb < NCOMB; ++cb) {
+      int c = CI == 16 ? cb : 2 * cb + sel;             // this lane's combination
+      if (c > 8) c = 8;                                 // the phantom second half of the last pair (its tile half is discarded)
+      const int dx = c / 3, dy = c - 3 * dx;
+      const char* R = xring + ((px + dx - 1 + 3) % 3) * XSLOT + b_off + (row + dy) * XROW;   // source row = row + 1 + (dy - 1)
+      vu32x4 w[2];
+      unsigned pw[2], nw[2];
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
-        const char* R = S + (row + dy) * XROW;          // source row = row + 1 + (dy - 1)
-        vu32x4 w[2];
-        unsigned pw[2], nw[2];
-#pragma unroll
-        for (int hl = 0; hl < 2; ++hl) {
-          w[hl] = *(const vu32x4*)(R + hl * XHL);
-          pw[hl] = *(const unsigned*)(R + hl * XHL - 4);
-          nw[hl] = *(const unsigned*)(R + hl * XHL + 16);
-        }
-        vbf16x8 bm[2], bz[2], bp[2];                    // dz = -1, 0, +1
-#pragma unroll
-        for (int hl = 0; hl < 2; ++hl) {
-          const vu32x4 q = w[hl];
-          bz[hl] = __builtin_bit_cast(vbf16x8, q);
-          const vu32x4 m = {__builtin_amdgcn_alignbyte(q.x, pw[hl], 2), __builtin_amdgcn_alignbyte(q.y, q.x, 2),
-                            __builtin_amdgcn_alignbyte(q.z, q.y, 2), __builtin_amdgcn_alignbyte(q.w, q.z, 2)};
-          const vu32x4 pl = {__builtin_amdgcn_alignbyte(q.y, q.x, 2), __builtin_amdgcn_alignbyte(q.z, q.y, 2),
-                             __builtin_amdgcn_alignbyte(q.w, q.z, 2), __builtin_amdgcn_alignbyte(nw[hl], q.w, 2)};
-          bm[hl] = __builtin_bit_cast(vbf16x8, m);
-          bp[hl] = __builtin_bit_cast(vbf16x8, pl);
-        }
-        const int t0 = (dx * 3 + dy) * 3;
-        acc[t0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bm[0], acc[t0], 0, 0, 0);
-        acc[t0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[1], acc[t0], 0, 0, 0);
-        acc[t0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[0], acc[t0], 0, 0, 0);
-        acc[t0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bz[0], acc[t0 + 1], 0, 0, 0);
-        acc[t0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bz[1], acc[t0 + 1], 0, 0, 0);
-        acc[t0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bz[0], acc[t0 + 1], 0, 0, 0);
-        acc[t0 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bp[0], acc[t0 + 2], 0, 0, 0);
-        acc[t0 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bp[1], acc[t0 + 2], 0, 0, 0);
-        acc[t0 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bp[0], acc[t0 + 2], 0, 0, 0);
+      for (int hl = 0; hl < 2; ++hl) {
+        w[hl] = *(const vu32x4*)(R + hl * XHL);
+        pw[hl] = *(const unsigned*)(R + hl * XHL - 4);
+        nw[hl] = *(const unsigned*)(R + hl * XHL + 16);
       }
+      vbf16x8 bm[2], bz[2], bp[2];                      // dz = -1, 0, +1
+#pragma unroll
+      for (int hl = 0; hl < 2; ++hl) {
+        const vu32x4 q = w[hl];
+        bz[hl] = __builtin_bit_cast(vbf16x8, q);
+        const vu32x4 m = {__builtin_amdgcn_alignbyte(q.x, pw[hl], 2), __builtin_amdgcn_alignbyte(q.y, q.x, 2),
+                          __builtin_amdgcn_alignbyte(q.z, q.y, 2), __builtin_amdgcn_alignbyte(q.w, q.z, 2)};
+        const vu32x4 pl = {__builtin_amdgcn_alignbyte(q.y, q.x, 2), __builtin_amdgcn_alignbyte(q.z, q.y, 2),
+                           __builtin_amdgcn_alignbyte(q.w, q.z, 2), __builtin_amdgcn_alignbyte(nw[hl], q.w, 2)};
+        bm[hl] = __builtin_bit_cast(vbf16x8, m);
+        bp[hl] = __builtin_bit_cast(vbf16x8, pl);
+      }
+      const int t0 = cb * 3;
+      acc[t0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bm[0], acc[t0], 0, 0, 0);
+      acc[t0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[1], acc[t0], 0, 0, 0);
+      acc[t0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[0], acc[t0], 0, 0, 0);
+      acc[t0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bz[0], acc[t0 + 1], 0, 0, 0);
+      acc[t0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bz[1], acc[t0 + 1], 0, 0, 0);
+      acc[t0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bz[0], acc[t0 + 1], 0, 0, 0);
+      acc[t0 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bp[0], acc[t0 + 2], 0, 0, 0);
+      acc[t0 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bp[1], acc[t0 + 2], 0, 0, 0);
+      acc[t0 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bp[0], acc[t0 + 2], 0, 0, 0);
     }
     __syncthreads();
   }
-  // workgroup reduction of the 27 tiles through LDS (the rings are free now), then one set of atomics
-  float* red = (float*)wsm;                                             // [27][16 co][16 ci]
-  for (int i = tid; i < 27 * 256; i += 512) red[i] = 0.f;
+  // workgroup reduction of the accumulator tiles through LDS (the rings are free now), then one set of atomics
+  float* red = (float*)wsm;                                             // [NT][16 co][16 columns]
+  for (int i = tid; i < NT * 256; i += 512) red[i] = 0.f;
   __syncthreads();
 #pragma unroll
-  for (int t = 0; t < 27; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) atomicAdd(red + (t * 16 + 4 * kg + r) * 16 + j, acc[t][r]);
   __syncthreads();
-  for (int i = tid; i < 27 * 256; i += 512) {
-    const int ci = i & 15, co = (i >> 4) & 15, t = i >> 8;
+  for (int i = tid; i < NT * 256; i += 512) {
+    const int col = i & 15, co = (i >> 4) & 15, t = i >> 8;
+    int ci, tap;
+    if (CI == 16) { ci = col; tap = t; }
+    else {
+      const int comb = 2 * (t / 3) + (col >> 3);                        // (dx, dy) combination of this column
+      ci = col & 7;
+      tap = comb <= 8 ? comb * 3 + t % 3 : -1;
+    }
     const float vsum = red[i];
-    if (co < a.Cout && ci0 + ci < a.Cin && vsum != 0.f) atomicAdd(dw + ((long)co * a.Cin + ci0 + ci) * 27 + t, vsum);
+    if (tap >= 0 && co < a.Cout && ci0 + ci < a.Cin && vsum != 0.f) atomicAdd(dw + ((long)co * a.Cin + ci0 + ci) * 27 + tap, vsum);
   }
   if (blockIdx.y == 0 && dbias && tid < a.Cout) atomicAdd(dbias + tid, dbsum[tid]);
 }
@@ -842,14 +853,14 @@ static int launch_vox_wgrad(const muvo_conv_desc* d, const float* x, const float
 }
 
 bool vox_bf3_wgrad_shape_ok(const muvo_conv_desc* d) {
-  return vox_wgrad_applicable(d) && d->Cin % 16 == 0 && d->Cin <= 64 && (d->Cout == 8 || d->Cout == 16);
+  return vox_wgrad_applicable(d) && (d->Cin == 8 || d->Cin % 16 == 0) && d->Cin <= 64 && (d->Cout == 8 || d->Cout == 16);
 }
 
-template <int Z>
+template <int Z, int CI>
 static int launch_vox_bf3_wgrad(const muvo_conv_desc* d, const float* x, const float* dz, float* dw, float* dbias, hipStream_t st) {
   constexpr int ZH = Z / 32, WROWS = 8 / ZH, ROWS = WROWS + 2;
-  constexpr size_t lds = (size_t)3 * 2 * 16 * (ROWS * (Z + 16) * 2 + 16) + (size_t)2 * 2 * 16 * (WROWS * Z * 2 + 16) + 64;
-  static_assert(lds >= 27 * 256 * 4, "the reduction reuses the rings");
+  constexpr size_t lds = (size_t)3 * 2 * CI * (ROWS * (Z + 16) * 2 + 16) + (size_t)2 * 2 * 16 * (WROWS * Z * 2 + 16) + 64;
+  static_assert(lds >= (CI == 16 ? 27 : 15) * 256 * 4, "the reduction reuses the rings");
   VoxArgs a;
   a.N = d->N; a.Cin = d->Cin; a.Cout = d->Cout; a.X = d->in_sz[0]; a.Y = d->in_sz[1];
   a.ytiles = cdiv(a.Y, WROWS);
@@ -857,24 +868,27 @@ static int launch_vox_bf3_wgrad(const muvo_conv_desc* d, const float* x, const f
   a.XYZ = a.X * a.Y * Z;
   a.sN_in = (long)a.Cin * a.XYZ; a.sN_out = (long)a.Cout * a.XYZ;
   int xseg = a.X;
-  while ((long)a.N * a.ytiles * cdiv(a.X, xseg) * (a.Cin / 16) < 1024 && xseg > 12) xseg = cdiv(xseg, 2);
+  while ((long)a.N * a.ytiles * cdiv(a.X, xseg) * (a.Cin / CI) < 1024 && xseg > 12) xseg = cdiv(xseg, 2);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)vox_bf3_wgrad_kernel<Z>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)vox_bf3_wgrad_kernel<Z, CI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       muvo_set_error("vox_bf3_wgrad: cannot raise the dynamic LDS limit to %zu bytes", lds);
       return MUVO_ERR_HIP;
     }
     attr_set = true;
   }
-  dim3 grid((unsigned)((long)a.N * a.ytiles * cdiv(a.X, xseg)), a.Cin / 16);
-  hipLaunchKernelGGL((vox_bf3_wgrad_kernel<Z>), grid, dim3(512), lds, st, a, x, dz, dw, dbias, xseg);
+  dim3 grid((unsigned)((long)a.N * a.ytiles * cdiv(a.X, xseg)), a.Cin / CI);
+  hipLaunchKernelGGL((vox_bf3_wgrad_kernel<Z, CI>), grid, dim3(512), lds, st, a, x, dz, dw, dbias, xseg);
   MUVO_CHECK_LAUNCH("vox_bf3_wgrad_kernel");
   return MUVO_OK;
 }
 
 int vox_wgrad(const muvo_conv_desc* d, const float* x, const float* dz, float* dw, float* dbias, hipStream_t st, bool bf3) {
   const int Z = d->in_sz[2];
-  if (bf3) return Z == 64 ? launch_vox_bf3_wgrad<64>(d, x, dz, dw, dbias, st) : launch_vox_bf3_wgrad<32>(d, x, dz, dw, dbias, st);
+  if (bf3) {
+    if (d->Cin == 8) return Z == 64 ? launch_vox_bf3_wgrad<64, 8>(d, x, dz, dw, dbias, st) : launch_vox_bf3_wgrad<32, 8>(d, x, dz, dw, dbias, st);
+    return Z == 64 ? launch_vox_bf3_wgrad<64, 16>(d, x, dz, dw, dbias, st) : launch_vox_bf3_wgrad<32, 16>(d, x, dz, dw, dbias, st);
+  }
   const bool r4 = d->Cin % 16 == 0;
   // 16 input channels per workgroup with 2 output quads per role, or 8 input channels with 1 output quad per role
   if (Z == 64) return r4 ? launch_vox_wgrad<4, 2, 64, 4>(d, x, dz, dw, dbias, st) : launch_vox_wgrad<2, 1, 64, 4>(d, x, dz, dw, dbias, st);
