@@ -77,7 +77,13 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    force_dist = os.environ.get('MUVO_BENCH_FORCE_DIST') == '1'   # one-rank RCCL group: exercises the collective path on one GPU
+    if world > 1 or force_dist:
+        if world == 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29511')
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=dev)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
@@ -95,7 +101,7 @@ def main():
     tr.train()
     opts, scheds = tr.configure_optimizers()
     opt, sched = opts[0], scheds[0]['scheduler']
-    reducer = SegmentedGradReducer(tr.store)
+    reducer = SegmentedGradReducer(tr.store, force_collectives=force_dist)
     tr.model.segment_done = reducer.segment_done
     opt.grad_scale = reducer.grad_scale
 
@@ -117,7 +123,7 @@ def main():
         step(i)
     if not args.no_kernel_timing:
         ops.KERNEL_TIMING = ops.KernelTiming()
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -163,7 +169,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(usable_cores())
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

@@ -13,13 +13,16 @@ import torch.distributed as dist
 
 
 class SegmentedGradReducer:
-    def __init__(self, store, group=None, overlap=True):
+    def __init__(self, store, group=None, overlap=True, force_collectives=False):
+        """force_collectives: issue the all-reduces even in a one-rank group (exercises the RCCL / side-stream path on a
+        single GPU; `bench.py` sets it when MUVO_BENCH_FORCE_DIST=1)."""
         self.store = store
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.force = bool(force_collectives) and dist.is_initialized()
         self.overlap = overlap
         self.is_cuda = store.flat_grad.is_cuda
-        self.side = torch.cuda.Stream() if (self.is_cuda and self.world > 1) else None
+        self.side = torch.cuda.Stream() if (self.is_cuda and (self.world > 1 or self.force)) else None
         self._done = set()
         self._handles = []
         self.ranges = {name: (a, b) for name, a, b in store.segment_ranges}
@@ -37,7 +40,7 @@ class SegmentedGradReducer:
         if name in self._done or name not in self.ranges:
             return
         self._done.add(name)
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         a, b = self.ranges[name]
         buf = self.store.flat_grad[a:b]
