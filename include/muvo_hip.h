@@ -224,6 +224,13 @@ int muvo_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, flo
  *   tp/fp/fn of class j over voxels with label != 255 (trainer.py:482-490, SSCMetrics.add_batch, metrics.py:77-100). */
 int muvo_ssim_frames(const float* pred, const float* target, const float* window, double* sums, int N, int C, int H, int W,
                      float c1, float c2, void* stream);
+/* SSIM as a training loss (LOSSES.SSIM: trainer.py:312-318, SSIMLoss losses.py:292-348): muvo_ssim_maps = muvo_ssim_frames plus
+ * the derivative maps dA, dB, dC (N*C*(H-10)*(W-10) floats each) of every SSIM value w.r.t. the prediction's window mean,
+ * E[p^2] and E[p t]; muvo_ssim_bwd: dpred = scale * adjoint window pass (scale = upstream gradient / number of SSIM values) */
+int muvo_ssim_maps(const float* pred, const float* target, const float* window, double* sums, float* dA, float* dB, float* dC, int N,
+                   int C, int H, int W, float c1, float c2, void* stream);
+int muvo_ssim_bwd(const float* pred, const float* target, const float* window, const float* dA, const float* dB, const float* dC,
+                  float* dpred, int N, int C, int H, int W, float scale, void* stream);
 int muvo_sqdiff_frames(const float* pred, const float* target, double* sums, int N, int64_t L, void* stream);
 int muvo_chamfer_sums(const float* a, const float* b, double* sums, int N, int P, int Q, void* stream);
 int muvo_ssc_counts(const float* logits, const uint8_t* label, uint64_t* counts, int64_t F, int C, int64_t V, void* stream);

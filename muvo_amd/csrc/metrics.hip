@@ -47,6 +47,91 @@ ssim_kernel(const float* __restrict__ pred, const float* __restrict__ target, co
   if (tid == 0) atomicAdd(out + nc / C, red[0] + red[1] + red[2] + red[3]);
 }
 
+
+// ---- SSIM as a training loss (LOSSES.SSIM, trainer.py:312-318 with SSIMLoss, losses.py:292-348): forward sum as above plus
+// the partial derivatives of every SSIM value w.r.t. the window statistics of the PREDICTION (mu2, E[p^2], E[p t]), then
+// the adjoint window pass:  dS_o/dp_i = w(o, i) (A_o + 2 B_o p_i + C_o t_i).
+__global__ void __launch_bounds__(SSIM_T * SSIM_T)
+ssim_maps_kernel(const float* __restrict__ pred, const float* __restrict__ target, const float* __restrict__ win2d,
+                 double* __restrict__ out, float* __restrict__ dA, float* __restrict__ dB, float* __restrict__ dC, int C, int H, int W,
+                 float c1, float c2) {
+  constexpr int IT = SSIM_T + SSIM_WIN - 1;
+  __shared__ float sp[IT][IT + 1], st[IT][IT + 1], sw[SSIM_WIN * SSIM_WIN];
+  __shared__ double red[4];
+  const int tid = threadIdx.x, tx = tid % SSIM_T, ty = tid / SSIM_T;
+  const int nc = blockIdx.z, x0 = blockIdx.x * SSIM_T, y0 = blockIdx.y * SSIM_T;
+  const int OH = H - SSIM_WIN + 1, OW = W - SSIM_WIN + 1;
+  const float* p = pred + (size_t)nc * H * W;
+  const float* t = target + (size_t)nc * H * W;
+  for (int i = tid; i < IT * IT; i += SSIM_T * SSIM_T) {
+    const int yy = i / IT, xx = i % IT, gy = y0 + yy, gx = x0 + xx;
+    const bool ok = gy < H && gx < W;
+    sp[yy][xx] = ok ? p[(size_t)gy * W + gx] : 0.f;
+    st[yy][xx] = ok ? t[(size_t)gy * W + gx] : 0.f;
+  }
+  if (tid < SSIM_WIN * SSIM_WIN) sw[tid] = win2d[tid];
+  __syncthreads();
+  double v = 0.0;
+  if (y0 + ty < OH && x0 + tx < OW) {
+    float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+    for (int i = 0; i < SSIM_WIN; ++i)
+#pragma unroll
+      for (int j = 0; j < SSIM_WIN; ++j) {
+        const float w = sw[i * SSIM_WIN + j], a = st[ty + i][tx + j], b = sp[ty + i][tx + j];
+        mu1 += w * a; mu2 += w * b; e11 += w * (a * a); e22 += w * (b * b); e12 += w * (a * b);
+      }
+    const float s1 = e11 - mu1 * mu1, s2 = e22 - mu2 * mu2, s12 = e12 - mu1 * mu2;
+    const float n1 = 2.f * mu1 * mu2 + c1, n2 = 2.f * s12 + c2, d1 = mu1 * mu1 + mu2 * mu2 + c1, d2 = s1 + s2 + c2;
+    const float inv = 1.f / (d1 * d2);
+    v = (double)(n1 * n2 * inv);
+    // d/dmu2 with E[p^2], E[p t] fixed: n1' = 2 mu1, n2' = -2 mu1, d1' = 2 mu2, d2' = -2 mu2
+    const float num_p = 2.f * mu1 * n2 - 2.f * mu1 * n1, den_p = 2.f * mu2 * d2 - 2.f * mu2 * d1;
+    const size_t o = ((size_t)nc * OH + (y0 + ty)) * OW + x0 + tx;
+    dA[o] = (num_p * d1 * d2 - n1 * n2 * den_p) * inv * inv;
+    dB[o] = -n1 * n2 * inv / d2;
+    dC[o] = 2.f * n1 * inv;
+  }
+  v = wave_sum_d(v);
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  if (tid == 0) atomicAdd(out + nc / C, red[0] + red[1] + red[2] + red[3]);
+}
+
+// dpred[i] = scale * sum over the window positions o that cover pixel i of w(i - o) (A_o + 2 B_o p_i + C_o t_i)
+__global__ void __launch_bounds__(SSIM_T * SSIM_T)
+ssim_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target, const float* __restrict__ win2d,
+                const float* __restrict__ dA, const float* __restrict__ dB, const float* __restrict__ dC, float* __restrict__ dpred,
+                int H, int W, float scale) {
+  constexpr int IT = SSIM_T + SSIM_WIN - 1;
+  __shared__ float sa[IT][IT + 1], sb[IT][IT + 1], sc[IT][IT + 1], sw[SSIM_WIN * SSIM_WIN];
+  const int tid = threadIdx.x, tx = tid % SSIM_T, ty = tid / SSIM_T;
+  const int nc = blockIdx.z, x0 = blockIdx.x * SSIM_T, y0 = blockIdx.y * SSIM_T;
+  const int OH = H - SSIM_WIN + 1, OW = W - SSIM_WIN + 1;
+  // pixel (y, x) is covered by the outputs (y - k, x - l), k, l in [0, 10]: tile of outputs [y0 - 10, y0 + 15] x [x0 - 10, x0 + 15]
+  for (int i = tid; i < IT * IT; i += SSIM_T * SSIM_T) {
+    const int yy = i / IT, xx = i % IT, oy = y0 - (SSIM_WIN - 1) + yy, ox = x0 - (SSIM_WIN - 1) + xx;
+    const bool ok = oy >= 0 && oy < OH && ox >= 0 && ox < OW;
+    const size_t o = ((size_t)nc * OH + oy) * OW + ox;
+    sa[yy][xx] = ok ? dA[o] : 0.f;
+    sb[yy][xx] = ok ? dB[o] : 0.f;
+    sc[yy][xx] = ok ? dC[o] : 0.f;
+  }
+  if (tid < SSIM_WIN * SSIM_WIN) sw[tid] = win2d[tid];
+  __syncthreads();
+  const int y = y0 + ty, x = x0 + tx;
+  if (y >= H || x >= W) return;
+  float a = 0.f, b = 0.f, c = 0.f;
+  for (int k = 0; k < SSIM_WIN; ++k)
+#pragma unroll
+    for (int l = 0; l < SSIM_WIN; ++l) {
+      const float w = sw[k * SSIM_WIN + l];          // output (y - k, x - l) sees this pixel at window offset (k, l)
+      const int yy = ty + (SSIM_WIN - 1) - k, xx = tx + (SSIM_WIN - 1) - l;
+      a += w * sa[yy][xx]; b += w * sb[yy][xx]; c += w * sc[yy][xx];
+    }
+  const size_t i = ((size_t)nc * H + y) * W + x;
+  dpred[i] = scale * (a + 2.f * b * pred[i] + c * target[i]);
+}
+
 // out[n] += sum_i (p - t)^2 over the L elements of frame n; grid = (blocks, N)
 __global__ void __launch_bounds__(256)
 sqdiff_kernel(const float* __restrict__ p, const float* __restrict__ t, double* __restrict__ out, long L) {
@@ -142,6 +227,26 @@ int muvo_ssim_frames(const float* pred, const float* target, const float* window
   dim3 grid((W - SSIM_WIN + 1 + SSIM_T - 1) / SSIM_T, (H - SSIM_WIN + 1 + SSIM_T - 1) / SSIM_T, N * C);
   hipLaunchKernelGGL(ssim_kernel, grid, dim3(SSIM_T * SSIM_T), 0, ST, pred, target, window, sums, C, H, W, c1, c2);
   MUVO_CHECK_LAUNCH("ssim_kernel");
+  return MUVO_OK;
+}
+
+int muvo_ssim_maps(const float* pred, const float* target, const float* window, double* sums, float* dA, float* dB, float* dC, int N,
+                   int C, int H, int W, float c1, float c2, void* stream) {
+  MUVO_CHECK_ARG(pred && target && window && sums && dA && dB && dC, "ssim_maps: null pointer");
+  MUVO_CHECK_ARG(N > 0 && C > 0 && H >= SSIM_WIN && W >= SSIM_WIN && (long)N * C <= 65535, "ssim_maps: bad sizes");
+  dim3 grid((W - SSIM_WIN + 1 + SSIM_T - 1) / SSIM_T, (H - SSIM_WIN + 1 + SSIM_T - 1) / SSIM_T, N * C);
+  hipLaunchKernelGGL(ssim_maps_kernel, grid, dim3(SSIM_T * SSIM_T), 0, ST, pred, target, window, sums, dA, dB, dC, C, H, W, c1, c2);
+  MUVO_CHECK_LAUNCH("ssim_maps_kernel");
+  return MUVO_OK;
+}
+
+int muvo_ssim_bwd(const float* pred, const float* target, const float* window, const float* dA, const float* dB, const float* dC,
+                  float* dpred, int N, int C, int H, int W, float scale, void* stream) {
+  MUVO_CHECK_ARG(pred && target && window && dA && dB && dC && dpred, "ssim_bwd: null pointer");
+  MUVO_CHECK_ARG(N > 0 && C > 0 && H >= SSIM_WIN && W >= SSIM_WIN && (long)N * C <= 65535, "ssim_bwd: bad sizes");
+  dim3 grid((W + SSIM_T - 1) / SSIM_T, (H + SSIM_T - 1) / SSIM_T, N * C);
+  hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(SSIM_T * SSIM_T), 0, ST, pred, target, window, dA, dB, dC, dpred, H, W, scale);
+  MUVO_CHECK_LAUNCH("ssim_bwd_kernel");
   return MUVO_OK;
 }
 

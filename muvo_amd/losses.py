@@ -93,3 +93,46 @@ class SegmentationLoss(nn.Module):
             k = int(self.top_k_ratio * loss.shape[2])
             loss = loss.topk(k, dim=-1)[0]
         return torch.mean(loss)
+
+
+class _SSIMMeanFn(torch.autograd.Function):
+    """mean over frames of the per-frame mean SSIM map (SSIMLoss.forward, losses.py:341-348), differentiable in the prediction."""
+
+    @staticmethod
+    def forward(ctx, prediction, target, win, c1, c2):
+        n, c, h, w = prediction.shape
+        p, t = prediction.contiguous(), target.float().contiguous()
+        oh, ow = h - 10, w - 10
+        sums = torch.zeros(n, dtype=torch.float64, device=p.device)
+        maps = torch.empty(3, n, c, oh, ow, device=p.device, dtype=torch.float32)
+        ops._ck(ops.lib().muvo_ssim_maps(ops._f(p), ops._f(t), ops._f(win), ops._p(sums), ops._f(maps[0]), ops._f(maps[1]), ops._f(maps[2]),
+                                        n, c, h, w, ops._fl(c1), ops._fl(c2), ops._st()))
+        ctx.save_for_backward(p, t, win, maps)
+        return (sums / (c * oh * ow)).mean().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        p, t, win, maps = ctx.saved_tensors
+        n, c, h, w = p.shape
+        dp = torch.empty_like(p)
+        scale = float(g) / (n * c * (h - 10) * (w - 10))
+        ops._ck(ops.lib().muvo_ssim_bwd(ops._f(p), ops._f(t), ops._f(win), ops._f(maps[0]), ops._f(maps[1]), ops._f(maps[2]), ops._f(dp), n, c,
+                                       h, w, ops._fl(scale), ops._st()))
+        return dp, None, None, None, None
+
+
+class SSIMLoss(nn.Module):
+    """muvo/losses.py:292-348 (returns the mean SSIM; the trainer uses 1 - it, trainer.py:312-318)."""
+
+    def __init__(self, channel=1, window_size=11, sigma=1.5, L=1, non_negative=False):
+        super().__init__()
+        if window_size != 11 or non_negative:
+            raise NotImplementedError('the kernels implement the reference configuration (window 11, non_negative=False)')
+        from .metrics import _gauss_window
+        self.channel, self.C1, self.C2 = channel, (0.01 * L) ** 2, (0.03 * L) ** 2
+        self.register_buffer('window2d', _gauss_window(window_size, sigma), persistent=False)
+
+    def forward(self, prediction, target):
+        b, s, c, h, w = prediction.shape
+        win = self.window2d.to(prediction.device)
+        return _SSIMMeanFn.apply(prediction.reshape(b * s, c, h, w).float(), target.reshape(b * s, c, h, w), win, self.C1, self.C2)

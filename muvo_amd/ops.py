@@ -58,7 +58,7 @@ EXPORTS = [
     'muvo_ssim_frames', 'muvo_sqdiff_frames', 'muvo_chamfer_sums', 'muvo_ssc_counts',
     'muvo_frustum_cells', 'muvo_frustum_pool_fwd', 'muvo_frustum_pool_bwd', 'muvo_depth_expectation',
     'muvo_resize_bilinear_bwd', 'muvo_softmax_channel_fwd', 'muvo_softmax_channel_bwd',
-    'muvo_range_projection', 'muvo_voxel_grid', 'muvo_seg_ce_fwd', 'muvo_seg_ce_bwd',
+    'muvo_range_projection', 'muvo_voxel_grid', 'muvo_seg_ce_fwd', 'muvo_seg_ce_bwd', 'muvo_ssim_maps', 'muvo_ssim_bwd',
 ]
 
 

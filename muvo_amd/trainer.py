@@ -185,6 +185,11 @@ class WorldModelTrainer(_Base):
                 w = 0.1 * (1 / f)  # rgb_weight literal 0.1 (trainer.py:296)
                 pred = output[f'rgb_{f}']
                 losses[f'rgb_{f}'] = ops.spatial_losses(pred, batch[f'rgb_label_{f}'], [(0, pred.shape[2], 1, w)])[0]
+                if cfg.LOSSES.SSIM:               # trainer.py:312-318: 0.6 * (1 - mean SSIM), same rgb weight and discount
+                    if '_ssim_loss' not in self.__dict__:
+                        from .losses import SSIMLoss
+                        self.__dict__['_ssim_loss'] = SSIMLoss(channel=3)
+                    losses[f'ssim_{f}'] = (1 - self.__dict__['_ssim_loss'](pred, batch[f'rgb_label_{f}'])) * (w * 0.6)
         if cfg.LIDAR_RE.ENABLED:
             for f in (1, 2, 4):
                 w = (1 / f) * cfg.LOSSES.WEIGHT_LIDAR_RE

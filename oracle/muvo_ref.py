@@ -619,6 +619,8 @@ def compute_losses(batch, out, cfg) -> Dict[str, torch.Tensor]:
     for f in (1, 2, 4):
         d = 1 / f
         L[f'rgb_{f}'] = cfg['W_RGB'] * d * _spatial_regression(out[f'rgb_{f}'], batch[f'rgb_label_{f}'], 1)
+        if cfg.get('SSIM'):                      # LOSSES.SSIM (trainer.py:312-318): 0.6 * (1 - mean SSIM)
+            L[f'ssim_{f}'] = cfg['W_RGB'] * d * (1 - ssim_frames(out[f'rgb_{f}'], batch[f'rgb_label_{f}']).mean()) * 0.6
     for f in (1, 2, 4):
         d = 1 / f
         p, t = out[f'lidar_reconstruction_{f}'], batch[f'range_view_label_{f}']
