@@ -25,6 +25,7 @@ extern "C" {
 #define MUVO_ACT_LEAKY 2 /* slope parameter */
 #define MUVO_ACT_ELU 3   /* alpha = 1 */
 #define MUVO_ACT_TANH 4
+#define MUVO_ACT_SIGMOID 5
 
 const char* muvo_last_error(void);
 int muvo_abi_version(void);
@@ -274,6 +275,12 @@ int muvo_range_projection(const float* points_xyz, const uint8_t* obj_tag, const
                           float* xyzd, uint8_t* seg, void* stream);
 int muvo_voxel_grid(const int64_t* rows, int64_t Q, const uint8_t* remap, int X, int Y, int Z, uint32_t* scratch, uint8_t* voxels,
                     void* stream);
+/* convert_instance_mask_to_center_and_offset_label (muvo/utils/instance_utils.py:4-35, called from
+ * PreProcess.prepare_bev_labels, preprocess.py:68-100): instance ids (F,H,W) uint8 (0 = background) -> centre heat map
+ * center (F,H,W) = max over the instances of the frame of exp(-d^2 / sigma^2) around the rounded centroid, and offset (F,2,H,W)
+ * = centroid - pixel (rows, then columns) on instance pixels, `ignore` elsewhere.  scratch: F*256*3 doubles. */
+int muvo_instance_labels(const uint8_t* instance, int64_t F, int H, int W, float sigma, float ignore, double* scratch, float* center,
+                         float* offset, void* stream);
 
 #ifdef __cplusplus
 }

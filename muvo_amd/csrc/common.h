@@ -49,6 +49,7 @@ __device__ __forceinline__ float act_apply(float v, int act, float slope) {
     case MUVO_ACT_LEAKY: return v > 0.f ? v : v * slope;
     case MUVO_ACT_ELU: return v > 0.f ? v : expm1f(v);
     case MUVO_ACT_TANH: return tanhf(v);
+    case MUVO_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
     default: return v;
   }
 }
@@ -59,6 +60,7 @@ __device__ __forceinline__ float act_grad_from_out(float y, int act, float slope
     case MUVO_ACT_LEAKY: return y > 0.f ? 1.f : slope;
     case MUVO_ACT_ELU: return y > 0.f ? 1.f : y + 1.f;
     case MUVO_ACT_TANH: return 1.f - y * y;
+    case MUVO_ACT_SIGMOID: return y * (1.f - y);
     default: return 1.f;
   }
 }

@@ -91,6 +91,58 @@ voxel_decode_kernel(const unsigned int* __restrict__ key, unsigned char* __restr
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) vox[i] = (unsigned char)(key[i] & 0xffu);
 }
 
+
+// ---- instance ids -> centre heat map and offset labels (muvo/utils/instance_utils.py:4-35) -------------------------------
+// pass 1: per (frame, id) pixel count and coordinate sums; pass 2: per pixel the heat-map maximum over the instances present in
+// its frame and the offset to the centroid of its own instance.  Centroid = round-half-even of the mean (torch.round).
+__global__ void __launch_bounds__(256)
+instance_sums_kernel(const unsigned char* __restrict__ inst, long F, int H, int W, double* __restrict__ sums) {
+  const long n = F * H * W;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int id = inst[i];
+    if (id == 0) continue;
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const long f = i / ((long)W * H);
+    double* s = sums + (f * 256 + id) * 3;
+    atomicAdd(s, 1.0); atomicAdd(s + 1, (double)y); atomicAdd(s + 2, (double)x);
+  }
+}
+__global__ void __launch_bounds__(256)
+instance_labels_kernel(const unsigned char* __restrict__ inst, const double* __restrict__ sums, long F, int H, int W, float sigma,
+                       float ignore, float* __restrict__ center, float* __restrict__ offset) {
+  __shared__ float cy[256], cx[256];
+  __shared__ int present[256], npres;
+  const long f = blockIdx.y;
+  if (threadIdx.x == 0) npres = 0;
+  __syncthreads();
+  {
+    const int id = threadIdx.x;
+    const double* s = sums + (f * 256 + id) * 3;
+    if (id > 0 && s[0] > 0.0) {
+      // x[instance_mask].mean().round(): float32 mean of exact integer sums, then round-half-even
+      cy[id] = rintf((float)s[1] / (float)s[0]);
+      cx[id] = rintf((float)s[2] / (float)s[0]);
+      present[atomicAdd(&npres, 1)] = id;
+    }
+  }
+  __syncthreads();
+  const long HW = (long)H * W;
+  const float inv = 1.f / (sigma * sigma);
+  for (long p = blockIdx.x * 256L + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
+    const float y = (float)(p / W), x = (float)(p % W);
+    float g = 0.f;
+    for (int k = 0; k < npres; ++k) {
+      const int id = present[k];
+      const float oy = cy[id] - y, ox = cx[id] - x;
+      g = fmaxf(g, expf(-(oy * oy + ox * ox) * inv));
+    }
+    center[f * HW + p] = g;
+    const int id = inst[f * HW + p];
+    offset[(f * 2) * HW + p] = id ? cy[id] - y : ignore;
+    offset[(f * 2 + 1) * HW + p] = id ? cx[id] - x : ignore;
+  }
+}
+
 #define ST ((hipStream_t)stream)
 extern "C" {
 
@@ -132,6 +184,22 @@ int muvo_voxel_grid(const int64_t* rows, int64_t Q, const uint8_t* remap, int X,
   if (Q > 0) hipLaunchKernelGGL(voxel_scatter_kernel, dim3(ew_grid(Q)), dim3(256), 0, ST, (const long long*)rows, (long)Q, remap, X, Y, Z, scratch);
   hipLaunchKernelGGL(voxel_decode_kernel, dim3(ew_grid(n)), dim3(256), 0, ST, scratch, voxels, n);
   MUVO_CHECK_LAUNCH("voxel_grid");
+  return MUVO_OK;
+}
+
+int muvo_instance_labels(const uint8_t* instance, int64_t F, int H, int W, float sigma, float ignore, double* scratch, float* center,
+                         float* offset, void* stream) {
+  MUVO_CHECK_ARG(instance && scratch && center && offset && F > 0 && F <= 65535 && H > 0 && W > 0 && sigma > 0.f, "instance_labels: bad args");
+  if (hipMemsetAsync(scratch, 0, sizeof(double) * (size_t)F * 256 * 3, ST) != hipSuccess) {
+    muvo_set_error("instance_labels: memset failed");
+    return MUVO_ERR_HIP;
+  }
+  hipLaunchKernelGGL(instance_sums_kernel, dim3(ew_grid(F * H * W)), dim3(256), 0, ST, instance, (long)F, H, W, scratch);
+  long nb = ((long)H * W + 255) / 256;
+  if (nb > 64) nb = 64;
+  hipLaunchKernelGGL(instance_labels_kernel, dim3((unsigned)nb, (unsigned)F), dim3(256), 0, ST, instance, scratch, (long)F, H, W, sigma, ignore,
+                     center, offset);
+  MUVO_CHECK_LAUNCH("instance_labels");
   return MUVO_OK;
 }
 

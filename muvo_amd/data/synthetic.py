@@ -72,3 +72,22 @@ def make_aux_inputs(b, s, seed, image_hw=(600, 960), range_hw=(64, 1024), n_clas
         'depth': torch.from_numpy(detinit.uniform_01(k + 3, n * image_hw[0] * image_hw[1]).astype(np.float32)).view(b, s, 1, *image_hw),
     }
     return {kk: v.to(device) for kk, v in out.items()} if device != 'cpu' else out
+
+
+def make_bev_labels(b, s, seed, size=(192, 192), n_classes=8, n_instances=6, device='cpu'):
+    """`birdview_label` class map and `instance_label` id map (b, s, 1, H, W) int64 of the SEMANTIC_SEG head (dataset.py:253-273):
+    a few axis-aligned boxes per frame carry instance ids 1..n_instances (some absent in some frames), background 0."""
+    k = detinit.name_key(f'bev:{seed}')
+    n = b * s
+    bev = torch.from_numpy((detinit.hash_u64(k + 1, n * size[0] * size[1]) % np.uint64(n_classes)).astype(np.int64)).view(b, s, 1, *size)
+    inst = torch.zeros(b, s, 1, *size, dtype=torch.int64)
+    r = detinit.hash_u64(k + 2, n * n_instances * 5).reshape(n, n_instances, 5)
+    for f in range(n):
+        for i in range(n_instances):
+            if int(r[f, i, 4] % np.uint64(5)) == 0:
+                continue                                          # this instance is not in this frame
+            y0, x0 = int(r[f, i, 0] % np.uint64(size[0] - 24)), int(r[f, i, 1] % np.uint64(size[1] - 24))
+            hh, ww = 5 + int(r[f, i, 2] % np.uint64(16)), 5 + int(r[f, i, 3] % np.uint64(16))
+            inst[f // s, f % s, 0, y0:y0 + hh, x0:x0 + ww] = i + 1
+    out = {'birdview_label': bev, 'instance_label': inst}
+    return {kk: v.to(device) for kk, v in out.items()} if device != 'cpu' else out

@@ -107,6 +107,98 @@ class ConvInstanceNorm3d(nn.Module):
         return self.adaptive_norm(x, w, pre_act=ops.ACT_LEAKY, pre_slope=0.2)
 
 
+class AdaptiveInstanceNorm(nn.Module):
+    """common.py:205-224 (2-D): the 3-D kernel with a unit depth."""
+
+    def __init__(self, latent_n_channels, out_channels, epsilon=1e-8):
+        super().__init__()
+        self.out_channels = out_channels
+        self.epsilon = epsilon
+        self.latent_affine = hnn.Linear(latent_n_channels, 2 * out_channels)
+
+    def forward(self, x, style, pre_act=ops.ACT_NONE, pre_slope=0.0):
+        x5 = x.unsqueeze(-3)                       # (N, C, 1, H, W) or the broadcast parameter (C, 1, H, W)
+        y = ops.adain(x5, self.latent_affine(style), self.epsilon, style.shape[0], pre_act, pre_slope)
+        return y.squeeze(2)
+
+
+class ConvInstanceNorm(nn.Module):
+    """common.py:175-187."""
+
+    def __init__(self, in_channels, out_channels, latent_n_channels):
+        super().__init__()
+        self.conv_act = nn.Sequential(hnn.Conv2d(in_channels, out_channels, 3, 1, 1), hnn.Placeholder())
+        self.adaptive_norm = AdaptiveInstanceNorm(latent_n_channels, out_channels)
+
+    def forward(self, x, w):
+        x = self.conv_act[0](x, act=ops.ACT_LEAKY, slope=0.2, act_bwd_fused=True)
+        return self.adaptive_norm(x, w, pre_act=ops.ACT_LEAKY, pre_slope=0.2)
+
+
+class DecoderBlock(nn.Module):
+    """common.py:147-159: bilinear x2 upsample + two ConvInstanceNorm."""
+
+    def __init__(self, in_channels, out_channels, latent_n_channels, upsample=False):
+        super().__init__()
+        self.upsample = upsample
+        self.conv1 = ConvInstanceNorm(in_channels, out_channels, latent_n_channels)
+        self.conv2 = ConvInstanceNorm(out_channels, out_channels, latent_n_channels)
+
+    def forward(self, x, w):
+        if self.upsample:
+            x = ops.interpolate_bilinear(x, (2 * x.shape[-2], 2 * x.shape[-1]))
+        return self.conv2(self.conv1(x, w), w)
+
+
+class SegmentationHead(nn.Module):
+    """common.py:249-271: semantic logits, instance offset and (sigmoid) instance centre."""
+
+    def __init__(self, in_channels, n_classes, downsample_factor):
+        super().__init__()
+        self.downsample_factor = downsample_factor
+        self.segmentation_head = nn.Sequential(hnn.Conv2d(in_channels, n_classes, 1, 1, 0))
+        self.instance_offset_head = nn.Sequential(hnn.Conv2d(in_channels, 2, 1, 1, 0))
+        self.instance_center_head = nn.Sequential(hnn.Conv2d(in_channels, 1, 1, 1, 0), hnn.Placeholder())
+
+    def forward(self, x):
+        f = self.downsample_factor
+        return {f'bev_segmentation_{f}': self.segmentation_head[0](x),
+                f'bev_instance_offset_{f}': self.instance_offset_head[0](x),
+                f'bev_instance_center_{f}': self.instance_center_head[0](x, act=ops.ACT_SIGMOID)}
+
+
+class BevDecoder(nn.Module):
+    """common.py:370-424 (head='bev')."""
+
+    def __init__(self, latent_n_channels, semantic_n_channels, constant_size=(3, 3), head='bev'):
+        super().__init__()
+        assert head == 'bev'
+        n = 512
+        self.constant_tensor = nn.Parameter(torch.randn((n, *constant_size), dtype=torch.float32))
+        self.first_norm = AdaptiveInstanceNorm(latent_n_channels, out_channels=n)
+        self.first_conv = ConvInstanceNorm(n, n, latent_n_channels)
+        self.middle_conv = nn.ModuleList(DecoderBlock(n, n, latent_n_channels, upsample=True) for _ in range(3))
+        self.conv1 = DecoderBlock(n, 256, latent_n_channels, upsample=True)
+        self.head_4 = SegmentationHead(256, semantic_n_channels, downsample_factor=4)
+        self.conv2 = DecoderBlock(256, 128, latent_n_channels, upsample=True)
+        self.head_2 = SegmentationHead(128, semantic_n_channels, downsample_factor=2)
+        self.conv3 = DecoderBlock(128, 64, latent_n_channels, upsample=True)
+        self.head_1 = SegmentationHead(64, semantic_n_channels, downsample_factor=1)
+
+    def forward(self, w):
+        x = self.first_norm(self.constant_tensor, w)      # the parameter is broadcast over the batch inside the kernel
+        x = self.first_conv(x, w)
+        for module in self.middle_conv:
+            x = module(x, w)
+        x = self.conv1(x, w)
+        output_4 = self.head_4(x)
+        x = self.conv2(x, w)
+        output_2 = self.head_2(x)
+        x = self.conv3(x, w)
+        output_1 = self.head_1(x)
+        return {**output_4, **output_2, **output_1}
+
+
 class DecoderBlock3d(nn.Module):
     def __init__(self, in_channels, out_channels, latent_n_channels, upsample=False):
         super().__init__()

@@ -8,7 +8,7 @@ from muvo_amd import nn as hnn
 from muvo_amd import ops
 from muvo_amd.layers.layers import BasicBlock
 from muvo_amd.bev import FrustumPooling
-from muvo_amd.models.common import (ConvDecoder, Decoder, DecoderDS, Policy, RouteEncode, VoxelDecoder1,
+from muvo_amd.models.common import (BevDecoder, ConvDecoder, Decoder, DecoderDS, Policy, RouteEncode, VoxelDecoder1,
                                     position_embedding_sine)
 from muvo_amd.models.resnet import ResNet18Features
 from muvo_amd.models.transition import RSSM
@@ -41,8 +41,8 @@ class Mile(nn.Module):
             unsupported.append('LIDAR off / POINT_PILLAR')
         if m.MEASUREMENTS.ENABLED or m.REWARD.ENABLED or not m.TRANSITION.ENABLED or not m.ROUTE.ENABLED:
             unsupported.append('MEASUREMENTS/REWARD/TRANSITION off/ROUTE off')
-        if cfg.SEMANTIC_SEG.ENABLED:
-            unsupported.append('SEMANTIC_SEG (BevDecoder) head')
+        if cfg.SEMANTIC_SEG.ENABLED and cfg.EVAL.MASK_VIEW:
+            unsupported.append('EVAL.MASK_VIEW')
         if unsupported:
             raise NotImplementedError('muvo_amd implements the base_1d hot path (SURVEY.md §8); not in scope: '
                                       + ', '.join(unsupported))
@@ -86,6 +86,8 @@ class Mile(nn.Module):
                          dropout_probability=m.TRANSITION.DROPOUT_PROBABILITY)
         state_dim = m.TRANSITION.HIDDEN_STATE_DIM + m.TRANSITION.STATE_DIM
         self.policy = Policy(in_channels=state_dim)
+        if cfg.SEMANTIC_SEG.ENABLED:      # bird's-eye-view semantic + instance segmentation (mile.py:307-313)
+            self.bev_decoder = BevDecoder(state_dim, cfg.SEMANTIC_SEG.N_CHANNELS, head='bev')
         if cfg.EVAL.RGB_SUPERVISION:
             self.rgb_decoder = ConvDecoder(state_dim, 3, constant_size=(5, 13), head='rgb')
         if cfg.LIDAR_RE.ENABLED:
@@ -179,6 +181,8 @@ class Mile(nn.Module):
 
     def _aux_heads(self, state, b, s):
         out = {}
+        if self.cfg.SEMANTIC_SEG.ENABLED:
+            out.update(unpack_sequence_dim(self.bev_decoder(state), b, s))
         if self.cfg.LIDAR_SEG.ENABLED:
             out.update(unpack_sequence_dim(self.lidar_segmentation(state), b, s))
         if self.cfg.SEMANTIC_IMAGE.ENABLED:

@@ -43,6 +43,25 @@ class PreProcess(nn.Module):
             h, w = rv.shape[-2:]
             for f in (2, 4):
                 batch[f'range_view_label_{f}'] = ops.resize_nearest(batch[f'range_view_label_{f // 2}'], (h // f, w // f))
+        # bird's-eye-view labels (preprocess.py:50-100; EVAL.MASK_VIEW off): rotate 90 degrees clockwise, nearest pyramids,
+        # instance ids -> centre heat map + offsets at every scale (sigma / scale)
+        if cfg.SEMANTIC_SEG.ENABLED and 'birdview_label' in batch:
+            bev = torch.rot90(batch['birdview_label'], k=-1, dims=[3, 4]).to(torch.uint8).contiguous()
+            batch['birdview_label'] = bev
+            batch['birdview_label_1'] = bev
+            h, w = bev.shape[-2:]
+            for f in (2, 4):
+                batch[f'birdview_label_{f}'] = ops.resize_nearest(batch[f'birdview_label_{f // 2}'], (h // f, w // f))
+        if cfg.SEMANTIC_SEG.ENABLED and 'instance_label' in batch:
+            inst = torch.rot90(batch['instance_label'], k=-1, dims=[3, 4]).to(torch.uint8).contiguous()
+            batch['instance_label'] = inst
+            sigma, ign = cfg.INSTANCE_SEG.CENTER_LABEL_SIGMA_PX, cfg.INSTANCE_SEG.IGNORE_INDEX
+            batch['center_label'], batch['offset_label'] = ops.instance_labels(inst, sigma, ign)
+            batch['instance_label_1'], batch['center_label_1'], batch['offset_label_1'] = inst, batch['center_label'], batch['offset_label']
+            h, w = inst.shape[-2:]
+            for f in (2, 4):
+                batch[f'instance_label_{f}'] = ops.resize_nearest(batch[f'instance_label_{f // 2}'], (h // f, w // f))
+                batch[f'center_label_{f}'], batch[f'offset_label_{f}'] = ops.instance_labels(batch[f'instance_label_{f}'], sigma / f, ign)
         # config-off inputs of base_1d (preprocess.py:127-149,164-175,228-241): crop like the image, then label pyramids
         left, top, right, bottom = self.crop
         if cfg.SEMANTIC_IMAGE.ENABLED:

@@ -20,7 +20,7 @@ _LIB_PATH = os.path.join(_HERE, 'libmuvo_hip.so')
 _lib = None
 _lock = threading.Lock()
 
-ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_ELU, ACT_TANH = 0, 1, 2, 3, 4
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_ELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4, 5
 
 
 class ConvDesc(C.Structure):
@@ -59,6 +59,7 @@ EXPORTS = [
     'muvo_frustum_cells', 'muvo_frustum_pool_fwd', 'muvo_frustum_pool_bwd', 'muvo_depth_expectation',
     'muvo_resize_bilinear_bwd', 'muvo_softmax_channel_fwd', 'muvo_softmax_channel_bwd',
     'muvo_range_projection', 'muvo_voxel_grid', 'muvo_seg_ce_fwd', 'muvo_seg_ce_bwd', 'muvo_ssim_maps', 'muvo_ssim_bwd',
+    'muvo_instance_labels',
 ]
 
 
@@ -1084,6 +1085,18 @@ class _SoftmaxChannelFn(torch.autograd.Function):
         dx = torch.empty_like(y)
         _ck(lib().muvo_softmax_channel_bwd(_f(y), _f(g.contiguous()), _f(dx), B, C, _i64(y[0, 0].numel()), _st()))
         return dx
+
+
+def instance_labels(instance_label, sigma, ignore_index=255):
+    """convert_instance_mask_to_center_and_offset_label (instance_utils.py:4-35): instance ids (b, s, 1, h, w) ->
+    center (b, s, 1, h, w), offset (b, s, 2, h, w) float32."""
+    b, s, _, h, w = instance_label.shape
+    inst = instance_label.to(torch.uint8).contiguous()
+    center = torch.empty(b, s, 1, h, w, device=inst.device, dtype=torch.float32)
+    offset = torch.empty(b, s, 2, h, w, device=inst.device, dtype=torch.float32)
+    scratch = torch.empty(b * s * 256 * 3, device=inst.device, dtype=torch.float64)
+    _ck(lib().muvo_instance_labels(_p(inst), _i64(b * s), h, w, _fl(sigma), _fl(ignore_index), _p(scratch), _f(center), _f(offset), _st()))
+    return center, offset
 
 
 def softmax_channel(x):

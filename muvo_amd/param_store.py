@@ -13,7 +13,7 @@ import torch
 # reverse-execution order of the base_1d model: backward completes these prefixes top to bottom
 SEGMENTS = (
     ('decoders', ('voxel_decoder.', 'lidar_re.', 'rgb_decoder.', 'policy.', 'lidar_segmentation.', 'sem_image_decoder.',
-                  'depth_image_decoder.')),            # done when d(state) arrives
+                  'depth_image_decoder.', 'bev_decoder.')),            # done when d(state) arrives
     ('rssm', ('rssm.',)),                                                                  # done when d(embedding) arrives
     ('fusion', ('features_combine.', 'speed_enc.', 'backbone_route.', 'image_feature_conv.', 'lidar_feature_conv.',
                 'transformer_encoder.')),                                                  # done when d(tokens) arrives

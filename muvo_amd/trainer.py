@@ -180,6 +180,19 @@ class WorldModelTrainer(_Base):
             pr, po = output['prior'], output['posterior']
             losses['probabilistic'] = ops.kl_loss(pr['mu'], pr['sigma'], po['mu'], po['sigma'],
                                                   cfg.LOSSES.WEIGHT_PROBABILISTIC, cfg.LOSSES.KL_BALANCING_ALPHA)[0]
+        if cfg.SEMANTIC_SEG.ENABLED:              # trainer.py:266-291
+            crit = self._seg_loss('bev', cfg.SEMANTIC_SEG, is_bev=True)
+            ign = float(cfg.INSTANCE_SEG.IGNORE_INDEX)
+            for f in (1, 2, 4):
+                d = 1 / f
+                losses[f'bev_segmentation_{f}'] = crit(output[f'bev_segmentation_{f}'], batch[f'birdview_label_{f}']) \
+                    * (d * cfg.LOSSES.WEIGHT_SEGMENTATION)
+                wc = d * cfg.LOSSES.WEIGHT_INSTANCE * cfg.INSTANCE_SEG.CENTER_LOSS_WEIGHT
+                losses[f'bev_center_{f}'] = ops.spatial_losses(output[f'bev_instance_center_{f}'], batch[f'center_label_{f}'],
+                                                               [(0, 1, 2, wc)])[0]
+                wo = cfg.LOSSES.WEIGHT_INSTANCE * cfg.INSTANCE_SEG.OFFSET_LOSS_WEIGHT   # offsets are discounted in the labels
+                losses[f'bev_offset_{f}'] = ops.spatial_losses(output[f'bev_instance_offset_{f}'], batch[f'offset_label_{f}'],
+                                                               [(0, 2, 1, wo)], ign)[0]
         if cfg.EVAL.RGB_SUPERVISION:
             for f in (1, 2, 4):
                 w = 0.1 * (1 / f)  # rgb_weight literal 0.1 (trainer.py:296)
@@ -222,12 +235,12 @@ class WorldModelTrainer(_Base):
                 losses[f'geo_scal_{f}'] = three[2]
         return losses
 
-    def _seg_loss(self, tag, c):
-        """trainer.py:132-161: SegmentationLoss(use_top_k, top_k_ratio, use_weights, is_bev=False)."""
+    def _seg_loss(self, tag, c, is_bev=False):
+        """trainer.py:61-66,132-161: SegmentationLoss(use_top_k, top_k_ratio, use_weights, is_bev)."""
         from .losses import SegmentationLoss
         cache = self.__dict__.setdefault('_seg_losses', {})
         if tag not in cache:
-            cache[tag] = SegmentationLoss(use_top_k=c.USE_TOP_K, top_k_ratio=c.TOP_K_RATIO, use_weights=c.USE_WEIGHTS, is_bev=False)
+            cache[tag] = SegmentationLoss(use_top_k=c.USE_TOP_K, top_k_ratio=c.TOP_K_RATIO, use_weights=c.USE_WEIGHTS, is_bev=is_bev)
         return cache[tag]
 
     def loss_reducing(self, loss):

@@ -75,6 +75,25 @@ def preprocess(batch: Dict[str, torch.Tensor], cfg: dict) -> Dict[str, torch.Ten
         prev = F.interpolate(prev.flatten(0, 1), size=(x // f, y // f, z // f), mode='nearest').view(
             b, s, 1, x // f, y // f, z // f)
         out[f'voxel_label_{f}'] = prev
+    # bird's-eye-view labels, when present (preprocess.py:50-100, EVAL.MASK_VIEW off)
+    if 'birdview_label' in batch:
+        bev = torch.rot90(batch['birdview_label'], k=-1, dims=[3, 4]).contiguous()
+        out['birdview_label'] = out['birdview_label_1'] = bev
+        h, w = bev.shape[-2:]
+        prev = bev
+        for f in (2, 4):
+            prev = F.interpolate(prev.flatten(0, 1).float(), size=(h // f, w // f), mode='nearest').to(bev.dtype).view(b, s, 1, h // f, w // f)
+            out[f'birdview_label_{f}'] = prev
+    if 'instance_label' in batch:
+        inst = torch.rot90(batch['instance_label'], k=-1, dims=[3, 4]).contiguous()
+        out['instance_label'] = out['instance_label_1'] = inst
+        out['center_label_1'], out['offset_label_1'] = instance_center_offset(inst, 255, 4.0)    # config.py:234-235
+        h, w = inst.shape[-2:]
+        prev = inst
+        for f in (2, 4):
+            prev = F.interpolate(prev.flatten(0, 1).float(), size=(h // f, w // f), mode='nearest').to(inst.dtype).view(b, s, 1, h // f, w // f)
+            out[f'instance_label_{f}'] = prev
+            out[f'center_label_{f}'], out[f'offset_label_{f}'] = instance_center_offset(prev, 255, 4.0 / f)
     # inputs of the config-off heads, when present (preprocess.py:127-149,164-175,228-241): crop like the image, pyramids
     if 'semantic_image' in batch:
         sem = batch['semantic_image'][..., top:bottom, left:right]
@@ -361,6 +380,118 @@ class DecBlock3d(nn.Module):
         return self.conv2(self.conv1(x, w), w)
 
 
+class AdaIN2d(nn.Module):
+    """common.py:205-224."""
+
+    def __init__(self, latent, c):
+        super().__init__()
+        self.c = c
+        self.latent_affine = nn.Linear(latent, 2 * c)
+
+    def forward(self, x, w):
+        mean = x.mean(dim=(-1, -2), keepdim=True)
+        x = x - mean
+        std = torch.sqrt(torch.mean(x ** 2, dim=(-1, -2), keepdim=True) + 1e-8)
+        x = x / std
+        scale, bias = torch.split(self.latent_affine(w)[:, :, None, None], self.c, dim=1)
+        return scale * x + bias
+
+
+class ConvIN2d(nn.Module):
+    """common.py:175-187."""
+
+    def __init__(self, cin, cout, latent):
+        super().__init__()
+        self.conv_act = nn.Sequential(nn.Conv2d(cin, cout, 3, 1, 1), nn.LeakyReLU(0.2))
+        self.adaptive_norm = AdaIN2d(latent, cout)
+
+    def forward(self, x, w):
+        return self.adaptive_norm(self.conv_act(x), w)
+
+
+class DecBlock2d(nn.Module):
+    """common.py:147-159 (upsample=True)."""
+
+    def __init__(self, cin, cout, latent):
+        super().__init__()
+        self.conv1 = ConvIN2d(cin, cout, latent)
+        self.conv2 = ConvIN2d(cout, cout, latent)
+
+    def forward(self, x, w):
+        x = F.interpolate(x, scale_factor=2.0, mode='bilinear', align_corners=False)
+        return self.conv2(self.conv1(x, w), w)
+
+
+class SegmentationHead(nn.Module):
+    """common.py:249-271."""
+
+    def __init__(self, cin, n_classes, f):
+        super().__init__()
+        self.f = f
+        self.segmentation_head = nn.Sequential(nn.Conv2d(cin, n_classes, 1))
+        self.instance_offset_head = nn.Sequential(nn.Conv2d(cin, 2, 1))
+        self.instance_center_head = nn.Sequential(nn.Conv2d(cin, 1, 1), nn.Sigmoid())
+
+    def forward(self, x):
+        return {f'bev_segmentation_{self.f}': self.segmentation_head(x), f'bev_instance_offset_{self.f}': self.instance_offset_head(x),
+                f'bev_instance_center_{self.f}': self.instance_center_head(x)}
+
+
+class BevDecoder(nn.Module):
+    """common.py:370-424 (head='bev')."""
+
+    def __init__(self, latent, n_classes, const_size=(3, 3)):
+        super().__init__()
+        n = 512
+        self.constant_tensor = nn.Parameter(torch.randn(n, *const_size))
+        self.first_norm = AdaIN2d(latent, n)
+        self.first_conv = ConvIN2d(n, n, latent)
+        self.middle_conv = nn.ModuleList(DecBlock2d(n, n, latent) for _ in range(3))
+        self.conv1 = DecBlock2d(n, 256, latent)
+        self.head_4 = SegmentationHead(256, n_classes, 4)
+        self.conv2 = DecBlock2d(256, 128, latent)
+        self.head_2 = SegmentationHead(128, n_classes, 2)
+        self.conv3 = DecBlock2d(128, 64, latent)
+        self.head_1 = SegmentationHead(64, n_classes, 1)
+
+    def forward(self, w):
+        x = self.constant_tensor.unsqueeze(0).repeat([w.shape[0], 1, 1, 1])
+        x = self.first_conv(self.first_norm(x, w), w)
+        for m in self.middle_conv:
+            x = m(x, w)
+        x = self.conv1(x, w)
+        o4 = self.head_4(x)
+        x = self.conv2(x, w)
+        o2 = self.head_2(x)
+        x = self.conv3(x, w)
+        return {**o4, **o2, **self.head_1(x)}
+
+
+def instance_center_offset(instance_label, ignore_index=255, sigma=3.0):
+    """convert_instance_mask_to_center_and_offset_label (instance_utils.py:4-35): per frame and instance id the rounded
+    centroid; centre = max over instances of exp(-d^2 / sigma^2), offset = centroid - pixel on the instance, ignore elsewhere."""
+    inst = instance_label.squeeze(2)
+    b, s, h, w = inst.shape
+    center = torch.zeros(b, s, 1, h, w)
+    offset = ignore_index * torch.ones(b, s, 2, h, w)
+    x, y = torch.meshgrid(torch.arange(h, dtype=torch.float), torch.arange(w, dtype=torch.float), indexing='ij')
+    for bi in range(b):
+        for t in range(s):
+            for iid in torch.unique(inst[bi, t]).tolist():
+                if iid == 0:
+                    continue
+                m = inst[bi, t] == iid
+                xc, yc = x[m].mean().round(), y[m].mean().round()
+                g = torch.exp(-((xc - x) ** 2 + (yc - y) ** 2) / sigma ** 2)
+                center[bi, t, 0] = torch.maximum(center[bi, t, 0], g)
+                offset[bi, t, 0][m] = (xc - x)[m]
+                offset[bi, t, 1][m] = (yc - y)[m]
+    return center, offset
+
+
+SEMANTIC_SEG_WEIGHTS = (1.0, 1.0, 1.0, 2.0, 3.0, 1.0, 1.0, 1.0)      # constants.py:33 (is_bev=True, trainer.py:61-66)
+
+
 class VoxelDecoder1(nn.Module):
     """common.py:498-546."""
 
@@ -458,6 +589,8 @@ class MileRef(nn.Module):
         self.rgb_decoder = ConvDecoder(sd, 3, (5, 13), 'rgb_head', 'rgb')
         self.lidar_re = ConvDecoder(sd, cfg['LIDAR_RE_CHANNELS'], (1, 16), 'lidar_re_head', 'lidar_reconstruction')
         self.voxel_decoder = VoxelDecoder1(sd, cfg['VOXEL_N_CLASSES'], cfg['VOXEL_DIMENSION'])
+        if 'bev' in self.aux_heads:             # SEMANTIC_SEG (mile.py:307-313)
+            self.bev_decoder = BevDecoder(sd, 8)
         if 'lidar_seg' in self.aux_heads:
             self.lidar_segmentation = ConvDecoder(sd, 9, (1, 16), 'seg_head', 'lidar_segmentation')
         if 'sem_image' in self.aux_heads:
@@ -517,7 +650,8 @@ class MileRef(nn.Module):
         return out
 
     def aux_decoders(self):
-        return tuple(getattr(self, n) for n in ('lidar_segmentation', 'sem_image_decoder', 'depth_image_decoder') if hasattr(self, n))
+        return tuple(getattr(self, n) for n in ('bev_decoder', 'lidar_segmentation', 'sem_image_decoder', 'depth_image_decoder')
+                     if hasattr(self, n))
 
 
 def imagine(model, state, future_horizon, noise):
@@ -633,9 +767,14 @@ def compute_losses(batch, out, cfg) -> Dict[str, torch.Tensor]:
         L[f'voxel_{f}'] = d * cfg['W_VOXEL'] * F.cross_entropy(logits, tgt.long(), reduction='none').mean()
         L[f'sem_scal_{f}'] = d * cfg['W_VOXEL'] * _sem_scal(logits, tgt)
         L[f'geo_scal_{f}'] = d * cfg['W_VOXEL'] * _geo_scal(logits, tgt)
-    # config-off heads (trainer.py:338-365), when the model produced them
+    # config-off heads (trainer.py:266-291,338-365), when the model produced them
     for f in (1, 2, 4):
         d = 1 / f
+        if f'bev_segmentation_{f}' in out:       # SEMANTIC_SEG: top-k 0.25, SEMANTIC_SEG_WEIGHTS; INSTANCE_SEG weights 200 / 0.1
+            L[f'bev_segmentation_{f}'] = d * 0.1 * _segmentation_loss(out[f'bev_segmentation_{f}'], batch[f'birdview_label_{f}'], True, 0.25,
+                                                                      True, SEMANTIC_SEG_WEIGHTS)
+            L[f'bev_center_{f}'] = d * 0.1 * 200.0 * _spatial_regression(out[f'bev_instance_center_{f}'], batch[f'center_label_{f}'], 2)
+            L[f'bev_offset_{f}'] = 0.1 * 0.1 * _spatial_regression(out[f'bev_instance_offset_{f}'], batch[f'offset_label_{f}'], 1)
         if f'lidar_segmentation_{f}' in out:      # LIDAR_SEG: top-k 0.5, class weights (config.py:255-260)
             L[f'lidar_seg_{f}'] = _segmentation_loss(out[f'lidar_segmentation_{f}'], batch[f'range_view_seg_label_{f}'], True, 0.5, True) * d * 0.1
         if f'semantic_image_{f}' in out:          # SEMANTIC_IMAGE: no top-k, class weights (config.py:263-268)
@@ -648,10 +787,10 @@ def compute_losses(batch, out, cfg) -> Dict[str, torch.Tensor]:
 VOXEL_SEG_WEIGHTS = (1.0, 1.0, 1.0, 1.5, 2.0, 3.0, 1.0, 1.0, 1.0)      # constants.py:39 (is_bev=False, trainer.py:137,161)
 
 
-def _segmentation_loss(prediction, target, use_top_k, top_k_ratio, use_weights):
+def _segmentation_loss(prediction, target, use_top_k, top_k_ratio, use_weights, class_weights=VOXEL_SEG_WEIGHTS):
     """SegmentationLoss.forward (losses.py:22-50) without poly-1."""
     b, s, c, h, w = prediction.shape
-    weights = torch.tensor(VOXEL_SEG_WEIGHTS, dtype=prediction.dtype) if use_weights else None
+    weights = torch.tensor(class_weights, dtype=prediction.dtype) if use_weights else None
     loss = F.cross_entropy(prediction.view(b * s, c, h, w), target.reshape(b * s, h, w).long(), reduction='none', weight=weights)
     loss = loss.view(b, s, -1)
     if use_top_k:

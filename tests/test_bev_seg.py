@@ -1,0 +1,110 @@
+"""Bird's-eye-view segmentation head (SEMANTIC_SEG=True — BevDecoder, SegmentationHead, BEV / instance label
+preparation, top-k weighted cross entropy + centre / offset regression; common.py:147-271,370-424, preprocess.py:50-100,
+instance_utils.py:4-35, trainer.py:266-291) against the golden training step of the REAL reference
+(tests/golden/bevseg_b1s2.*, oracle/refimport/make_golden_bevseg.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def _fixture():
+    return json.load(open(os.path.join(GOLD, 'bevseg_b1s2.json'))), np.load(os.path.join(GOLD, 'bevseg_b1s2_samples.npz'))
+
+
+def _check_outputs(fx, smp, out, batch, tol):
+    for k, st in fx['outputs'].items():
+        t = batch[k[6:]] if k.startswith('batch.') else out[k]
+        assert list(t.shape) == st['shape'], k
+        f = t.detach().float().contiguous().view(-1)
+        ref = torch.from_numpy(smp[('' if k.startswith('batch.') else 'out.') + k])
+        got = f[::st['stride']][:ref.numel()].cpu()
+        err = (got - ref).abs().max().item()
+        assert err <= tol * max(st['absmean'], ref.abs().max().item(), 1e-6), f'{k}: {err}'
+
+
+def test_oracle_bev_seg_step_matches_reference():
+    from muvo_amd.data.synthetic import make_batch, make_bev_labels, make_noise
+    from muvo_amd.utils import detinit
+    from oracle import muvo_ref as R
+    fx, smp = _fixture()
+    b, s = fx['b'], fx['s']
+    model = R.MileRef(aux_heads=('bev',))
+    assert {k: list(v.shape) for k, v in model.state_dict().items()} == fx['state_dict']
+    detinit.fill_state_dict_(model)
+    model.train()
+    model.set_dropout(0.0)
+    eps, use_prior = make_noise(b, s, seed=fx['seed'])
+    batch = make_batch(b, s, seed=fx['seed'])
+    batch.update(make_bev_labels(b, s, fx['seed']))
+    total, losses, out, pb = R.training_step(model, batch, eps, use_prior)
+    assert set(losses) == set(fx['losses']) and len(losses) == 30
+    for k, v in fx['losses'].items():
+        assert abs(float(losses[k].detach()) - v) <= 2e-5 * max(abs(v), 1e-12), k
+    _check_outputs(fx, smp, out, pb, 2e-4)
+
+
+def test_oracle_instance_labels_edge_cases():
+    from oracle import muvo_ref as R
+    inst = torch.zeros(1, 2, 1, 12, 16, dtype=torch.int64)
+    c, o = R.instance_center_offset(inst, 255, 3.0)
+    assert float(c.abs().max()) == 0.0 and bool((o == 255).all())            # no instances: empty heat map, all ignored
+    inst[0, 0, 0, 2:5, 3:8] = 1                                                # one 3 x 5 box: centroid (3, 5)
+    c, o = R.instance_center_offset(inst, 255, 3.0)
+    assert float(c[0, 0, 0, 3, 5]) == 1.0 and float(o[0, 0, 0, 2, 3]) == 1.0 and float(o[0, 0, 1, 2, 3]) == 2.0
+    assert float(c[0, 1].abs().max()) == 0.0                                  # the instance is absent from frame 1
+
+
+@pytest.mark.gpu
+def test_hip_instance_labels_match_oracle(dev):
+    from muvo_amd import ops
+    from muvo_amd.data.synthetic import make_bev_labels
+    from oracle import muvo_ref as R
+    inst = make_bev_labels(2, 3, 11)['instance_label']
+    inst[0, 1] = 0                                                            # a frame without instances
+    for sigma in (4.0, 2.0, 1.0):
+        c_ref, o_ref = R.instance_center_offset(inst, 255, sigma)
+        c, o = ops.instance_labels(inst.to(dev), sigma, 255)
+        assert torch.equal(o.cpu(), o_ref)                                    # integer-valued offsets: exact
+        assert float((c.cpu() - c_ref).abs().max()) <= 1e-6
+
+
+@pytest.mark.gpu
+def test_hip_bev_seg_step_matches_reference(dev):
+    from muvo_amd.config import base_1d_cfg
+    from muvo_amd.data.synthetic import make_batch, make_bev_labels, make_noise
+    from muvo_amd.trainer import WorldModelTrainer
+    from muvo_amd.utils import detinit
+    fx, smp = _fixture()
+    b, s = fx['b'], fx['s']
+    cfg = base_1d_cfg(RECEPTIVE_FIELD=s, FUTURE_HORIZON=0, STEPS=100000)
+    cfg.SEMANTIC_SEG.ENABLED = True
+    for key in ('N_CHANNELS', 'USE_TOP_K', 'TOP_K_RATIO', 'USE_WEIGHTS'):
+        assert getattr(cfg.SEMANTIC_SEG, key) == fx['cfg']['SEMANTIC_SEG'][key], key
+    tr = WorldModelTrainer(cfg.convert_to_dict(), device=dev)
+    tr.train()
+    assert {k: list(v.shape) for k, v in tr.model.state_dict().items()} == fx['state_dict']
+    detinit.fill_state_dict_(tr.model)
+    for layer in tr.model.transformer_encoder.layers:
+        layer.p = 0.0
+    opts, _ = tr.configure_optimizers()
+    eps, use_prior = make_noise(b, s, seed=fx['seed'])
+    batch = make_batch(b, s, seed=fx['seed'], device=dev)
+    batch.update(make_bev_labels(b, s, fx['seed'], device=dev))
+    opts[0].zero_grad()
+    losses, output, _, _ = tr.shared_step(batch, mode='train', noise=eps.to(dev), use_prior=use_prior)
+    total = tr.loss_reducing(losses)
+    total.backward()
+    assert set(losses) == set(fx['losses']) and len(losses) == 30
+    for k, v in fx['losses'].items():
+        assert abs(losses[k].item() - v) <= 1e-3 * max(abs(v), 1e-12), (k, losses[k].item(), v)
+    assert abs(total.item() - fx['total']) <= 1e-3 * fx['total']
+    _check_outputs(fx, smp, output, batch, 2e-3)
+    params = dict(tr.model.named_parameters())
+    bad = [f'{n} x{params[n].grad.double().pow(2).sum().sqrt().item() / max(ref, 1e-30):.4f}' for n, ref in fx['grad_l2'].items()
+           if abs(params[n].grad.double().pow(2).sum().sqrt().item() - ref) > 5e-3 * max(ref, 1e-12) + 1e-7]
+    assert not bad, '; '.join(bad)
