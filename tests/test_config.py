@@ -59,4 +59,6 @@ def test_scope_guard():
     from muvo_amd.config import base_1d_cfg
     from muvo_amd.models.mile import Mile
     with pytest.raises(NotImplementedError):
-        Mile(base_1d_cfg(**{'SEMANTIC_SEG.ENABLED': True}))
+        Mile(base_1d_cfg(**{'MODEL.TRANSFORMER.LARGE': True}))          # configurations outside the built rows fail loudly
+    with pytest.raises(NotImplementedError):
+        Mile(base_1d_cfg(**{'MODEL.LIDAR.POINT_PILLAR.ENABLED': True}))
