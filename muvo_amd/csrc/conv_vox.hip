@@ -681,6 +681,138 @@ vox_bf3_wgrad_kernel(const VoxArgs a, const float* __restrict__ x, const float* 
   if (blockIdx.y == 0 && dbias && tid < a.Cout) atomicAdd(dbias + tid, dbsum[tid]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// 8 -> 8 channels: two output rows per MFMA.  With 8 produced channels half of the 16 MFMA rows would idle; instead rows
+// 0-7 hold the channels of output row y and rows 8-15 those of row y + 1.  Both read the same four input rows
+// (y - 1 .. y + 2), so K runs over the 36 "super taps" (dx, ry in 0..3, dz) x 8 channels = 9 steps of 32, with zero
+// weights where a tap does not exist for a row half (ry = 3 for row y, ry = 0 for row y + 1): 27 MFMAs and 18 fragment
+// reads per 2 x 16 voxels instead of 42 and 28.  Workgroup = 8 waves x 2 rows = 16 output rows.
+// Packed weights (vox_bf3_pack2_kernel): step s, lane (m = lane & 15, g = lane >> 4): super tap 4 s + g.
+// ------------------------------------------------------------------------------------------------
+template <int Z>
+__global__ void __launch_bounds__(512)
+vox_bf3_2row_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* __restrict__ wp, const float* __restrict__ bias,
+                    float* __restrict__ out, int act, float slope, int xseg) {
+  constexpr int TY = 16, NSTEP = 9, ZT = Z / 16;
+  constexpr int ROWS = TY + 2, COLS = Z + 2;
+  constexpr int PLANE = 2 * ROWS * COLS;                        // uint4 per ring plane: [hi/lo][rows][cols]
+  constexpr int NTASK = ROWS * Z, TPT = (NTASK + 511) / 512;
+  extern __shared__ vu32x4 vsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nseg = (a.X + xseg - 1) / xseg;
+  int bid = blockIdx.x;
+  const int seg = bid % nseg; bid /= nseg;
+  const int ytile = bid % a.ytiles, n = bid / a.ytiles;
+  const int y0 = ytile * TY, xs = seg * xseg, xe = xs + xseg < a.X ? xs + xseg : a.X;
+  const long YZ = (long)a.Y * Z;
+  const float* inb = in + (long)n * a.sN_in;
+  vbf16x8 wh[NSTEP], wl[NSTEP];
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) {
+    wh[s] = __builtin_bit_cast(vbf16x8, wp[(s * 2) * 64 + lane]);
+    wl[s] = __builtin_bit_cast(vbf16x8, wp[(s * 2 + 1) * 64 + lane]);
+  }
+  for (int i = tid; i < 3 * PLANE; i += 512) vsm[i] = vu32x4{0u, 0u, 0u, 0u};
+  __syncthreads();
+  float stg[TPT][8];
+  auto stage_load = [&](int x) {
+#pragma unroll
+    for (int k = 0; k < TPT; ++k) {
+      const int t = tid + k * 512;
+      const int z = t % Z, r = t / Z;
+      const int gy = y0 - 1 + r;
+      const bool ok = t < NTASK && x >= 0 && x < a.X && gy >= 0 && gy < a.Y;
+      const float* p = inb + (long)x * YZ + (long)gy * Z + z;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) stg[k][e] = ok ? p[(long)e * a.XYZ] : 0.f;
+    }
+  };
+  auto stage_store = [&](int slot) {
+    vu32x4* P = vsm + slot * PLANE;
+#pragma unroll
+    for (int k = 0; k < TPT; ++k) {
+      const int t = tid + k * 512;
+      if (t >= NTASK) continue;
+      const int z = t % Z, r = t / Z;
+      unsigned h[4], l[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) vox_split2(stg[k][2 * q], stg[k][2 * q + 1], h[q], l[q]);
+      P[r * COLS + z + 1] = vu32x4{h[0], h[1], h[2], h[3]};
+      P[(ROWS + r) * COLS + z + 1] = vu32x4{l[0], l[1], l[2], l[3]};
+    }
+  };
+  const int v = lane & 15, g = lane >> 4;
+  int fdx[NSTEP], foff[NSTEP];
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) {
+    const int st = s * 4 + g;                         // super tap: (dx, ry, dz), ry = input row - (y - 1)
+    const int dx = st / 12 - 1, ry = (st / 3) % 4, dz = st % 3 - 1;
+    fdx[s] = dx;
+    foff[s] = (2 * wave + ry) * COLS + (v + 1 + dz);   // LDS row of input row (y - 1 + ry), y = y0 + 2 wave
+  }
+  stage_load(xs - 1); stage_store((xs - 1 + 3) % 3);
+  stage_load(xs); stage_store(xs % 3);
+  stage_load(xs + 1);
+  __syncthreads();
+  for (int x = xs; x < xe; ++x) {
+    stage_store((x + 1) % 3);
+    __syncthreads();
+    if (x + 1 < xe) stage_load(x + 2);
+    const vu32x4* P[3] = {vsm + ((x - 1 + 3) % 3) * PLANE, vsm + (x % 3) * PLANE, vsm + ((x + 1) % 3) * PLANE};
+    const vu32x4* fb[NSTEP];
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) fb[s] = (fdx[s] < 0 ? P[0] : (fdx[s] == 0 ? P[1] : P[2])) + foff[s];
+    const int gy = y0 + 2 * wave + (g >> 1);           // lanes g = 0, 1: row y (channels 4 g + i); g = 2, 3: row y + 1
+    const int cb = 4 * (g & 1);
+#pragma unroll
+    for (int zt = 0; zt < ZT; ++zt) {
+      vf32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < NSTEP; ++s) {
+        const vbf16x8 bh = __builtin_bit_cast(vbf16x8, fb[s][zt * 16]);
+        const vbf16x8 bl = __builtin_bit_cast(vbf16x8, fb[s][zt * 16 + ROWS * COLS]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[s], bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], bh, acc, 0, 0, 0);
+      }
+      if (gy < a.Y) {
+        float* ob = out + (long)n * a.sN_out + (long)x * YZ + (long)gy * Z + zt * 16 + v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float r = acc[i];
+          if (bias) r += bias[cb + i];
+          ob[(long)(cb + i) * a.XYZ] = act_apply(r, act, slope);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// rows 0-7: channel m of output row y (tap dy index = ry, valid for ry <= 2); rows 8-15: channel m - 8 of row y + 1 (dy index ry - 1)
+__global__ void __launch_bounds__(256)
+vox_bf3_pack2_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int dgrad) {
+  const int total = 9 * 64 * 8;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    const int e = idx & 7, lane = (idx >> 3) & 63, s = idx >> 9;
+    const int m = lane & 15, g = lane >> 4;
+    const int st = s * 4 + g, dx = st / 12, ry = (st / 3) % 4, dz = st % 3;
+    const int co = m & 7, dy = m < 8 ? ry : ry - 1;
+    float val = 0.f;
+    if (dy >= 0 && dy <= 2) {
+      const int tap = (dx * 3 + dy) * 3 + dz;
+      val = dgrad ? w[((size_t)e * 8 + co) * 27 + (26 - tap)] : w[((size_t)co * 8 + e) * 27 + tap];
+    }
+    unsigned u = __float_as_uint(val);
+    unsigned hu = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    const float rem = val - __uint_as_float(hu << 16);
+    unsigned r = __float_as_uint(rem);
+    unsigned lu = (r + 0x7fffu + ((r >> 16) & 1u)) >> 16;
+    wp[((size_t)(s * 2) * 64 + lane) * 8 + e] = (unsigned short)hu;
+    wp[((size_t)(s * 2 + 1) * 64 + lane) * 8 + e] = (unsigned short)lu;
+  }
+}
+
 // wp[(step*2 + hl)*64 + lane] (uint4 = 8 bf16) for the forward (dgrad = 0: rows = Cout, reduction = Cin, W[m][c][tap]) or
 // the data gradient (dgrad = 1: rows = Cin, reduction = Cout, W[c][m][26 - tap])
 __global__ void __launch_bounds__(256)
@@ -740,6 +872,11 @@ long vox_pack_floats(const muvo_conv_desc* d) {
 }
 
 int vox_pack(const muvo_conv_desc* d, const float* w, float* wp, int dgrad, hipStream_t st, bool bf3) {
+  if (bf3 && d->Cin == 8 && d->Cout == 8) {      // two-row variant
+    hipLaunchKernelGGL(vox_bf3_pack2_kernel, dim3(18), dim3(256), 0, st, w, (unsigned short*)wp, dgrad);
+    MUVO_CHECK_LAUNCH("vox_bf3_pack2_kernel");
+    return MUVO_OK;
+  }
   if (bf3) {
     const int ck = dgrad ? d->Cout : d->Cin, cp = dgrad ? d->Cin : d->Cout, ns = vox_bf3_steps(ck);
     hipLaunchKernelGGL(vox_bf3_pack_kernel, dim3(cdiv(cdiv(cp, 16) * ns * 512, 256)), dim3(256), 0, st, w, (unsigned short*)wp, d->Cin, d->Cout,
@@ -798,9 +935,38 @@ static int launch_vox_bf3(const muvo_conv_desc* d, int Cin, int Cout, const floa
   return MUVO_OK;
 }
 
+template <int Z>
+static int launch_vox_bf3_2row(const muvo_conv_desc* d, const float* in, const float* wp, const float* bias, float* out, int act,
+                               float slope, hipStream_t st) {
+  constexpr int TY = 16;
+  VoxArgs a;
+  a.N = d->N; a.Cin = 8; a.Cout = 8; a.X = d->in_sz[0]; a.Y = d->in_sz[1];
+  a.ytiles = cdiv(a.Y, TY);
+  a.xgroups = 0;
+  a.XYZ = a.X * a.Y * Z;
+  a.sN_in = (long)8 * a.XYZ; a.sN_out = (long)8 * a.XYZ;
+  int xseg = a.X;
+  while ((long)a.N * a.ytiles * cdiv(a.X, xseg) < 1024 && xseg > 12) xseg = cdiv(xseg, 2);
+  constexpr size_t lds = (size_t)3 * 2 * (TY + 2) * (Z + 2) * 16;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)vox_bf3_2row_kernel<Z>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      muvo_set_error("vox_bf3_2row: cannot raise the dynamic LDS limit to %zu bytes", lds);
+      return MUVO_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((vox_bf3_2row_kernel<Z>), dim3((unsigned)((long)a.N * a.ytiles * cdiv(a.X, xseg))), dim3(512), lds, st, a, in,
+                     (const vu32x4*)wp, bias, out, act, slope, xseg);
+  MUVO_CHECK_LAUNCH("vox_bf3_2row_kernel");
+  return MUVO_OK;
+}
+
 static int vox_conv_dispatch(const muvo_conv_desc* d, int Cin, int Cout, const float* in, const float* wp, const float* bias,
                              float* out, int act, float slope, hipStream_t st, bool bf3) {
   const int Z = d->in_sz[2];
+  if (bf3 && Cin == 8 && Cout == 8) return Z == 64 ? launch_vox_bf3_2row<64>(d, in, wp, bias, out, act, slope, st)
+                                                   : launch_vox_bf3_2row<32>(d, in, wp, bias, out, act, slope, st);
   if (bf3) {
     if (Cin == 16 && Z == 64) return launch_vox_bf3<16, 64>(d, Cin, Cout, in, wp, bias, out, act, slope, st);
     if (Cin == 16 && Z == 32) return launch_vox_bf3<16, 32>(d, Cin, Cout, in, wp, bias, out, act, slope, st);
