@@ -689,14 +689,15 @@ vox_bf3_wgrad_kernel(const VoxArgs a, const float* __restrict__ x, const float* 
 // reads per 2 x 16 voxels instead of 42 and 28.  Workgroup = 8 waves x 2 rows = 16 output rows.
 // Packed weights (vox_bf3_pack2_kernel): step s, lane (m = lane & 15, g = lane >> 4): super tap 4 s + g.
 // ------------------------------------------------------------------------------------------------
-template <int Z>
-__global__ void __launch_bounds__(512)
+template <int Z, int CK>
+__global__ void __launch_bounds__(CK == 16 ? 256 : 512)
 vox_bf3_2row_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* __restrict__ wp, const float* __restrict__ bias,
                     float* __restrict__ out, int act, float slope, int xseg) {
-  constexpr int TY = 16, NSTEP = 9, ZT = Z / 16;
+  constexpr int CG = CK / 8, TPS = 4 / CG, NSTEP = 36 / TPS, ZT = Z / 16;
+  constexpr int TY = CK == 16 ? 8 : 16, NT = 32 * TY;      // two rows per wave; 16 channels: 8 rows (LDS budget)
   constexpr int ROWS = TY + 2, COLS = Z + 2;
-  constexpr int PLANE = 2 * ROWS * COLS;                        // uint4 per ring plane: [hi/lo][rows][cols]
-  constexpr int NTASK = ROWS * Z, TPT = (NTASK + 511) / 512;
+  constexpr int PLANE = 2 * CG * ROWS * COLS;                   // uint4 per ring plane: [hi/lo][channel group][rows][cols]
+  constexpr int NTASK = CG * ROWS * Z, TPT = (NTASK + NT - 1) / NT;
   extern __shared__ vu32x4 vsm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nseg = (a.X + xseg - 1) / xseg;
@@ -712,17 +713,17 @@ vox_bf3_2row_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4*
     wh[s] = __builtin_bit_cast(vbf16x8, wp[(s * 2) * 64 + lane]);
     wl[s] = __builtin_bit_cast(vbf16x8, wp[(s * 2 + 1) * 64 + lane]);
   }
-  for (int i = tid; i < 3 * PLANE; i += 512) vsm[i] = vu32x4{0u, 0u, 0u, 0u};
+  for (int i = tid; i < 3 * PLANE; i += NT) vsm[i] = vu32x4{0u, 0u, 0u, 0u};
   __syncthreads();
   float stg[TPT][8];
   auto stage_load = [&](int x) {
 #pragma unroll
     for (int k = 0; k < TPT; ++k) {
-      const int t = tid + k * 512;
-      const int z = t % Z, r = t / Z;
+      const int t = tid + k * NT;
+      const int z = t % Z, r = (t / Z) % ROWS, cg = t / (Z * ROWS);
       const int gy = y0 - 1 + r;
       const bool ok = t < NTASK && x >= 0 && x < a.X && gy >= 0 && gy < a.Y;
-      const float* p = inb + (long)x * YZ + (long)gy * Z + z;
+      const float* p = inb + (long)(cg * 8) * a.XYZ + (long)x * YZ + (long)gy * Z + z;
 #pragma unroll
       for (int e = 0; e < 8; ++e) stg[k][e] = ok ? p[(long)e * a.XYZ] : 0.f;
     }
@@ -731,24 +732,24 @@ vox_bf3_2row_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4*
     vu32x4* P = vsm + slot * PLANE;
 #pragma unroll
     for (int k = 0; k < TPT; ++k) {
-      const int t = tid + k * 512;
+      const int t = tid + k * NT;
       if (t >= NTASK) continue;
-      const int z = t % Z, r = t / Z;
+      const int z = t % Z, r = (t / Z) % ROWS, cg = t / (Z * ROWS);
       unsigned h[4], l[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) vox_split2(stg[k][2 * q], stg[k][2 * q + 1], h[q], l[q]);
-      P[r * COLS + z + 1] = vu32x4{h[0], h[1], h[2], h[3]};
-      P[(ROWS + r) * COLS + z + 1] = vu32x4{l[0], l[1], l[2], l[3]};
+      P[(cg * ROWS + r) * COLS + z + 1] = vu32x4{h[0], h[1], h[2], h[3]};
+      P[((CG + cg) * ROWS + r) * COLS + z + 1] = vu32x4{l[0], l[1], l[2], l[3]};
     }
   };
   const int v = lane & 15, g = lane >> 4;
   int fdx[NSTEP], foff[NSTEP];
 #pragma unroll
   for (int s = 0; s < NSTEP; ++s) {
-    const int st = s * 4 + g;                         // super tap: (dx, ry, dz), ry = input row - (y - 1)
+    const int st = s * TPS + g / CG;                  // super tap: (dx, ry, dz), ry = input row - (y - 1)
     const int dx = st / 12 - 1, ry = (st / 3) % 4, dz = st % 3 - 1;
     fdx[s] = dx;
-    foff[s] = (2 * wave + ry) * COLS + (v + 1 + dz);   // LDS row of input row (y - 1 + ry), y = y0 + 2 wave
+    foff[s] = ((g % CG) * ROWS + 2 * wave + ry) * COLS + (v + 1 + dz);   // LDS row of input row (y - 1 + ry), y = y0 + 2 wave
   }
   stage_load(xs - 1); stage_store((xs - 1 + 3) % 3);
   stage_load(xs); stage_store(xs % 3);
@@ -770,7 +771,7 @@ vox_bf3_2row_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4*
 #pragma unroll
       for (int s = 0; s < NSTEP; ++s) {
         const vbf16x8 bh = __builtin_bit_cast(vbf16x8, fb[s][zt * 16]);
-        const vbf16x8 bl = __builtin_bit_cast(vbf16x8, fb[s][zt * 16 + ROWS * COLS]);
+        const vbf16x8 bl = __builtin_bit_cast(vbf16x8, fb[s][zt * 16 + CG * ROWS * COLS]);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[s], bh, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], bl, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], bh, acc, 0, 0, 0);
@@ -791,17 +792,19 @@ vox_bf3_2row_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4*
 
 // rows 0-7: channel m of output row y (tap dy index = ry, valid for ry <= 2); rows 8-15: channel m - 8 of row y + 1 (dy index ry - 1)
 __global__ void __launch_bounds__(256)
-vox_bf3_pack2_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int dgrad) {
-  const int total = 9 * 64 * 8;
+vox_bf3_pack2_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int Cin, int Cout, int dgrad) {
+  // reduction channels CK = (dgrad ? Cout : Cin) in {8, 16}; 8 produced channels
+  const int CK = dgrad ? Cout : Cin, CG = CK / 8, TPS = 4 / CG, nstep = 36 / TPS;
+  const int total = nstep * 64 * 8;
   for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
     const int e = idx & 7, lane = (idx >> 3) & 63, s = idx >> 9;
     const int m = lane & 15, g = lane >> 4;
-    const int st = s * 4 + g, dx = st / 12, ry = (st / 3) % 4, dz = st % 3;
-    const int co = m & 7, dy = m < 8 ? ry : ry - 1;
+    const int st = s * TPS + g / CG, dx = st / 12, ry = (st / 3) % 4, dz = st % 3;
+    const int co = m & 7, dy = m < 8 ? ry : ry - 1, c = (g % CG) * 8 + e;
     float val = 0.f;
     if (dy >= 0 && dy <= 2) {
       const int tap = (dx * 3 + dy) * 3 + dz;
-      val = dgrad ? w[((size_t)e * 8 + co) * 27 + (26 - tap)] : w[((size_t)co * 8 + e) * 27 + tap];
+      val = dgrad ? w[((size_t)c * Cin + co) * 27 + (26 - tap)] : w[((size_t)co * Cin + c) * 27 + tap];
     }
     unsigned u = __float_as_uint(val);
     unsigned hu = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
@@ -858,6 +861,9 @@ bool vox_dgrad_applicable(const muvo_conv_desc* d) {
 bool vox_wgrad_applicable(const muvo_conv_desc* d) {
   return vox_geometry_ok(d) && d->Cout % 8 == 0 && d->Cin % 8 == 0 && d->Cout <= 32 && d->Cin <= 64;
 }
+// 8 produced channels: two output rows share one MFMA (vox_bf3_2row_kernel)
+// (with 16 reduction channels the 18 weight steps push the kernel to one wave per SIMD and it loses: measured 3.05 vs 2.81 ms)
+static bool vox_bf3_two_rows(int ck, int cp) { return cp == 8 && ck == 8; }
 // bf16x3 variant: reduction and produced channels in {8, 16}
 bool vox_bf3_shape_ok(const muvo_conv_desc* d, int dgrad) {
   if (!vox_geometry_ok(d)) return false;
@@ -872,8 +878,8 @@ long vox_pack_floats(const muvo_conv_desc* d) {
 }
 
 int vox_pack(const muvo_conv_desc* d, const float* w, float* wp, int dgrad, hipStream_t st, bool bf3) {
-  if (bf3 && d->Cin == 8 && d->Cout == 8) {      // two-row variant
-    hipLaunchKernelGGL(vox_bf3_pack2_kernel, dim3(18), dim3(256), 0, st, w, (unsigned short*)wp, dgrad);
+  if (bf3 && vox_bf3_two_rows(dgrad ? d->Cout : d->Cin, dgrad ? d->Cin : d->Cout)) {      // two-row variant
+    hipLaunchKernelGGL(vox_bf3_pack2_kernel, dim3(36), dim3(256), 0, st, w, (unsigned short*)wp, d->Cin, d->Cout, dgrad);
     MUVO_CHECK_LAUNCH("vox_bf3_pack2_kernel");
     return MUVO_OK;
   }
@@ -935,28 +941,29 @@ static int launch_vox_bf3(const muvo_conv_desc* d, int Cin, int Cout, const floa
   return MUVO_OK;
 }
 
-template <int Z>
+template <int Z, int CK>
 static int launch_vox_bf3_2row(const muvo_conv_desc* d, const float* in, const float* wp, const float* bias, float* out, int act,
                                float slope, hipStream_t st) {
-  constexpr int TY = 16;
+  constexpr int TY = CK == 16 ? 8 : 16;
   VoxArgs a;
-  a.N = d->N; a.Cin = 8; a.Cout = 8; a.X = d->in_sz[0]; a.Y = d->in_sz[1];
+  a.N = d->N; a.Cin = CK; a.Cout = 8; a.X = d->in_sz[0]; a.Y = d->in_sz[1];
   a.ytiles = cdiv(a.Y, TY);
   a.xgroups = 0;
   a.XYZ = a.X * a.Y * Z;
-  a.sN_in = (long)8 * a.XYZ; a.sN_out = (long)8 * a.XYZ;
+  a.sN_in = (long)CK * a.XYZ; a.sN_out = (long)8 * a.XYZ;
   int xseg = a.X;
   while ((long)a.N * a.ytiles * cdiv(a.X, xseg) < 1024 && xseg > 12) xseg = cdiv(xseg, 2);
-  constexpr size_t lds = (size_t)3 * 2 * (TY + 2) * (Z + 2) * 16;
+  constexpr size_t lds = (size_t)3 * 2 * (CK / 8) * (TY + 2) * (Z + 2) * 16;
+  static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)vox_bf3_2row_kernel<Z>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)vox_bf3_2row_kernel<Z, CK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       muvo_set_error("vox_bf3_2row: cannot raise the dynamic LDS limit to %zu bytes", lds);
       return MUVO_ERR_HIP;
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((vox_bf3_2row_kernel<Z>), dim3((unsigned)((long)a.N * a.ytiles * cdiv(a.X, xseg))), dim3(512), lds, st, a, in,
+  hipLaunchKernelGGL((vox_bf3_2row_kernel<Z, CK>), dim3((unsigned)((long)a.N * a.ytiles * cdiv(a.X, xseg))), dim3(32 * TY), lds, st, a, in,
                      (const vu32x4*)wp, bias, out, act, slope, xseg);
   MUVO_CHECK_LAUNCH("vox_bf3_2row_kernel");
   return MUVO_OK;
@@ -965,8 +972,12 @@ static int launch_vox_bf3_2row(const muvo_conv_desc* d, const float* in, const f
 static int vox_conv_dispatch(const muvo_conv_desc* d, int Cin, int Cout, const float* in, const float* wp, const float* bias,
                              float* out, int act, float slope, hipStream_t st, bool bf3) {
   const int Z = d->in_sz[2];
-  if (bf3 && Cin == 8 && Cout == 8) return Z == 64 ? launch_vox_bf3_2row<64>(d, in, wp, bias, out, act, slope, st)
-                                                   : launch_vox_bf3_2row<32>(d, in, wp, bias, out, act, slope, st);
+  if (bf3 && vox_bf3_two_rows(Cin, Cout)) {
+    if (Cin == 8) return Z == 64 ? launch_vox_bf3_2row<64, 8>(d, in, wp, bias, out, act, slope, st)
+                                 : launch_vox_bf3_2row<32, 8>(d, in, wp, bias, out, act, slope, st);
+    return Z == 64 ? launch_vox_bf3_2row<64, 16>(d, in, wp, bias, out, act, slope, st)
+                   : launch_vox_bf3_2row<32, 16>(d, in, wp, bias, out, act, slope, st);
+  }
   if (bf3) {
     if (Cin == 16 && Z == 64) return launch_vox_bf3<16, 64>(d, Cin, Cout, in, wp, bias, out, act, slope, st);
     if (Cin == 16 && Z == 32) return launch_vox_bf3<16, 32>(d, Cin, Cout, in, wp, bias, out, act, slope, st);
