@@ -377,7 +377,7 @@ __device__ __forceinline__ void vox_split2(float a, float b, unsigned& hi, unsig
 template <int CK, int Z, int TY>
 __global__ void __launch_bounds__(64 * TY)
 vox_bf3_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* __restrict__ wp, const float* __restrict__ bias,
-               float* __restrict__ out, int act, float slope, int xseg) {
+               float* __restrict__ out, int act, float slope, int xseg, int accum) {
   constexpr int CG = CK / 8, TPS = 4 / CG, NSTEP = (27 + TPS - 1) / TPS, ZT = Z / 16;
   constexpr int ROWS = TY + 2, COLS = Z + 2;
   constexpr int PLANE = 2 * CG * ROWS * COLS;                   // uint4 per ring plane
@@ -479,6 +479,7 @@ vox_bf3_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* __re
           const int co = co0 + 4 * g + i;
           if (co < a.Cout) {
             float r = acc[i];
+            if (accum) r += ob[(long)co * a.XYZ];      // second half of a 32-channel reduction: add the first pass
             if (bias) r += bias[co];
             ob[(long)co * a.XYZ] = act_apply(r, act, slope);
           }
@@ -821,14 +822,14 @@ vox_bf3_pack2_kernel(const float* __restrict__ w, unsigned short* __restrict__ w
 __global__ void __launch_bounds__(256)
 vox_bf3_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int Cin, int Cout, int dgrad, int CK, int nstep) {
   const int CG = CK / 8, TPS = 4 / CG;
-  const int rows = dgrad ? Cin : Cout;
-  const int nrb = (rows + 15) / 16;
-  const int total = nrb * nstep * 64 * 8;
+  const int rows = dgrad ? Cin : Cout, red = dgrad ? Cout : Cin;
+  const int nrb = (rows + 15) / 16, halves = red / CK;      // 32 reduction channels: two passes of 16 ([half][row block][step])
+  const int total = halves * nrb * nstep * 64 * 8;
   for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
     const int e = idx & 7, lane = (idx >> 3) & 63, sb = idx >> 9;
-    const int s = sb % nstep, rb = sb / nstep;
+    const int s = sb % nstep, rb = (sb / nstep) % nrb, half = sb / (nstep * nrb);
     const int m = rb * 16 + (lane & 15), g = lane >> 4;
-    const int tap = s * TPS + g / CG, c = (g % CG) * 8 + e;
+    const int tap = s * TPS + g / CG, c = half * CK + (g % CG) * 8 + e;
     float val = 0.f;
     if (tap < 27 && m < rows) val = dgrad ? w[((size_t)c * Cin + m) * 27 + (26 - tap)] : w[((size_t)m * Cin + c) * 27 + tap];
     unsigned u = __float_as_uint(val);
@@ -836,8 +837,8 @@ vox_bf3_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp
     const float rem = val - __uint_as_float(hu << 16);
     unsigned r = __float_as_uint(rem);
     unsigned lu = (r + 0x7fffu + ((r >> 16) & 1u)) >> 16;
-    wp[((size_t)((rb * nstep + s) * 2) * 64 + lane) * 8 + e] = (unsigned short)hu;
-    wp[((size_t)((rb * nstep + s) * 2 + 1) * 64 + lane) * 8 + e] = (unsigned short)lu;
+    wp[((size_t)(((half * nrb + rb) * nstep + s) * 2) * 64 + lane) * 8 + e] = (unsigned short)hu;
+    wp[((size_t)(((half * nrb + rb) * nstep + s) * 2 + 1) * 64 + lane) * 8 + e] = (unsigned short)lu;
   }
 }
 
@@ -869,11 +870,12 @@ bool vox_bf3_shape_ok(const muvo_conv_desc* d, int dgrad) {
   if (!vox_geometry_ok(d)) return false;
   const int ck = dgrad ? d->Cout : d->Cin, cp = dgrad ? d->Cin : d->Cout;
   // reduction channels 8 / 16 (the weights of one 16-row block live in registers); produced channels in blocks of 16 rows
-  return (ck == 8 || ck == 16) && (cp == 8 || cp == 16 || cp == 32);
+  // (32 reduction channels run as two accumulating passes of 16)
+  return (ck == 8 || ck == 16 || ck == 32) && (cp == 8 || cp == 16 || cp == 32);
 }
-static int vox_bf3_steps(int ck) { return ck == 8 ? 7 : 14; }
+static int vox_bf3_steps(int ck) { return ck == 8 ? 7 : 14; }      // per pass
 long vox_pack_floats(const muvo_conv_desc* d) {
-  const long plain = 27l * d->Cin * d->Cout, bf3 = 14l * 2 * 64 * 4 * 2;   // bf16x3 layout: row blocks x steps x (hi, lo) x 64 lanes x 16 B
+  const long plain = 27l * d->Cin * d->Cout, bf3 = 14l * 2 * 64 * 4 * 4;   // bf16x3 layout: (halves x row blocks <= 4) x steps x (hi, lo) x 64 lanes x 16 B
   return plain > bf3 ? plain : bf3;
 }
 
@@ -884,9 +886,10 @@ int vox_pack(const muvo_conv_desc* d, const float* w, float* wp, int dgrad, hipS
     return MUVO_OK;
   }
   if (bf3) {
-    const int ck = dgrad ? d->Cout : d->Cin, cp = dgrad ? d->Cin : d->Cout, ns = vox_bf3_steps(ck);
-    hipLaunchKernelGGL(vox_bf3_pack_kernel, dim3(cdiv(cdiv(cp, 16) * ns * 512, 256)), dim3(256), 0, st, w, (unsigned short*)wp, d->Cin, d->Cout,
-                       dgrad, ck, ns);
+    const int red = dgrad ? d->Cout : d->Cin, cp = dgrad ? d->Cin : d->Cout;
+    const int ck = red == 32 ? 16 : red, ns = vox_bf3_steps(ck);
+    hipLaunchKernelGGL(vox_bf3_pack_kernel, dim3(cdiv((red / ck) * cdiv(cp, 16) * ns * 512, 256)), dim3(256), 0, st, w, (unsigned short*)wp,
+                       d->Cin, d->Cout, dgrad, ck, ns);
     MUVO_CHECK_LAUNCH("vox_bf3_pack_kernel");
     return MUVO_OK;
   }
@@ -914,14 +917,14 @@ static int launch_vox_conv(const muvo_conv_desc* d, int Cin, int Cout, const flo
 
 template <int CK, int Z>
 static int launch_vox_bf3(const muvo_conv_desc* d, int Cin, int Cout, const float* in, const float* wp, const float* bias,
-                          float* out, int act, float slope, hipStream_t st) {
+                          float* out, int act, float slope, hipStream_t st, int cin_total = 0, int accum = 0) {
   constexpr int TY = 8;
   VoxArgs a;
   a.N = d->N; a.Cin = Cin; a.Cout = Cout; a.X = d->in_sz[0]; a.Y = d->in_sz[1];
   a.ytiles = cdiv(a.Y, TY);
   a.xgroups = 0;
   a.XYZ = a.X * a.Y * Z;
-  a.sN_in = (long)Cin * a.XYZ; a.sN_out = (long)Cout * a.XYZ;
+  a.sN_in = (long)(cin_total ? cin_total : Cin) * a.XYZ; a.sN_out = (long)Cout * a.XYZ;
   // split x into segments until the grid fills the chip (each segment re-reads two halo planes)
   int xseg = a.X;
   while ((long)a.N * a.ytiles * cdiv(a.X, xseg) < 1024 && xseg > 12) xseg = cdiv(xseg, 2);
@@ -936,7 +939,7 @@ static int launch_vox_bf3(const muvo_conv_desc* d, int Cin, int Cout, const floa
   }
   const long blocks = (long)a.N * a.ytiles * cdiv(a.X, xseg);
   hipLaunchKernelGGL((vox_bf3_kernel<CK, Z, TY>), dim3((unsigned)blocks, cdiv(Cout, 16)), dim3(64 * TY), lds, st, a, in, (const vu32x4*)wp, bias, out, act,
-                     slope, xseg);
+                     slope, xseg, accum);
   MUVO_CHECK_LAUNCH("vox_bf3_kernel");
   return MUVO_OK;
 }
@@ -977,6 +980,16 @@ static int vox_conv_dispatch(const muvo_conv_desc* d, int Cin, int Cout, const f
                                  : launch_vox_bf3_2row<32, 8>(d, in, wp, bias, out, act, slope, st);
     return Z == 64 ? launch_vox_bf3_2row<64, 16>(d, in, wp, bias, out, act, slope, st)
                    : launch_vox_bf3_2row<32, 16>(d, in, wp, bias, out, act, slope, st);
+  }
+  if (bf3 && Cin == 32) {
+    // two accumulating passes over 16 reduction channels each; bias and activation ride on the second
+    const long XYZ = (long)d->in_sz[0] * d->in_sz[1] * Z;
+    const float* wp2 = wp + (size_t)cdiv(Cout, 16) * 14 * 2 * 64 * 4;
+    int rc = Z == 64 ? launch_vox_bf3<16, 64>(d, 16, Cout, in, wp, nullptr, out, MUVO_ACT_NONE, 0.f, st, 32, 0)
+                     : launch_vox_bf3<16, 32>(d, 16, Cout, in, wp, nullptr, out, MUVO_ACT_NONE, 0.f, st, 32, 0);
+    if (rc) return rc;
+    return Z == 64 ? launch_vox_bf3<16, 64>(d, 16, Cout, in + 16 * XYZ, wp2, bias, out, act, slope, st, 32, 1)
+                   : launch_vox_bf3<16, 32>(d, 16, Cout, in + 16 * XYZ, wp2, bias, out, act, slope, st, 32, 1);
   }
   if (bf3) {
     if (Cin == 16 && Z == 64) return launch_vox_bf3<16, 64>(d, Cin, Cout, in, wp, bias, out, act, slope, st);
