@@ -55,8 +55,11 @@ typedef struct muvo_conv_desc {
 #define MUVO_CONV_MODE_DEFAULT MUVO_CONV_BF16X3
 int muvo_conv_set_mode(int mode);
 int muvo_conv_get_mode(void);
-/* In MUVO_CONV_BF16X3 mode only phases with at least this much work per batch item (GFLOP, 2*MAC) use the split-product
- * kernel; smaller ones stay on exact fp32 MFMA.  Initial value: env MUVO_BF16X3_MIN_GFLOP, default 2.0. */
+/* Which convolutions use the split-product kernels in MUVO_CONV_BF16X3 mode.  gflop_per_item >= 0: every phase with
+ * at least this much work per batch item (GFLOP, 2*MAC); smaller ones stay on exact fp32 MFMA (env
+ * MUVO_BF16X3_MIN_GFLOP sets the same threshold at start-up).  Negative (the initial state without the env variable):
+ * the built-in policy fitted to per-layer timings on MI355X - an operation needs >= 0.1 GFLOP and >= 256 result pixels
+ * per batch item and >= 16 reduction channels (weight gradients: >= 0.05 GFLOP per item and more than one tap). */
 int muvo_conv_set_bf16x3_min_gflop(double gflop_per_item);
 /* sizes (in floats) of the K-major packed weight buffers used by forward/wgrad and by dgrad */
 int muvo_conv_pack_sizes(const muvo_conv_desc* d, int64_t* fwd_floats, int64_t* dgrad_floats);

@@ -425,14 +425,25 @@ static int conv_mode() {
   return g_conv_mode;
 }
 
+// Which phases run on the bf16x3 kernels (bf16x3 mode).  An explicit work threshold (muvo_conv_set_bf16x3_min_gflop or
+// env MUVO_BF16X3_MIN_GFLOP) is applied to each phase on its own: GFLOP per batch item >= threshold.  Without one the
+// built-in policy applies, fitted to per-layer timings of both families on MI355X (profiles/r01q_family_choice.txt): an
+// operation goes to bf16x3 when it has >= 0.1 GFLOP and >= 256 result pixels per batch item and >= 16 reduction
+// channels (below that the fp32 kernel's smaller tiles fill the chip better than the 256x128 ping-pong tiles, and
+// 3/4-channel stems waste most of a 32-channel K step).
 static double g_bf3_min_gflop = -1.0;
+static bool bf3_default_policy() {
+  static const bool env_set = getenv("MUVO_BF16X3_MIN_GFLOP") != nullptr;
+  return g_bf3_min_gflop < 0.0 && !env_set;
+}
 static double bf3_min_gflop() {
-  double& v = g_bf3_min_gflop;
-  if (v < 0.0) {
-    const char* e = getenv("MUVO_BF16X3_MIN_GFLOP");
-    v = e ? atof(e) : 2.0;
-  }
-  return v;
+  if (bf3_default_policy()) return 0.1;
+  return g_bf3_min_gflop >= 0.0 ? g_bf3_min_gflop : atof(getenv("MUVO_BF16X3_MIN_GFLOP"));
+}
+static thread_local int t_nphase = 1;         // sub-pixel phases of the operation being planned (work / pixels are per phase)
+static bool bf3_wants_phase(double gflop_phase, int C, double pix_phase) {
+  if (!bf3_default_policy()) return gflop_phase >= bf3_min_gflop();
+  return gflop_phase * t_nphase >= 0.1 && pix_phase * t_nphase >= 256.0 && C >= 16;
 }
 
 static thread_local int t_force_family = 0;   // +1 / -1: make this phase bf16x3 / fp32 regardless of its own size (see below)
@@ -467,7 +478,7 @@ static void finish_phase(ConvPhase& g) {
   // the ConvDecoder stacks and the widest DecoderDS conv; the rest (encoders, voxel trunk) stays on exact fp32 MFMA.
   const double gflop = 2.0 * g.Msub * g.T * g.C * (double)g.SD * g.SH * g.SW * 1e-9;   // per original phase
   const bool structural = g.M > 32 && (long)g.T * g.C >= 32;
-  if (t_plan_mode == 1 && structural && t_force_family >= 0 && (gflop >= bf3_min_gflop() || t_force_family > 0)) {
+  if (t_plan_mode == 1 && structural && t_force_family >= 0 && (bf3_wants_phase(gflop, g.C, (double)g.SD * g.SH * g.SW) || t_force_family > 0)) {
     g.bf3 = 1;
     bf3_finish_phase(g);
     return;
@@ -505,6 +516,7 @@ static int build_conv_form(const muvo_conv_desc* d, const int* in_dims, const in
   g.in_sC = g.ID * g.IH * g.IW; g.out_sC = g.OD * g.OH * g.OW;
   g.in_sN = (long)C * g.in_sC; g.out_sN = (long)M * g.out_sC;
   g.wsm = wsm; g.wsc = wsc;
+  t_nphase = 1;
   finish_phase(g);
   *ph = g;
   return MUVO_OK;
@@ -517,6 +529,7 @@ static int build_transposed_form(const muvo_conv_desc* d, const int* in_dims, co
   int count = 0;
   const int s0 = d->stride[0], s1 = d->stride[1], s2 = d->stride[2];
   MUVO_CHECK_ARG(s0 * s1 * s2 <= 8, "transposed form: too many phases");
+  t_nphase = s0 * s1 * s2;
   for (int p0 = 0; p0 < s0; ++p0)
     for (int p1 = 0; p1 < s1; ++p1)
       for (int p2 = 0; p2 < s2; ++p2) {
@@ -714,8 +727,7 @@ int muvo_conv_set_mode(int mode) {
 }
 int muvo_conv_get_mode(void) { return conv_mode(); }
 int muvo_conv_set_bf16x3_min_gflop(double gflop_per_item) {
-  MUVO_CHECK_ARG(gflop_per_item >= 0.0, "conv_set_bf16x3_min_gflop: negative threshold");
-  g_bf3_min_gflop = gflop_per_item;
+  g_bf3_min_gflop = gflop_per_item < 0.0 ? -1.0 : gflop_per_item;   // negative: back to the built-in policy
   return MUVO_OK;
 }
 
@@ -899,18 +911,27 @@ static double bf3_wgrad_min_gflop() {
   static const char* e = getenv("MUVO_BF16X3_WGRAD_MIN_GFLOP");
   static const double env_v = e ? atof(e) : -1.0;
   if (env_v >= 0.0) return env_v;
+  if (bf3_default_policy()) return 0.05;
   return bf3_min_gflop() < 0.5 ? bf3_min_gflop() : 0.5;   // follows muvo_conv_set_bf16x3_min_gflop
 }
 
-// does the weight gradient of this conv run on the bf16x3 kernel (conv_bf3.hip)?  Same per-item work threshold as
-// forward/dgrad, every phase must have > 32 output and >= 32 input channels.
+// does the weight gradient of this conv run on the bf16x3 kernel (conv_bf3.hip)?  Every phase must have > 32 output and
+// >= 32 input channels.  Explicit threshold: per-phase work as for forward/dgrad; built-in policy: >= 0.05 GFLOP per
+// batch item over the whole operation and more than one tap (1x1 weight gradients are faster on the fp32 kernel).
 static bool wgrad_uses_bf3(const ConvPlan& pf) {
   if (conv_mode() != 1) return false;
+  const bool dflt = bf3_default_policy() && !getenv("MUVO_BF16X3_WGRAD_MIN_GFLOP");
+  double total = 0.0;
+  int taps = 0;
   for (int i = 0; i < pf.nfwd; ++i) {
     const ConvPhase& g = pf.fwd[i];
     const double gflop = 2.0 * g.Msub * g.T * g.C * (double)g.SD * g.SH * g.SW * 1e-9;   // per original phase
-    if (g.Msub <= 32 || g.C < 32 || g.Msub % 16 != 0 && g.nmerge > 1 || gflop < bf3_wgrad_min_gflop()) return false;
+    if (g.Msub <= 32 || g.C < 32 || g.Msub % 16 != 0 && g.nmerge > 1) return false;
+    if (!dflt && gflop < bf3_wgrad_min_gflop()) return false;
+    total += gflop * g.nmerge;
+    taps += g.T * g.nmerge;
   }
+  if (dflt && (total < bf3_wgrad_min_gflop() || taps <= 1)) return false;
   return pf.nfwd > 0;
 }
 

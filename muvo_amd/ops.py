@@ -124,7 +124,7 @@ CONV_F32, CONV_BF16X3 = 0, 1
 
 def set_conv_mode(mode, min_gflop=None):
     """Select the matrix-pipe arithmetic of the large convolutions (CONV_F32 exact / CONV_BF16X3 split products;
-    min_gflop = per-item work below which a phase stays on fp32 MFMA).  Packed weights and plans depend on it, so both
+    min_gflop = per-item work below which a phase stays on fp32 MFMA; negative = the library's built-in per-layer policy).  Packed weights and plans depend on it, so both
     caches are invalidated."""
     _ck(lib().muvo_conv_set_mode(int(mode)))
     if min_gflop is not None:

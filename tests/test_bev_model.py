@@ -1,7 +1,10 @@
 """BEV-lifting model variant (MODEL.TRANSFORMER.BEV=True — Decoder with bilinear upsampling, mono depth
 head, FrustumPooling, bev_down_sample_4; mile.py:33-59,506-524) against the golden training step of the REAL reference
 (tests/golden/bev_b1s2.*, oracle/refimport/make_golden_bev.py).  CPU: the oracle restatement.  GPU: the HIP model —
-losses within 1e-3 relative, outputs within 2e-3, gradient norms of the BEV-specific parameters within 5e-3."""
+losses within 1e-3 relative, outputs within 2e-3, gradient norms of the BEV-specific parameters within 5e-3 on the exact
+fp32 kernels; on the default bf16x3 policy within 5e-3 + 2x the reference's OWN gradient-norm change under a 4e-6 relative
+perturbation of its conv outputs (fixture field rounding_sensitivity: up to 1.5e-2 for this b1s2 step, because ReLU / L1
+sign decisions flip)."""
 import json
 import os
 
@@ -51,7 +54,18 @@ def test_oracle_bev_step_matches_reference():
 
 
 @pytest.mark.gpu
-def test_hip_bev_step_matches_reference(dev):
+@pytest.mark.parametrize('arith', ['f32', 'policy'])
+def test_hip_bev_step_matches_reference(dev, arith):
+    from muvo_amd import ops
+    old = ops.get_conv_mode()
+    ops.set_conv_mode(ops.CONV_F32 if arith == 'f32' else ops.CONV_BF16X3, min_gflop=-1.0)
+    try:
+        _hip_bev_step(dev, arith)
+    finally:
+        ops.set_conv_mode(old, min_gflop=-1.0)
+
+
+def _hip_bev_step(dev, arith):
     from muvo_amd.config import base_1d_cfg
     from muvo_amd.data.frustum_inputs import camera_pose
     from muvo_amd.data.synthetic import make_batch, make_noise
@@ -82,8 +96,9 @@ def test_hip_bev_step_matches_reference(dev):
     _check_outputs(fx, smp, output, 2e-3)
     params = dict(tr.model.named_parameters())
     bad = []
+    rtol = 5e-3 + (2.0 * max(fx['rounding_sensitivity']['grad_l2'].values()) if arith == 'policy' else 0.0)
     for n, ref in fx['grad_l2'].items():
         got = params[n].grad.double().pow(2).sum().sqrt().item()
-        if abs(got - ref) > 5e-3 * max(ref, 1e-12) + 1e-7:
+        if abs(got - ref) > rtol * max(ref, 1e-12) + 1e-7:
             bad.append((n, got, ref))
     assert not bad, '; '.join(f'{n} x{g / r:.4f}' for n, g, r in bad)

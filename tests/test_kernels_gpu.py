@@ -69,7 +69,7 @@ def conv_mode(request):
     old = ops.get_conv_mode()
     ops.set_conv_mode(ops.CONV_BF16X3 if request.param == 'bf16x3' else ops.CONV_F32, min_gflop=0.0)
     yield request.param
-    ops.set_conv_mode(old, min_gflop=2.0)
+    ops.set_conv_mode(old, min_gflop=-1.0)
 
 
 @pytest.mark.parametrize('case', CONV_CASES, ids=[str(i) for i in range(len(CONV_CASES))])
@@ -543,4 +543,4 @@ def test_conv_strided_dgrad_uses_one_arithmetic_for_all_phases(dev):
         _close(m.weight.grad, w.grad, rtol=5e-4, name='wgrad')
         _close(m.bias.grad, b.grad, rtol=5e-4, name='dbias')
     finally:
-        ops.set_conv_mode(old, min_gflop=2.0)
+        ops.set_conv_mode(old, min_gflop=-1.0)

@@ -1,6 +1,10 @@
 """-m gpu: the full HIP training step (preprocess -> forward -> 21 losses -> backward -> fused AdamW, through the
 C ABI) against the golden fixture generated from the REAL reference (tests/golden/base1d_b1s2*.{json,npz},
-oracle/refimport/make_golden.py).  Tolerance: 1e-3 relative fp32 (BASELINE.json north_star); voxel argmax bit-exact."""
+oracle/refimport/make_golden.py).  Tolerance: 1e-3 relative fp32 (BASELINE.json north_star); voxel argmax bit-exact.  Every test runs twice: on the exact
+fp32 MFMA kernels ('f32') and on the library's default arithmetic policy ('policy': bf16x3 split products for most
+convolutions).  The gradient bars of the 'policy' run add the REAL reference's own gradient change under a 4e-6 relative
+perturbation of its convolution outputs (tests/golden/base1d_b1s2_rounding.json,
+oracle/refimport/make_rounding_sensitivity.py: median 1.2e-2 relative, because ReLU / max-pool / L1-sign decisions flip)."""
 import hashlib
 import json
 import os
@@ -13,8 +17,21 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), 'golden')
 
 
-@pytest.fixture(scope='module')
-def run(dev):
+@pytest.fixture(scope='module', params=['f32', 'policy'])
+def run(dev, request):
+    from muvo_amd import ops
+    old = ops.get_conv_mode()
+    ops.set_conv_mode(ops.CONV_F32 if request.param == 'f32' else ops.CONV_BF16X3, min_gflop=-1.0)
+    try:
+        fx, smp, recs = _run_steps(dev)
+    finally:
+        ops.set_conv_mode(old, min_gflop=-1.0)
+    rounding = json.load(open(os.path.join(GOLD, 'base1d_b1s2_rounding.json'))) if request.param == 'policy' else None
+    fx = dict(fx, rounding=rounding)
+    return fx, smp, recs
+
+
+def _run_steps(dev):
     from muvo_amd.config import base_1d_cfg
     from muvo_amd.data.synthetic import make_batch, make_noise
     from muvo_amd.trainer import WorldModelTrainer
@@ -117,13 +134,14 @@ def test_gradients_match_reference(run):
     weight-gradient kernels accumulate split-K partials with float atomics, so the last digits vary run to run)."""
     fx, smp, recs = run
     st = fx['steps'][0]
+    rnd = fx['rounding']     # None on the exact-fp32 run
     bad = []
     for n, ref in st['grad_l2_fp64'].items():
         got = recs[0]['grad_l2'][n]
         if ref is None:
             assert got is None or got == 0.0, n  # never-used encoder_layer.* (SURVEY App. B 2)
             continue
-        tol = max(2e-3 * abs(ref), 6.0 * st['grad_l2_ref32_err'][n], 1e-5)
+        tol = max(2e-3 * abs(ref), 6.0 * st['grad_l2_ref32_err'][n], 1e-5, 2.0 * rnd['grad_l2_err'][n] if rnd else 0.0)
         if abs(got - ref) > tol:
             bad.append((n, got, ref, tol))
     assert not bad, f'{len(bad)} gradient norms off, first: {bad[:5]}'
@@ -147,6 +165,9 @@ def test_gradients_match_reference(run):
             err_l2 = (got - ref).norm().item()
             tol = max(2e-2 * ref.abs().max().item(), 6.0 * noise, 1e-12)
             tol_l2 = max(5e-3 * ref.norm().item(), 6.0 * noise_l2, 1e-12)
+            if rnd:   # the reference's own response to bf16x3-sized rounding, scaled to the strided sample
+                tol = max(tol, 2.0 * rnd['grad_max_err'][n])
+                tol_l2 = max(tol_l2, 3.0 * rnd['grad_l2_err'][n] * (ref.numel() / t.numel()) ** 0.5)
             assert err <= tol, f'{n}: max err {err:.3e} > tol {tol:.3e} (reference fp32 noise {noise:.3e})'
             assert err_l2 <= tol_l2, f'{n}: L2 err {err_l2:.3e} > tol {tol_l2:.3e} (reference fp32 noise {noise_l2:.3e})'
 
