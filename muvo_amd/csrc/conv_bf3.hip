@@ -1210,9 +1210,18 @@ int bf3_launch_fwd_phase(const ConvPhase& g, const void* ws, const float* wp, co
     if (g.M > 64) return bf3_launch<128, 256, 2, 4, 4, 2>(g, ws, wp, bias, out, act, slope, st);
   }
   if (variant == 16 && g.M > 128 && g.npix >= 256 * 256) return bf3_launch_k16<256, 256, 2, 4>(g, ws, wp, bias, out, act, slope, st);
-  if (g.M > 128) return bf3_launch<256, 128, 4, 2, 4, 3>(g, ws, wp, bias, out, act, slope, st);
-  if (g.M > 64) return bf3_launch<128, 256, 2, 4, 4, 3>(g, ws, wp, bias, out, act, slope, st);
-  return bf3_launch<64, 256, 1, 4, 4, 2>(g, ws, wp, bias, out, act, slope, st);
+  // Launches whose eight-wave tiles (one 147 KB workgroup per CU) would cover less than half of the 256 CUs, and all
+  // 64-row launches, use the four-wave 64x128 tile: 49 KB of LDS, three workgroups per CU.  Measured per layer
+  // (profiles/r01q_tile_choice.txt): 64x128 beats 64x256 (one workgroup per CU) by 1.4-1.6x on every 64-row layer and
+  // the big tiles by 1.2-1.35x below 128 workgroups; a four-wave 128x128 tile lost to the ping-pong tiles everywhere.
+  if (g.M > 64) {
+    const long big = g.M > 128 ? (long)cdiv(g.npix, 128) * cdiv(g.M, 256) : (long)cdiv(g.npix, 256) * cdiv(g.M, 128);
+    if (big >= 128) {
+      if (g.M > 128) return bf3_launch<256, 128, 4, 2, 4, 3>(g, ws, wp, bias, out, act, slope, st);
+      return bf3_launch<128, 256, 2, 4, 4, 3>(g, ws, wp, bias, out, act, slope, st);
+    }
+  }
+  return bf3_launch<64, 128, 1, 4, 4, 2>(g, ws, wp, bias, out, act, slope, st);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -1284,6 +1293,7 @@ int bf3_wgrad_phase(const ConvPhase& g, const void* ws_x, int Cin_total, const v
                     float* dw, hipStream_t st) {
   if (g.npix <= 0 || g.T == 0) return MUVO_OK;
   int rc;
+  static const int w64 = getenv("MUVO_BF3_WGRAD_64") ? atoi(getenv("MUVO_BF3_WGRAD_64")) : 1;
   static const int wvariant = getenv("MUVO_BF3_WGRAD_VARIANT") ? atoi(getenv("MUVO_BF3_WGRAD_VARIANT")) : 0;   // 1: in-phase DMA kernels
   if (g.M > 128) rc = wvariant == 1 ? bf3_wgrad_launch<256, 128, 4, 2, 1>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st)
                                     : bf3_wgrad_pp_launch<256, 128, 4, 2>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st);
@@ -1291,7 +1301,8 @@ int bf3_wgrad_phase(const ConvPhase& g, const void* ws_x, int Cin_total, const v
                                                      : bf3_wgrad_pp_launch<128, 256, 2, 4>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st))
                                     : bf3_wgrad_launch<128, 128, 2, 2, 2>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st);
   else rc = g.C > 128 ? bf3_wgrad_launch<64, 256, 1, 4, 2>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st)
-                      : bf3_wgrad_launch<64, 128, 1, 2, 2>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st);
+            : g.C > 64 || w64 == 0 ? bf3_wgrad_launch<64, 128, 1, 2, 2>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st)
+                                   : bf3_wgrad_launch<64, 64, 1, 2, 2>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st);
   if (rc) return rc;
   const long total = (long)g.M * g.C * g.T;
   hipLaunchKernelGGL(bf3_unpack_wgrad_kernel, dim3(ew_grid(total)), dim3(256), 0, st, g, wg, dw);

@@ -207,6 +207,66 @@ __global__ void __launch_bounds__(256) gemm_skinny_kcontig_kernel(const GemmArgs
   }
 }
 
+// Same product for 16-byte aligned, k-contiguous A and B with K % 4 == 0 (every nn.Linear forward of the model).  A
+// workgroup owns four output columns and ALL rows: its four waves split k (lanes read float4), so the weight is streamed
+// from HBM exactly once and A is re-read from L2 once per four columns (the two-column kernel above re-read it per column
+// pair and made several passes over the weight for M > 8).
+template <int RM>
+__global__ void __launch_bounds__(512) gemm_skinny_kvec_kernel(const GemmArgs g, const float* __restrict__ A,
+                                                               const float* __restrict__ B, float* __restrict__ C) {
+  // eight waves x two k chunks x four columns of float4 in flight per workgroup: a cold 68 MB weight needs ~8 MB of
+  // outstanding loads to approach HBM speed (HBM latency x bandwidth)
+  __shared__ float red[8][RM][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = blockIdx.x * 4;
+  float acc[RM][4];
+#pragma unroll
+  for (int r = 0; r < RM; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[r][c] = 0.f;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = (wave * 64 + lane) * 4; k < g.K; k += 4096) {
+    const int k2 = k + 2048;
+    const bool has2 = k2 < g.K;
+    float4 w[2][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float* bp = B + (long)(n0 + c < g.N ? n0 + c : n0) * g.sbn;
+      w[0][c] = *reinterpret_cast<const float4*>(bp + k);
+      w[1][c] = has2 ? *reinterpret_cast<const float4*>(bp + k2) : zero4;
+    }
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+      if (r < g.M) {   // wave-uniform
+        const float4 a0 = *reinterpret_cast<const float4*>(A + (long)r * g.sam + k);
+        const float4 a1 = has2 ? *reinterpret_cast<const float4*>(A + (long)r * g.sam + k2) : zero4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          acc[r][c] += a0.x * w[0][c].x + a0.y * w[0][c].y + a0.z * w[0][c].z + a0.w * w[0][c].w +
+                       a1.x * w[1][c].x + a1.y * w[1][c].y + a1.z * w[1][c].z + a1.w * w[1][c].w;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RM; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float sum = wave_sum(acc[r][c]);
+      if (lane == 0) red[wave][r][c] = sum;
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < RM * 4; i += 512) {
+    const int r = i >> 2, c = i & 3;
+    if (r < g.M && n0 + c < g.N) {
+      float sum = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) sum += red[w8][r][c];
+      const float bv = g.bias ? g.bias[(n0 + c) / g.bias_div] : 0.f;
+      C[(long)r * g.scm + n0 + c] = act_apply(g.alpha * sum + bv, g.act, g.slope);
+    }
+  }
+}
+
 // B n-contiguous (data gradient of nn.Linear: B(k,n) = W[k][n]).  Lanes along n (coalesced weight rows); the four waves of
 // a workgroup and the KS workgroups of grid.y split k.  KS > 1: partial sums are added into the pre-zeroed C with float
 // atomics (only offered without bias/activation).
@@ -279,9 +339,20 @@ extern "C" int muvo_gemm(const muvo_gemm_desc* d, const float* A, const float* B
   g.act = d->act; g.slope = d->slope; g.mode = d->mode;
   const int nb = d->B1 * d->B2;
   hipStream_t st = (hipStream_t)stream;
-  if (d->M <= 32 && d->mode == 0 && nb == 1 && d->N >= 64 && d->K >= 16) {
+  const bool kvec = d->M <= 32 && d->mode == 0 && nb == 1 && d->K >= 64 && d->sbk == 1 && d->sak == 1 && d->K % 4 == 0 &&
+                    d->sam % 4 == 0 && d->sbn % 4 == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0;
+  if (d->M <= 32 && d->mode == 0 && nb == 1 && ((d->N >= 64 && d->K >= 16) || kvec)) {
     g.ksplit = 1;
-    if (d->sbk == 1) {
+    const bool vec = d->sbk == 1 && d->sak == 1 && d->K % 4 == 0 && d->sam % 4 == 0 && d->sbn % 4 == 0 &&
+                     (((uintptr_t)A | (uintptr_t)B) & 15) == 0;
+    if (vec) {
+      const dim3 grid(cdiv(d->N, 4));
+      if (d->M <= 4) hipLaunchKernelGGL((gemm_skinny_kvec_kernel<4>), grid, dim3(512), 0, st, g, A, B, C);
+      else if (d->M <= 8) hipLaunchKernelGGL((gemm_skinny_kvec_kernel<8>), grid, dim3(512), 0, st, g, A, B, C);
+      else if (d->M <= 16) hipLaunchKernelGGL((gemm_skinny_kvec_kernel<16>), grid, dim3(512), 0, st, g, A, B, C);
+      else if (d->M <= 24) hipLaunchKernelGGL((gemm_skinny_kvec_kernel<24>), grid, dim3(512), 0, st, g, A, B, C);
+      else hipLaunchKernelGGL((gemm_skinny_kvec_kernel<32>), grid, dim3(512), 0, st, g, A, B, C);
+    } else if (d->sbk == 1) {
       const int blocks = cdiv(d->N, 8);
       if (d->M <= 4) hipLaunchKernelGGL((gemm_skinny_kcontig_kernel<4>), dim3(blocks), dim3(256), 0, st, g, A, B, C);
       else hipLaunchKernelGGL((gemm_skinny_kcontig_kernel<8>), dim3(blocks), dim3(256), 0, st, g, A, B, C);

@@ -43,13 +43,14 @@ class ParamStore:
                 for n, p in used:
                     is_nodecay = p.dim() == 1 or any(s in n for s in skip_decay)
                     if seg_of[n] == si and (not is_nodecay) == decay:
+                        off = (off + 3) & ~3       # 16-byte aligned tensors: the kernels read weights as float4
                         order.append((n, p, off))
                         off += p.numel()
                 if off > start:
                     self.ranges.append((si, decay, start, off))
         self.numel = off
         dev = used[0][1].device
-        self.flat_param = torch.empty(off, device=dev, dtype=torch.float32)
+        self.flat_param = torch.zeros(off, device=dev, dtype=torch.float32)   # alignment gaps stay zero
         self.flat_grad = torch.zeros(off, device=dev, dtype=torch.float32)
         self.exp_avg = torch.zeros(off, device=dev, dtype=torch.float32)
         self.exp_avg_sq = torch.zeros(off, device=dev, dtype=torch.float32)

@@ -18,11 +18,15 @@ def step(i):
 for i in range(2): step(i)
 torch.cuda.synchronize()
 rec = []
+strides = set()
 _gemm = ops.gemm
 def logged(A, Bm, Cout, M, N, K, sam, sak, sbk, sbn, scm, *a, **kw):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); _gemm(A, Bm, Cout, M, N, K, sam, sak, sbk, sbn, scm, *a, **kw); e1.record()
     rec.append(((M, N, K, kw.get('B1', 1) * kw.get('B2', 1), int(sak == 1), int(sbn == 1), kw.get('mode', 0)), e0, e1))
+    if M <= 32 and os.environ.get('GEMM_TABLE_STRIDES'):
+        strides.add((M, N, K, sam, sak, sbk, sbn, scm, (A.data_ptr() + 4 * kw.get('a_off', 0)) % 16, (Bm.data_ptr() + 4 * kw.get('b_off', 0)) % 16,
+                     kw.get('bias') is not None, kw.get('act', 0)))
 ops.gemm = logged
 STEPS = 3
 for i in range(STEPS): step(2 + i)
@@ -33,6 +37,8 @@ for key, e0, e1 in rec:
 rows = sorted(tab.items(), key=lambda kv: -kv[1][1])
 tot = sum(v[1] for v in tab.values()) / STEPS
 print(f'# {len(rec) // STEPS} gemm calls/step, {tot:.2f} ms/step (event time, includes launch gaps)')
+for t in sorted(strides):
+    print('# skinny M N K sam sak sbk sbn scm A%16 B%16 bias act:', t)
 print('   M      N      K  batch kA nB mode  calls/step  ms/step   us/call  TFLOP/s')
 for (M, N, K, b, ka, nb, mode), (n, ms) in rows:
     fl = 2.0 * M * N * K * b
