@@ -151,6 +151,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32' if args.conv_mfma == 'f32' else 'f32 storage/accumulate; decoder contractions as bf16x3 split products',
             'data': 'synthetic',
+            'peak_hbm_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
             'config': {'workload': f'base_1d (resnet18 + range-view + transformer fusion + 1D latent), batch={args.batch} '
                                    f'per GPU, seq_len={s}, 600x960 RGB (crop 320x832) + 64x1024 range-view + '
                                    f'192x192x64 voxels, full step incl. 21 losses, backward, AdamW',

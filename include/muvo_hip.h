@@ -61,6 +61,22 @@ int muvo_conv_get_mode(void);
  * the built-in policy fitted to per-layer timings on MI355X - an operation needs >= 0.1 GFLOP and >= 256 result pixels
  * per batch item and >= 16 reduction channels (weight gradients: >= 0.05 GFLOP per item and more than one tap). */
 int muvo_conv_set_bf16x3_min_gflop(double gflop_per_item);
+/* nn.Linear on token-major activations [rows][features] with thousands of rows (the transformer encoder:
+ * muvo/models/mile.py:96-101, 558-561 - nn.TransformerEncoderLayer in_proj / out_proj / linear1 / linear2) on the bf16x3
+ * implicit-GEMM kernels, as a 1x1 convolution over a one-row image of `rows` pixels.  Needs in_f % 8 == 0, out_f % 16 == 0,
+ * both >= 64.  pack: w [out_f][in_f] -> the two packed operands (sizes from pack_floats); split: x -> bf16 hi/lo planes
+ * (workspace_bytes(rows, features)); forward: y = act(x W^T + b) from the planes of x; dgrad: dx = dz W from the planes
+ * of dz; wgrad: dw += dz^T x from both (scratch: out_f * in_f floats). */
+int muvo_linear_bf16x3_pack_floats(int in_f, int out_f, int64_t* fwd_floats, int64_t* dgrad_floats);
+int muvo_linear_bf16x3_pack(int in_f, int out_f, const float* w, float* wp_fwd, float* wp_dgrad, void* stream);
+int64_t muvo_linear_bf16x3_workspace_bytes(int64_t rows, int features);
+int muvo_linear_bf16x3_split(const float* x, int64_t rows, int features, void* ws, void* stream);
+int muvo_linear_bf16x3_forward(int64_t rows, int in_f, int out_f, const void* ws_x, const float* wp_fwd, const float* bias,
+                               float* y, int act, float slope, void* stream);
+int muvo_linear_bf16x3_dgrad(int64_t rows, int in_f, int out_f, const void* ws_dz, const float* wp_dgrad, float* dx,
+                             void* stream);
+int muvo_linear_bf16x3_wgrad(int64_t rows, int in_f, int out_f, const void* ws_x, const void* ws_dz, float* scratch,
+                             float* dw, void* stream);
 /* sizes (in floats) of the K-major packed weight buffers used by forward/wgrad and by dgrad */
 int muvo_conv_pack_sizes(const muvo_conv_desc* d, int64_t* fwd_floats, int64_t* dgrad_floats);
 /* repack w into wp_fwd and/or wp_dgrad (either may be NULL) */

@@ -16,3 +16,5 @@ int bf3_launch_fwd_phase(const ConvPhase& g, const void* ws, const float* wp, co
 // of dy with Cout_total channels); wg = zeroed scratch, g.wp_off = float offset of the phase's [T][M][C] slab in it
 int bf3_wgrad_phase(const ConvPhase& g, const void* ws_x, int Cin_total, const void* ws_dz, int Cout_total, float* wg,
                     float* dw, hipStream_t st);
+// token-major fp32 [rows][C] (C % 8 == 0) -> the same split planes ((rows * C * 4 + 16) bytes)
+int bf3_split_rows(const float* x, void* ws, long rows, int C, hipStream_t st);

@@ -376,6 +376,20 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
       const size_t obase = (size_t)nn * g.out_sN +
                            ((size_t)(jz * g.os[0] + g.mop[grp][0]) * g.OH + (jy * g.os[1] + g.mop[grp][1])) * g.OW +
                            (jx * g.os[2] + g.mop[grp][2]);
+      if (g.out_sC == 1) {   // (uniform) token-major output of a Linear layer, M % 4 == 0: four consecutive rows per store
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int m = mo + 8 * q + 4 * (lane >> 5);
+          if (m < g.M) {
+            float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+            if (bias) { v.x += bias[m]; v.y += bias[m + 1]; v.z += bias[m + 2]; v.w += bias[m + 3]; }
+            v.x = act_apply(v.x, act, slope); v.y = act_apply(v.y, act, slope);
+            v.z = act_apply(v.z, act, slope); v.w = act_apply(v.w, act, slope);
+            *reinterpret_cast<float4*>(out + obase + m) = v;
+          }
+        }
+        continue;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -1151,6 +1165,31 @@ int bf3_split_input(const float* x, void* ws, int N, int C, long S, hipStream_t 
   hipLaunchKernelGGL(nchw_split_nhwc_kernel, grid, dim3(256), 0, st, x, hi, lo, C, Cp, S, yact, act, slope, rep);
   if (dbias) hipLaunchKernelGGL(bias_replica_reduce_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, rep, dbias, C, Cp);
   MUVO_CHECK_LAUNCH("nchw_split_nhwc_kernel");
+  return MUVO_OK;
+}
+
+// fp32 row-major [rows][C] (tokens x features, C % 8 == 0) -> the same channels-last hi / lo planes: no transpose, each
+// thread splits 8 consecutive features (two float4 loads, two 16-byte stores).
+__global__ void __launch_bounds__(256) rows_split_kernel(const float* __restrict__ in, uint4* __restrict__ out_hi,
+                                                         uint4* __restrict__ out_lo, long n_u4) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n_u4; i += (long)gridDim.x * 256) {
+    const float4 a = reinterpret_cast<const float4*>(in)[2 * i], b = reinterpret_cast<const float4*>(in)[2 * i + 1];
+    uint4 h, l;
+    split2(a.x, a.y, h.x, l.x);
+    split2(a.z, a.w, h.y, l.y);
+    split2(b.x, b.y, h.z, l.z);
+    split2(b.z, b.w, h.w, l.w);
+    out_hi[i] = h;
+    out_lo[i] = l;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) out_hi[2 * n_u4] = make_uint4(0u, 0u, 0u, 0u);   // zero page after the planes
+}
+
+int bf3_split_rows(const float* x, void* ws, long rows, int C, hipStream_t st) {
+  const long n_u4 = rows * C / 8;
+  uint4* hi = (uint4*)ws;
+  hipLaunchKernelGGL(rows_split_kernel, dim3(ew_grid(n_u4)), dim3(256), 0, st, x, hi, hi + n_u4, n_u4);
+  MUVO_CHECK_LAUNCH("rows_split_kernel");
   return MUVO_OK;
 }
 

@@ -1006,4 +1006,103 @@ int muvo_bias_grad_nchw(const float* dy, float* db, int N, int M, int64_t S, voi
   return MUVO_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// nn.Linear on token-major activations ([rows][features], rows in the thousands: the transformer encoder) as a 1x1
+// convolution over a one-row "image" of `rows` pixels on the bf16x3 implicit-GEMM kernels: the token matrix already is the
+// channels-last layout those kernels stage from, so only the fp32 -> hi/lo split pass remains, and the epilogue stores
+// channel-contiguous rows (out_sC == 1).  Forward-form phase: reduction over in_f, rows of the GEMM = out_f.
+// ------------------------------------------------------------------------------------------------
+static int linear_phase(int rows, int c, int m, long wsm, long wsc, bool token_major_out, ConvPhase* ph) {
+  MUVO_CHECK_ARG(rows > 0 && c >= 32 && m > 32 && c % 8 == 0 && m % 4 == 0,
+                 "linear_bf16x3: needs in/out features >= 32, reduction features %% 8 == 0, produced features %% 4 == 0");
+  muvo_conv_desc d;
+  memset(&d, 0, sizeof(d));
+  d.nd = 2; d.N = 1; d.Cin = c; d.Cout = m;
+  for (int a = 0; a < 3; ++a) { d.in_sz[a] = d.out_sz[a] = d.ksz[a] = d.stride[a] = d.dil[a] = 1; d.pad[a] = 0; }
+  d.in_sz[2] = d.out_sz[2] = rows;
+  t_plan_mode = 1;
+  t_allow_merge = false;
+  t_force_family = 1;
+  const int rc = build_conv_form(&d, d.in_sz, d.out_sz, c, m, wsm, wsc, ph);
+  t_force_family = 0;
+  if (rc) return rc;
+  ph->wp_off = 0;
+  if (token_major_out) { ph->os[2] = m; ph->out_sC = 1; }   // out[pixel * m + channel]
+  return MUVO_OK;
+}
+
+int muvo_linear_bf16x3_pack_floats(int in_f, int out_f, int64_t* fwd_floats, int64_t* dgrad_floats) {
+  ConvPhase f, b;
+  int rc = linear_phase(1, in_f, out_f, in_f, 1, true, &f);
+  if (rc) return rc;
+  rc = linear_phase(1, out_f, in_f, 1, in_f, true, &b);
+  if (rc) return rc;
+  if (fwd_floats) *fwd_floats = (int64_t)f.Kp * f.Mp;
+  if (dgrad_floats) *dgrad_floats = (int64_t)b.Kp * b.Mp;
+  return MUVO_OK;
+}
+
+// w: [out_f][in_f] (nn.Linear layout).  Either destination may be NULL.
+int muvo_linear_bf16x3_pack(int in_f, int out_f, const float* w, float* wp_fwd, float* wp_dgrad, void* stream) {
+  MUVO_CHECK_ARG(w, "linear_bf16x3_pack: null weight");
+  ConvPhase g;
+  int rc;
+  if (wp_fwd) {
+    rc = linear_phase(1, in_f, out_f, in_f, 1, true, &g);
+    if (rc) return rc;
+    rc = bf3_pack_phase(g, w, wp_fwd, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  if (wp_dgrad) {
+    rc = linear_phase(1, out_f, in_f, 1, in_f, true, &g);
+    if (rc) return rc;
+    rc = bf3_pack_phase(g, w, wp_dgrad, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  return MUVO_OK;
+}
+
+int64_t muvo_linear_bf16x3_workspace_bytes(int64_t rows, int features) { return rows * features * 4 + 16; }
+
+// x: [rows][features] fp32 -> hi / lo planes in ws (muvo_linear_bf16x3_workspace_bytes)
+int muvo_linear_bf16x3_split(const float* x, int64_t rows, int features, void* ws, void* stream) {
+  MUVO_CHECK_ARG(x && ws && rows > 0 && features > 0 && features % 8 == 0, "linear_bf16x3_split: bad args");
+  return bf3_split_rows(x, ws, rows, features, (hipStream_t)stream);
+}
+
+// y[rows][out_f] = act(x W^T + bias) from the split planes of x
+int muvo_linear_bf16x3_forward(int64_t rows, int in_f, int out_f, const void* ws_x, const float* wp_fwd, const float* bias,
+                               float* y, int act, float slope, void* stream) {
+  MUVO_CHECK_ARG(ws_x && wp_fwd && y && rows < (1 << 30), "linear_bf16x3_forward: bad args");
+  ConvPhase g;
+  const int rc = linear_phase((int)rows, in_f, out_f, in_f, 1, true, &g);
+  if (rc) return rc;
+  return bf3_launch_fwd_phase(g, ws_x, wp_fwd, bias, y, act, slope, (hipStream_t)stream);
+}
+
+// dx[rows][in_f] = dz W from the split planes of dz
+int muvo_linear_bf16x3_dgrad(int64_t rows, int in_f, int out_f, const void* ws_dz, const float* wp_dgrad, float* dx,
+                             void* stream) {
+  MUVO_CHECK_ARG(ws_dz && wp_dgrad && dx && rows < (1 << 30), "linear_bf16x3_dgrad: bad args");
+  ConvPhase g;
+  const int rc = linear_phase((int)rows, out_f, in_f, 1, in_f, true, &g);
+  if (rc) return rc;
+  return bf3_launch_fwd_phase(g, ws_dz, wp_dgrad, nullptr, dx, MUVO_ACT_NONE, 0.f, (hipStream_t)stream);
+}
+
+// dw[out_f][in_f] += dz^T x from both sets of split planes; scratch: out_f * in_f floats (overwritten)
+int muvo_linear_bf16x3_wgrad(int64_t rows, int in_f, int out_f, const void* ws_x, const void* ws_dz, float* scratch,
+                             float* dw, void* stream) {
+  MUVO_CHECK_ARG(ws_x && ws_dz && scratch && dw && rows < (1 << 30), "linear_bf16x3_wgrad: bad args");
+  ConvPhase g;
+  int rc = linear_phase((int)rows, in_f, out_f, in_f, 1, false, &g);
+  if (rc) return rc;
+  MUVO_CHECK_ARG(out_f % 16 == 0, "linear_bf16x3_wgrad: out features %% 16");
+  if (hipMemsetAsync(scratch, 0, sizeof(float) * (size_t)out_f * in_f, (hipStream_t)stream) != hipSuccess) {
+    muvo_set_error("linear_bf16x3_wgrad: memset failed");
+    return MUVO_ERR_HIP;
+  }
+  return bf3_wgrad_phase(g, ws_x, in_f, ws_dz, out_f, scratch, dw, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -44,6 +44,8 @@ EXPORTS = [
     'muvo_last_error', 'muvo_abi_version', 'muvo_selftest_mfma',
     'muvo_conv_set_mode', 'muvo_conv_get_mode', 'muvo_conv_set_bf16x3_min_gflop', 'muvo_conv_pack_sizes', 'muvo_conv_workspace_bytes', 'muvo_conv_kernel_family', 'muvo_conv_pack_weights', 'muvo_conv_forward', 'muvo_conv_dgrad', 'muvo_conv_prepare_dy', 'muvo_conv_wgrad', 'muvo_bias_grad_nchw',
     'muvo_gemm',
+    'muvo_linear_bf16x3_pack_floats', 'muvo_linear_bf16x3_pack', 'muvo_linear_bf16x3_workspace_bytes', 'muvo_linear_bf16x3_split',
+    'muvo_linear_bf16x3_forward', 'muvo_linear_bf16x3_dgrad', 'muvo_linear_bf16x3_wgrad',
     'muvo_bn_train_fwd', 'muvo_bn_train_bwd', 'muvo_adain_fwd', 'muvo_adain_bwd',
     'muvo_add_dropout_layernorm_fwd', 'muvo_add_dropout_layernorm_bwd',
     'muvo_act_fwd', 'muvo_act_bwd', 'muvo_dropout', 'muvo_axpby', 'muvo_copy2d', 'muvo_colsum_acc', 'muvo_batchsum',
@@ -75,6 +77,7 @@ def lib():
                 L = C.CDLL(_LIB_PATH)
                 L.muvo_last_error.restype = C.c_char_p
                 L.muvo_conv_workspace_bytes.restype = C.c_int64
+                L.muvo_linear_bf16x3_workspace_bytes.restype = C.c_int64
                 for name in EXPORTS:
                     getattr(L, name)  # AttributeError if a declared symbol is missing
                 _lib = L
@@ -295,7 +298,91 @@ class LinearFn(torch.autograd.Function):
         return dx, None, None, None, None
 
 
+class _LinearPacked:
+    __slots__ = ('fwd', 'dgr', 'fwd_key', 'dgr_key')
+
+    def __init__(self):
+        self.fwd = self.dgr = self.fwd_key = self.dgr_key = None
+
+
+class LinearBf16x3Fn(torch.autograd.Function):
+    """The same Linear for token matrices with thousands of rows (transformer encoder) on the bf16x3 implicit-GEMM
+    kernels (include/muvo_hip.h: muvo_linear_bf16x3_*): x and dz are split once into bf16 hi/lo planes; forward, data
+    gradient and weight gradient all read those planes."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, slope):
+        x = x.contiguous()
+        out_f, in_f = weight.shape
+        rows = x.numel() // in_f
+        L = lib()
+        pk = getattr(weight, '_bf3_packed', None)
+        if pk is None:
+            pk = weight._bf3_packed = _LinearPacked()
+        ff, df = C.c_int64(0), C.c_int64(0)
+        _ck(L.muvo_linear_bf16x3_pack_floats(in_f, out_f, C.byref(ff), C.byref(df)))
+        k = _wkey(weight)
+        if pk.fwd is None or pk.fwd_key != k:
+            if pk.fwd is None:
+                pk.fwd = torch.empty(ff.value, device=x.device, dtype=torch.float32)
+            _ck(L.muvo_linear_bf16x3_pack(in_f, out_f, _f(weight), _f(pk.fwd), None, _st()))
+            pk.fwd_key = k
+        keep = ctx.needs_input_grad[1]      # a backward follows: wgrad reuses the planes of x
+        nws = (L.muvo_linear_bf16x3_workspace_bytes(_i64(rows), in_f) + 3) // 4
+        ws_x = torch.empty(nws, device=x.device, dtype=torch.float32) if keep else scratch('lin_ws_x', nws, x.device)
+        _ck(L.muvo_linear_bf16x3_split(_f(x), _i64(rows), in_f, _p(ws_x), _st()))
+        y = torch.empty(*x.shape[:-1], out_f, device=x.device, dtype=torch.float32)
+        _ck(L.muvo_linear_bf16x3_forward(_i64(rows), in_f, out_f, _p(ws_x), _f(pk.fwd), _f(bias), _f(y), act, _fl(slope),
+                                         _st()))
+        ctx.act, ctx.slope, ctx.weight, ctx.bias, ctx.pk = act, slope, weight, bias, pk
+        ctx.ws_x = ws_x if keep else None
+        ctx.dims = (rows, in_f, out_f, df.value)
+        ctx.x_shape = x.shape
+        ctx.save_for_backward(y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, = ctx.saved_tensors
+        weight, bias, pk = ctx.weight, ctx.bias, ctx.pk
+        rows, in_f, out_f, df = ctx.dims
+        L = lib()
+        dy = dy.contiguous()
+        if ctx.act != ACT_NONE:
+            dz = torch.empty_like(dy)
+            _ck(L.muvo_act_bwd(_f(y), _f(dy), _f(dz), _i64(dy.numel()), ctx.act, _fl(ctx.slope), _st()))
+        else:
+            dz = dy
+        nws = (L.muvo_linear_bf16x3_workspace_bytes(_i64(rows), out_f) + 3) // 4
+        ws_dz = scratch('lin_ws_dz', nws, dy.device)
+        _ck(L.muvo_linear_bf16x3_split(_f(dz), _i64(rows), out_f, _p(ws_dz), _st()))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            k = _wkey(weight)
+            if pk.dgr is None or pk.dgr_key != k:
+                if pk.dgr is None:
+                    pk.dgr = torch.empty(df, device=dy.device, dtype=torch.float32)
+                _ck(L.muvo_linear_bf16x3_pack(in_f, out_f, _f(weight), None, _f(pk.dgr), _st()))
+                pk.dgr_key = k
+            dx = torch.empty(ctx.x_shape, device=dy.device, dtype=torch.float32)
+            _ck(L.muvo_linear_bf16x3_dgrad(_i64(rows), in_f, out_f, _p(ws_dz), _f(pk.dgr), _f(dx), _st()))
+        if weight.requires_grad:
+            sc = scratch('lin_wgrad', out_f * in_f, dy.device)
+            _ck(L.muvo_linear_bf16x3_wgrad(_i64(rows), in_f, out_f, _p(ctx.ws_x), _p(ws_dz), _f(sc), _f(grad_of(weight)),
+                                           _st()))
+            if bias is not None:
+                _ck(L.muvo_colsum_acc(_f(dz), _f(grad_of(bias)), _i64(rows), _i64(out_f), _i64(out_f), _st()))
+        return dx, None, None, None, None
+
+
+LINEAR_BF16X3_MIN_ROWS = int(os.environ.get('MUVO_LINEAR_BF16X3_MIN_ROWS', '2048'))
+
+
 def linear(x, weight, bias=None, act=ACT_NONE, slope=0.0):
+    out_f, in_f = weight.shape
+    if (x.numel() // in_f >= LINEAR_BF16X3_MIN_ROWS and in_f % 8 == 0 and out_f % 16 == 0 and in_f >= 64 and out_f >= 64
+            and get_conv_mode() == CONV_BF16X3):
+        return LinearBf16x3Fn.apply(x, weight, bias, act, slope)
     return LinearFn.apply(x, weight, bias, act, slope)
 
 
@@ -362,6 +449,9 @@ def _wkey(w):
     return (w._version, _weight_epoch[0], w.data_ptr())
 
 
+_KEEP_WS = os.environ.get('MUVO_KEEP_WS', '1') != '0'
+
+
 class ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, geom, packed, act, slope, act_bwd_fused=False):
@@ -387,7 +477,8 @@ class ConvFn(torch.autograd.Function):
                                 math.prod(geom.stride) if geom.transposed else 1, _conv_tag(geom, n, in_sz))
             e0.record()
         wsb = geom.ws_bytes[(n, in_sz, _plan_epoch[0])]
-        keep_ws = wsb[0] > 0 and wsb[2] > 0 and weight.requires_grad and torch.is_grad_enabled()  # wgrad reuses the copy of x
+        # wgrad reuses the split copy of x (grad mode is off inside forward: needs_input_grad says whether a backward follows)
+        keep_ws = wsb[0] > 0 and wsb[2] > 0 and ctx.needs_input_grad[1] and _KEEP_WS
         if keep_ws:
             ws = torch.empty((wsb[0] + 3) // 4, device=x.device, dtype=torch.float32)
         else:

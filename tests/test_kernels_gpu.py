@@ -154,6 +154,47 @@ def test_linear(dev, shape):
         _close(lin.bias.grad, b.grad, rtol=5e-4, name='linear db')
 
 
+@pytest.mark.parametrize('shape', [(2500, 384, 384), (2101, 2048, 384), (2048, 384, 2048), (3000, 1152, 384), (2200, 64, 72)])
+def test_linear_bf16x3_token_matrix(dev, shape):
+    """nn.Linear on token matrices with thousands of rows runs on the bf16x3 implicit-GEMM kernels
+    (muvo_linear_bf16x3_*): ragged row counts, produced features above / below the 128-workgroup tile switch, a second
+    backward accumulating into the same weight gradient."""
+    from muvo_amd import nn as hnn
+    from muvo_amd import ops
+    rows, out_f, in_f = shape
+    assert ops.get_conv_mode() == ops.CONV_BF16X3 and rows >= ops.LINEAR_BF16X3_MIN_ROWS
+    torch.manual_seed(3)
+    with torch.device(dev):
+        lin = hnn.Linear(in_f, out_f)
+    x = torch.randn(rows, in_f)
+    for act in (0, 1):
+        xg = x.to(dev).requires_grad_(True)
+        lin.weight.grad = torch.zeros_like(lin.weight)
+        lin.bias.grad = torch.zeros_like(lin.bias)
+        y = lin(xg, act=act)
+        assert y.grad_fn.name().startswith('LinearBf16x3Fn')
+        w = lin.weight.detach().cpu().double().requires_grad_(True)
+        b = lin.bias.detach().cpu().double().requires_grad_(True)
+        xc = x.double().requires_grad_(True)
+        yr = F.linear(xc, w, b)
+        yr = F.relu(yr) if act == 1 else yr
+        _close(y, yr, rtol=5e-5, name=f'fwd act{act}')
+        g = torch.randn_like(yr)
+        if act == 1:
+            g = g * (yr.abs() > 1e-3)     # keep the ReLU mask decision away from rounding noise
+        yr.backward(g)
+        y.backward(g.float().to(dev))
+        _close(xg.grad, xc.grad, rtol=5e-5, name='dx')
+        _close(lin.weight.grad, w.grad, rtol=1e-4, name='dW')
+        _close(lin.bias.grad, b.grad, rtol=1e-4, name='db')
+    y2 = lin(x.to(dev))
+    y2.backward(torch.ones_like(y2))
+    y2 = lin(x.to(dev))
+    y2.backward(torch.ones_like(y2))
+    ref = x.double().sum(0)[None, :].expand(out_f, in_f)
+    _close(lin.weight.grad - w.grad.float().to(dev), 2 * ref, rtol=1e-4, name='dW accumulate')
+
+
 def test_seed_convt_as_gemm(dev):
     from muvo_amd.models.common import _Seed1x1ConvTFn
     from muvo_amd import ops
