@@ -86,8 +86,11 @@ int muvo_conv_pack_weights(const muvo_conv_desc* d, const float* w, float* wp_fw
  * which the call writes there first).  The copy of x is the same for op 0 and op 2, the copy of dy for op 1 and op 3. */
 int64_t muvo_conv_workspace_bytes(const muvo_conv_desc* d, int op);
 /* kernel family that serves this shape in the current mode (for profiling/roofline attribution): 0 exact-fp32 implicit
- * GEMM, 1 bf16x3 implicit GEMM, 2 4x4x1-MFMA small-channel Conv3d, 3 float4 VALU heads; op 0 fwd, 1 dgrad, 2 wgrad */
+ * GEMM, 1 bf16x3 implicit GEMM, 2 4x4x1-MFMA small-channel Conv3d, 3 float4 VALU heads, 4 bf16x3 small-channel Conv3d;
+ * op 0 fwd, 1 dgrad, 2 wgrad */
 int muvo_conv_kernel_family(const muvo_conv_desc* d, int op);
+/* family 1 only: 1 = the launch uses the eight-wave ping-pong tiles (256x128 / 128x256), 0 = the four-wave small tiles */
+int muvo_conv_kernel_variant(const muvo_conv_desc* d, int op);
 /* y = act(conv(x, w) + bias); bias may be NULL; ws may be NULL when muvo_conv_workspace_bytes(d, 0) == 0 */
 int muvo_conv_forward(const muvo_conv_desc* d, const float* x, const float* wp_fwd, const float* bias, float* y, int act,
                       float slope, void* ws, void* stream);

@@ -18,3 +18,6 @@ int bf3_wgrad_phase(const ConvPhase& g, const void* ws_x, int Cin_total, const v
                     float* dw, hipStream_t st);
 // token-major fp32 [rows][C] (C % 8 == 0) -> the same split planes ((rows * C * 4 + 16) bytes)
 int bf3_split_rows(const float* x, void* ws, long rows, int C, hipStream_t st);
+// tile class of a bf16x3 phase: eight-wave ping-pong tiles (true) or the four-wave small tiles (false)
+bool bf3_fwd_uses_pp(const ConvPhase& g);
+bool bf3_wgrad_uses_pp(const ConvPhase& g);

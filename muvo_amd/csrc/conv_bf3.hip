@@ -1238,6 +1238,14 @@ static int bf3_launch_k16(const ConvPhase& g, const void* ws, const float* wp, c
   return MUVO_OK;
 }
 
+// does this phase run on the eight-wave ping-pong tiles (256x128 / 128x256) or on the four-wave 64x128 tile?
+bool bf3_fwd_uses_pp(const ConvPhase& g) {
+  if (g.M <= 64) return false;
+  const long big = g.M > 128 ? (long)cdiv(g.npix, 128) * cdiv(g.M, 256) : (long)cdiv(g.npix, 256) * cdiv(g.M, 128);
+  return big >= 128;
+}
+bool bf3_wgrad_uses_pp(const ConvPhase& g) { return g.M > 128 || (g.M > 64 && g.C > 128); }
+
 int bf3_launch_fwd_phase(const ConvPhase& g, const void* ws, const float* wp, const float* bias, float* out, int act,
                          float slope, hipStream_t st) {
   if (g.npix <= 0) return MUVO_OK;
@@ -1253,12 +1261,9 @@ int bf3_launch_fwd_phase(const ConvPhase& g, const void* ws, const float* wp, co
   // 64-row launches, use the four-wave 64x128 tile: 49 KB of LDS, three workgroups per CU.  Measured per layer
   // (profiles/r01q_tile_choice.txt): 64x128 beats 64x256 (one workgroup per CU) by 1.4-1.6x on every 64-row layer and
   // the big tiles by 1.2-1.35x below 128 workgroups; a four-wave 128x128 tile lost to the ping-pong tiles everywhere.
-  if (g.M > 64) {
-    const long big = g.M > 128 ? (long)cdiv(g.npix, 128) * cdiv(g.M, 256) : (long)cdiv(g.npix, 256) * cdiv(g.M, 128);
-    if (big >= 128) {
-      if (g.M > 128) return bf3_launch<256, 128, 4, 2, 4, 3>(g, ws, wp, bias, out, act, slope, st);
-      return bf3_launch<128, 256, 2, 4, 4, 3>(g, ws, wp, bias, out, act, slope, st);
-    }
+  if (bf3_fwd_uses_pp(g)) {
+    if (g.M > 128) return bf3_launch<256, 128, 4, 2, 4, 3>(g, ws, wp, bias, out, act, slope, st);
+    return bf3_launch<128, 256, 2, 4, 4, 3>(g, ws, wp, bias, out, act, slope, st);
   }
   return bf3_launch<64, 128, 1, 4, 4, 2>(g, ws, wp, bias, out, act, slope, st);
 }

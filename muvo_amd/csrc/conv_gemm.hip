@@ -841,6 +841,23 @@ int muvo_conv_kernel_family(const muvo_conv_desc* d, int op) {
   return 0;
 }
 
+// 1 when muvo_conv_kernel_family(d, op) == 1 and the launch uses the eight-wave ping-pong tiles (256x128 / 128x256;
+// weight gradient: conv_bf3_wgrad_pp_kernel), 0 otherwise (four-wave 64x128 tile / the smaller weight-gradient tiles)
+int muvo_conv_kernel_variant(const muvo_conv_desc* d, int op) {
+  if (muvo_conv_kernel_family(d, op) != 1) return 0;
+  ConvPlan pl;
+  if (op == 2) {
+    if (build_plan(d, &pl, 0, true) || !wgrad_uses_bf3(pl)) {
+      if (build_plan(d, &pl, 0, false)) return 0;
+    }
+    return pl.nfwd > 0 && bf3_wgrad_uses_pp(pl.fwd[0]) ? 1 : 0;
+  }
+  if (build_plan(d, &pl)) return 0;
+  const ConvPhase* ph = op == 0 ? pl.fwd : pl.dgr;
+  const int nph = op == 0 ? pl.nfwd : pl.ndgr;
+  return nph > 0 && bf3_fwd_uses_pp(ph[0]) ? 1 : 0;
+}
+
 static int run_phases(const ConvPhase* ph, int nph, const float* in, const float* wp, const float* bias, float* out, int act,
                       float slope, void* ws, hipStream_t st, bool ws_valid = false) {
   bool split_done = ws_valid;

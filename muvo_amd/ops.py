@@ -42,7 +42,7 @@ class GemmDesc(C.Structure):
 # every exported symbol of include/muvo_hip.h (tests/test_abi.py checks this list against the header)
 EXPORTS = [
     'muvo_last_error', 'muvo_abi_version', 'muvo_selftest_mfma',
-    'muvo_conv_set_mode', 'muvo_conv_get_mode', 'muvo_conv_set_bf16x3_min_gflop', 'muvo_conv_pack_sizes', 'muvo_conv_workspace_bytes', 'muvo_conv_kernel_family', 'muvo_conv_pack_weights', 'muvo_conv_forward', 'muvo_conv_dgrad', 'muvo_conv_prepare_dy', 'muvo_conv_wgrad', 'muvo_bias_grad_nchw',
+    'muvo_conv_set_mode', 'muvo_conv_get_mode', 'muvo_conv_set_bf16x3_min_gflop', 'muvo_conv_pack_sizes', 'muvo_conv_workspace_bytes', 'muvo_conv_kernel_family', 'muvo_conv_kernel_variant', 'muvo_conv_pack_weights', 'muvo_conv_forward', 'muvo_conv_dgrad', 'muvo_conv_prepare_dy', 'muvo_conv_wgrad', 'muvo_bias_grad_nchw',
     'muvo_gemm',
     'muvo_linear_bf16x3_pack_floats', 'muvo_linear_bf16x3_pack', 'muvo_linear_bf16x3_workspace_bytes', 'muvo_linear_bf16x3_split',
     'muvo_linear_bf16x3_forward', 'muvo_linear_bf16x3_dgrad', 'muvo_linear_bf16x3_wgrad',
@@ -224,14 +224,19 @@ class KernelTiming:
         return roof, classes
 
 
-FAMILY = {0: 'f32_implicit_gemm', 1: 'bf16x3_implicit_gemm', 2: 'vox_4x4x1', 3: 'heads_valu', 4: 'vox_bf16x3', -1: 'unknown'}
+FAMILY = {0: 'f32_implicit_gemm', 1: 'bf16x3_implicit_gemm', 2: 'vox_4x4x1', 3: 'heads_valu', 4: 'vox_bf16x3',
+          5: 'bf16x3_small_tile', -1: 'unknown'}
 KERNEL_NAMES = {'f32_implicit_gemm': 'conv_fwd_kernel / conv_wgrad_kernel (v_mfma_f32_32x32x2_f32)',
-                'bf16x3_implicit_gemm': 'conv_bf3_kernel / conv_bf3_wgrad_kernel (v_mfma_f32_32x32x16_bf16, 3 products)',
+                'bf16x3_implicit_gemm': 'conv_bf3_kernel<256,128|128,256> / conv_bf3_wgrad_pp_kernel: eight-wave ping-pong tiles '
+                                        '(v_mfma_f32_32x32x16_bf16, 3 products)',
+                'bf16x3_small_tile': 'conv_bf3_kernel<64,128> / conv_bf3_wgrad_kernel: four-wave tiles of the same arithmetic',
                 'vox_4x4x1': 'vox_conv_kernel / vox_wgrad_kernel (v_mfma_f32_4x4x1_16b_f32)',
                 'vox_bf16x3': 'vox_bf3_kernel (v_mfma_f32_16x16x32_bf16, 3 products, rows padded to 16)'}
 # dense MFMA peaks from /opt/skills/guides/MI355X_MICROARCH.md
-PEAK_TFLOPS = {'f32_implicit_gemm': 157.3, 'bf16x3_implicit_gemm': 2500.0, 'vox_4x4x1': 157.3, 'vox_bf16x3': 2500.0}
-MFMA_FLOPS_PER_ALGORITHMIC_FLOP = {'f32_implicit_gemm': 1.0, 'bf16x3_implicit_gemm': 3.0, 'vox_4x4x1': 1.0, 'vox_bf16x3': 3.0}
+PEAK_TFLOPS = {'f32_implicit_gemm': 157.3, 'bf16x3_implicit_gemm': 2500.0, 'bf16x3_small_tile': 2500.0, 'vox_4x4x1': 157.3,
+               'vox_bf16x3': 2500.0}
+MFMA_FLOPS_PER_ALGORITHMIC_FLOP = {'f32_implicit_gemm': 1.0, 'bf16x3_implicit_gemm': 3.0, 'bf16x3_small_tile': 3.0,
+                                   'vox_4x4x1': 1.0, 'vox_bf16x3': 3.0}
 
 
 def _conv_tag(geom, n, in_sz):
@@ -406,6 +411,7 @@ class ConvGeom:
         self._plans = {}
         self.ws_bytes = {}
         self.family = {}
+        self.tclass = {}
 
     def out_size(self, in_sz):
         o = []
@@ -432,6 +438,10 @@ class ConvGeom:
                 raise RuntimeError(f'muvo_hip error: {lib().muvo_last_error().decode()}')
             self.ws_bytes[(n, in_sz, _plan_epoch[0])] = (wsf, wsd, wsx, wsy)
             self.family[(n, in_sz, _plan_epoch[0])] = tuple(lib().muvo_conv_kernel_family(C.byref(d), op) for op in (0, 1, 2))
+            # timing label: family 1 launches on the four-wave small tiles are reported as their own class (5)
+            self.tclass[(n, in_sz, _plan_epoch[0])] = tuple(
+                5 if (f == 1 and lib().muvo_conv_kernel_variant(C.byref(d), op) == 0) else f
+                for op, f in enumerate(self.family[(n, in_sz, _plan_epoch[0])]))
             pl = (d, out_sz, ff.value, df.value)
             self._plans[key] = pl
         return pl
@@ -473,7 +483,7 @@ class ConvFn(torch.autograd.Function):
         kt = KERNEL_TIMING
         if kt is not None:
             import math
-            e0, e1 = kt.bracket(FAMILY[geom.family[(n, in_sz, _plan_epoch[0])][0]] + ':fwd', _conv_flops(geom, n, in_sz, out_sz),
+            e0, e1 = kt.bracket(FAMILY[geom.tclass[(n, in_sz, _plan_epoch[0])][0]] + ':fwd', _conv_flops(geom, n, in_sz, out_sz),
                                 math.prod(geom.stride) if geom.transposed else 1, _conv_tag(geom, n, in_sz))
             e0.record()
         wsb = geom.ws_bytes[(n, in_sz, _plan_epoch[0])]
@@ -532,7 +542,7 @@ class ConvFn(torch.autograd.Function):
             kt = KERNEL_TIMING
             if kt is not None:
                 import math
-                e0, e1 = kt.bracket(FAMILY[geom.family[(x.shape[0], ctx.in_sz, _plan_epoch[0])][1]] + ':dgrad',
+                e0, e1 = kt.bracket(FAMILY[geom.tclass[(x.shape[0], ctx.in_sz, _plan_epoch[0])][1]] + ':dgrad',
                                     _conv_flops(geom, x.shape[0], ctx.in_sz, out_sz),
                                     1 if geom.transposed else math.prod(geom.stride), _conv_tag(geom, x.shape[0], ctx.in_sz))
                 e0.record()
@@ -548,7 +558,7 @@ class ConvFn(torch.autograd.Function):
             kt = KERNEL_TIMING
             if kt is not None:
                 import math
-                e0, e1 = kt.bracket(FAMILY[geom.family[(x.shape[0], ctx.in_sz, _plan_epoch[0])][2]] + ':wgrad',
+                e0, e1 = kt.bracket(FAMILY[geom.tclass[(x.shape[0], ctx.in_sz, _plan_epoch[0])][2]] + ':wgrad',
                                     _conv_flops(geom, x.shape[0], ctx.in_sz, out_sz),
                                     math.prod(geom.stride) if geom.transposed else 1, _conv_tag(geom, x.shape[0], ctx.in_sz))
                 e0.record()
