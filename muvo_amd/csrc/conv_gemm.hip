@@ -413,7 +413,7 @@ static int check_desc(const muvo_conv_desc* d) {
 
 static int choose_cp(int C) { return C <= 4 ? 4 : (C <= 8 ? 8 : roundup(C, 16)); }
 
-// 0: exact fp32 MFMA everywhere; 1: bf16x3 split-product MFMA for phases with more than 32 output channels
+// 0: exact fp32 MFMA everywhere; 1: bf16x3 split-product MFMA for phases with at least 32 output channels
 static int g_conv_mode = -1;
 static thread_local int t_plan_mode = 0;
 static thread_local bool t_allow_merge = true;
@@ -440,6 +440,7 @@ static double bf3_min_gflop() {
   if (bf3_default_policy()) return 0.1;
   return g_bf3_min_gflop >= 0.0 ? g_bf3_min_gflop : atof(getenv("MUVO_BF16X3_MIN_GFLOP"));
 }
+static const int g_bf3_min_m = getenv("MUVO_BF3_MIN_M") ? atoi(getenv("MUVO_BF3_MIN_M")) : 32;   // smallest row count on bf16x3 (half of the 64-row tile idles at 32; still 1.4x the fp32 kernel)
 static thread_local int t_nphase = 1;         // sub-pixel phases of the operation being planned (work / pixels are per phase)
 static bool bf3_wants_phase(double gflop_phase, int C, double pix_phase) {
   if (!bf3_default_policy()) return gflop_phase >= bf3_min_gflop();
@@ -477,7 +478,7 @@ static void finish_phase(ConvPhase& g) {
   // bf16x3 only where it pays: phases with >= MUVO_BF16X3_MIN_GFLOP (default 2) GFLOP of work per batch item, i.e.
   // the ConvDecoder stacks and the widest DecoderDS conv; the rest (encoders, voxel trunk) stays on exact fp32 MFMA.
   const double gflop = 2.0 * g.Msub * g.T * g.C * (double)g.SD * g.SH * g.SW * 1e-9;   // per original phase
-  const bool structural = g.M > 32 && (long)g.T * g.C >= 32;
+  const bool structural = g.M >= g_bf3_min_m && (long)g.T * g.C >= 32;
   if (t_plan_mode == 1 && structural && t_force_family >= 0 && (bf3_wants_phase(gflop, g.C, (double)g.SD * g.SH * g.SW) || t_force_family > 0)) {
     g.bf3 = 1;
     bf3_finish_phase(g);
@@ -590,7 +591,7 @@ static int build_transposed_form(const muvo_conv_desc* d, const int* in_dims, co
     bool any = false, all_struct = true;
     for (int i = 0; i < count; ++i) {
       any = any || phs[i].bf3;
-      all_struct = all_struct && phs[i].M > 32 && (long)phs[i].T * phs[i].C >= 32;
+      all_struct = all_struct && phs[i].M >= g_bf3_min_m && (long)phs[i].T * phs[i].C >= 32;
     }
     if (any) {
       t_force_family = all_struct ? 1 : -1;
@@ -679,9 +680,10 @@ static int phase_ksplit(const ConvPhase& g) {
   const int bm = g.M > 64 ? 128 : (g.M > 32 ? 64 : 32);
   const long blocks = (long)cdiv(g.npix, 128) * cdiv(g.M, bm);
   const int nk = g.Kp / 16;
-  if (blocks >= 192 || nk < 32) return 1;
+  static const int min_steps = getenv("MUVO_KSPLIT_MIN_STEPS") ? atoi(getenv("MUVO_KSPLIT_MIN_STEPS")) : 8;
+  if (blocks >= 192 || nk < 4 * min_steps) return 1;
   int ks = cdiv(768, blocks);
-  if (ks > nk / 8) ks = nk / 8;
+  if (ks > nk / min_steps) ks = nk / min_steps;
   return ks < 1 ? 1 : ks;
 }
 
@@ -861,9 +863,17 @@ int muvo_conv_kernel_variant(const muvo_conv_desc* d, int op) {
 static int run_phases(const ConvPhase* ph, int nph, const float* in, const float* wp, const float* bias, float* out, int act,
                       float slope, void* ws, hipStream_t st, bool ws_valid = false) {
   bool split_done = ws_valid;
-  // split-K needs a zeroed output and a finishing bias/activation pass; use it only when every phase wants it
-  bool use_ksplit = nph > 0;
-  for (int i = 0; i < nph; ++i) use_ksplit = use_ksplit && phase_ksplit(ph[i]) > 1;
+  // split-K needs a zeroed output and a finishing bias/activation pass for the whole tensor, so all phases of the operation
+  // switch together as soon as one of them wants it (the sub-pixel phases of a strided data gradient differ in tap count: a
+  // one-tap phase alone would not, and used to keep its four-tap sibling on a serial 64-step loop); a phase that would not
+  // split on its own runs with two K ranges
+  static const int any_rule = getenv("MUVO_KSPLIT_ANY") ? atoi(getenv("MUVO_KSPLIT_ANY")) : 1;
+  bool use_ksplit = nph > 0 && !any_rule, any_ks = false;
+  for (int i = 0; i < nph; ++i) {
+    use_ksplit = use_ksplit && phase_ksplit(ph[i]) > 1;
+    any_ks = any_ks || phase_ksplit(ph[i]) > 1;
+  }
+  if (any_rule) use_ksplit = any_ks;
   const long out_total = nph > 0 ? (long)ph[0].N * ph[0].out_sN : 0;
   if (use_ksplit && hipMemsetAsync(out, 0, sizeof(float) * out_total, st) != hipSuccess) {
     muvo_set_error("conv: memset of the split-K output failed");
@@ -876,7 +886,8 @@ static int run_phases(const ConvPhase* ph, int nph, const float* in, const float
       if (rc) return rc;
       split_done = true;
     }
-    int rc = launch_fwd_phase(ph[i], in, wp, bias, out, act, slope, st, ws, use_ksplit ? phase_ksplit(ph[i]) : 1);
+    const int ks_i = phase_ksplit(ph[i]);
+    int rc = launch_fwd_phase(ph[i], in, wp, bias, out, act, slope, st, ws, use_ksplit ? (ks_i > 1 ? ks_i : 2) : 1);
     if (rc) return rc;
   }
   if (use_ksplit && (bias != nullptr || act != MUVO_ACT_NONE)) {
@@ -932,9 +943,10 @@ static double bf3_wgrad_min_gflop() {
   return bf3_min_gflop() < 0.5 ? bf3_min_gflop() : 0.5;   // follows muvo_conv_set_bf16x3_min_gflop
 }
 
-// does the weight gradient of this conv run on the bf16x3 kernel (conv_bf3.hip)?  Every phase must have > 32 output and
-// >= 32 input channels.  Explicit threshold: per-phase work as for forward/dgrad; built-in policy: >= 0.05 GFLOP per
+// does the weight gradient of this conv run on the bf16x3 kernel (conv_bf3.hip)?  Every phase must have >= 32 output and
+// >= 32 input channels (>= 64 input channels when there are only 32 output channels).  Explicit threshold: per-phase work as for forward/dgrad; built-in policy: >= 0.05 GFLOP per
 // batch item over the whole operation and more than one tap (1x1 weight gradients are faster on the fp32 kernel).
+static const int g_bf3_wgrad_min_m = getenv("MUVO_BF3_WGRAD_MIN_M") ? atoi(getenv("MUVO_BF3_WGRAD_MIN_M")) : 32;
 static bool wgrad_uses_bf3(const ConvPlan& pf) {
   if (conv_mode() != 1) return false;
   const bool dflt = bf3_default_policy() && !getenv("MUVO_BF16X3_WGRAD_MIN_GFLOP");
@@ -943,7 +955,8 @@ static bool wgrad_uses_bf3(const ConvPlan& pf) {
   for (int i = 0; i < pf.nfwd; ++i) {
     const ConvPhase& g = pf.fwd[i];
     const double gflop = 2.0 * g.Msub * g.T * g.C * (double)g.SD * g.SH * g.SW * 1e-9;   // per original phase
-    if (g.Msub <= 32 || g.C < 32 || g.Msub % 16 != 0 && g.nmerge > 1) return false;
+    if (g.Msub < g_bf3_wgrad_min_m || g.C < 32 || g.Msub % 16 != 0 && g.nmerge > 1) return false;
+    if (g.Msub <= 32 && g.C < 64) return false;     // 32 x 32 channels: the fp32 kernel is as fast (measured)
     if (!dflt && gflop < bf3_wgrad_min_gflop()) return false;
     total += gflop * g.nmerge;
     taps += g.T * g.nmerge;
