@@ -149,7 +149,7 @@ def main():
             'metric': 'world-model training samples/sec (seq_len=10)', 'value': samples / dt, 'unit': 'samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if args.conv_mfma == 'f32' else 'f32 storage/accumulate; decoder contractions as bf16x3 split products',
+            'dtype': 'f32' if args.conv_mfma == 'f32' else 'f32 storage/accumulate; large contractions (convolutions, transformer Linear) as bf16x3 split products',
             'data': 'synthetic',
             'peak_hbm_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
             'config': {'workload': f'base_1d (resnet18 + range-view + transformer fusion + 1D latent), batch={args.batch} '
