@@ -66,7 +66,7 @@ int muvo_conv_set_bf16x3_min_gflop(double gflop_per_item);
  * implicit-GEMM kernels, as a 1x1 convolution over a one-row image of `rows` pixels.  Needs in_f % 8 == 0, out_f % 16 == 0,
  * both >= 64.  pack: w [out_f][in_f] -> the two packed operands (sizes from pack_floats); split: x -> bf16 hi/lo planes
  * (workspace_bytes(rows, features)); forward: y = act(x W^T + b) from the planes of x; dgrad: dx = dz W from the planes
- * of dz; wgrad: dw += dz^T x from both (scratch: out_f * in_f floats). */
+ * of dz; wgrad: dw += dz^T x from both (scratch: out_f * in_f floats, all-zero on entry, left all-zero). */
 int muvo_linear_bf16x3_pack_floats(int in_f, int out_f, int64_t* fwd_floats, int64_t* dgrad_floats);
 int muvo_linear_bf16x3_pack(int in_f, int out_f, const float* w, float* wp_fwd, float* wp_dgrad, void* stream);
 int64_t muvo_linear_bf16x3_workspace_bytes(int64_t rows, int features);
@@ -103,7 +103,8 @@ int muvo_conv_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp_dg
 int muvo_conv_prepare_dy(const muvo_conv_desc* d, const float* y, const float* dy, int act, float slope, void* ws_dy,
                          float* dbias, void* stream);
 /* dw += conv_weight_grad(x, dy) (PyTorch layout); dbias += sum(dy) if non-NULL.
- * dwp_scratch: fwd_floats floats of workspace (overwritten).  ws_x / ws_dy: see muvo_conv_workspace_bytes (may be NULL
+ * dwp_scratch: fwd_floats floats of workspace that must be ALL-ZERO on entry and is left all-zero on return (the split-K
+ * partial sums accumulate in it with float atomics; the unpack pass clears what it reads, so no memset is needed per call).  ws_x / ws_dy: see muvo_conv_workspace_bytes (may be NULL
  * when 0 bytes); flags bit 0 / bit 1: ws_x / ws_dy already hold the copies written by muvo_conv_forward(x) /
  * muvo_conv_dgrad(dy) for the same tensors, so wgrad does not rewrite them. */
 int muvo_conv_wgrad(const muvo_conv_desc* d, const float* x, const float* dy, float* dwp_scratch, float* dw, float* dbias,

@@ -991,13 +991,13 @@ conv_bf3_wgrad_pp_kernel(const ConvPhase g, const uint4* __restrict__ xs, long x
 }
 
 // dw[m*wsm + c*wsc + tap_w[t]] += Wg[t][m][c]   (thread order follows the PyTorch weight layout)
-__global__ void __launch_bounds__(256) bf3_unpack_wgrad_kernel(const ConvPhase g, const float* __restrict__ wg,
+__global__ void __launch_bounds__(256) bf3_unpack_wgrad_kernel(const ConvPhase g, float* __restrict__ wg,
                                                                float* __restrict__ dw) {
   __shared__ int s_tw[MAX_TAPS];
   if (threadIdx.x < MAX_TAPS) s_tw[threadIdx.x] = g.tap_w[threadIdx.x];
   __syncthreads();
   const long total = (long)g.M * g.C * g.T;
-  const float* base = wg + g.wp_off;
+  float* base = wg + g.wp_off;        // cleared as it is read: the scratch stays all-zero between weight gradients
   for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const int t = (int)(idx % g.T);
     const long r = idx / g.T;
@@ -1005,8 +1005,9 @@ __global__ void __launch_bounds__(256) bf3_unpack_wgrad_kernel(const ConvPhase g
     if (g.wsm > g.wsc) { c = (int)(r % g.C); m = (int)(r / g.C); }
     else { m = (int)(r % g.M); c = (int)(r / g.M); }
     const int grp = m / g.Msub, co = m - grp * g.Msub;
-    dw[(size_t)co * g.wsm + (size_t)c * g.wsc + (g.nmerge > 1 ? g.tap_wm[grp][t] : s_tw[t])] +=
-        base[((size_t)t * g.M + m) * g.C + c];
+    float* src = base + ((size_t)t * g.M + m) * g.C + c;
+    dw[(size_t)co * g.wsm + (size_t)c * g.wsc + (g.nmerge > 1 ? g.tap_wm[grp][t] : s_tw[t])] += *src;
+    *src = 0.f;
   }
 }
 

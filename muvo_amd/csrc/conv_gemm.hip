@@ -349,7 +349,9 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const ConvPhase g, co
 }
 
 // One thread per (m, c, t) of the phase: coalesced along t/c on the PyTorch side.
-__global__ void __launch_bounds__(256) unpack_wgrad_kernel(const ConvPhase g, const float* __restrict__ dwp,
+// The scratch is left all-zero again (valid entries are cleared by the thread that read them, the padding of the [Kp][Mp]
+// image by a second sweep), so the next weight gradient needs no memset (muvo_conv_wgrad contract).
+__global__ void __launch_bounds__(256) unpack_wgrad_kernel(const ConvPhase g, float* __restrict__ dwp,
                                                            float* __restrict__ dw) {
   __shared__ int s_tw[MAX_TAPS];
   if (threadIdx.x < MAX_TAPS) s_tw[threadIdx.x] = g.tap_w[threadIdx.x];
@@ -362,8 +364,16 @@ __global__ void __launch_bounds__(256) unpack_wgrad_kernel(const ConvPhase g, co
     int m, c;
     if (g.wsm > g.wsc) { c = (int)(r % g.C); m = (int)(r / g.C); }
     else { m = (int)(r % g.M); c = (int)(r / g.M); }
-    const float v = dwp[g.wp_off + (size_t)(t * g.Cp + c) * g.Mp + m];
+    float* src = dwp + g.wp_off + (size_t)(t * g.Cp + c) * g.Mp + m;
+    const float v = *src;
+    *src = 0.f;
     dw[(size_t)m * g.wsm + (size_t)c * g.wsc + s_tw[t]] += v;
+  }
+  const long padded = (long)g.Kp * g.Mp;
+  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < padded; idx += (long)gridDim.x * 256) {
+    const int k = (int)(idx / g.Mp), m = (int)(idx - (long)k * g.Mp);
+    const int t = k / g.Cp, c = k - t * g.Cp;
+    if (!(t < g.T && c < g.C && m < g.M)) dwp[g.wp_off + idx] = 0.f;
   }
 }
 
@@ -965,7 +975,8 @@ static bool wgrad_uses_bf3(const ConvPlan& pf) {
   return pf.nfwd > 0;
 }
 
-// dw (PyTorch layout) += grad;  dbias += sum(dy).  dwp_scratch: fwd_floats floats of workspace (overwritten).
+// dw (PyTorch layout) += grad;  dbias += sum(dy).  dwp_scratch: fwd_floats floats of workspace, ALL-ZERO on entry and
+// left all-zero on exit (the split-K atomics accumulate into it; the unpack pass clears what it reads).
 // ws_x / ws_dy: muvo_conv_workspace_bytes(d, 2) / (d, 3) bytes (NULL when 0); flags bit 0 / bit 1: ws_x / ws_dy already
 // hold the split planes of x / dy (left there by muvo_conv_forward / muvo_conv_dgrad of the same tensors).
 int muvo_conv_wgrad(const muvo_conv_desc* d, const float* x, const float* dy, float* dwp_scratch, float* dw, float* dbias,
@@ -988,11 +999,7 @@ int muvo_conv_wgrad(const muvo_conv_desc* d, const float* x, const float* dy, fl
     if (!(flags & 2)) { rc = bf3_split_input(dy, ws_dy, d->N, d->Cout, S_out, st); if (rc) return rc; }
     long off = 0;
     for (int i = 0; i < pl.nfwd; ++i) off += (long)pl.fwd[i].T * pl.fwd[i].M * pl.fwd[i].C;
-    if (hipMemsetAsync(dwp_scratch, 0, sizeof(float) * off, st) != hipSuccess) {
-      muvo_set_error("conv_wgrad: memset failed");
-      return MUVO_ERR_HIP;
-    }
-    off = 0;
+    off = 0;       // dwp_scratch is all-zero on entry and left all-zero by the unpack kernels
     for (int i = 0; i < pl.nfwd; ++i) {
       ConvPhase g = pl.fwd[i];
       g.wp_off = off;
@@ -1002,10 +1009,6 @@ int muvo_conv_wgrad(const muvo_conv_desc* d, const float* x, const float* dy, fl
       if (rc) return rc;
     }
   } else {
-    if (hipMemsetAsync(dwp_scratch, 0, sizeof(float) * pl.fwd_floats, st) != hipSuccess) {
-      muvo_set_error("conv_wgrad: memset failed");
-      return MUVO_ERR_HIP;
-    }
     for (int i = 0; i < pl.nfwd; ++i) {
       rc = launch_wgrad_phase(pl.fwd[i], x, dy, dwp_scratch, st);
       if (rc) return rc;
@@ -1120,7 +1123,7 @@ int muvo_linear_bf16x3_dgrad(int64_t rows, int in_f, int out_f, const void* ws_d
   return bf3_launch_fwd_phase(g, ws_dz, wp_dgrad, nullptr, dx, MUVO_ACT_NONE, 0.f, (hipStream_t)stream);
 }
 
-// dw[out_f][in_f] += dz^T x from both sets of split planes; scratch: out_f * in_f floats (overwritten)
+// dw[out_f][in_f] += dz^T x from both sets of split planes; scratch: out_f * in_f floats, all-zero on entry and on exit
 int muvo_linear_bf16x3_wgrad(int64_t rows, int in_f, int out_f, const void* ws_x, const void* ws_dz, float* scratch,
                              float* dw, void* stream) {
   MUVO_CHECK_ARG(ws_x && ws_dz && scratch && dw && rows < (1 << 30), "linear_bf16x3_wgrad: bad args");
@@ -1128,10 +1131,6 @@ int muvo_linear_bf16x3_wgrad(int64_t rows, int in_f, int out_f, const void* ws_x
   int rc = linear_phase((int)rows, in_f, out_f, in_f, 1, false, &g);
   if (rc) return rc;
   MUVO_CHECK_ARG(out_f % 16 == 0, "linear_bf16x3_wgrad: out features %% 16");
-  if (hipMemsetAsync(scratch, 0, sizeof(float) * (size_t)out_f * in_f, (hipStream_t)stream) != hipSuccess) {
-    muvo_set_error("linear_bf16x3_wgrad: memset failed");
-    return MUVO_ERR_HIP;
-  }
   return bf3_wgrad_phase(g, ws_x, in_f, ws_dz, out_f, scratch, dw, (hipStream_t)stream);
 }
 

@@ -153,6 +153,15 @@ def grad_of(p):
 _scratch = {}
 
 
+def scratch_zeroed(name, nfloats, device):
+    """Scratch that is all-zero at allocation; its users (weight-gradient kernels + unpack) leave it all-zero."""
+    t = _scratch.get((name, device, torch.float32))
+    if t is None or t.numel() < nfloats:
+        t = torch.zeros(int(nfloats), device=device, dtype=torch.float32)
+        _scratch[(name, device, torch.float32)] = t
+    return t
+
+
 def scratch(name, nfloats, device, dtype=torch.float32):
     t = _scratch.get((name, device, dtype))
     if t is None or t.numel() < nfloats:
@@ -372,7 +381,7 @@ class LinearBf16x3Fn(torch.autograd.Function):
             dx = torch.empty(ctx.x_shape, device=dy.device, dtype=torch.float32)
             _ck(L.muvo_linear_bf16x3_dgrad(_i64(rows), in_f, out_f, _p(ws_dz), _f(pk.dgr), _f(dx), _st()))
         if weight.requires_grad:
-            sc = scratch('lin_wgrad', out_f * in_f, dy.device)
+            sc = scratch_zeroed('lin_wgrad', out_f * in_f, dy.device)
             _ck(L.muvo_linear_bf16x3_wgrad(_i64(rows), in_f, out_f, _p(ctx.ws_x), _p(ws_dz), _f(sc), _f(grad_of(weight)),
                                            _st()))
             if bias is not None:
@@ -553,7 +562,7 @@ class ConvFn(torch.autograd.Function):
             if kt is not None:
                 e1.record()
         if weight.requires_grad:
-            ws = scratch('wgrad', ff, x.device)
+            ws = scratch_zeroed('wgrad', ff, x.device)
             db = grad_of(bias) if (bias is not None and not fused_dy) else None   # fused_dy: already accumulated
             kt = KERNEL_TIMING
             if kt is not None:

@@ -72,7 +72,7 @@ def main():
         in_sz = tuple(sz) if len(sz) == 3 else (1,) + tuple(sz)
         d, out_sz, ff, df = geom.plan(args.n, in_sz)
         y.backward(g)  # packs dgrad weights, warms everything
-        ws = ops.scratch('wgrad', ff, dev)
+        ws = ops.scratch_zeroed('wgrad', ff, dev)
         import ctypes as C
 
         def run(fn):
