@@ -77,6 +77,17 @@ int muvo_linear_bf16x3_dgrad(int64_t rows, int in_f, int out_f, const void* ws_d
                              void* stream);
 int muvo_linear_bf16x3_wgrad(int64_t rows, int in_f, int out_f, const void* ws_x, const void* ws_dz, float* scratch,
                              float* dw, void* stream);
+/* Batched weight packing: all packed copies go stale with every optimizer step; instead of one or more small launches per
+ * layer, list the layers once in a host array of muvo_pack_table_item_bytes()-sized entries (add appends the phases of a
+ * layer and advances *n_items / *n_blocks; it returns 1 and appends nothing for shapes served by the voxel / head kernels,
+ * which keep using muvo_conv_pack_weights), copy the array to the device, and call run after each optimizer step: one
+ * launch refreshes every listed copy.  Source and destination pointers are captured at add time. */
+int64_t muvo_pack_table_item_bytes(void);
+int muvo_conv_pack_table_add(void* host_items, int capacity, int* n_items, int64_t* n_blocks, const muvo_conv_desc* d,
+                             const float* w, float* wp_fwd, float* wp_dgrad);
+int muvo_linear_bf16x3_pack_table_add(void* host_items, int capacity, int* n_items, int64_t* n_blocks, int in_f, int out_f,
+                                      const float* w, float* wp_fwd, float* wp_dgrad);
+int muvo_pack_table_run(const void* dev_items, int n_items, int64_t n_blocks, void* stream);
 /* sizes (in floats) of the K-major packed weight buffers used by forward/wgrad and by dgrad */
 int muvo_conv_pack_sizes(const muvo_conv_desc* d, int64_t* fwd_floats, int64_t* dgrad_floats);
 /* repack w into wp_fwd and/or wp_dgrad (either may be NULL) */

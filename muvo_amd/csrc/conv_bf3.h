@@ -21,3 +21,12 @@ int bf3_split_rows(const float* x, void* ws, long rows, int C, hipStream_t st);
 // tile class of a bf16x3 phase: eight-wave ping-pong tiles (true) or the four-wave small tiles (false)
 bool bf3_fwd_uses_pp(const ConvPhase& g);
 bool bf3_wgrad_uses_pp(const ConvPhase& g);
+// one entry of the batched pack table (muvo_pack_table_*): a phase, its PyTorch-layout source and its packed destination
+struct PackItem {
+  ConvPhase g;
+  const float* w;
+  float* dst;
+  long blk0;      // first workgroup of this item
+  int nblk, pad_;
+};
+int pack_table_launch(const PackItem* dev_items, int n, long n_blocks, hipStream_t st);

@@ -1128,6 +1128,77 @@ __global__ void __launch_bounds__(256) bf3_pack_kernel(const ConvPhase g, const 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Batched weight packing: every packed copy is stale after an optimizer step, which used to mean ~290 pack launches of a
+// few microseconds each per training step.  A device-resident table (built once per set of plans) lists every phase with
+// its source and destination; ONE launch re-packs them all.  Workgroup b serves table item i with blk0[i] <= b < blk0[i+1].
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pack_table_kernel(const PackItem* __restrict__ items, int n) {
+  int lo = 0, hi = n - 1;
+  const long b = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].blk0 <= b) lo = mid; else hi = mid - 1;
+  }
+  const PackItem& it = items[lo];
+  // everything the element loop needs goes to registers / LDS first (the table lives in global memory, and the stores below
+  // would otherwise force a reload of every field per element)
+  __shared__ int s_tw[8 * MAX_TAPS];
+  const int Mp = it.g.Mp, Cp = it.g.Cp, C = it.g.C, M = it.g.M, T = it.g.T, Msub = it.g.Msub, nmerge = it.g.nmerge;
+  const long wsm = it.g.wsm, wsc = it.g.wsc, wp_off = it.g.wp_off;
+  const bool bf3 = it.g.bf3 != 0, tin = bf3_tap_inner(it.g);
+  const float* __restrict__ w = it.w;
+  float* __restrict__ dst = it.dst;
+  // 32-bit index math (a packed phase has < 2^31 elements): the loop is bound by its divisions and strided gathers
+  const unsigned total = (unsigned)it.g.Kp * (unsigned)Mp;
+  const unsigned first = (unsigned)(b - it.blk0) * 256u + threadIdx.x, stride = (unsigned)it.nblk * 256u;
+  const unsigned uMp = Mp, uCp = Cp, uT = T, uMsub = Msub;
+  for (int i = threadIdx.x; i < (nmerge > 1 ? nmerge : 1) * MAX_TAPS; i += 256)
+    s_tw[i] = nmerge > 1 ? it.g.tap_wm[i / MAX_TAPS][i % MAX_TAPS] : it.g.tap_w[i];
+  __syncthreads();
+  if (bf3) {
+    unsigned short* base = (unsigned short*)dst + wp_off * 2;
+    for (unsigned idx = first; idx < total; idx += stride) {
+      const unsigned k = idx / uMp, m = idx - k * uMp;
+      unsigned t = k / uCp, c = k - t * uCp;
+      if (tin) {
+        const unsigned q = (k >> 5) / uT;
+        t = (k >> 5) - q * uT;
+        c = q * 32 + (k & 31);
+      }
+      float v = 0.f;
+      if (t < uT && c < (unsigned)C && m < (unsigned)M) {
+        const unsigned grp = nmerge > 1 ? m / uMsub : 0u, co = m - grp * uMsub;
+        v = w[(size_t)co * wsm + (size_t)c * wsc + s_tw[grp * MAX_TAPS + t]];
+      }
+      unsigned hi16, lo16;
+      split2(v, 0.f, hi16, lo16);
+      const unsigned kt = k >> 5, chunk = (k >> 3) & 3, e = k & 7;
+      const size_t o = (((size_t)(kt * 2) * 4 + chunk) * uMp + m) * 8 + e;
+      base[o] = (unsigned short)(hi16 & 0xffff);
+      base[o + (size_t)4 * uMp * 8] = (unsigned short)(lo16 & 0xffff);
+    }
+  } else {
+    for (unsigned idx = first; idx < total; idx += stride) {
+      const unsigned k = idx / uMp, m = idx - k * uMp;
+      const unsigned t = k / uCp, c = k - t * uCp;
+      float v = 0.f;
+      if (t < uT && c < (unsigned)C && m < (unsigned)M) {
+        const unsigned grp = nmerge > 1 ? m / uMsub : 0u, co = m - grp * uMsub;
+        v = w[(size_t)co * wsm + (size_t)c * wsc + s_tw[grp * MAX_TAPS + t]];
+      }
+      dst[wp_off + idx] = v;
+    }
+  }
+}
+
+int pack_table_launch(const PackItem* dev_items, int n, long n_blocks, hipStream_t st) {
+  if (n <= 0 || n_blocks <= 0) return MUVO_OK;
+  hipLaunchKernelGGL(pack_table_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, dev_items, n);
+  MUVO_CHECK_LAUNCH("pack_table_kernel");
+  return MUVO_OK;
+}
+
 void bf3_finish_phase(ConvPhase& g) {
   g.Cp = roundup(g.C, 8);
   g.Mp = g.M > 128 ? roundup(g.M, 256) : (g.M > 64 ? 128 : 64);

@@ -1134,4 +1134,70 @@ int muvo_linear_bf16x3_wgrad(int64_t rows, int in_f, int out_f, const void* ws_x
   return bf3_wgrad_phase(g, ws_x, in_f, ws_dz, out_f, scratch, dw, (hipStream_t)stream);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Batched weight packing (conv_bf3.hip: pack_table_kernel).  The caller keeps a host array of muvo_pack_table_item_bytes()
+// sized entries, appends the phases of every layer whose packed copies it wants refreshed together (add returns 1 without
+// appending for layers served by the voxel / head kernels: pack those with muvo_conv_pack_weights), copies the array to
+// the device once, and calls run after every optimizer step.  Pointers are captured at add time.
+// ------------------------------------------------------------------------------------------------
+static int table_append(void* host_items, int capacity, int* n_items, int64_t* n_blocks, const ConvPhase* ph, int nph,
+                        const float* w, float* dst) {
+  PackItem* items = (PackItem*)host_items;
+  for (int i = 0; i < nph; ++i) {
+    const long total = (long)ph[i].Kp * ph[i].Mp;
+    if (total == 0) continue;
+    MUVO_CHECK_ARG(*n_items < capacity, "pack_table_add: table full (%d items)", capacity);
+    PackItem& it = items[*n_items];
+    it.g = ph[i];
+    it.w = w;
+    it.dst = dst;
+    it.blk0 = *n_blocks;
+    long nb = cdiv(total, 512);
+    it.nblk = (int)(nb < 1 ? 1 : (nb > 4096 ? 4096 : nb));
+    it.pad_ = 0;
+    *n_blocks += it.nblk;
+    ++*n_items;
+  }
+  return MUVO_OK;
+}
+
+int64_t muvo_pack_table_item_bytes(void) { return (int64_t)sizeof(PackItem); }
+
+int muvo_conv_pack_table_add(void* host_items, int capacity, int* n_items, int64_t* n_blocks, const muvo_conv_desc* d,
+                             const float* w, float* wp_fwd, float* wp_dgrad) {
+  MUVO_CHECK_ARG(host_items && n_items && n_blocks && d && w, "conv_pack_table_add: null pointer");
+  ConvPlan pl;
+  int rc = build_plan(d, &pl);
+  if (rc) return rc;
+  if (pw_applicable(d) || (wp_fwd && vox_fwd_ok(d)) || (wp_dgrad && vox_dgrad_ok(d))) return 1;
+  if (wp_fwd) { rc = table_append(host_items, capacity, n_items, n_blocks, pl.fwd, pl.nfwd, w, wp_fwd); if (rc) return rc; }
+  if (wp_dgrad) { rc = table_append(host_items, capacity, n_items, n_blocks, pl.dgr, pl.ndgr, w, wp_dgrad); if (rc) return rc; }
+  return MUVO_OK;
+}
+
+int muvo_linear_bf16x3_pack_table_add(void* host_items, int capacity, int* n_items, int64_t* n_blocks, int in_f, int out_f,
+                                      const float* w, float* wp_fwd, float* wp_dgrad) {
+  MUVO_CHECK_ARG(host_items && n_items && n_blocks && w, "linear_pack_table_add: null pointer");
+  ConvPhase g;
+  int rc;
+  if (wp_fwd) {
+    rc = linear_phase(1, in_f, out_f, in_f, 1, true, &g);
+    if (rc) return rc;
+    rc = table_append(host_items, capacity, n_items, n_blocks, &g, 1, w, wp_fwd);
+    if (rc) return rc;
+  }
+  if (wp_dgrad) {
+    rc = linear_phase(1, out_f, in_f, 1, in_f, true, &g);
+    if (rc) return rc;
+    rc = table_append(host_items, capacity, n_items, n_blocks, &g, 1, w, wp_dgrad);
+    if (rc) return rc;
+  }
+  return MUVO_OK;
+}
+
+int muvo_pack_table_run(const void* dev_items, int n_items, int64_t n_blocks, void* stream) {
+  MUVO_CHECK_ARG(dev_items || n_items == 0, "pack_table_run: null table");
+  return pack_table_launch((const PackItem*)dev_items, n_items, (long)n_blocks, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -12,6 +12,7 @@ return None for parameters and only propagate activation gradients.
 import ctypes as C
 import os
 import threading
+import weakref
 
 import torch
 
@@ -44,6 +45,7 @@ EXPORTS = [
     'muvo_last_error', 'muvo_abi_version', 'muvo_selftest_mfma',
     'muvo_conv_set_mode', 'muvo_conv_get_mode', 'muvo_conv_set_bf16x3_min_gflop', 'muvo_conv_pack_sizes', 'muvo_conv_workspace_bytes', 'muvo_conv_kernel_family', 'muvo_conv_kernel_variant', 'muvo_conv_pack_weights', 'muvo_conv_forward', 'muvo_conv_dgrad', 'muvo_conv_prepare_dy', 'muvo_conv_wgrad', 'muvo_bias_grad_nchw',
     'muvo_gemm',
+    'muvo_pack_table_item_bytes', 'muvo_conv_pack_table_add', 'muvo_linear_bf16x3_pack_table_add', 'muvo_pack_table_run',
     'muvo_linear_bf16x3_pack_floats', 'muvo_linear_bf16x3_pack', 'muvo_linear_bf16x3_workspace_bytes', 'muvo_linear_bf16x3_split',
     'muvo_linear_bf16x3_forward', 'muvo_linear_bf16x3_dgrad', 'muvo_linear_bf16x3_wgrad',
     'muvo_bn_train_fwd', 'muvo_bn_train_bwd', 'muvo_adain_fwd', 'muvo_adain_bwd',
@@ -78,6 +80,7 @@ def lib():
                 L.muvo_last_error.restype = C.c_char_p
                 L.muvo_conv_workspace_bytes.restype = C.c_int64
                 L.muvo_linear_bf16x3_workspace_bytes.restype = C.c_int64
+                L.muvo_pack_table_item_bytes.restype = C.c_int64
                 for name in EXPORTS:
                     getattr(L, name)  # AttributeError if a declared symbol is missing
                 _lib = L
@@ -313,7 +316,7 @@ class LinearFn(torch.autograd.Function):
 
 
 class _LinearPacked:
-    __slots__ = ('fwd', 'dgr', 'fwd_key', 'dgr_key')
+    __slots__ = ('fwd', 'dgr', 'fwd_key', 'dgr_key', '__weakref__')
 
     def __init__(self):
         self.fwd = self.dgr = self.fwd_key = self.dgr_key = None
@@ -341,6 +344,7 @@ class LinearBf16x3Fn(torch.autograd.Function):
                 pk.fwd = torch.empty(ff.value, device=x.device, dtype=torch.float32)
             _ck(L.muvo_linear_bf16x3_pack(in_f, out_f, _f(weight), _f(pk.fwd), None, _st()))
             pk.fwd_key = k
+            _PACKS.register((id(pk), _plan_epoch[0]), ('lin', (in_f, out_f), weight, weakref.ref(pk), _plan_epoch[0]))
         keep = ctx.needs_input_grad[1]      # a backward follows: wgrad reuses the planes of x
         nws = (L.muvo_linear_bf16x3_workspace_bytes(_i64(rows), in_f) + 3) // 4
         ws_x = torch.empty(nws, device=x.device, dtype=torch.float32) if keep else scratch('lin_ws_x', nws, x.device)
@@ -462,10 +466,93 @@ class _PackedWeights:
     def __init__(self):
         self.fwd = self.dgr = None
         self.fwd_key = self.dgr_key = None
+        self.fwd_plan = self.dgr_plan = None     # (batch, input size, plan epoch) the copy was packed for
 
 
 def _wkey(w):
     return (w._version, _weight_epoch[0], w.data_ptr())
+
+
+# ------------------------------------------------------------------------------------------------
+# Batched weight packing (include/muvo_hip.h: muvo_pack_table_*).  Layers register themselves the first time they pack;
+# repack_all() (called once per training forward) refreshes every registered copy that already exists with ONE launch and
+# marks it current, so the per-layer staleness checks in ConvFn / LinearBf16x3Fn find nothing to do.
+class _PackRegistry:
+    def __init__(self):
+        self.entries, self.seen = [], set()
+        self.sig, self.dev, self.n, self.nblk, self.batched = None, None, 0, 0, []
+
+    def register(self, key, entry):
+        """entry: (kind, desc, weight, weakref to the layer's packed-copy holder, plan key)"""
+        if key not in self.seen:
+            self.seen.add(key)
+            self.entries.append(entry)
+
+
+_PACKS = _PackRegistry()
+_PACK_BATCH = os.environ.get('MUVO_PACK_BATCH', '1') != '0'
+
+
+def repack_all():
+    R = _PACKS
+    if not R.entries or not _PACK_BATCH:
+        return
+    L = lib()
+    ptr = lambda t: 0 if t is None else t.data_ptr()
+    # drop layers that no longer exist and copies that belong to an earlier plan epoch (conv mode / policy change: their
+    # buffers are re-sized lazily by the layer itself, which then registers again)
+    live = []
+    for e in R.entries:
+        pk = e[3]()
+        if pk is None or (e[0] == 'conv' and e[4][2] != _plan_epoch[0]) or (e[0] == 'lin' and e[4] != _plan_epoch[0]):
+            R.seen.discard((id(pk) if pk is not None else None, e[4]))
+            continue
+        live.append(e)
+    if len(live) != len(R.entries):
+        R.entries = live
+        R.seen = {(id(e[3]()), e[4]) for e in live}
+        R.sig = None
+    if not R.entries:
+        return
+    ents = [(e[0], e[1], e[2], e[3](), e[4]) for e in R.entries]
+    sig = tuple((ptr(e[3].fwd), ptr(e[3].dgr), e[2].data_ptr()) for e in ents)
+    if sig != R.sig:
+        item = L.muvo_pack_table_item_bytes()
+        cap = 16 * len(R.entries) + 8
+        host = torch.zeros(cap * item, dtype=torch.uint8)
+        n, nblk = C.c_int(0), C.c_int64(0)
+        R.batched = []
+        for e, orig in zip(ents, R.entries):
+            kind, desc, weight, pk, _ = e
+            if pk.fwd is None and pk.dgr is None:
+                continue
+            if kind == 'conv':
+                rc = L.muvo_conv_pack_table_add(C.c_void_p(host.data_ptr()), cap, C.byref(n), C.byref(nblk), C.byref(desc),
+                                                _f(weight), _f(pk.fwd), _f(pk.dgr))
+            else:
+                rc = L.muvo_linear_bf16x3_pack_table_add(C.c_void_p(host.data_ptr()), cap, C.byref(n), C.byref(nblk),
+                                                         desc[0], desc[1], _f(weight), _f(pk.fwd), _f(pk.dgr))
+            if rc == 0:
+                R.batched.append(orig)
+            elif rc != 1:
+                _ck(rc)
+        R.n, R.nblk = n.value, nblk.value
+        R.dev = host[:max(R.n, 1) * item].to(ents[0][2].device)
+        R.sig = sig
+    if R.n:
+        _ck(L.muvo_pack_table_run(C.c_void_p(R.dev.data_ptr()), R.n, _i64(R.nblk), _st()))
+        for kind, _, weight, pkref, pkey in R.batched:
+            pk = pkref()
+            if pk is None:
+                continue
+            k = _wkey(weight)
+            if pk.fwd is not None:
+                pk.fwd_key = k
+            if pk.dgr is not None:
+                pk.dgr_key = k
+            if kind == 'conv':
+                pk.fwd_plan = pkey if pk.fwd is not None else pk.fwd_plan
+                pk.dgr_plan = pkey if pk.dgr is not None else pk.dgr_plan
 
 
 _KEEP_WS = os.environ.get('MUVO_KEEP_WS', '1') != '0'
@@ -484,9 +571,11 @@ class ConvFn(torch.autograd.Function):
             packed.fwd = torch.empty(ff, device=x.device, dtype=torch.float32)
             packed.fwd_key = None
         k = _wkey(weight)
-        if packed.fwd_key != k:
+        pkey = (n, in_sz, _plan_epoch[0])
+        if packed.fwd_key != k or packed.fwd_plan != pkey:
             _ck(L.muvo_conv_pack_weights(C.byref(d), _f(weight), _f(packed.fwd), None, _st()))
-            packed.fwd_key = k
+            packed.fwd_key, packed.fwd_plan = k, pkey
+            _PACKS.register((id(packed), pkey), ('conv', d, weight, weakref.ref(packed), pkey))
         oshape = (n, geom.cout) + (out_sz if geom.nd == 3 else out_sz[1:])
         y = torch.empty(oshape, device=x.device, dtype=torch.float32)
         kt = KERNEL_TIMING
@@ -544,9 +633,9 @@ class ConvFn(torch.autograd.Function):
                 packed.dgr = torch.empty(df, device=x.device, dtype=torch.float32)
                 packed.dgr_key = None
             k = _wkey(weight)
-            if packed.dgr_key != k:
+            if packed.dgr_key != k or packed.dgr_plan != key:
                 _ck(L.muvo_conv_pack_weights(C.byref(d), _f(weight), None, _f(packed.dgr), _st()))
-                packed.dgr_key = k
+                packed.dgr_key, packed.dgr_plan = k, key
             dx = torch.empty_like(x)
             kt = KERNEL_TIMING
             if kt is not None:

@@ -72,6 +72,7 @@ class WorldModelTrainer(_Base):
 
     # ------------------------------------------------------------------ forward / losses
     def forward(self, batch, deployment=False, noise=None, use_prior=None):
+        ops.repack_all()           # one launch refreshes every packed weight copy made stale by the optimizer step
         batch = self.preprocess(batch)
         output, state_dict = self.model.forward(batch, deployment=deployment, noise=noise, use_prior=use_prior)
         return output, state_dict
