@@ -996,16 +996,17 @@ __global__ void __launch_bounds__(256) bf3_unpack_wgrad_kernel(const ConvPhase g
   __shared__ int s_tw[MAX_TAPS];
   if (threadIdx.x < MAX_TAPS) s_tw[threadIdx.x] = g.tap_w[threadIdx.x];
   __syncthreads();
-  const long total = (long)g.M * g.C * g.T;
+  const unsigned total = (unsigned)g.M * (unsigned)g.C * (unsigned)g.T;   // < 2^31: 32-bit index math (division-bound loop)
   float* base = wg + g.wp_off;        // cleared as it is read: the scratch stays all-zero between weight gradients
-  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int t = (int)(idx % g.T);
-    const long r = idx / g.T;
-    int m, c;
-    if (g.wsm > g.wsc) { c = (int)(r % g.C); m = (int)(r / g.C); }
-    else { m = (int)(r % g.M); c = (int)(r / g.M); }
-    const int grp = m / g.Msub, co = m - grp * g.Msub;
-    float* src = base + ((size_t)t * g.M + m) * g.C + c;
+  const unsigned uT = g.T, uC = g.C, uM = g.M, uMsub = g.Msub;
+  const bool m_major = g.wsm > g.wsc;
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+    const unsigned r = idx / uT, t = idx - r * uT;
+    unsigned m, c;
+    if (m_major) { m = r / uC; c = r - m * uC; }
+    else { c = r / uM; m = r - c * uM; }
+    const unsigned grp = g.nmerge > 1 ? m / uMsub : 0u, co = m - grp * uMsub;
+    float* src = base + ((size_t)t * uM + m) * uC + c;
     dw[(size_t)co * g.wsm + (size_t)c * g.wsc + (g.nmerge > 1 ? g.tap_wm[grp][t] : s_tw[t])] += *src;
     *src = 0.f;
   }

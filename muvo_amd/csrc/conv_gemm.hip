@@ -356,24 +356,25 @@ __global__ void __launch_bounds__(256) unpack_wgrad_kernel(const ConvPhase g, fl
   __shared__ int s_tw[MAX_TAPS];
   if (threadIdx.x < MAX_TAPS) s_tw[threadIdx.x] = g.tap_w[threadIdx.x];
   __syncthreads();
-  const long total = (long)g.M * g.C * g.T;
-  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+  const unsigned total = (unsigned)g.M * (unsigned)g.C * (unsigned)g.T;   // < 2^31: 32-bit index math
+  const unsigned uT = g.T, uC = g.C, uM = g.M, uMp = g.Mp, uCp = g.Cp;
+  const bool m_major = g.wsm > g.wsc;
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
     // order (outer->inner): the slower of (m,c) by weight stride first, taps innermost
-    int t = (int)(idx % g.T);
-    long r = idx / g.T;
-    int m, c;
-    if (g.wsm > g.wsc) { c = (int)(r % g.C); m = (int)(r / g.C); }
-    else { m = (int)(r % g.M); c = (int)(r / g.M); }
-    float* src = dwp + g.wp_off + (size_t)(t * g.Cp + c) * g.Mp + m;
+    const unsigned r = idx / uT, t = idx - r * uT;
+    unsigned m, c;
+    if (m_major) { m = r / uC; c = r - m * uC; }
+    else { c = r / uM; m = r - c * uM; }
+    float* src = dwp + g.wp_off + (size_t)(t * uCp + c) * uMp + m;
     const float v = *src;
     *src = 0.f;
     dw[(size_t)m * g.wsm + (size_t)c * g.wsc + s_tw[t]] += v;
   }
-  const long padded = (long)g.Kp * g.Mp;
-  for (long idx = blockIdx.x * 256L + threadIdx.x; idx < padded; idx += (long)gridDim.x * 256) {
-    const int k = (int)(idx / g.Mp), m = (int)(idx - (long)k * g.Mp);
-    const int t = k / g.Cp, c = k - t * g.Cp;
-    if (!(t < g.T && c < g.C && m < g.M)) dwp[g.wp_off + idx] = 0.f;
+  const unsigned padded = (unsigned)g.Kp * uMp;
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < padded; idx += gridDim.x * 256u) {
+    const unsigned k = idx / uMp, m = idx - k * uMp;
+    const unsigned t = k / uCp, c = k - t * uCp;
+    if (!(t < uT && c < uC && m < uM)) dwp[g.wp_off + idx] = 0.f;
   }
 }
 
