@@ -195,6 +195,55 @@ def test_linear_bf16x3_token_matrix(dev, shape):
     _close(lin.weight.grad - w.grad.float().to(dev), 2 * ref, rtol=1e-4, name='dW accumulate')
 
 
+def test_batched_repack_matches_per_layer_pack(dev):
+    """ops.repack_all(): one launch over the device table (muvo_pack_table_*) must leave every packed copy bit-identical to
+    what muvo_conv_pack_weights / muvo_linear_bf16x3_pack write per layer - exact-fp32 phases, bf16x3 phases with taps inside
+    the channel groups, merged sub-pixel phases of a transposed conv, the strided data-gradient phases, a token Linear."""
+    import ctypes as C
+    from muvo_amd import nn as hnn
+    from muvo_amd import ops
+    assert ops.get_conv_mode() == ops.CONV_BF16X3
+    torch.manual_seed(5)
+    with torch.device(dev):
+        layers = [(hnn.Conv2d(3, 64, 7, 2, 3), (2, 3, 64, 96)),              # fp32 family (3 reduction channels)
+                  (hnn.Conv2d(64, 64, 3, 1, 1), (2, 64, 40, 52)),            # bf16x3, taps inside 32-channel groups
+                  (hnn.Conv2d(64, 128, 3, 2, 1), (2, 64, 40, 52)),           # strided: four data-gradient phases
+                  (hnn.ConvTranspose2d(128, 64, 6, 2, 2), (2, 128, 20, 26)),  # merged sub-pixel phases
+                  (hnn.Conv2d(512, 512, 3, 1, 1), (2, 512, 2, 4))]           # tiny grid: fp32 family
+        lin = hnn.Linear(384, 1152)
+        xl = torch.randn(2100, 384, requires_grad=True)
+    xs = []
+    for m, shp in layers:
+        x = torch.randn(*shp, device=dev, requires_grad=True)
+        m.weight.grad, m.bias.grad = torch.zeros_like(m.weight), torch.zeros_like(m.bias)
+        m(x).sum().backward()                       # first use: per-layer packs, registration
+        xs.append(x)
+    lin.weight.grad, lin.bias.grad = torch.zeros_like(lin.weight), torch.zeros_like(lin.bias)
+    lin(xl).sum().backward()
+    with torch.no_grad():
+        for m, _ in layers:
+            m.weight.mul_(1.5).add_(0.01)
+        lin.weight.mul_(0.5).sub_(0.02)
+    ops.bump_weight_epoch()                         # what optimizer.step() does
+    ops.repack_all()
+    L = ops.lib()
+    for (m, shp), x in zip(layers, xs):
+        pk = m._packed
+        assert pk.fwd_key == ops._wkey(m.weight) and pk.dgr_key == ops._wkey(m.weight)
+        d = m.geom.plan(shp[0], (1,) + tuple(shp[2:]))[0]
+        ref_f, ref_d = torch.full_like(pk.fwd, 7.0), torch.full_like(pk.dgr, 7.0)
+        got_f, got_d = pk.fwd.clone(), pk.dgr.clone()
+        ops._ck(L.muvo_conv_pack_weights(C.byref(d), ops._f(m.weight), ops._f(ref_f), ops._f(ref_d), ops._st()))
+        # padding the per-layer kernels never write keeps the 7.0 marker: compare where they wrote
+        wf, wd = ref_f.view(torch.int32) != torch.tensor(7.0).view(torch.int32).item(), ref_d.view(torch.int32) != torch.tensor(7.0).view(torch.int32).item()
+        assert torch.equal(got_f.view(torch.int32)[wf], ref_f.view(torch.int32)[wf]), type(m).__name__
+        assert torch.equal(got_d.view(torch.int32)[wd], ref_d.view(torch.int32)[wd]), type(m).__name__
+    pk = lin.weight._bf3_packed
+    ref_f, ref_d = torch.empty_like(pk.fwd), torch.empty_like(pk.dgr)
+    ops._ck(L.muvo_linear_bf16x3_pack(384, 1152, ops._f(lin.weight), ops._f(ref_f), ops._f(ref_d), ops._st()))
+    assert torch.equal(pk.fwd.view(torch.int32), ref_f.view(torch.int32)) and torch.equal(pk.dgr.view(torch.int32), ref_d.view(torch.int32))
+
+
 def test_seed_convt_as_gemm(dev):
     from muvo_amd.models.common import _Seed1x1ConvTFn
     from muvo_amd import ops
