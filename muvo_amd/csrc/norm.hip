@@ -83,14 +83,36 @@ __global__ void __launch_bounds__(256) bwd_moments_kernel(const float* __restric
   }
 }
 
+// Statistics accumulator shared by all norm operations of the process (one compute stream per process): a device buffer
+// that is all-zero between operations - the moments passes add into it with double atomics and the finalize kernels clear
+// what they read - so no operation needs a memset in front of its statistics pass (that was ~180 memsets per step).
+static double* g_norm_sums = nullptr;
+static size_t g_norm_sums_cap = 0;
+static double* norm_sums(size_t n_doubles) {
+  if (n_doubles > g_norm_sums_cap) {
+    if (g_norm_sums) hipFree(g_norm_sums);           // synchronises the device: nobody is using the old buffer any more
+    g_norm_sums_cap = n_doubles < 65536 ? 65536 : 2 * n_doubles;
+    if (hipMalloc((void**)&g_norm_sums, g_norm_sums_cap * sizeof(double)) != hipSuccess ||
+        hipMemset(g_norm_sums, 0, g_norm_sums_cap * sizeof(double)) != hipSuccess) {
+      g_norm_sums = nullptr;
+      g_norm_sums_cap = 0;
+    }
+  }
+  return g_norm_sums;
+}
+
 // ------------------------------------------------------------------------------------------ BN
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, float* __restrict__ mean, float* __restrict__ rstd,
+// (the finalize kernels clear the sums they read: the workspace is all-zero between norm operations, so none of them
+// needs a memset in front of its statistics pass)
+__global__ void bn_finalize_kernel(double* __restrict__ sums, float* __restrict__ mean, float* __restrict__ rstd,
                                    float* __restrict__ run_mean, float* __restrict__ run_var, int C, double cnt,
                                    float eps, float momentum) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const double m = sums[2 * c] / cnt;
   double var = sums[2 * c + 1] / cnt - m * m;
+  sums[2 * c] = 0.0;
+  sums[2 * c + 1] = 0.0;
   if (var < 0) var = 0;
   mean[c] = (float)m;
   rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -143,12 +165,18 @@ __global__ void __launch_bounds__(256) bn_apply_scalar_kernel(const float* __res
   }
 }
 
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, float* __restrict__ dgamma,
+// sums -> dgamma/dbeta and a copy for the apply pass (fin: the caller's workspace), then cleared
+__global__ void bn_bwd_finalize_kernel(double* __restrict__ sums, double* __restrict__ fin, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  dbeta[c] += (float)sums[2 * c];
-  dgamma[c] += (float)sums[2 * c + 1];
+  const double s1 = sums[2 * c], s2 = sums[2 * c + 1];
+  dbeta[c] += (float)s1;
+  dgamma[c] += (float)s2;
+  fin[2 * c] = s1;
+  fin[2 * c + 1] = s2;
+  sums[2 * c] = 0.0;
+  sums[2 * c + 1] = 0.0;
 }
 
 // dx = gamma*rstd*(dz - s1/cnt - xhat*s2/cnt); dres = dz (res_mode 1 only)
@@ -179,12 +207,13 @@ extern "C" int muvo_bn_train_fwd(const float* x, const float* gamma, const float
   MUVO_CHECK_ARG(N > 0 && C > 0 && S > 0, "bn_train_fwd: bad sizes");
   MUVO_CHECK_ARG(res_mode >= 0 && res_mode <= 2 && (res_mode == 0 || residual), "bn_train_fwd: bad residual mode");
   hipStream_t st = (hipStream_t)stream;
-  hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st);
   const long cnt = (long)N * S;
   int chunks = cdiv(cnt, 16384);
   if (chunks > 256) chunks = 256;
-  hipLaunchKernelGGL(moments_kernel, dim3(C, chunks), dim3(256), 0, st, x, ws, (long)S, (long)C * S, cnt);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, ws, save_mean, save_rstd, running_mean,
+  double* sums = norm_sums(2 * (size_t)C);
+  MUVO_CHECK_ARG(sums != nullptr, "bn_train_fwd: cannot allocate the statistics buffer");
+  hipLaunchKernelGGL(moments_kernel, dim3(C, chunks), dim3(256), 0, st, x, sums, (long)S, (long)C * S, cnt);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, sums, save_mean, save_rstd, running_mean,
                      running_var, C, (double)cnt, eps, momentum);
   const long total = cnt * C;
   if (S % 4 == 0)
@@ -206,13 +235,14 @@ extern "C" int muvo_bn_train_bwd(const float* x, const float* y, const float* dy
                  "bn_train_bwd: null pointer");
   MUVO_CHECK_ARG(mask_mode >= 0 && mask_mode <= 2 && (mask_mode != 1 || y), "bn_train_bwd: bad mask mode");
   hipStream_t st = (hipStream_t)stream;
-  hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st);
   const long cnt = (long)N * S;
   int chunks = cdiv(cnt, 16384);
   if (chunks > 256) chunks = 256;
+  double* sums = norm_sums(2 * (size_t)C);
+  MUVO_CHECK_ARG(sums != nullptr, "bn_train_bwd: cannot allocate the statistics buffer");
   hipLaunchKernelGGL(bwd_moments_kernel, dim3(C, chunks), dim3(256), 0, st, x, y, dy, save_mean, save_rstd, gamma, beta,
-                     ws, (long)S, (long)C * S, (long)C * S, cnt, mask_mode, 0);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, ws, dgamma, dbeta, C);
+                     sums, (long)S, (long)C * S, (long)C * S, cnt, mask_mode, 0);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, sums, ws, dgamma, dbeta, C);
   const long total = cnt * C;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, st, x, y, dy, save_mean, save_rstd, gamma,
                      beta, ws, dx, dres, C, (long)S, total, (double)cnt, mask_mode);
@@ -221,12 +251,14 @@ extern "C" int muvo_bn_train_bwd(const float* x, const float* y, const float* dy
 }
 
 // ------------------------------------------------------------------------------------- AdaIN3d
-__global__ void in_finalize_kernel(const double* __restrict__ sums, float* __restrict__ mean, float* __restrict__ rstd,
+__global__ void in_finalize_kernel(double* __restrict__ sums, float* __restrict__ mean, float* __restrict__ rstd,
                                    int G, double cnt, float eps) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= G) return;
   const double m = sums[2 * g] / cnt;
   double var = sums[2 * g + 1] / cnt - m * m;
+  sums[2 * g] = 0.0;
+  sums[2 * g + 1] = 0.0;
   if (var < 0) var = 0;
   mean[g] = (float)m;
   rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
@@ -246,12 +278,18 @@ __global__ void __launch_bounds__(256) adain_apply_kernel(const float* __restric
   }
 }
 
-__global__ void adain_bwd_finalize_kernel(const double* __restrict__ sums, float* __restrict__ dstyle, int N, int C) {
+__global__ void adain_bwd_finalize_kernel(double* __restrict__ sums, double* __restrict__ fin, float* __restrict__ dstyle,
+                                          int N, int C) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= N * C) return;
   const int n = g / C, c = g - n * C;
-  dstyle[(long)n * 2 * C + c] = (float)sums[2 * g + 1];      // d scale = sum(dy * xhat)
-  dstyle[(long)n * 2 * C + C + c] = (float)sums[2 * g];      // d bias  = sum(dy)
+  const double s1 = sums[2 * g], s2 = sums[2 * g + 1];
+  dstyle[(long)n * 2 * C + c] = (float)s2;      // d scale = sum(dy * xhat)
+  dstyle[(long)n * 2 * C + C + c] = (float)s1;  // d bias  = sum(dy)
+  fin[2 * g] = s1;                              // copy for the apply pass, then clear
+  fin[2 * g + 1] = s2;
+  sums[2 * g] = 0.0;
+  sums[2 * g + 1] = 0.0;
 }
 
 __global__ void __launch_bounds__(256) adain_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
@@ -281,17 +319,18 @@ extern "C" int muvo_adain_fwd(const float* x, const float* style, float* y, floa
                  "adain_fwd: bad sizes");
   hipStream_t st = (hipStream_t)stream;
   const int G = N * C;
-  hipMemsetAsync(ws, 0, sizeof(double) * 2 * G, st);
   int chunks = cdiv(S, 16384);
   if (chunks > 128) chunks = 128;
+  double* sums = norm_sums(2 * (size_t)G);
+  MUVO_CHECK_ARG(sums != nullptr, "adain_fwd: cannot allocate the statistics buffer");
   if (x_batch_stride == 0) {
     // broadcast input: stats of instance (n,c) equal those of (0,c); compute C groups then replicate via kernel launch per n
     for (int n = 0; n < N; ++n)
-      hipLaunchKernelGGL(moments_kernel, dim3(C, chunks), dim3(256), 0, st, x, ws + 2L * n * C, (long)S, 0L, (long)S);
+      hipLaunchKernelGGL(moments_kernel, dim3(C, chunks), dim3(256), 0, st, x, sums + 2L * n * C, (long)S, 0L, (long)S);
   } else {
-    hipLaunchKernelGGL(moments_kernel, dim3(G, chunks), dim3(256), 0, st, x, ws, (long)S, 0L, (long)S);
+    hipLaunchKernelGGL(moments_kernel, dim3(G, chunks), dim3(256), 0, st, x, sums, (long)S, 0L, (long)S);
   }
-  hipLaunchKernelGGL(in_finalize_kernel, dim3(cdiv(G, 64)), dim3(64), 0, st, ws, save_mean, save_rstd, G, (double)S, eps);
+  hipLaunchKernelGGL(in_finalize_kernel, dim3(cdiv(G, 64)), dim3(64), 0, st, sums, save_mean, save_rstd, G, (double)S, eps);
   const long total = (long)G * S;
   hipLaunchKernelGGL(adain_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, st, x, save_mean, save_rstd, style, y, C,
                      (long)S, (long)x_batch_stride, total);
@@ -306,21 +345,22 @@ extern "C" int muvo_adain_bwd(const float* x, const float* style, const float* d
   MUVO_CHECK_ARG(x && style && dy && save_mean && save_rstd && dx && dstyle && ws, "adain_bwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
   const int G = N * C;
-  hipMemsetAsync(ws, 0, sizeof(double) * 2 * G, st);
   int chunks = cdiv(S, 16384);
   if (chunks > 128) chunks = 128;
+  double* sums = norm_sums(2 * (size_t)G);
+  MUVO_CHECK_ARG(sums != nullptr, "adain_bwd: cannot allocate the statistics buffer");
   // groups are (n,c) instances: x index = n*x_bs + c*S + s.  With outer_stride==0 trick the group index
   // addresses dy densely (g*S) and x through x_outer/g mapping: handle broadcast by per-n launches.
   if (x_batch_stride == 0) {
     for (int n = 0; n < N; ++n)
       hipLaunchKernelGGL(bwd_moments_kernel, dim3(C, chunks), dim3(256), 0, st, x, (const float*)nullptr,
                          dy + (long)n * C * S, save_mean + (long)n * C, save_rstd + (long)n * C, (const float*)nullptr,
-                         (const float*)nullptr, ws + 2L * n * C, (long)S, 0L, 0L, (long)S, 0, 0);
+                         (const float*)nullptr, sums + 2L * n * C, (long)S, 0L, 0L, (long)S, 0, 0);
   } else {
     hipLaunchKernelGGL(bwd_moments_kernel, dim3(G, chunks), dim3(256), 0, st, x, (const float*)nullptr, dy, save_mean,
-                       save_rstd, (const float*)nullptr, (const float*)nullptr, ws, (long)S, 0L, 0L, (long)S, 0, 0);
+                       save_rstd, (const float*)nullptr, (const float*)nullptr, sums, (long)S, 0L, 0L, (long)S, 0, 0);
   }
-  hipLaunchKernelGGL(adain_bwd_finalize_kernel, dim3(cdiv(G, 64)), dim3(64), 0, st, ws, dstyle, N, C);
+  hipLaunchKernelGGL(adain_bwd_finalize_kernel, dim3(cdiv(G, 64)), dim3(64), 0, st, sums, ws, dstyle, N, C);
   const long total = (long)G * S;
   hipLaunchKernelGGL(adain_bwd_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, st, x, dy, save_mean, save_rstd, style,
                      ws, dx, C, (long)S, (long)x_batch_stride, total, act, slope);
