@@ -466,7 +466,7 @@ class _PackedWeights:
     def __init__(self):
         self.fwd = self.dgr = None
         self.fwd_key = self.dgr_key = None
-        self.fwd_plan = self.dgr_plan = None     # (batch, input size, plan epoch) the copy was packed for
+        self.fwd_plan = self.dgr_plan = None     # (input size, plan epoch) the copy was packed for (layout is batch-independent)
 
 
 def _wkey(w):
@@ -504,7 +504,7 @@ def repack_all():
     live = []
     for e in R.entries:
         pk = e[3]()
-        if pk is None or (e[0] == 'conv' and e[4][2] != _plan_epoch[0]) or (e[0] == 'lin' and e[4] != _plan_epoch[0]):
+        if pk is None or (e[0] == 'conv' and e[4][1] != _plan_epoch[0]) or (e[0] == 'lin' and e[4] != _plan_epoch[0]):
             R.seen.discard((id(pk) if pk is not None else None, e[4]))
             continue
         live.append(e)
@@ -571,7 +571,7 @@ class ConvFn(torch.autograd.Function):
             packed.fwd = torch.empty(ff, device=x.device, dtype=torch.float32)
             packed.fwd_key = None
         k = _wkey(weight)
-        pkey = (n, in_sz, _plan_epoch[0])
+        pkey = (in_sz, _plan_epoch[0])
         if packed.fwd_key != k or packed.fwd_plan != pkey:
             _ck(L.muvo_conv_pack_weights(C.byref(d), _f(weight), _f(packed.fwd), None, _st()))
             packed.fwd_key, packed.fwd_plan = k, pkey
@@ -633,9 +633,9 @@ class ConvFn(torch.autograd.Function):
                 packed.dgr = torch.empty(df, device=x.device, dtype=torch.float32)
                 packed.dgr_key = None
             k = _wkey(weight)
-            if packed.dgr_key != k or packed.dgr_plan != key:
+            if packed.dgr_key != k or packed.dgr_plan != key[1:]:
                 _ck(L.muvo_conv_pack_weights(C.byref(d), _f(weight), None, _f(packed.dgr), _st()))
-                packed.dgr_key, packed.dgr_plan = k, key
+                packed.dgr_key, packed.dgr_plan = k, key[1:]
             dx = torch.empty_like(x)
             kt = KERNEL_TIMING
             if kt is not None:
