@@ -407,6 +407,8 @@ vox_bf3_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* __re
 
   // staging: task t -> (cg, row r, z); loads 8 channels of one voxel, splits, writes two 16-byte entries
   float stg[TPT][8];
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)inb, 0, (int)((long)CK * a.XYZ * 4), 0x00020000);
+  const unsigned xyz4 = (unsigned)a.XYZ * 4u;
   auto stage_load = [&](int x) {
 #pragma unroll
     for (int k = 0; k < TPT; ++k) {
@@ -414,9 +416,12 @@ vox_bf3_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* __re
       const int z = t % Z, r = (t / Z) % ROWS, cg = t / (Z * ROWS);
       const int gy = y0 - 1 + r;
       const bool ok = t < NTASK && x >= 0 && x < a.X && gy >= 0 && gy < a.Y;
-      const float* p = inb + (long)(cg * 8) * a.XYZ + (long)x * YZ + (long)gy * Z + z;
+      // buffer loads, out-of-range -> zeros: unconditional, so the loads stay in flight across the MFMA work of the previous
+      // plane (behind `ok ? p[..] : 0` the compiler branched around them and waited right there)
+      const unsigned off = ok ? (unsigned)(((long)(cg * 8) * a.XYZ + (long)x * YZ + (long)gy * Z + z) * 4) : 0x7fffff00u;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) stg[k][e] = ok ? p[(long)e * a.XYZ] : 0.f;
+      for (int e = 0; e < 8; ++e)
+        stg[k][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in, off + (unsigned)e * xyz4, 0, 0));
     }
   };
   auto stage_store = [&](int slot) {
@@ -717,6 +722,8 @@ vox_bf3_2row_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4*
   for (int i = tid; i < 3 * PLANE; i += NT) vsm[i] = vu32x4{0u, 0u, 0u, 0u};
   __syncthreads();
   float stg[TPT][8];
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)inb, 0, (int)((long)CK * a.XYZ * 4), 0x00020000);
+  const unsigned xyz4 = (unsigned)a.XYZ * 4u;
   auto stage_load = [&](int x) {
 #pragma unroll
     for (int k = 0; k < TPT; ++k) {
@@ -724,9 +731,12 @@ vox_bf3_2row_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4*
       const int z = t % Z, r = (t / Z) % ROWS, cg = t / (Z * ROWS);
       const int gy = y0 - 1 + r;
       const bool ok = t < NTASK && x >= 0 && x < a.X && gy >= 0 && gy < a.Y;
-      const float* p = inb + (long)(cg * 8) * a.XYZ + (long)x * YZ + (long)gy * Z + z;
+      // buffer loads, out-of-range -> zeros: unconditional, so the loads stay in flight across the MFMA work of the previous
+      // plane (behind `ok ? p[..] : 0` the compiler branched around them and waited right there)
+      const unsigned off = ok ? (unsigned)(((long)(cg * 8) * a.XYZ + (long)x * YZ + (long)gy * Z + z) * 4) : 0x7fffff00u;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) stg[k][e] = ok ? p[(long)e * a.XYZ] : 0.f;
+      for (int e = 0; e < 8; ++e)
+        stg[k][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in, off + (unsigned)e * xyz4, 0, 0));
     }
   };
   auto stage_store = [&](int slot) {
