@@ -1317,7 +1317,7 @@ bool bf3_fwd_uses_pp(const ConvPhase& g) {
   const long big = g.M > 128 ? (long)cdiv(g.npix, 128) * cdiv(g.M, 256) : (long)cdiv(g.npix, 256) * cdiv(g.M, 128);
   return big >= 128;
 }
-bool bf3_wgrad_uses_pp(const ConvPhase& g) { return g.M > 128 || (g.M > 64 && g.C > 128); }
+bool bf3_wgrad_uses_pp(const ConvPhase& g) { return g.M > 128 || (g.M > 64 && g.C > 64); }
 
 int bf3_launch_fwd_phase(const ConvPhase& g, const void* ws, const float* wp, const float* bias, float* out, int act,
                          float slope, hipStream_t st) {
@@ -1414,7 +1414,7 @@ int bf3_wgrad_phase(const ConvPhase& g, const void* ws_x, int Cin_total, const v
   static const int wvariant = getenv("MUVO_BF3_WGRAD_VARIANT") ? atoi(getenv("MUVO_BF3_WGRAD_VARIANT")) : 0;   // 1: in-phase DMA kernels
   if (g.M > 128) rc = wvariant == 1 ? bf3_wgrad_launch<256, 128, 4, 2, 1>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st)
                                     : bf3_wgrad_pp_launch<256, 128, 4, 2>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st);
-  else if (g.M > 64) rc = g.C > 128 ? (wvariant == 1 ? bf3_wgrad_launch<128, 256, 2, 4, 1>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st)
+  else if (g.M > 64) rc = g.C > 64 ? (wvariant == 1 ? bf3_wgrad_launch<128, 256, 2, 4, 1>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st)
                                                      : bf3_wgrad_pp_launch<128, 256, 2, 4>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st))
                                     : bf3_wgrad_launch<128, 128, 2, 2, 2>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st);
   else rc = g.C > 128 ? bf3_wgrad_launch<64, 256, 1, 4, 2>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st)
