@@ -693,7 +693,8 @@ static int phase_ksplit(const ConvPhase& g) {
   const int nk = g.Kp / 16;
   static const int min_steps = getenv("MUVO_KSPLIT_MIN_STEPS") ? atoi(getenv("MUVO_KSPLIT_MIN_STEPS")) : 8;
   if (blocks >= 192 || nk < 4 * min_steps) return 1;
-  int ks = cdiv(768, blocks);
+  static const int ks_tgt = getenv("MUVO_KSPLIT_BLOCKS") ? atoi(getenv("MUVO_KSPLIT_BLOCKS")) : 384;   // measured best of 128 ... 3072
+  int ks = cdiv(ks_tgt, blocks);
   if (ks > nk / min_steps) ks = nk / min_steps;
   return ks < 1 ? 1 : ks;
 }
@@ -717,9 +718,11 @@ static int launch_wgrad_phase(const ConvPhase& g, const float* in, const float* 
   if (g.M > 64) bn = 128; else if (g.M > 32) bn = 64; else bn = 32;
   bm = 128;
   const int gx = cdiv(rows, bm), gy = cdiv(g.M, bn);
-  // split-K: aim for >= 1024 blocks, each with >= 8 pixel tiles
-  int nsplit = cdiv(1024, gx * gy);
-  if (nsplit > cdiv(ntiles, 8)) nsplit = cdiv(ntiles, 8);
+  // split-K: aim for >= 2048 blocks, each with >= 4 pixel tiles (these launches are latency-bound: more, shorter ranges win)
+  static const int tgt = getenv("MUVO_F32_WGRAD_BLOCKS") ? atoi(getenv("MUVO_F32_WGRAD_BLOCKS")) : 2048;
+  static const int mint = getenv("MUVO_F32_WGRAD_MINTILES") ? atoi(getenv("MUVO_F32_WGRAD_MINTILES")) : 4;    // measured 3.4 -> 2.9 ms/step vs (1024, 8)
+  int nsplit = cdiv(tgt, gx * gy);
+  if (nsplit > cdiv(ntiles, mint)) nsplit = cdiv(ntiles, mint);
   if (nsplit < 1) nsplit = 1;
   const int tps = cdiv(ntiles, nsplit);
   nsplit = cdiv(ntiles, tps);

@@ -382,8 +382,10 @@ extern "C" int muvo_gemm(const muvo_gemm_desc* d, const float* A, const float* B
   int ksplit = 1;
   if (d->mode == 1) {
     const int nkt = cdiv(d->K, 16);
-    ksplit = cdiv(768, gx * gy * nb);
-    if (ksplit > cdiv(nkt, 8)) ksplit = cdiv(nkt, 8);
+    static const int tgt = getenv("MUVO_GEMM_KSPLIT_BLOCKS") ? atoi(getenv("MUVO_GEMM_KSPLIT_BLOCKS")) : 768;
+    static const int mint = getenv("MUVO_GEMM_KSPLIT_MINTILES") ? atoi(getenv("MUVO_GEMM_KSPLIT_MINTILES")) : 8;
+    ksplit = cdiv(tgt, gx * gy * nb);
+    if (ksplit > cdiv(nkt, mint)) ksplit = cdiv(nkt, mint);
     if (ksplit < 1) ksplit = 1;
   }
   g.ksplit = ksplit;
