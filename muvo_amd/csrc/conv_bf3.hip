@@ -1315,7 +1315,8 @@ static int bf3_launch_k16(const ConvPhase& g, const void* ws, const float* wp, c
 bool bf3_fwd_uses_pp(const ConvPhase& g) {
   if (g.M <= 64) return false;
   const long big = g.M > 128 ? (long)cdiv(g.npix, 128) * cdiv(g.M, 256) : (long)cdiv(g.npix, 256) * cdiv(g.M, 128);
-  return big >= 128;
+  static const int min_blocks = getenv("MUVO_BF3_PP_MIN_BLOCKS") ? atoi(getenv("MUVO_BF3_PP_MIN_BLOCKS")) : 128;
+  return big >= min_blocks;
 }
 bool bf3_wgrad_uses_pp(const ConvPhase& g) { return g.M > 128 || (g.M > 64 && g.C > 64); }
 

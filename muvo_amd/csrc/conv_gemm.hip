@@ -455,7 +455,9 @@ static const int g_bf3_min_m = getenv("MUVO_BF3_MIN_M") ? atoi(getenv("MUVO_BF3_
 static thread_local int t_nphase = 1;         // sub-pixel phases of the operation being planned (work / pixels are per phase)
 static bool bf3_wants_phase(double gflop_phase, int C, double pix_phase) {
   if (!bf3_default_policy()) return gflop_phase >= bf3_min_gflop();
-  return gflop_phase * t_nphase >= 0.1 && pix_phase * t_nphase >= 256.0 && C >= 16;
+  static const double pg = getenv("MUVO_BF16X3_POLICY_GFLOP") ? atof(getenv("MUVO_BF16X3_POLICY_GFLOP")) : 0.1;
+  static const double pp = getenv("MUVO_BF16X3_POLICY_PIXELS") ? atof(getenv("MUVO_BF16X3_POLICY_PIXELS")) : 256.0;
+  return gflop_phase * t_nphase >= pg && pix_phase * t_nphase >= pp && C >= 16;
 }
 
 static thread_local int t_force_family = 0;   // +1 / -1: make this phase bf16x3 / fp32 regardless of its own size (see below)

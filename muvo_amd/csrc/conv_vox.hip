@@ -943,6 +943,16 @@ static int launch_vox_conv(const muvo_conv_desc* d, int Cin, int Cout, const flo
   return MUVO_OK;
 }
 
+// Workgroups a voxel bf16x3 launch should at least have before the x axis stops being split into segments.  Every segment
+// pays a ring refill (two halo planes) and, in the weight gradient, a workgroup reduction plus a set of float atomics, so
+// fewer, longer segments win as soon as the chip is roughly covered: measured over all four weight-gradient layers 9.4 ms
+// with a target of 1024, 7.1 with 128 (no segmentation at N = 20); forward / data gradient 8.8 -> 8.4 ms with 256.
+static int vox_blocks_target(int wgrad) {
+  static const int f = getenv("MUVO_VOX_BLOCKS") ? atoi(getenv("MUVO_VOX_BLOCKS")) : 256;
+  static const int w = getenv("MUVO_VOX_WGRAD_BLOCKS") ? atoi(getenv("MUVO_VOX_WGRAD_BLOCKS")) : 128;
+  return wgrad ? w : f;
+}
+
 template <int CK, int Z>
 static int launch_vox_bf3(const muvo_conv_desc* d, int Cin, int Cout, const float* in, const float* wp, const float* bias,
                           float* out, int act, float slope, hipStream_t st, int cin_total = 0, int accum = 0) {
@@ -955,7 +965,7 @@ static int launch_vox_bf3(const muvo_conv_desc* d, int Cin, int Cout, const floa
   a.sN_in = (long)(cin_total ? cin_total : Cin) * a.XYZ; a.sN_out = (long)Cout * a.XYZ;
   // split x into segments until the grid fills the chip (each segment re-reads two halo planes)
   int xseg = a.X;
-  while ((long)a.N * a.ytiles * cdiv(a.X, xseg) < 1024 && xseg > 12) xseg = cdiv(xseg, 2);
+  while ((long)a.N * a.ytiles * cdiv(a.X, xseg) < vox_blocks_target(0) && xseg > 12) xseg = cdiv(xseg, 2);
   constexpr size_t lds = (size_t)3 * 2 * (CK / 8) * (TY + 2) * (Z + 2) * 16;
   static bool attr_set = false;
   if (!attr_set) {
@@ -983,7 +993,7 @@ static int launch_vox_bf3_2row(const muvo_conv_desc* d, const float* in, const f
   a.XYZ = a.X * a.Y * Z;
   a.sN_in = (long)CK * a.XYZ; a.sN_out = (long)8 * a.XYZ;
   int xseg = a.X;
-  while ((long)a.N * a.ytiles * cdiv(a.X, xseg) < 1024 && xseg > 12) xseg = cdiv(xseg, 2);
+  while ((long)a.N * a.ytiles * cdiv(a.X, xseg) < vox_blocks_target(0) && xseg > 12) xseg = cdiv(xseg, 2);
   constexpr size_t lds = (size_t)3 * 2 * (CK / 8) * (TY + 2) * (Z + 2) * 16;
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
@@ -1086,7 +1096,7 @@ static int launch_vox_bf3_wgrad(const muvo_conv_desc* d, const float* x, const f
   a.XYZ = a.X * a.Y * Z;
   a.sN_in = (long)a.Cin * a.XYZ; a.sN_out = (long)a.Cout * a.XYZ;
   int xseg = a.X;
-  while ((long)a.N * a.ytiles * cdiv(a.X, xseg) * (a.Cin / CI) < 1024 && xseg > 12) xseg = cdiv(xseg, 2);
+  while ((long)a.N * a.ytiles * cdiv(a.X, xseg) * (a.Cin / CI) < vox_blocks_target(1) && xseg > 12) xseg = cdiv(xseg, 2);
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)vox_bf3_wgrad_kernel<Z, CI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
