@@ -1,5 +1,6 @@
 // Shared helpers for the muvo_amd HIP kernels (gfx950 / CDNA4 only).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -37,7 +38,8 @@ static inline int roundup(int a, int b) { return ((a + b - 1) / b) * b; }
 // Grid size for a grid-stride elementwise kernel: enough blocks to fill 256 CUs x 8.
 static inline int ew_grid(long n, int block = 256) {
   long g = (n + block - 1) / block;
-  if (g > 256 * 16) g = 256 * 16;
+  static const long cap = getenv("MUVO_EW_GRID_CAP") ? atol(getenv("MUVO_EW_GRID_CAP")) : 256 * 16;
+  if (g > cap) g = cap;
   if (g < 1) g = 1;
   return (int)g;
 }
