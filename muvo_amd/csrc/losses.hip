@@ -394,7 +394,8 @@ int muvo_voxel_loss_fwd(const float* logits, const uint8_t* target, int64_t F, i
   MUVO_CHECK_ARG(F > 0 && V > 0 && C >= 2 && C <= MAXC, "voxel_loss_fwd: C=%d unsupported (2..%d)", C, MAXC);
   hipMemsetAsync(stats, 0, sizeof(double) * (2 + 5 * C + 5), ST);
   long nb = (F * V + 256L * 8 - 1) / (256L * 8);
-  if (nb > 4096) nb = 4096;
+  static const long nb_cap = getenv("MUVO_VOXLOSS_BLOCKS") ? atol(getenv("MUVO_VOXLOSS_BLOCKS")) : 4096;
+  if (nb > nb_cap) nb = nb_cap;
   hipLaunchKernelGGL(voxel_loss_fwd_kernel, dim3((int)nb), dim3(256), 0, ST, logits, target, (long)F, C, (long)V, class_w, stats);
   hipLaunchKernelGGL(voxel_loss_finalize_kernel, dim3(1), dim3(64), 0, ST, stats, C, (double)F * (double)V, weight, loss3, coef);
   MUVO_CHECK_LAUNCH("voxel_loss_fwd");
