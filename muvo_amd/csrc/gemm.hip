@@ -360,7 +360,8 @@ extern "C" int muvo_gemm(const muvo_gemm_desc* d, const float* A, const float* B
       const int blocks = cdiv(d->N, 64);
       int ks = 1;
       if (!bias && d->act == MUVO_ACT_NONE && d->scm == d->N) {   // dense C: zero it, then split k over workgroups
-        ks = cdiv(512, blocks);
+        static const int ks_tgt = getenv("MUVO_SKINNY_KS_BLOCKS") ? atoi(getenv("MUVO_SKINNY_KS_BLOCKS")) : 512;
+        ks = cdiv(ks_tgt, blocks);
         if (ks > d->K / 64) ks = d->K / 64;
         if (ks < 1) ks = 1;
       }

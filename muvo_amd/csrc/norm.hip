@@ -83,6 +83,10 @@ __global__ void __launch_bounds__(256) bwd_moments_kernel(const float* __restric
   }
 }
 
+static int norm_max_chunks(int dflt) {
+  static const int v = getenv("MUVO_NORM_MAXCHUNKS") ? atoi(getenv("MUVO_NORM_MAXCHUNKS")) : 0;
+  return v > 0 ? v : dflt;
+}
 static long norm_chunk_elems() {
   static const long v = getenv("MUVO_NORM_CHUNK") ? atol(getenv("MUVO_NORM_CHUNK")) : 4096;   // elements per statistics workgroup: 16384 -> 4096 was worth 1.3 ms/step
   return v;
@@ -214,7 +218,7 @@ extern "C" int muvo_bn_train_fwd(const float* x, const float* gamma, const float
   hipStream_t st = (hipStream_t)stream;
   const long cnt = (long)N * S;
   int chunks = cdiv(cnt, norm_chunk_elems());
-  if (chunks > 256) chunks = 256;
+  if (chunks > norm_max_chunks(256)) chunks = norm_max_chunks(256);
   double* sums = norm_sums(2 * (size_t)C);
   MUVO_CHECK_ARG(sums != nullptr, "bn_train_fwd: cannot allocate the statistics buffer");
   hipLaunchKernelGGL(moments_kernel, dim3(C, chunks), dim3(256), 0, st, x, sums, (long)S, (long)C * S, cnt);
@@ -242,7 +246,7 @@ extern "C" int muvo_bn_train_bwd(const float* x, const float* y, const float* dy
   hipStream_t st = (hipStream_t)stream;
   const long cnt = (long)N * S;
   int chunks = cdiv(cnt, norm_chunk_elems());
-  if (chunks > 256) chunks = 256;
+  if (chunks > norm_max_chunks(256)) chunks = norm_max_chunks(256);
   double* sums = norm_sums(2 * (size_t)C);
   MUVO_CHECK_ARG(sums != nullptr, "bn_train_bwd: cannot allocate the statistics buffer");
   hipLaunchKernelGGL(bwd_moments_kernel, dim3(C, chunks), dim3(256), 0, st, x, y, dy, save_mean, save_rstd, gamma, beta,
@@ -325,7 +329,7 @@ extern "C" int muvo_adain_fwd(const float* x, const float* style, float* y, floa
   hipStream_t st = (hipStream_t)stream;
   const int G = N * C;
   int chunks = cdiv(S, norm_chunk_elems());
-  if (chunks > 128) chunks = 128;
+  if (chunks > norm_max_chunks(128)) chunks = norm_max_chunks(128);
   double* sums = norm_sums(2 * (size_t)G);
   MUVO_CHECK_ARG(sums != nullptr, "adain_fwd: cannot allocate the statistics buffer");
   if (x_batch_stride == 0) {
@@ -351,7 +355,7 @@ extern "C" int muvo_adain_bwd(const float* x, const float* style, const float* d
   hipStream_t st = (hipStream_t)stream;
   const int G = N * C;
   int chunks = cdiv(S, norm_chunk_elems());
-  if (chunks > 128) chunks = 128;
+  if (chunks > norm_max_chunks(128)) chunks = norm_max_chunks(128);
   double* sums = norm_sums(2 * (size_t)G);
   MUVO_CHECK_ARG(sums != nullptr, "adain_bwd: cannot allocate the statistics buffer");
   // groups are (n,c) instances: x index = n*x_bs + c*S + s.  With outer_stride==0 trick the group index
