@@ -1018,11 +1018,13 @@ __global__ void __launch_bounds__(256) bf3_unpack_wgrad_kernel(const ConvPhase g
 // makes both the dword stores (lane = pixel) and the 4-dword reads (lane = (pixel, chunk)) bank-conflict free.
 // Optional fusion for the backward pass: in = dy, yact = the activation output y -> the planes hold dy * act'(y) and
 // dbias[c] += sum of it (the separate activation-gradient and bias-gradient passes disappear).
-// grid = (ceil(S / 64 / split_tiles), ceil(Cp / 64), N)
+// grid = (ceil(S / 64 / SPLIT_TILES), ceil(Cp / 64), N)
+// (compile-time: as a runtime argument the loop stopped being unrolled away and the kernel ran 1.5x slower)
+#define SPLIT_TILES 1
 #define BIAS_REPLICAS 64   // the per-tile bias partial sums are spread over this many replicas to avoid atomic contention
 __global__ void __launch_bounds__(256)
 nchw_split_nhwc_kernel(const float* __restrict__ in, uint4* __restrict__ out_hi, uint4* __restrict__ out_lo, int C, int Cp,
-                       long S, const float* __restrict__ yact, int act, float slope, float* __restrict__ dbias, int split_tiles) {
+                       long S, const float* __restrict__ yact, int act, float slope, float* __restrict__ dbias) {
   constexpr int RS = 33;
   __shared__ unsigned th[64 * RS], tl[64 * RS];
   const int tid = threadIdx.x, pl = tid & 63, w = tid >> 6;
@@ -1032,8 +1034,8 @@ nchw_split_nhwc_kernel(const float* __restrict__ in, uint4* __restrict__ out_hi,
   float bsum[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) bsum[r] = 0.f;
-  for (int it = 0; it < split_tiles; ++it) {
-    const long s0 = ((long)blockIdx.x * split_tiles + it) * 64;
+  for (int it = 0; it < SPLIT_TILES; ++it) {
+    const long s0 = ((long)blockIdx.x * SPLIT_TILES + it) * 64;
     if (s0 >= S) break;
     const long s = s0 + pl;
 #pragma unroll
@@ -1233,9 +1235,8 @@ int bf3_split_input(const float* x, void* ws, int N, int C, long S, hipStream_t 
       return MUVO_ERR_HIP;
     }
   }
-  static const int split_tiles = getenv("MUVO_SPLIT_TILES") ? atoi(getenv("MUVO_SPLIT_TILES")) : 1;
-  dim3 grid(cdiv(cdiv(S, 64), split_tiles), cdiv(Cp, 64), N);
-  hipLaunchKernelGGL(nchw_split_nhwc_kernel, grid, dim3(256), 0, st, x, hi, lo, C, Cp, S, yact, act, slope, rep, split_tiles);
+  dim3 grid(cdiv(cdiv(S, 64), SPLIT_TILES), cdiv(Cp, 64), N);
+  hipLaunchKernelGGL(nchw_split_nhwc_kernel, grid, dim3(256), 0, st, x, hi, lo, C, Cp, S, yact, act, slope, rep);
   if (dbias) hipLaunchKernelGGL(bias_replica_reduce_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, rep, dbias, C, Cp);
   MUVO_CHECK_LAUNCH("nchw_split_nhwc_kernel");
   return MUVO_OK;
