@@ -10,22 +10,37 @@
 //   x[(i / S) * outer_stride + g * S + (i % S)], i in [0, cnt)   (BN: outer = n; IN: outer unused)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) moments_kernel(const float* __restrict__ x, double* __restrict__ sums,
-                                                      long S, long outer_stride, long cnt) {
+                                                      long S, long outer_stride, long cnt, int vec4) {
   __shared__ double red[2][4];
   const int g = blockIdx.x;
-  const long per = (cnt + gridDim.y - 1) / gridDim.y;
+  const long per = (((cnt + gridDim.y - 1) / gridDim.y) + 3) & ~3L;
   const long i0 = blockIdx.y * per;
   long i1 = i0 + per;
   if (i1 > cnt) i1 = cnt;
   float s = 0.f, q = 0.f;
   double ds = 0.0, dq = 0.0;
   int k = 0;
-  for (long i = i0 + threadIdx.x; i < i1; i += 256) {
-    const long o = i / S, r = i - o * S;
-    const float v = x[o * outer_stride + (long)g * S + r];
-    s += v;
-    q += v * v;
-    if (++k == 64) { ds += s; dq += q; s = 0.f; q = 0.f; k = 0; }
+  if (vec4) {
+    // S % 4 == 0, chunk bounds multiples of 4, 16-byte aligned base: one float4 per lane and step, (segment, offset) advanced
+    // incrementally - no 64-bit division per element
+    long i = i0 + 4L * threadIdx.x;
+    long o = i / S, r = i - o * S;
+    for (; i < i1; i += 1024) {
+      const float4 v = *reinterpret_cast<const float4*>(x + o * outer_stride + (long)g * S + r);
+      s += (v.x + v.y) + (v.z + v.w);
+      q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      if (++k == 16) { ds += s; dq += q; s = 0.f; q = 0.f; k = 0; }
+      r += 1024;
+      while (r >= S) { r -= S; ++o; }
+    }
+  } else {
+    for (long i = i0 + threadIdx.x; i < i1; i += 256) {
+      const long o = i / S, r = i - o * S;
+      const float v = x[o * outer_stride + (long)g * S + r];
+      s += v;
+      q += v * v;
+      if (++k == 64) { ds += s; dq += q; s = 0.f; q = 0.f; k = 0; }
+    }
   }
   ds += s; dq += q;
   ds = wave_sum_d(ds);
@@ -46,11 +61,11 @@ __global__ void __launch_bounds__(256) bwd_moments_kernel(const float* __restric
                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, double* __restrict__ sums,
                                                           long S, long outer_stride, long x_outer_stride, long cnt,
-                                                          int mask_mode, int group_mod) {
+                                                          int mask_mode, int group_mod, int vec4) {
   __shared__ double red[2][4];
   const int g = blockIdx.x;
   const int ch = group_mod > 0 ? g % group_mod : g;
-  const long per = (cnt + gridDim.y - 1) / gridDim.y;
+  const long per = (((cnt + gridDim.y - 1) / gridDim.y) + 3) & ~3L;
   const long i0 = blockIdx.y * per;
   long i1 = i0 + per;
   if (i1 > cnt) i1 = cnt;
@@ -59,17 +74,42 @@ __global__ void __launch_bounds__(256) bwd_moments_kernel(const float* __restric
   float s = 0.f, q = 0.f;
   double ds = 0.0, dq = 0.0;
   int k = 0;
-  for (long i = i0 + threadIdx.x; i < i1; i += 256) {
-    const long o = i / S, r = i - o * S;
-    const long idx = o * outer_stride + (long)g * S + r;
-    const long xidx = o * x_outer_stride + (long)g * S + r;
-    const float xh = (x[xidx] - mu) * rs;
-    float d = dy[idx];
-    if (mask_mode == 1) d = y[idx] > 0.f ? d : 0.f;
-    else if (mask_mode == 2) d = (xh * ga + be) > 0.f ? d : 0.f;
-    s += d;
-    q += d * xh;
-    if (++k == 64) { ds += s; dq += q; s = 0.f; q = 0.f; k = 0; }
+  if (vec4) {    // as in moments_kernel: float4 per lane, no per-element division
+    long i = i0 + 4L * threadIdx.x;
+    long o = i / S, r = i - o * S;
+    for (; i < i1; i += 1024) {
+      const long idx = o * outer_stride + (long)g * S + r;
+      const float4 xv = *reinterpret_cast<const float4*>(x + o * x_outer_stride + (long)g * S + r);
+      const float4 dv = *reinterpret_cast<const float4*>(dy + idx);
+      float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (mask_mode == 1) yv = *reinterpret_cast<const float4*>(y + idx);
+      const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (xs[e] - mu) * rs;
+        float d = dd[e];
+        if (mask_mode == 1) d = ys[e] > 0.f ? d : 0.f;
+        else if (mask_mode == 2) d = (xh * ga + be) > 0.f ? d : 0.f;
+        s += d;
+        q += d * xh;
+      }
+      if (++k == 16) { ds += s; dq += q; s = 0.f; q = 0.f; k = 0; }
+      r += 1024;
+      while (r >= S) { r -= S; ++o; }
+    }
+  } else {
+    for (long i = i0 + threadIdx.x; i < i1; i += 256) {
+      const long o = i / S, r = i - o * S;
+      const long idx = o * outer_stride + (long)g * S + r;
+      const long xidx = o * x_outer_stride + (long)g * S + r;
+      const float xh = (x[xidx] - mu) * rs;
+      float d = dy[idx];
+      if (mask_mode == 1) d = y[idx] > 0.f ? d : 0.f;
+      else if (mask_mode == 2) d = (xh * ga + be) > 0.f ? d : 0.f;
+      s += d;
+      q += d * xh;
+      if (++k == 64) { ds += s; dq += q; s = 0.f; q = 0.f; k = 0; }
+    }
   }
   ds += s; dq += q;
   ds = wave_sum_d(ds);
@@ -221,7 +261,8 @@ extern "C" int muvo_bn_train_fwd(const float* x, const float* gamma, const float
   if (chunks > norm_max_chunks(256)) chunks = norm_max_chunks(256);
   double* sums = norm_sums(2 * (size_t)C);
   MUVO_CHECK_ARG(sums != nullptr, "bn_train_fwd: cannot allocate the statistics buffer");
-  hipLaunchKernelGGL(moments_kernel, dim3(C, chunks), dim3(256), 0, st, x, sums, (long)S, (long)C * S, cnt);
+  hipLaunchKernelGGL(moments_kernel, dim3(C, chunks), dim3(256), 0, st, x, sums, (long)S, (long)C * S, cnt,
+                     (int)(S % 4 == 0 && ((uintptr_t)x & 15) == 0));
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, sums, save_mean, save_rstd, running_mean,
                      running_var, C, (double)cnt, eps, momentum);
   const long total = cnt * C;
@@ -250,7 +291,8 @@ extern "C" int muvo_bn_train_bwd(const float* x, const float* y, const float* dy
   double* sums = norm_sums(2 * (size_t)C);
   MUVO_CHECK_ARG(sums != nullptr, "bn_train_bwd: cannot allocate the statistics buffer");
   hipLaunchKernelGGL(bwd_moments_kernel, dim3(C, chunks), dim3(256), 0, st, x, y, dy, save_mean, save_rstd, gamma, beta,
-                     sums, (long)S, (long)C * S, (long)C * S, cnt, mask_mode, 0);
+                     sums, (long)S, (long)C * S, (long)C * S, cnt, mask_mode, 0,
+                     (int)(S % 4 == 0 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)(mask_mode == 1 ? y : x)) & 15) == 0));
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, sums, ws, dgamma, dbeta, C);
   const long total = cnt * C;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, st, x, y, dy, save_mean, save_rstd, gamma,
@@ -335,9 +377,11 @@ extern "C" int muvo_adain_fwd(const float* x, const float* style, float* y, floa
   if (x_batch_stride == 0) {
     // broadcast input: stats of instance (n,c) equal those of (0,c); compute C groups then replicate via kernel launch per n
     for (int n = 0; n < N; ++n)
-      hipLaunchKernelGGL(moments_kernel, dim3(C, chunks), dim3(256), 0, st, x, sums + 2L * n * C, (long)S, 0L, (long)S);
+      hipLaunchKernelGGL(moments_kernel, dim3(C, chunks), dim3(256), 0, st, x, sums + 2L * n * C, (long)S, 0L, (long)S,
+                         (int)(S % 4 == 0 && ((uintptr_t)x & 15) == 0));
   } else {
-    hipLaunchKernelGGL(moments_kernel, dim3(G, chunks), dim3(256), 0, st, x, sums, (long)S, 0L, (long)S);
+    hipLaunchKernelGGL(moments_kernel, dim3(G, chunks), dim3(256), 0, st, x, sums, (long)S, 0L, (long)S,
+                       (int)(S % 4 == 0 && ((uintptr_t)x & 15) == 0));
   }
   hipLaunchKernelGGL(in_finalize_kernel, dim3(cdiv(G, 64)), dim3(64), 0, st, sums, save_mean, save_rstd, G, (double)S, eps);
   const long total = (long)G * S;
@@ -364,10 +408,12 @@ extern "C" int muvo_adain_bwd(const float* x, const float* style, const float* d
     for (int n = 0; n < N; ++n)
       hipLaunchKernelGGL(bwd_moments_kernel, dim3(C, chunks), dim3(256), 0, st, x, (const float*)nullptr,
                          dy + (long)n * C * S, save_mean + (long)n * C, save_rstd + (long)n * C, (const float*)nullptr,
-                         (const float*)nullptr, sums + 2L * n * C, (long)S, 0L, 0L, (long)S, 0, 0);
+                         (const float*)nullptr, sums + 2L * n * C, (long)S, 0L, 0L, (long)S, 0, 0,
+                         (int)(S % 4 == 0 && (((uintptr_t)x | (uintptr_t)dy) & 15) == 0));
   } else {
     hipLaunchKernelGGL(bwd_moments_kernel, dim3(G, chunks), dim3(256), 0, st, x, (const float*)nullptr, dy, save_mean,
-                       save_rstd, (const float*)nullptr, (const float*)nullptr, sums, (long)S, 0L, 0L, (long)S, 0, 0);
+                       save_rstd, (const float*)nullptr, (const float*)nullptr, sums, (long)S, 0L, 0L, (long)S, 0, 0,
+                       (int)(S % 4 == 0 && (((uintptr_t)x | (uintptr_t)dy) & 15) == 0));
   }
   hipLaunchKernelGGL(adain_bwd_finalize_kernel, dim3(cdiv(G, 64)), dim3(64), 0, st, sums, ws, dstyle, N, C);
   const long total = (long)G * S;
