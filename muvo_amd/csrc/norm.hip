@@ -329,6 +329,27 @@ __global__ void __launch_bounds__(256) adain_apply_kernel(const float* __restric
   }
 }
 
+// float4 variants of the AdaIN apply kernels (S % 4 == 0, 16-byte aligned tensors): grid = (chunks, N*C); a workgroup stays
+// inside one (n, c) instance, so the per-instance scalars are loaded once and there is no index division per element.
+__global__ void __launch_bounds__(256) adain_apply_vec_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, const float* __restrict__ style,
+                                                              float* __restrict__ y, int C, long S, long x_bs) {
+  const long g = blockIdx.y;
+  const long n = g / C;
+  const int c = (int)(g - n * C);
+  const float st = style[n * 2 * C + c], sh = style[n * 2 * C + C + c];
+  const float mu = mean[g], rs = rstd[g];
+  const float4* xp = reinterpret_cast<const float4*>(x + n * x_bs + (long)c * S);
+  float4* yp = reinterpret_cast<float4*>(y + g * S);
+  const long S4 = S >> 2;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < S4; i += (long)gridDim.x * 256) {
+    const float4 v = xp[i];
+    // same operation order as the scalar kernel: style * ((x - mean) * rstd) + bias
+    yp[i] = make_float4(st * ((v.x - mu) * rs) + sh, st * ((v.y - mu) * rs) + sh, st * ((v.z - mu) * rs) + sh,
+                        st * ((v.w - mu) * rs) + sh);
+  }
+}
+
 __global__ void adain_bwd_finalize_kernel(double* __restrict__ sums, double* __restrict__ fin, float* __restrict__ dstyle,
                                           int N, int C) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -363,6 +384,34 @@ __global__ void __launch_bounds__(256) adain_bwd_apply_kernel(const float* __res
   }
 }
 
+__global__ void __launch_bounds__(256) adain_bwd_apply_vec_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                  const float* __restrict__ mean,
+                                                                  const float* __restrict__ rstd,
+                                                                  const float* __restrict__ style,
+                                                                  const double* __restrict__ sums, float* __restrict__ dx,
+                                                                  int C, long S, long x_bs, int act, float slope) {
+  const long g = blockIdx.y;
+  const long n = g / C;
+  const int c = (int)(g - n * C);
+  const float rs = rstd[g], mu = mean[g], st = style[n * 2 * C + c];
+  const float m1 = (float)(sums[2 * g] / (double)S), m2 = (float)(sums[2 * g + 1] / (double)S);
+  const float4* xp = reinterpret_cast<const float4*>(x + n * x_bs + (long)c * S);
+  const float4* gp = reinterpret_cast<const float4*>(dy + g * S);
+  float4* op = reinterpret_cast<float4*>(dx + g * S);
+  const long S4 = S >> 2;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < S4; i += (long)gridDim.x * 256) {
+    const float4 xv = xp[i], dv = gp[i];
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xh = (xs[e] - mu) * rs;
+      o[e] = st * rs * (dd[e] - m1 - xh * m2) * act_grad_from_out(xs[e], act, slope);
+    }
+    op[i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 extern "C" int muvo_adain_fwd(const float* x, const float* style, float* y, float* save_mean, float* save_rstd,
                               double* ws, int N, int C, int64_t S, int64_t x_batch_stride, float eps, void* stream) {
   MUVO_CHECK_ARG(x && style && y && save_mean && save_rstd && ws, "adain_fwd: null pointer");
@@ -385,8 +434,14 @@ extern "C" int muvo_adain_fwd(const float* x, const float* style, float* y, floa
   }
   hipLaunchKernelGGL(in_finalize_kernel, dim3(cdiv(G, 64)), dim3(64), 0, st, sums, save_mean, save_rstd, G, (double)S, eps);
   const long total = (long)G * S;
-  hipLaunchKernelGGL(adain_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, st, x, save_mean, save_rstd, style, y, C,
-                     (long)S, (long)x_batch_stride, total);
+  if (S % 4 == 0 && G <= 65535 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+    int gx = cdiv(S / 4, 256 * 4);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(adain_apply_vec_kernel, dim3(gx, G), dim3(256), 0, st, x, save_mean, save_rstd, style, y, C, (long)S,
+                       (long)x_batch_stride);
+  } else
+    hipLaunchKernelGGL(adain_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, st, x, save_mean, save_rstd, style, y, C,
+                       (long)S, (long)x_batch_stride, total);
   MUVO_CHECK_LAUNCH("adain_fwd");
   return MUVO_OK;
 }
@@ -417,8 +472,14 @@ extern "C" int muvo_adain_bwd(const float* x, const float* style, const float* d
   }
   hipLaunchKernelGGL(adain_bwd_finalize_kernel, dim3(cdiv(G, 64)), dim3(64), 0, st, sums, ws, dstyle, N, C);
   const long total = (long)G * S;
-  hipLaunchKernelGGL(adain_bwd_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, st, x, dy, save_mean, save_rstd, style,
-                     ws, dx, C, (long)S, (long)x_batch_stride, total, act, slope);
+  if (S % 4 == 0 && G <= 65535 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0) {
+    int gx = cdiv(S / 4, 256 * 4);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(adain_bwd_apply_vec_kernel, dim3(gx, G), dim3(256), 0, st, x, dy, save_mean, save_rstd, style, ws, dx, C,
+                       (long)S, (long)x_batch_stride, act, slope);
+  } else
+    hipLaunchKernelGGL(adain_bwd_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, st, x, dy, save_mean, save_rstd, style,
+                       ws, dx, C, (long)S, (long)x_batch_stride, total, act, slope);
   MUVO_CHECK_LAUNCH("adain_bwd");
   return MUVO_OK;
 }
