@@ -248,6 +248,71 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
   }
 }
 
+// float4 variants (S % 4 == 0, 16-byte aligned tensors, N*C <= 65535): grid = (chunks, N*C), one (n, c) row per workgroup row
+__global__ void __launch_bounds__(256) bn_apply_vec_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                           float* __restrict__ y, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int C, long S, int res_mode,
+                                                           int relu) {
+  const long g = blockIdx.y;
+  const int c = (int)(g % C);
+  const float sc = rstd[c] * gamma[c], sh = beta[c] - mean[c] * sc;
+  const float4* xp = reinterpret_cast<const float4*>(x + g * S);
+  const float4* rp = reinterpret_cast<const float4*>(res + g * S);
+  float4* yp = reinterpret_cast<float4*>(y + g * S);
+  const long S4 = S >> 2;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < S4; i += (long)gridDim.x * 256) {
+    const float4 v = xp[i];
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (res_mode) r = rp[i];
+    float o[4] = {v.x * sc + sh, v.y * sc + sh, v.z * sc + sh, v.w * sc + sh};
+    const float rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (res_mode == 1) o[k] += rr[k];
+      if (relu) o[k] = o[k] > 0.f ? o[k] : 0.f;
+      if (res_mode == 2) o[k] += rr[k];
+    }
+    yp[i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_apply_vec_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                               const float* __restrict__ dy, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, const double* __restrict__ sums,
+                                                               float* __restrict__ dx, float* __restrict__ dres, int C, long S,
+                                                               double cnt, int mask_mode) {
+  const long g = blockIdx.y;
+  const int c = (int)(g % C);
+  const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
+  const float m1 = (float)(sums[2 * c] / cnt), m2 = (float)(sums[2 * c + 1] / cnt);
+  const float4* xp = reinterpret_cast<const float4*>(x + g * S);
+  const float4* yp = reinterpret_cast<const float4*>(y + g * S);
+  const float4* gp = reinterpret_cast<const float4*>(dy + g * S);
+  float4* op = reinterpret_cast<float4*>(dx + g * S);
+  float4* rp = reinterpret_cast<float4*>(dres + g * S);
+  const long S4 = S >> 2;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < S4; i += (long)gridDim.x * 256) {
+    const float4 xv = xp[i], dv = gp[i];
+    float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (mask_mode == 1) yv = yp[i];
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w};
+    float o[4], dm[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xh = (xs[e] - mu) * rs;
+      float d = dd[e];
+      if (mask_mode == 1) d = ys[e] > 0.f ? d : 0.f;
+      else if (mask_mode == 2) d = (xh * ga + be) > 0.f ? d : 0.f;
+      dm[e] = d;
+      o[e] = ga * rs * (d - m1 - xh * m2);
+    }
+    if (dres) rp[i] = make_float4(dm[0], dm[1], dm[2], dm[3]);
+    op[i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 extern "C" int muvo_bn_train_fwd(const float* x, const float* gamma, const float* beta, const float* residual,
                                  float* y, float* save_mean, float* save_rstd, float* running_mean,
                                  float* running_var, double* ws, int N, int C, int64_t S, float eps, float momentum,
@@ -266,7 +331,12 @@ extern "C" int muvo_bn_train_fwd(const float* x, const float* gamma, const float
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, sums, save_mean, save_rstd, running_mean,
                      running_var, C, (double)cnt, eps, momentum);
   const long total = cnt * C;
-  if (S % 4 == 0)
+  if (S % 4 == 0 && S >= 1024 && (long)N * C <= 65535 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)(residual ? residual : x)) & 15) == 0) {
+    int gx = cdiv(S / 4, 256 * 4);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(bn_apply_vec_kernel, dim3(gx, N * C), dim3(256), 0, st, x, residual, y, save_mean, save_rstd, gamma, beta,
+                       C, (long)S, res_mode, relu);
+  } else if (S % 4 == 0)
     hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(total / 4)), dim3(256), 0, st, x, residual, y, save_mean,
                        save_rstd, gamma, beta, C, (long)S, total / 4, res_mode, relu);
   else
@@ -295,8 +365,15 @@ extern "C" int muvo_bn_train_bwd(const float* x, const float* y, const float* dy
                      (int)(S % 4 == 0 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)(mask_mode == 1 ? y : x)) & 15) == 0));
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, sums, ws, dgamma, dbeta, C);
   const long total = cnt * C;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, st, x, y, dy, save_mean, save_rstd, gamma,
-                     beta, ws, dx, dres, C, (long)S, total, (double)cnt, mask_mode);
+  if (S % 4 == 0 && S >= 1024 && (long)N * C <= 65535 &&
+      (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)(mask_mode == 1 ? y : x) | (uintptr_t)(dres ? dres : dx)) & 15) == 0) {
+    int gx = cdiv(S / 4, 256 * 4);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3(gx, N * C), dim3(256), 0, st, x, y, dy, save_mean, save_rstd, gamma, beta,
+                       ws, dx, dres, C, (long)S, (double)cnt, mask_mode);
+  } else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, st, x, y, dy, save_mean, save_rstd, gamma,
+                       beta, ws, dx, dres, C, (long)S, total, (double)cnt, mask_mode);
   MUVO_CHECK_LAUNCH("bn_train_bwd");
   return MUVO_OK;
 }
@@ -434,7 +511,7 @@ extern "C" int muvo_adain_fwd(const float* x, const float* style, float* y, floa
   }
   hipLaunchKernelGGL(in_finalize_kernel, dim3(cdiv(G, 64)), dim3(64), 0, st, sums, save_mean, save_rstd, G, (double)S, eps);
   const long total = (long)G * S;
-  if (S % 4 == 0 && G <= 65535 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+  if (S % 4 == 0 && S >= 1024 && G <= 65535 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
     int gx = cdiv(S / 4, 256 * 4);
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(adain_apply_vec_kernel, dim3(gx, G), dim3(256), 0, st, x, save_mean, save_rstd, style, y, C, (long)S,
@@ -472,7 +549,7 @@ extern "C" int muvo_adain_bwd(const float* x, const float* style, const float* d
   }
   hipLaunchKernelGGL(adain_bwd_finalize_kernel, dim3(cdiv(G, 64)), dim3(64), 0, st, sums, ws, dstyle, N, C);
   const long total = (long)G * S;
-  if (S % 4 == 0 && G <= 65535 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0) {
+  if (S % 4 == 0 && S >= 1024 && G <= 65535 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0) {
     int gx = cdiv(S / 4, 256 * 4);
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(adain_bwd_apply_vec_kernel, dim3(gx, G), dim3(256), 0, st, x, dy, save_mean, save_rstd, style, ws, dx, C,
