@@ -74,30 +74,34 @@ __global__ void spatial_loss_bwd_kernel(const float* __restrict__ pred, const fl
 //   [0] CE sum, [1] valid count (all voxels: CE has no ignore in the reference call)
 //   per class i (5 each, at 2+5i): P_i=sum m p_i, N_i=sum m p_i ct_i, T_i=sum m ct_i, Q_i=sum m (1-p_i)(1-ct_i), R_i=sum m (1-ct_i)
 //   geo (at 2+5C): I=sum m net nep, A=sum m nep, B=sum m net, Sp=sum m (1-net) ep, Rn=sum m (1-net)
+// CT: compile-time class count (0 = any C <= MAXC at run time); CT = 2 is the VOXEL_SEG head of base_1d
+template <int CT>
 __global__ void __launch_bounds__(256) voxel_loss_fwd_kernel(const float* __restrict__ logits,
                                                              const uint8_t* __restrict__ target, long F, int C, long V,
                                                              const float* __restrict__ class_w, double* __restrict__ stats) {
+  constexpr int NCU = CT ? CT : MAXC;     // unrolled class loops
+  const int Cc = CT ? CT : C;
   __shared__ double red[4];
   const long n = F * V;
   float ce = 0.f, wsum = 0.f;
-  float P[MAXC], Nn[MAXC], T[MAXC], Q[MAXC], R[MAXC];
+  float P[NCU], Nn[NCU], T[NCU], Q[NCU], R[NCU];
   float gI = 0.f, gA = 0.f, gB = 0.f, gS = 0.f, gR = 0.f;
 #pragma unroll
-  for (int c = 0; c < MAXC; ++c) { P[c] = 0.f; Nn[c] = 0.f; T[c] = 0.f; Q[c] = 0.f; R[c] = 0.f; }
+  for (int c = 0; c < NCU; ++c) { P[c] = 0.f; Nn[c] = 0.f; T[c] = 0.f; Q[c] = 0.f; R[c] = 0.f; }
   // fp32 thread-local accumulation over <= ~2k voxels per thread (values in [0,1]) then fp64 combine
   GRID_STRIDE(i, n) {
     const long f = i / V, v = i - f * V;
     const float* lp = logits + f * C * V + v;
     const int t = target[i];
-    float l[MAXC];
+    float l[NCU];
     float mx = -INFINITY;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c)
-      if (c < C) { l[c] = lp[(long)c * V]; mx = fmaxf(mx, l[c]); }
+    for (int c = 0; c < NCU; ++c)
+      if (c < Cc) { l[c] = lp[(long)c * V]; mx = fmaxf(mx, l[c]); }
     float se = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c)
-      if (c < C) { l[c] = expf(l[c] - mx); se += l[c]; }
+    for (int c = 0; c < NCU; ++c)
+      if (c < Cc) { l[c] = expf(l[c] - mx); se += l[c]; }
     const float inv = 1.f / se;
     const float lse = logf(se) + mx;
     // cross entropy (target must be a valid class for CE; reference casts the same labels to long)
@@ -109,8 +113,8 @@ __global__ void __launch_bounds__(256) voxel_loss_fwd_kernel(const float* __rest
     const bool m = t != 255;
     if (m) {
 #pragma unroll
-      for (int c = 0; c < MAXC; ++c)
-        if (c < C) {
+      for (int c = 0; c < NCU; ++c)
+        if (c < Cc) {
           const float p = l[c] * inv;
           const float ct = t == c ? 1.f : 0.f;
           P[c] += p; Nn[c] += p * ct; T[c] += ct; Q[c] += (1.f - p) * (1.f - ct); R[c] += 1.f - ct;
@@ -122,7 +126,7 @@ __global__ void __launch_bounds__(256) voxel_loss_fwd_kernel(const float* __rest
   }
   block_atomic_add_d((double)ce, &stats[0], red);
   block_atomic_add_d((double)wsum, &stats[1], red);
-  for (int c = 0; c < C; ++c) {
+  for (int c = 0; c < Cc; ++c) {
     block_atomic_add_d((double)P[c], &stats[2 + 5 * c + 0], red);
     block_atomic_add_d((double)Nn[c], &stats[2 + 5 * c + 1], red);
     block_atomic_add_d((double)T[c], &stats[2 + 5 * c + 2], red);
@@ -183,11 +187,15 @@ __global__ void voxel_loss_finalize_kernel(const double* __restrict__ stats, int
 }
 
 // dlogits = w*( g_ce * (p - onehot)/N * cw + softmaxJ^T (g_sem * dsem/dp + g_geo * dgeo/dp) )
+// CT: compile-time class count (0 = any C <= MAXC at run time); CT = 2 is the VOXEL_SEG head of base_1d
+template <int CT>
 __global__ void __launch_bounds__(256) voxel_loss_bwd_kernel(const float* __restrict__ logits,
                                                              const uint8_t* __restrict__ target, float* __restrict__ dlogits,
                                                              long F, int C, long V, const float* __restrict__ class_w,
                                                              const float* __restrict__ coef, const float* __restrict__ gout,
                                                              float weight) {
+  constexpr int NCU = CT ? CT : MAXC;     // unrolled class loops
+  const int Cc = CT ? CT : C;
   const long n = F * V;
   const float gce = gout[0] * weight, gsem = gout[1] * weight, ggeo = gout[2] * weight;
   GRID_STRIDE(i, n) {
@@ -195,21 +203,21 @@ __global__ void __launch_bounds__(256) voxel_loss_bwd_kernel(const float* __rest
     const float* lp = logits + f * C * V + v;
     float* dp = dlogits + f * C * V + v;
     const int t = target[i];
-    float p[MAXC], g[MAXC];
+    float p[NCU], g[NCU];
     float mx = -INFINITY;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c)
-      if (c < C) { p[c] = lp[(long)c * V]; mx = fmaxf(mx, p[c]); }
+    for (int c = 0; c < NCU; ++c)
+      if (c < Cc) { p[c] = lp[(long)c * V]; mx = fmaxf(mx, p[c]); }
     float se = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c)
-      if (c < C) { p[c] = expf(p[c] - mx); se += p[c]; }
+    for (int c = 0; c < NCU; ++c)
+      if (c < Cc) { p[c] = expf(p[c] - mx); se += p[c]; }
     const float inv = 1.f / se;
     const bool m = t != 255;
     float dot = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c)
-      if (c < C) {
+    for (int c = 0; c < NCU; ++c)
+      if (c < Cc) {
         p[c] *= inv;
         float gc = 0.f;
         if (m) {
@@ -225,8 +233,8 @@ __global__ void __launch_bounds__(256) voxel_loss_bwd_kernel(const float* __rest
       }
     const float cw = (t < C) ? (class_w ? class_w[t] : 1.f) * gce * coef[0] : 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c)
-      if (c < C) dp[(long)c * V] = p[c] * (g[c] - dot) + cw * (p[c] - (t == c ? 1.f : 0.f));
+    for (int c = 0; c < NCU; ++c)
+      if (c < Cc) dp[(long)c * V] = p[c] * (g[c] - dot) + cw * (p[c] - (t == c ? 1.f : 0.f));
   }
 }
 
@@ -396,7 +404,8 @@ int muvo_voxel_loss_fwd(const float* logits, const uint8_t* target, int64_t F, i
   long nb = (F * V + 256L * 8 - 1) / (256L * 8);
   static const long nb_cap = getenv("MUVO_VOXLOSS_BLOCKS") ? atol(getenv("MUVO_VOXLOSS_BLOCKS")) : 4096;
   if (nb > nb_cap) nb = nb_cap;
-  hipLaunchKernelGGL(voxel_loss_fwd_kernel, dim3((int)nb), dim3(256), 0, ST, logits, target, (long)F, C, (long)V, class_w, stats);
+  if (C == 2) hipLaunchKernelGGL(voxel_loss_fwd_kernel<2>, dim3((int)nb), dim3(256), 0, ST, logits, target, (long)F, C, (long)V, class_w, stats);
+  else hipLaunchKernelGGL(voxel_loss_fwd_kernel<0>, dim3((int)nb), dim3(256), 0, ST, logits, target, (long)F, C, (long)V, class_w, stats);
   hipLaunchKernelGGL(voxel_loss_finalize_kernel, dim3(1), dim3(64), 0, ST, stats, C, (double)F * (double)V, weight, loss3, coef);
   MUVO_CHECK_LAUNCH("voxel_loss_fwd");
   return MUVO_OK;
@@ -405,8 +414,12 @@ int muvo_voxel_loss_bwd(const float* logits, const uint8_t* target, float* dlogi
                         const float* class_w, float weight, const float* coef, const float* gout3, void* stream) {
   MUVO_CHECK_ARG(logits && target && dlogits && coef && gout3, "voxel_loss_bwd: null pointer");
   MUVO_CHECK_ARG(C >= 2 && C <= MAXC, "voxel_loss_bwd: bad C");
-  hipLaunchKernelGGL(voxel_loss_bwd_kernel, dim3(ew_grid(F * V)), dim3(256), 0, ST, logits, target, dlogits, (long)F, C, (long)V,
-                     class_w, coef, gout3, weight);
+  if (C == 2)
+    hipLaunchKernelGGL(voxel_loss_bwd_kernel<2>, dim3(ew_grid(F * V)), dim3(256), 0, ST, logits, target, dlogits, (long)F, C,
+                       (long)V, class_w, coef, gout3, weight);
+  else
+    hipLaunchKernelGGL(voxel_loss_bwd_kernel<0>, dim3(ew_grid(F * V)), dim3(256), 0, ST, logits, target, dlogits, (long)F, C,
+                       (long)V, class_w, coef, gout3, weight);
   MUVO_CHECK_LAUNCH("voxel_loss_bwd");
   return MUVO_OK;
 }
