@@ -76,6 +76,10 @@ class BatchNorm2d(nn.Module):
     def forward(self, x, residual=None, res_mode=1, relu=False):
         return ops.bn_act(x, self, residual, res_mode, relu)
 
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        ops.flush_bn_counters()          # num_batches_tracked increments are applied lazily, in one fused launch
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
 
 class LayerNorm(nn.Module):
     def __init__(self, e, eps=1e-5):

@@ -494,6 +494,7 @@ _PACK_BATCH = os.environ.get('MUVO_PACK_BATCH', '1') != '0'
 
 
 def repack_all():
+    flush_bn_counters()
     R = _PACKS
     if not R.entries or not _PACK_BATCH:
         return
@@ -698,7 +699,7 @@ class BNActFn(torch.autograd.Function):
         _ck(lib().muvo_bn_train_fwd(_f(x), _f(bn.weight), _f(bn.bias), _f(residual), _f(y), _f(mean), _f(rstd),
                                     _f(bn.running_mean), _f(bn.running_var), _p(ws), n, c, _i64(s), _fl(bn.eps),
                                     _fl(bn.momentum), res_mode if residual is not None else 0, int(relu), _st()))
-        bn.num_batches_tracked += 1
+        _BN_PENDING.append(bn)           # num_batches_tracked += 1, applied in one fused launch (flush_bn_counters)
         ctx.bn, ctx.dims = bn, (n, c, s)
         ctx.mask_mode = 0 if not relu else (2 if (residual is not None and res_mode == 2) else 1)
         ctx.has_res, ctx.res_mode = residual is not None, res_mode
@@ -721,6 +722,26 @@ class BNActFn(torch.autograd.Function):
                                     _f(grad_of(bn.weight)), _f(grad_of(bn.bias)), _p(ws), n, c, _i64(s), ctx.mask_mode,
                                     _st()))
         return dx, dres, None, None, None, None
+
+
+_BN_PENDING = []
+
+
+def flush_bn_counters():
+    """Apply the pending `num_batches_tracked += 1` of every BatchNorm forward since the last flush with one
+    torch._foreach_add_ (76 one-element launches per step otherwise).  Called at the start of every training forward and
+    before a BatchNorm's buffers are read (state_dict)."""
+    if not _BN_PENDING:
+        return
+    counts = {}
+    for bn in _BN_PENDING:
+        counts[id(bn)] = (bn, counts.get(id(bn), (bn, 0))[1] + 1)
+    _BN_PENDING.clear()
+    by_k = {}
+    for bn, k in counts.values():
+        by_k.setdefault(k, []).append(bn.num_batches_tracked)
+    for k, tensors in by_k.items():
+        torch._foreach_add_(tensors, k)
 
 
 def bn_act(x, bn, residual=None, res_mode=1, relu=True):

@@ -270,9 +270,14 @@ def test_seed_convt_as_gemm(dev):
 
 @pytest.mark.parametrize('res_mode,relu', [(0, True), (0, False), (1, True), (2, True)])
 def test_batchnorm(dev, res_mode, relu):
+    _batchnorm_case(dev, res_mode, relu, (5, 24, 9, 14))        # 126 elements per row: scalar kernels
+    _batchnorm_case(dev, res_mode, relu, (3, 10, 32, 40))       # 1280 per row, % 4 == 0: float4 kernels
+
+
+def _batchnorm_case(dev, res_mode, relu, shape):
     from muvo_amd import nn as hnn
     torch.manual_seed(3)
-    n, c, h, w = 5, 24, 9, 14
+    n, c, h, w = shape
     with torch.device(dev):
         bn = hnn.BatchNorm2d(c)
     with torch.no_grad():
@@ -308,13 +313,15 @@ def test_batchnorm(dev, res_mode, relu):
     _close(bn.bias.grad, ref.bias.grad, rtol=5e-4, name='bn dbeta')
     if res_mode:
         _close(rg.grad, rc.grad, name='bn dres')
+    bn(x.to(dev))
+    assert int(bn.state_dict()['num_batches_tracked']) == 2      # increments are applied lazily, before the buffer is read
 
 
 def test_adain(dev):
     from muvo_amd import ops
     torch.manual_seed(4)
     n, c = 3, 10
-    for shape, bcast in (((n, c, 6, 6, 4), False), ((c, 3, 3, 1), True)):
+    for shape, bcast in (((n, c, 6, 6, 4), False), ((c, 3, 3, 1), True), ((n, c, 16, 16, 8), False)):   # last: float4 kernels
         x = torch.randn(*shape) + 0.3
         style = torch.randn(n, 2 * c)
         xg, sg = x.to(dev).requires_grad_(True), style.to(dev).requires_grad_(True)
