@@ -318,8 +318,9 @@ __global__ void __launch_bounds__(256) upsample3d_x2_fwd_vec8_kernel(const float
     o[2 * e + 1] = 0.75f * c[e + 1] + 0.25f * c[e + 2];
   }
   float4* yp = (float4*)(y + ((nc * (2 * D) + od) * OH + oh) * (long)OW) + 2 * j;
-  yp[0] = make_float4(o[0], o[1], o[2], o[3]);
-  yp[1] = make_float4(o[4], o[5], o[6], o[7]);
+  typedef float nt_f4 __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store((nt_f4){o[0], o[1], o[2], o[3]}, (nt_f4*)yp);
+  __builtin_nontemporal_store((nt_f4){o[4], o[5], o[6], o[7]}, (nt_f4*)yp + 1);
 }
 
 // weights with which input index i (of n) receives output indices 2i-1 .. 2i+2 (out-of-range outputs get 0)
