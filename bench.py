@@ -172,14 +172,14 @@ def main():
             out['roofline'], out['kernel_classes'] = timing.summary()
             # HBM-side bytes per launch of the dominant class: PMC counters cannot be read from inside this process, so the
             # figure comes from the committed rocprofv3 --pmc passes over this same command (tools/pmc_step.sh)
-            tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01q_hbm_traffic.json')
+            tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01w_hbm_traffic.json')
             if out['roofline'] is not None and os.path.exists(tf):
                 pm = json.load(open(tf))
                 for cname, c in pm['classes'].items():
                     if ops.KERNEL_NAMES.get(cname) == out['roofline']['kernel']:
                         out['roofline']['traffic'] = c['hbm_bytes_per_launch']
                         out['roofline']['traffic_unit'] = 'bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, includes Infinity-Cache hits)'
-                        out['roofline']['traffic_source'] = 'profiles/r01q_hbm_traffic.json (tools/pmc_step.sh)'
+                        out['roofline']['traffic_source'] = 'profiles/r01w_hbm_traffic.json (tools/pmc_step.sh)'
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(usable_cores())
         print(json.dumps(out), flush=True)
