@@ -1,7 +1,7 @@
 """bench.py — world-model training samples/sec of the MI355X-native MUVO step (BASELINE.json metric).
 
-`python bench.py --gpus N --steps K --warmup W`; for N > 1 launch through torch.distributed.run (one rank per GPU,
-RCCL).  One "step" = preprocess + forward + 21 losses + backward + gradient all-reduce + fused AdamW on one
+`python bench.py --gpus N --steps K --warmup W`; for N > 1 either launch it through torch.distributed.run (one rank per
+GPU, RCCL) or run it plainly — it then starts that launcher itself as a child process.  One "step" = preprocess + forward + 21 losses + backward + gradient all-reduce + fused AdamW on one
 synthetic base_1d batch (per-GPU batch 2 x seq_len 10, 600x960 RGB -> 320x832 crop, 64x1024 range view,
 192x192x64 voxels) that is already resident in HBM.  Prints ONE JSON line on rank 0.
 """
@@ -16,7 +16,6 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 GFLOP_PER_FRAME = 794.36       # fwd 265.35 + bwd 529.01 (2*MAC, conv/convT/matmul)
 
 
@@ -69,10 +68,23 @@ def main():
     ap.add_argument('--seq-len', type=int, default=10)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-exact-f32', action='store_true', help='skip the extra exact-fp32 steps after the timed region')
     ap.add_argument('--conv-mfma', default=os.environ.get('MUVO_CONV_MFMA', 'bf16x3'), choices=['f32', 'bf16x3'],
                     help='matrix-pipe arithmetic of the large convolutions (DESIGN.md section 5)')
     ap.add_argument('--layer-table', default='', help='write the per-layer conv timing table to this file')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start one rank per GPU through torch.distributed.run as a CHILD
+        # process (before anything in this process touches the GPU) and pass its output and exit code through
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
 
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -104,20 +116,21 @@ def main():
     tr.train()
     opts, scheds = tr.configure_optimizers()
     opt, sched = opts[0], scheds[0]['scheduler']
-    reducer = SegmentedGradReducer(tr.store, force_collectives=force_dist)
-    tr.model.segment_done = reducer.segment_done
-    opt.grad_scale = reducer.grad_scale
+    if tr._reducer is None and force_dist:   # one-rank RCCL group: same wiring as WorldModelTrainer._attach_reducer
+        tr._reducer = SegmentedGradReducer(tr.store, force_collectives=True)
+        tr.model.segment_done = tr._reducer.segment_done
+    assert (tr._reducer is not None) == (world > 1 or force_dist)
+    torch.manual_seed(1234 + 7919 * rank)    # RSSM noise / use-prior coins differ per rank from here on
 
     # two distinct synthetic batches per rank, staged in HBM before the timed region
     batches = [make_batch(args.batch, s, seed=1234 + 2 * rank + k, device=dev) for k in range(2)]
 
     def step(i):
         batch = dict(batches[i % 2])
-        reducer.begin_step()
         opt.zero_grad()
-        loss = tr.training_step(batch, i)
+        loss = tr.training_step(batch, i)      # begins the reducer's step; backward hooks launch the segment all-reduces
         loss.backward()
-        reducer.finish()
+        tr.on_after_backward()                 # sends what is left, optimizer stream waits for the side stream
         opt.step()
         sched.step()
         return loss
@@ -132,13 +145,18 @@ def main():
     if world > 1 or force_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         loss = step(args.warmup + i)
+        marks[i + 1].record()                  # stream-side step boundaries (no host sync): median step time
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     timing = ops.KERNEL_TIMING
     ops.KERNEL_TIMING = None
     full_timing, extra_steps = None, 2
@@ -149,10 +167,29 @@ def main():
         torch.cuda.synchronize()
         ops.KERNEL_TIMING = None
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt, median_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+        dt, median_ms = t[0].item(), t[1].item()
     loss_val = float(loss.item())
+    # the same step with every contraction on exact-fp32 MFMA, a few steps after the timed region
+    exact_f32 = None
+    if args.conv_mfma != 'f32' and not args.no_exact_f32:
+        ops.set_conv_mode(ops.CONV_F32)
+        step(10_000)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record()
+        for i in range(3):
+            step(10_001 + i)
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        f32_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(3))[1]
+        if world > 1:
+            t = torch.tensor([f32_ms], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            f32_ms = t.item()
+        exact_f32 = dict(ms_per_step=f32_ms, value=args.batch * world / (f32_ms * 1e-3), unit='samples/s', steps=3,
+                         note='median of 3 steps after 1 warm-up with MUVO_CONV_MFMA=f32 (v_mfma_f32_32x32x2_f32 everywhere)')
+        ops.set_conv_mode(ops.CONV_BF16X3)
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -170,11 +207,15 @@ def main():
                                    f'192x192x64 voxels, full step incl. 21 losses, backward, AdamW',
                        'global_batch': args.batch * world, 'seq_len': s, 'parallelism': f'dp{world}',
                        'conv_mfma': args.conv_mfma},
+            'median_ms_per_step': median_ms, 'value_at_median': args.batch * world / (median_ms * 1e-3),
             'frames_per_s': samples * s / dt,
             'step_tflops_per_gpu': GFLOP_PER_FRAME * frames_per_gpu_step / (ms * 1e-3) / 1e3,
-            'step_frac_of_fp32_mfma_peak': GFLOP_PER_FRAME * frames_per_gpu_step / (ms * 1e-3) / 1e3 / PEAK_FP32_MFMA_TFLOPS,
             'final_loss': loss_val,
+            'n_ranks_seen': dist.get_world_size() if dist.is_initialized() else 1,
+            'rccl_version': '.'.join(str(v) for v in torch.cuda.nccl.version()) if (world > 1 or force_dist) else None,
         }
+        if exact_f32 is not None:
+            out['exact_f32'] = exact_f32
         if full_timing is not None and args.layer_table:
             with open(args.layer_table, 'w') as f:
                 f.write(full_timing.layer_table() + '\n')

@@ -198,6 +198,22 @@ int muvo_preprocess_image(const uint8_t* img, float* label, float* norm, int64_t
                           int CH, int CW, const float* mean3, const float* std3, void* stream);
 int muvo_preprocess_route(const uint8_t* img, float* norm, int64_t NC, int C, int H, int W, int OH, int OW,
                           const float* mean3, const float* std3, void* stream);
+/* Training-time augmentation inside PreProcess.forward (muvo/models/preprocess.py:45-48,213-214; PixelAugmentation :295-333,
+ * RouteAugmentation :336-367; torchvision 0.15.2 tensor algorithms).  The random draws are explicit inputs.
+ * muvo_pixel_augment: img (F,3,H,W) in [0,1] (the cropped image = rgb_label_1) is augmented IN PLACE, norm (F,3,H,W) receives
+ *   the ImageNet-normalised result; frames whose row says "nothing" are left untouched in both.  params: F rows of
+ *   MUVO_PIXAUG_STRIDE floats: [0] 0 none / 1 gaussian blur 5x5 / 2 sharpen, [1] sigma | sharpness factor, [2] colour jitter
+ *   on (0/1), [3..6] order of the colour ops (0 brightness, 1 contrast, 2 saturation, 3 hue), [7..10] their factors.
+ *   tmp: F*3*H*W floats, gray_sum: F doubles (scratch).
+ * muvo_preprocess_route_aug: muvo_preprocess_route + RouteAugmentation of sample b (all S frames alike); params (may be
+ *   NULL): B rows of MUVO_ROUTEAUG_STRIDE floats: [0] 0 none / 1 drop / 2 end of route / 3 affine, [1] rows zeroed (mode 2),
+ *   [2..7] torchvision's inverse affine matrix (_get_inverse_affine_matrix, center (0,0)). */
+#define MUVO_PIXAUG_STRIDE 16
+#define MUVO_ROUTEAUG_STRIDE 8
+int muvo_pixel_augment(float* img, float* norm, float* tmp, const float* params, double* gray_sum, int64_t frames, int H, int W,
+                       const float* mean3, const float* std3, void* stream);
+int muvo_preprocess_route_aug(const uint8_t* img, float* out, const float* params, int B, int S, int C, int H, int W, int OH,
+                              int OW, const float* mean3, const float* std3, void* stream);
 int muvo_divide_scalar(const float* x, float* y, int64_t n, float divisor, void* stream);
 int muvo_resize_bilinear(const float* x, float* y, int64_t NC, int H, int W, int OH, int OW, void* stream);
 int muvo_resize_nearest_f32(const float* x, float* y, int64_t NC, int D, int H, int W, int OD, int OH, int OW, void* stream);

@@ -49,6 +49,31 @@ def make_batch(b: int, s: int, seed: int = 1234, image_hw=(600, 960), route_hw=(
     return out
 
 
+def make_aug_batch(b: int, s: int, seed: int, device='cpu'):
+    """make_batch with image-like structure (integer triangle waves + 1/4 hash noise, integer arithmetic only so every host
+    builds the same bytes): blur / sharpen / hue act on edges and gradients instead of white noise.  Input of the
+    augmentation fixture (tests/golden/augment.*)."""
+    batch = make_batch(b, s, seed=seed)
+
+    def tri(t, p):
+        return np.abs((t % (2 * p)) - p) * 255 // p
+
+    img = batch['image'].numpy().astype(np.int64)
+    x, y = np.arange(img.shape[-1], dtype=np.int64), np.arange(img.shape[-2], dtype=np.int64)
+    for f in range(b * s):
+        for c in range(3):
+            base = (tri(x * (c + 2) + 13 * f, 97)[None, :] * tri(y * (c + 1) + 7 * f, 61)[:, None]) // 255
+            img[f // s, f % s, c] = (3 * base + img[f // s, f % s, c]) // 4
+    batch['image'] = torch.from_numpy(img.astype(np.uint8))
+    r = batch['route_map'].numpy().astype(np.int64)
+    h, w = r.shape[-2:]
+    ramp = (np.arange(h, dtype=np.int64)[:, None] + np.arange(w, dtype=np.int64)[None, :]) * 255 // (h + w - 2)
+    batch['route_map'] = torch.from_numpy(((r + 3 * ramp) // 4).astype(np.uint8))
+    if device != 'cpu':
+        batch = {k: v.to(device) for k, v in batch.items()}
+    return batch
+
+
 def make_noise(b: int, s: int, state_dim: int = 512, seed: int = 1234, use_prior_prob: float = 0.15):
     """RSSM noise eps (b, s, 2, state_dim): [:, :, 0] prior, [:, :, 1] posterior sample noise
     (reference draws: transition.py:179), and the per-timestep 'use prior sample' coin (transition.py:118)."""

@@ -107,6 +107,8 @@ class Mile(nn.Module):
         self.segment_done = None
         self._step_seed = 0
         self.dropout_seed = 0x5EED
+        self.dropout_rank = 0     # data-parallel rank (set by WorldModelTrainer.configure_optimizers)
+        self.seed_epoch = 0       # optimizer steps taken so far (set by WorldModelTrainer.training_step)
 
     def _pos(self, h, w, device):
         key = (h, w, str(device))
@@ -118,6 +120,21 @@ class Mile(nn.Module):
         if self.segment_done is not None and t.requires_grad:
             cb = self.segment_done
             t.register_hook(lambda g, _s=segment: (cb(_s), None)[1])
+
+    def _mark(self, t, segment):
+        """Identity on the INPUT of a sub-network: its backward runs after every backward node of that sub-network
+        (autograd executes the most recently recorded nodes first), so `segment` and all earlier ones are complete."""
+        if self.segment_done is not None and t.requires_grad:
+            return ops.segment_mark(t, self.segment_done, segment)
+        return t
+
+    def step_seed(self):
+        """Dropout seed of this forward: a function of (base seed, data-parallel rank, optimizer steps taken so far —
+        restored from a checkpoint —, forwards since construction), so masks differ across ranks and do not repeat
+        after a restart."""
+        self._step_seed += 1
+        return (self.dropout_seed + 0x9E3779B97F4A7C15 * (self.dropout_rank + 1) + 0xBF58476D1CE4E5B9 * self.seed_epoch
+                + 0x2545F4914F6CDD1D * self._step_seed) & 0x3FFFFFFFFFFFFFFF
 
     def forward(self, batch, deployment=False, noise=None, use_prior=None):
         if deployment:
@@ -131,17 +148,17 @@ class Mile(nn.Module):
         output = {**state_dict}
         post = state_dict['posterior']
         state = ops.cat_last([pack_sequence_dim(post['hidden_state']), pack_sequence_dim(post['sample'])])
-        self._hook(state, 'decoders')
+        self._hook(state, 'policy')        # d(state) complete: every decoder and the policy are done
         pol = self.policy(state)
         output['throttle_brake'] = unpack_sequence_dim(ops.slice_last(pol, 0, 1), b, s)
         output['steering'] = unpack_sequence_dim(ops.slice_last(pol, 1, 2), b, s)
         if self.cfg.EVAL.RGB_SUPERVISION:
-            output.update(unpack_sequence_dim(self.rgb_decoder(state), b, s))
+            output.update(unpack_sequence_dim(self.rgb_decoder(self._mark(state, 'rgb_decoder')), b, s))
         if self.cfg.LIDAR_RE.ENABLED:
-            output.update(unpack_sequence_dim(self.lidar_re(state), b, s))
+            output.update(unpack_sequence_dim(self.lidar_re(self._mark(state, 'lidar_re')), b, s))
         output.update(self._aux_heads(state, b, s))
         if self.cfg.VOXEL_SEG.ENABLED:
-            output.update(unpack_sequence_dim(self.voxel_decoder(state), b, s))
+            output.update(unpack_sequence_dim(self.voxel_decoder(self._mark(state, 'voxel_decoder')), b, s))
         return output, state_dict
 
     def imagine(self, batch, predict_action=False, future_horizon=None, noise=None):
@@ -182,13 +199,13 @@ class Mile(nn.Module):
     def _aux_heads(self, state, b, s):
         out = {}
         if self.cfg.SEMANTIC_SEG.ENABLED:
-            out.update(unpack_sequence_dim(self.bev_decoder(state), b, s))
+            out.update(unpack_sequence_dim(self.bev_decoder(self._mark(state, 'bev_decoder')), b, s))
         if self.cfg.LIDAR_SEG.ENABLED:
-            out.update(unpack_sequence_dim(self.lidar_segmentation(state), b, s))
+            out.update(unpack_sequence_dim(self.lidar_segmentation(self._mark(state, 'lidar_segmentation')), b, s))
         if self.cfg.SEMANTIC_IMAGE.ENABLED:
-            out.update(unpack_sequence_dim(self.sem_image_decoder(state), b, s))
+            out.update(unpack_sequence_dim(self.sem_image_decoder(self._mark(state, 'sem_image_decoder')), b, s))
         if self.cfg.DEPTH.ENABLED:
-            out.update(unpack_sequence_dim(self.depth_image_decoder(state), b, s))
+            out.update(unpack_sequence_dim(self.depth_image_decoder(self._mark(state, 'depth_image_decoder')), b, s))
         return out
 
     def encode(self, batch):
@@ -207,6 +224,8 @@ class Mile(nn.Module):
             x = self.frustum_pooling.lift(x, depth, pack_sequence_dim(batch['intrinsics']).float(),
                                           pack_sequence_dim(batch['extrinsics']).float(), depth_mask)
             x = self.bev_down_sample_4[2](self.bev_down_sample_4[0](x, act=ops.ACT_RELU))
+        # recorded before the range-view branch: its backward fires when that branch (and the token gradient) is done
+        x = self._mark(x, 'lidar_branch')
         lidar_features = self.range_view_decoder(self.range_view_encoder(pack_sequence_dim(batch['range_view_pcd_xyzd'])))
         hi, wi = x.shape[-2:]
         hl, wl = lidar_features.shape[-2:]
@@ -214,8 +233,7 @@ class Mile(nn.Module):
         tokens = ops.make_tokens(x, lidar_features, self._pos(hi, wi, x.device), self._pos(hl, wl, x.device),
                                  self.type_embedding)
         self._hook(tokens, 'fusion')
-        self._step_seed += 1
-        tokens_out = self.transformer_encoder(tokens, self.dropout_seed + 1000 * self._step_seed)
+        tokens_out = self.transformer_encoder(tokens, self.step_seed())
         image_tokens_out = ops.untoken(tokens_out, 0, hi, wi)
         lidar_tokens_out = ops.untoken(tokens_out, hi * wi, hl, wl)
         features = [self.image_feature_conv(image_tokens_out), self.lidar_feature_conv(lidar_tokens_out),

@@ -2,8 +2,11 @@
 
 Same contract as the reference: mutates and returns the caller's batch dict, adding rgb_label_{1,2,4},
 range_view_label_{1,2,4}, voxel_label_{1,2,4}; `rgb_label_1` is the cropped [0,1] image (pre-normalisation) and
-`range_view_label_1` IS the range-view network input.  Pixel/route augmentation
-(preprocess.py:295-367, training only, torchvision) is not part of this round's path (next rows)."""
+`range_view_label_1` IS the range-view network input.  In training mode the pixel / route augmentation
+of the reference (preprocess.py:45-48,213-214,295-367) runs too: the random draws are made on the host in the reference's
+RNG call order (muvo_amd/augment.py) — or passed in as explicit tables (`batch['_pixel_aug']`, `batch['_route_aug']`) —
+and applied by csrc/augment.hip.  Like in the reference the pixel augmentation alters `rgb_label_1` (it IS the image) but
+not `rgb_label_2/4`, which are made before it (preprocess.py:104-113 run before :213-214)."""
 import torch
 import torch.nn as nn
 
@@ -18,14 +21,42 @@ class PreProcess(nn.Module):
         self.route_map_size = cfg.ROUTE.SIZE
         self.mean = tuple(float(v) for v in cfg.IMAGE.IMAGENET_MEAN)
         self.std = tuple(float(v) for v in cfg.IMAGE.IMAGENET_STD)
+        if cfg.EVAL.RESOLUTION.ENABLED:
+            raise NotImplementedError('EVAL.RESOLUTION.ENABLED (preprocess.py:209-210: antialiased down-scaling of the input '
+                                      'for evaluation) is outside the training hot path (SURVEY.md §8)')
+        self._pins, self._pin_i = {}, 0
+        self.augment = True     # False: no augmentation even in training mode (parity runs against augmentation-free fixtures)
+
+    def _to_device(self, table, device):
+        """Small host table -> device through one of four rotating pinned buffers (no host/stream synchronisation)."""
+        key = tuple(table.shape)
+        ring = self._pins.get(key)
+        if ring is None:
+            ring = self._pins[key] = [torch.empty(table.shape, dtype=torch.float32).pin_memory() for _ in range(4)]
+        self._pin_i = (self._pin_i + 1) % 4
+        ring[self._pin_i].copy_(table)
+        return ring[self._pin_i].to(device, non_blocking=True)
 
     def forward(self, batch):
         cfg = self.cfg
         # /255, crop, label pyramid, ImageNet normalisation (preprocess.py:203-218, :102-113)
+        b, s = batch['image'].shape[:2]
+        dev = batch['image'].device
+        pix_aug = batch.pop('_pixel_aug', None)
+        route_aug = batch.pop('_route_aug', None)
+        if self.training and self.augment and pix_aug is None:          # same RNG call order as the reference: pixels first, then routes
+            from muvo_amd import augment
+            pix_aug = augment.draw_pixel_params(cfg, b, s)
+            if 'route_map' in batch and route_aug is None:
+                route_aug = augment.draw_route_params(cfg, b, self.route_map_size)
         label1, image = ops.preprocess_image(batch['image'], self.crop, self.mean, self.std)
         batch['image'] = image
         if 'route_map' in batch:
-            batch['route_map'] = ops.preprocess_route(batch['route_map'], self.route_map_size, self.mean, self.std)
+            if route_aug is not None and bool((route_aug[:, 0] != 0).any()):
+                route_aug = route_aug if route_aug.is_cuda else self._to_device(route_aug, dev)
+                batch['route_map'] = ops.preprocess_route_aug(batch['route_map'], self.route_map_size, self.mean, self.std, route_aug)
+            else:
+                batch['route_map'] = ops.preprocess_route(batch['route_map'], self.route_map_size, self.mean, self.std)
         if 'intrinsics' in batch:
             intr = batch['intrinsics'].clone()
             intr[..., 0, 2] -= self.crop[0]
@@ -36,6 +67,10 @@ class PreProcess(nn.Module):
             h, w = label1.shape[-2:]
             for f in (2, 4):
                 batch[f'rgb_label_{f}'] = ops.resize_bilinear(batch[f'rgb_label_{f // 2}'], h // f, w // f)
+        # PixelAugmentation: after the label pyramid, in place on the [0,1] image = rgb_label_1, re-normalising `image`
+        if pix_aug is not None and bool(((pix_aug[:, 0] != 0) | (pix_aug[:, 2] != 0)).any()):
+            pix_aug = pix_aug if pix_aug.is_cuda else self._to_device(pix_aug, dev)
+            ops.pixel_augment(label1, image, pix_aug, self.mean, self.std)
         if cfg.LIDAR_RE.ENABLED:
             rv = ops.divide_scalar(batch['range_view_pcd_xyzd'].float(), cfg.LIDAR_RE.SCALE)
             batch['range_view_pcd_xyzd'] = rv

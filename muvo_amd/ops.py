@@ -63,7 +63,7 @@ EXPORTS = [
     'muvo_frustum_cells', 'muvo_frustum_pool_fwd', 'muvo_frustum_pool_bwd', 'muvo_depth_expectation',
     'muvo_resize_bilinear_bwd', 'muvo_softmax_channel_fwd', 'muvo_softmax_channel_bwd',
     'muvo_range_projection', 'muvo_voxel_grid', 'muvo_seg_ce_fwd', 'muvo_seg_ce_bwd', 'muvo_ssim_maps', 'muvo_ssim_bwd',
-    'muvo_instance_labels',
+    'muvo_instance_labels', 'muvo_pixel_augment', 'muvo_preprocess_route_aug',
 ]
 
 
@@ -147,9 +147,20 @@ _plan_epoch = [0]
 
 
 def grad_of(p):
-    """The gradient buffer the kernels accumulate into (allocated on demand)."""
+    """The gradient buffer the kernels accumulate into.  With a ParamStore that is the parameter's slot of the flat gradient
+    buffer: if something set p.grad to None (nn.Module.zero_grad(), optimizer.zero_grad(set_to_none=True) of a foreign
+    loop) the slot is zeroed and re-bound here, so gradients never land in a detached tensor.  Without a store the tensor is
+    allocated on demand.  Frozen parameters (requires_grad=False, OPTIMIZER.FROZEN) get no buffer of their own: the kernels
+    that always write a parameter gradient (BatchNorm / LayerNorm backward) add into one shared dump nobody reads."""
+    if not p.requires_grad:
+        return scratch('frozen_grad_dump', p.numel(), p.device).view(-1)[:p.numel()].view(p.shape)
     if p.grad is None:
-        p.grad = torch.zeros_like(p)
+        view = getattr(p, '_muvo_flat_grad', None)
+        if view is not None:
+            view.zero_()
+            p.grad = view
+        else:
+            p.grad = torch.zeros_like(p)
     return p.grad
 
 
@@ -194,18 +205,18 @@ class KernelTiming:
         self.rec = []
         self.only = only
 
-    def bracket(self, cls, flops, launches, tag=''):
+    def bracket(self, cls, flops, launches, tag='', nbytes=0.0):
         if self.only is not None and cls.split(':')[0] != self.only:
             return _NO_EVENT, _NO_EVENT
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        self.rec.append((cls, flops, launches, e0, e1, tag))
+        self.rec.append((cls, flops, launches, e0, e1, tag, nbytes))
         return e0, e1
 
     def layer_table(self):
         """Per (kernel class, layer shape) rows sorted by time: the optimisation worklist."""
         torch.cuda.synchronize()
         agg = {}
-        for cls, flops, launches, e0, e1, tag in self.rec:
+        for cls, flops, launches, e0, e1, tag, _nb in self.rec:
             a = agg.setdefault((cls, tag), [0.0, 0.0, 0])
             a[0] += e0.elapsed_time(e1) * 1e-3
             a[1] += flops
@@ -221,20 +232,22 @@ class KernelTiming:
         launch stream around the C-ABI call (they include the small pack/split/unpack helper launches of that call)."""
         torch.cuda.synchronize()
         agg = {}
-        for cls, flops, launches, e0, e1, _tag in self.rec:
-            a = agg.setdefault(cls, [0.0, 0.0, 0])
+        for cls, flops, launches, e0, e1, _tag, nb in self.rec:
+            a = agg.setdefault(cls, [0.0, 0.0, 0, 0.0])
             a[0] += e0.elapsed_time(e1) * 1e-3
             a[1] += flops
             a[2] += launches
-        classes = {k: dict(seconds=v[0], tflop=v[1] / 1e12, launches=v[2],
+            a[3] += nb
+        classes = {k: dict(seconds=v[0], tflop=v[1] / 1e12, launches=v[2], algorithmic_gb=v[3] / 1e9,
                            avg_launch_us=v[0] / max(v[2], 1) * 1e6, tflops=v[1] / max(v[0], 1e-12) / 1e12)
                    for k, v in agg.items()}
         fam = {}
         for k, c in classes.items():
-            f = fam.setdefault(k.split(':')[0], dict(seconds=0.0, tflop=0.0, launches=0))
+            f = fam.setdefault(k.split(':')[0], dict(seconds=0.0, tflop=0.0, launches=0, gb=0.0))
             f['seconds'] += c['seconds']
             f['tflop'] += c['tflop']
             f['launches'] += c['launches']
+            f['gb'] += c['algorithmic_gb']
         mfma = {k: v for k, v in fam.items() if k in PEAK_TFLOPS}
         roof = None
         if mfma:
@@ -245,6 +258,9 @@ class KernelTiming:
             roof = dict(bound='mfma', kernel=KERNEL_NAMES[dom], achieved=alg * mult, peak=PEAK_TFLOPS[dom], unit='TFLOP/s',
                         frac=alg * mult / PEAK_TFLOPS[dom], traffic=None, algorithmic_tflops=alg,
                         mfma_flops_per_algorithmic_flop=mult, launches=f['launches'],
+                        algorithmic_bytes=f['gb'] * 1e9 / max(f['launches'], 1),
+                        algorithmic_bytes_unit='bytes per launch: fp32 operand tensors read once + result written once '
+                                               '(4 * (N*Cin*in_pixels + N*Cout*out_pixels + weight elements))',
                         avg_launch_us=f['seconds'] / max(f['launches'], 1) * 1e6,
                         share_of_conv_time=f['seconds'] / max(sum(v['seconds'] for v in fam.values()), 1e-12))
         return roof, classes
@@ -268,6 +284,14 @@ MFMA_FLOPS_PER_ALGORITHMIC_FLOP = {'f32_implicit_gemm': 1.0, 'bf16x3_implicit_ge
 def _conv_tag(geom, n, in_sz):
     return (f'{"convT" if geom.transposed else "conv"}{geom.nd}d {geom.cin}->{geom.cout} k{geom.ksz} s{geom.stride} '
             f'n{n} in{tuple(in_sz)}')
+
+
+def _conv_bytes(geom, n, in_sz, out_sz):
+    """Algorithmic HBM bytes of one conv operation (forward, data gradient or weight gradient alike): both activation
+    tensors and the weight, fp32, each touched once."""
+    import math
+    return 4.0 * (n * geom.cin * math.prod(in_sz) + n * geom.cout * math.prod(out_sz)
+                  + geom.cin * geom.cout * math.prod(geom.ksz))
 
 
 def _conv_flops(geom, n, in_sz, out_sz):
@@ -597,7 +621,8 @@ class ConvFn(torch.autograd.Function):
         if kt is not None:
             import math
             e0, e1 = kt.bracket(FAMILY[geom.tclass[(n, in_sz, _plan_epoch[0])][0]] + ':fwd', _conv_flops(geom, n, in_sz, out_sz),
-                                math.prod(geom.stride) if geom.transposed else 1, _conv_tag(geom, n, in_sz))
+                                math.prod(geom.stride) if geom.transposed else 1, _conv_tag(geom, n, in_sz),
+                                _conv_bytes(geom, n, in_sz, out_sz))
             e0.record()
         wsb = geom.ws_bytes[(n, in_sz, _plan_epoch[0])]
         # wgrad reuses the split copy of x (grad mode is off inside forward: needs_input_grad says whether a backward follows)
@@ -657,7 +682,8 @@ class ConvFn(torch.autograd.Function):
                 import math
                 e0, e1 = kt.bracket(FAMILY[geom.tclass[(x.shape[0], ctx.in_sz, _plan_epoch[0])][1]] + ':dgrad',
                                     _conv_flops(geom, x.shape[0], ctx.in_sz, out_sz),
-                                    1 if geom.transposed else math.prod(geom.stride), _conv_tag(geom, x.shape[0], ctx.in_sz))
+                                    1 if geom.transposed else math.prod(geom.stride), _conv_tag(geom, x.shape[0], ctx.in_sz),
+                                    _conv_bytes(geom, x.shape[0], ctx.in_sz, out_sz))
                 e0.record()
             nb = max(wsb[1], wsb[3])
             ws_dy = scratch('conv_ws_dy', (nb + 3) // 4, x.device) if nb else None
@@ -673,7 +699,8 @@ class ConvFn(torch.autograd.Function):
                 import math
                 e0, e1 = kt.bracket(FAMILY[geom.tclass[(x.shape[0], ctx.in_sz, _plan_epoch[0])][2]] + ':wgrad',
                                     _conv_flops(geom, x.shape[0], ctx.in_sz, out_sz),
-                                    math.prod(geom.stride) if geom.transposed else 1, _conv_tag(geom, x.shape[0], ctx.in_sz))
+                                    math.prod(geom.stride) if geom.transposed else 1, _conv_tag(geom, x.shape[0], ctx.in_sz),
+                                    _conv_bytes(geom, x.shape[0], ctx.in_sz, out_sz))
                 e0.record()
             ws_x = ctx.ws_x
             flags = (1 if ws_x is not None else 0) | (2 if (dy_split and wsb[3] > 0) else 0)
@@ -1265,6 +1292,33 @@ def preprocess_route(route_u8, size, mean, std):
     return out
 
 
+PIXAUG_STRIDE, ROUTEAUG_STRIDE = 16, 8
+
+
+def pixel_augment(label, norm, params, mean, std):
+    """PixelAugmentation (preprocess.py:295-333) on the cropped [0,1] image `label` (b,s,3,h,w), IN PLACE (it is rgb_label_1),
+    re-normalising the augmented frames into `norm`.  params: (b*s, PIXAUG_STRIDE) float32 device table (muvo_amd/augment.py)."""
+    b, s, c, h, w = label.shape
+    assert c == 3 and label.is_contiguous() and norm.is_contiguous() and params.shape == (b * s, PIXAUG_STRIDE)
+    tmp = scratch('pixaug_tmp', label.numel(), label.device)
+    gsum = scratch('pixaug_gray', b * s, label.device, torch.float64)
+    m = (C.c_float * 3)(*mean)
+    sd = (C.c_float * 3)(*std)
+    _ck(lib().muvo_pixel_augment(_f(label), _f(norm), _f(tmp), _f(params), _p(gsum), _i64(b * s), h, w, m, sd, _st()))
+
+
+def preprocess_route_aug(route_u8, size, mean, std, params=None):
+    """preprocess_route + RouteAugmentation (preprocess.py:336-367); params: (b, ROUTEAUG_STRIDE) float32 device table or None."""
+    route_u8 = route_u8.contiguous()
+    b, s, c, h, w = route_u8.shape
+    out = torch.empty(b, s, c, size, size, device=route_u8.device, dtype=torch.float32)
+    m = (C.c_float * 3)(*mean)
+    sd = (C.c_float * 3)(*std)
+    assert params is None or params.shape == (b, ROUTEAUG_STRIDE)
+    _ck(lib().muvo_preprocess_route_aug(_p(route_u8), _f(out), _f(params), b, s, c, h, w, size, size, m, sd, _st()))
+    return out
+
+
 def divide_scalar(x, divisor):
     x = x.contiguous()
     y = torch.empty_like(x)
@@ -1577,6 +1631,25 @@ class UnstackTimeFn(torch.autograd.Function):
 
 def unstack_time(x):
     return UnstackTimeFn.apply(x)
+
+
+class SegmentMarkFn(torch.autograd.Function):
+    """Identity whose backward calls `cb(name)` first: placed on the input of a sub-network it tells the data-parallel
+    reducer that backward has issued every kernel of that sub-network (muvo_amd/parallel.py)."""
+
+    @staticmethod
+    def forward(ctx, x, cb, name):
+        ctx.cb, ctx.name = cb, name
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.cb(ctx.name)
+        return g, None, None
+
+
+def segment_mark(x, cb, name):
+    return SegmentMarkFn.apply(x, cb, name)
 
 
 class SumScalarsFn(torch.autograd.Function):

@@ -2,48 +2,69 @@
 "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
 
 The reference has no explicit collective (Lightning's implicit DDP would all-reduce ~440 tensors in 25 MB
-buckets).  Here the gradient buffer is laid out in the order backward completes it (param_store.SEGMENTS), so
-each segment is ONE contiguous sum-all-reduce (357 MB decoders, 53 MB RSSM, ~210 MB fusion, ~75 MB encoders at
-base_1d), issued on a side HIP stream the moment autograd leaves the segment and overlapped with the rest of
-backward.  xGMI is point-to-point, so few large messages keep all 7 links per GPU busy; BatchNorm statistics stay
-per-GPU (reference: sync_batchnorm commented out, train.py:98).  The 1/world_size averaging is folded into the
-fused AdamW kernel (grad_scale)."""
+buckets, train.py:93-98).  Here the gradient buffer is laid out in the order backward completes it
+(param_store.SEGMENTS: voxel decoder 12 MB, range-view decoder 135 MB, RGB decoder 186 MB, policy 24 MB, RSSM
+53 MB, fusion ~210 MB, the two encoder branches ~57 MB each at base_1d), so each segment is ONE contiguous
+sum-all-reduce, issued on a side HIP stream the moment autograd leaves the segment and overlapped with the rest
+of backward: the first 333 MB are in flight while the RGB decoder (the longest stretch of backward) still runs, and
+only the image-encoder segment is exposed after backward.  xGMI is point-to-point, so few large messages keep all 7
+links per GPU busy; BatchNorm statistics stay per-GPU (reference: sync_batchnorm commented out, train.py:98).  The
+1/world_size averaging is folded into the fused AdamW kernel (grad_scale)."""
 import torch
 import torch.distributed as dist
 
 
 class SegmentedGradReducer:
-    def __init__(self, store, group=None, overlap=True, force_collectives=False):
+    def __init__(self, store, group=None, overlap=True, force_collectives=False, verify=False):
         """force_collectives: issue the all-reduces even in a one-rank group (exercises the RCCL / side-stream path on a
-        single GPU; `bench.py` sets it when MUVO_BENCH_FORCE_DIST=1)."""
+        single GPU; `bench.py` sets it when MUVO_BENCH_FORCE_DIST=1).
+        verify: keep a copy of every segment as it is handed to the collective and compare it in finish() with what the
+        segment holds once backward has ended (one-rank groups only: a sum over one rank changes nothing) — proves that
+        no kernel wrote into a segment after its hook fired (tests/test_dp_gpu.py)."""
         self.store = store
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.force = bool(force_collectives) and dist.is_initialized()
         self.overlap = overlap
+        self.verify = verify
+        self.accumulating = False     # True while backward runs for a non-final micro-batch of gradient accumulation
         self.is_cuda = store.flat_grad.is_cuda
         self.side = torch.cuda.Stream() if (self.is_cuda and (self.world > 1 or self.force)) else None
-        self._done = set()
+        self._done = []
         self._handles = []
+        self._snap = {}
+        self._begun = False
         self.ranges = {name: (a, b) for name, a, b in store.segment_ranges}
         self.order = [name for name, _, _ in store.segment_ranges]
+        from muvo_amd.param_store import SEGMENTS
+        self._rank = {name: i for i, (name, _) in enumerate(SEGMENTS)}     # completion order, also of absent segments
+        self.launch_log = []          # (segment, was launched from a backward hook) of the last step
+        self.late_writes = {}         # verify: segment -> max |difference|
 
     @property
     def grad_scale(self):
         return 1.0 / self.world
 
     def begin_step(self):
-        self._done.clear()
-        self._handles.clear()
+        """Start of an optimisation step (before backward).  Optional since finish() resets the state, but calling it
+        twice without a finish() in between means a backward ended without its exchange: refuse."""
+        if self._begun and self._done:
+            raise RuntimeError('SegmentedGradReducer.begin_step(): the previous backward was never finish()ed '
+                               f'(segments already sent: {self._done})')
+        self._done, self._handles, self._snap = [], [], {}
+        self._begun = True
 
-    def _launch(self, name):
+    def _launch(self, name, from_hook):
         if name in self._done or name not in self.ranges:
             return
-        self._done.add(name)
+        self._done.append(name)
+        self.launch_log.append((name, from_hook))
         if self.world == 1 and not self.force:
             return
         a, b = self.ranges[name]
         buf = self.store.flat_grad[a:b]
+        if self.verify:
+            self._snap[name] = buf.clone()
         if self.side is not None:
             self.side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.side):
@@ -53,18 +74,39 @@ class SegmentedGradReducer:
 
     def segment_done(self, name):
         """autograd hook: backward has finished every parameter of `name` (and of all earlier segments)."""
-        if not self.overlap:
+        if not self.overlap or self.accumulating:
             return
+        if not self._done:
+            self.launch_log = []
+        upto = self._rank[name]
         for n in self.order:
-            self._launch(n)
-            if n == name:
+            if self._rank[n] > upto:
                 break
+            self._launch(n, True)
+
+    def skip(self):
+        """End of a backward whose gradients stay local (gradient accumulation: only the last micro-batch exchanges).
+        Hooks must not have sent anything: set `overlap=False` / `accumulating=True` before such a backward."""
+        if self._done:
+            raise RuntimeError('SegmentedGradReducer.skip(): segments were already sent during this backward; set '
+                               '`reducer.accumulating = True` before the backward of a non-final micro-batch')
+        self._begun = False
 
     def finish(self):
         """after backward: reduce whatever is left and make the optimizer stream wait for the exchange."""
+        if not self._done:
+            self.launch_log = []
         for n in self.order:
-            self._launch(n)
+            self._launch(n, False)
         for h in self._handles:
             h.wait()
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
+        assert self._done == self.order, (self._done, self.order)   # every segment exactly once, in layout order
+        if self.verify and self.world == 1:
+            self.late_writes = {}
+            for name, snap in self._snap.items():
+                a, b = self.ranges[name]
+                self.late_writes[name] = float((self.store.flat_grad[a:b] - snap).abs().max())
+        self._done, self._handles, self._snap = [], [], {}
+        self._begun = False

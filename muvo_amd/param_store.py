@@ -10,14 +10,24 @@ Parameters the reference registers but never uses (`encoder_layer.*`, SURVEY App
 never get a gradient and are skipped by the optimizer, exactly like torch.optim.AdamW skips `grad is None`."""
 import torch
 
-# reverse-execution order of the base_1d model: backward completes these prefixes top to bottom
+# Order in which backward finishes the parameters of the model (autograd runs the most recently recorded forward nodes
+# first: mile.py:437-487 calls policy, rgb, lidar_re, the config-off heads and the voxel decoder in that order, so their
+# gradients complete in reverse).  Each entry is one contiguous range of the flat gradient buffer = ONE all-reduce, launched
+# by the hook named in the comment (muvo_amd/models/mile.py `_mark` / `_hook`).
 SEGMENTS = (
-    ('decoders', ('voxel_decoder.', 'lidar_re.', 'rgb_decoder.', 'policy.', 'lidar_segmentation.', 'sem_image_decoder.',
-                  'depth_image_decoder.', 'bev_decoder.')),            # done when d(state) arrives
-    ('rssm', ('rssm.',)),                                                                  # done when d(embedding) arrives
+    ('voxel_decoder', ('voxel_decoder.',)),                      # d(input of the voxel decoder) computed
+    ('depth_image_decoder', ('depth_image_decoder.',)),
+    ('sem_image_decoder', ('sem_image_decoder.',)),
+    ('lidar_segmentation', ('lidar_segmentation.',)),
+    ('bev_decoder', ('bev_decoder.',)),
+    ('lidar_re', ('lidar_re.',)),
+    ('rgb_decoder', ('rgb_decoder.',)),
+    ('policy', ('policy.',)),                                    # d(state) complete (every consumer of the state done)
+    ('rssm', ('rssm.',)),                                        # d(embedding) arrives
     ('fusion', ('features_combine.', 'speed_enc.', 'backbone_route.', 'image_feature_conv.', 'lidar_feature_conv.',
-                'transformer_encoder.')),                                                  # done when d(tokens) arrives
-    ('encoders', ('type_embedding', 'feat_decoder.', 'range_view_decoder.', 'encoder.', 'range_view_encoder.')),
+                'transformer_encoder.')),                        # d(tokens) arrives
+    ('lidar_branch', ('type_embedding', 'range_view_decoder.', 'range_view_encoder.')),   # image branch about to start
+    ('image_branch', ('feat_decoder.', 'depth_decoder.', 'depth.', 'bev_down_sample_4.', 'frustum_pooling.', 'encoder.')),
 )
 UNUSED_PREFIXES = ('encoder_layer.',)
 
@@ -69,17 +79,44 @@ class ParamStore:
                 self.segment_ranges.append((SEGMENTS[si][0], min(r[2] for r in rs), max(r[3] for r in rs)))
         self.params = [p for _, p, _ in order]
         self._off = {id(p): o for _, p, o in order}
-        self.nodecay_params = [p for n, p, _ in order if p.dim() == 1 or any(s in n for s in skip_decay)]
-        self.decay_params = [p for n, p, _ in order if not (p.dim() == 1 or any(s in n for s in skip_decay))]
+        # optimizer param groups in the REFERENCE's order (trainer.py:1031-1051 walks model.named_parameters()), so a
+        # torch.optim.AdamW state_dict of the reference maps index -> parameter identically (muvo_amd/optim.py)
+        nodecay = lambda n, p: p.dim() == 1 or any(s in n for s in skip_decay)
+        self.nodecay_params = [p for n, p in named if nodecay(n, p)]
+        self.decay_params = [p for n, p in named if not nodecay(n, p)]
+        self.used_ids = {id(p) for p in self.params}
+        for n, p, o in order:
+            p._muvo_flat_grad = self.flat_grad[o:o + p.numel()].view(p.shape)   # ops.grad_of re-binds to it
 
     def zero_grad(self):
         self.flat_grad.zero_()
+        self.rebind_grads()
         for _, p in self.unused:
             p.grad = None
 
     def rebind_grads(self):
-        """Re-attach p.grad views (after something set them to None, e.g. optimizer.zero_grad(set_to_none=True))."""
+        """Re-attach the p.grad views after something replaced them (nn.Module.zero_grad() / `p.grad = None` set them to
+        None; a kernel that found None re-binds through ops.grad_of).  A gradient tensor that is NOT the flat view (assigned
+        from outside) is copied into its slot first, so its contents are not lost."""
+        base = self.flat_grad.data_ptr()
         for p in self.params:
-            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * self._off[id(p)]:
-                o = self._off[id(p)]
-                p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+            view = p._muvo_flat_grad
+            g = p.grad
+            if g is None:
+                p.grad = view
+            elif g.data_ptr() != base + 4 * self._off[id(p)]:
+                view.copy_(g)
+                p.grad = view
+
+    def settle_grads(self):
+        """Before the optimizer reads flat_grad: a parameter whose .grad is None got no gradient since something reset it
+        (its slot may hold the previous step's values) -> zero the slot; foreign gradient tensors are copied in."""
+        base = self.flat_grad.data_ptr()
+        for p in self.params:
+            g = p.grad
+            if g is None:
+                p._muvo_flat_grad.zero_()
+                p.grad = p._muvo_flat_grad
+            elif g.data_ptr() != base + 4 * self._off[id(p)]:
+                p._muvo_flat_grad.copy_(g)
+                p.grad = p._muvo_flat_grad

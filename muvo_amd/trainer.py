@@ -26,6 +26,18 @@ except Exception:  # pragma: no cover
     _Base = torch.nn.Module
 
 
+_DDP_MSG = ('muvo_amd.WorldModelTrainer exchanges its gradients itself (segmented RCCL all-reduce on a side stream, '
+            'muvo_amd/parallel.py): run one process per GPU with torch.distributed initialised and do NOT wrap the '
+            'module in DistributedDataParallel (Lightning: use a single-device strategy per process, INTEGRATION.md §5)')
+
+
+def _refuse_ddp(module, args):
+    tr = getattr(module, '_trainer', None) if pl is not None else None
+    strategy = getattr(tr, 'strategy', None)
+    if strategy is not None and isinstance(getattr(strategy, 'model', None), torch.nn.parallel.DistributedDataParallel):
+        raise RuntimeError(_DDP_MSG)
+
+
 class WorldModelTrainer(_Base):
     def __init__(self, hparams, path_to_conf_file=None, pretrained_path=None, device=None):
         super().__init__()
@@ -51,6 +63,10 @@ class WorldModelTrainer(_Base):
         self.store = None
         self._optimizer = None
         self._reducer = None
+        self._global_step = 0          # plain-loop counterpart of LightningModule.global_step
+        self.log_fn = None             # plain loop: callable(name, value) receiving what Lightning's self.log would
+        self.logged = {}
+        self.accumulate_now = False    # plain loop: True while a non-final micro-batch of gradient accumulation runs
         # evaluation metrics per validation / test dataloader (trainer.py:51-55,100-129,191-197); created on first use
         # because they hold device accumulators
         self.metrics_vals = [{}, {}, {}]
@@ -249,9 +265,65 @@ class WorldModelTrainer(_Base):
         return ops.sum_scalars(vals)
 
     def training_step(self, batch, batch_idx=0, noise=None, use_prior=None):
+        """trainer.py:392-402: switch the RSSM to active inference at batch STEPS, shared_step('train'), log the 21 terms,
+        return their sum."""
+        if batch_idx == self.cfg.STEPS and self.cfg.MODEL.TRANSITION.ENABLED:
+            print('!' * 50)
+            print('ACTIVE INFERENCE ACTIVATED')
+            print('!' * 50)
+            self.model.rssm.active_inference = True
+        if self._optimizer is not None:
+            self.model.seed_epoch = self._optimizer._step
+        if self._reducer is not None:
+            self._reducer.accumulating = self._is_accumulating()
+            self._reducer.begin_step()
         losses, output, _, _ = self.shared_step(batch, mode='train', noise=noise, use_prior=use_prior)
         self.last_losses = losses
+        self.logging_and_visualisation(batch, output, [], losses, None, batch_idx, prefix='train')
         return self.loss_reducing(losses)
+
+    def logging_and_visualisation(self, batch, output, output_imagine, loss, loss_imagines, batch_idx, prefix='train'):
+        """The logging half of trainer.py:492-509 (`self.log(f'{prefix}_{key}', value)` per loss term, `-global_step`);
+        the TensorBoard visualisation half (`visualise`, trainer.py:569-1020: cv2 / open3d / matplotlib) is out of scope.
+        Under Lightning `self.log` is the LightningModule's; in a plain loop the values are handed to `self.log_fn(name,
+        value)` if one is set, else kept (still device tensors: no host sync) in `self.logged`."""
+        step = getattr(self, 'global_step', 0) if pl is not None else self._global_step
+        self.log('-global_step', torch.tensor(-float(step), dtype=torch.float32))
+        for key, value in loss.items():
+            self.log(f'{prefix}_{key}', value)
+        if loss_imagines:
+            for key, value in loss_imagines[0].items():
+                self.log(f'{prefix}_{key}_imagine', value)
+
+    if pl is None:
+        def log(self, name, value, *args, **kwargs):
+            if self.log_fn is not None:
+                self.log_fn(name, value)
+            else:
+                self.logged[name] = value
+
+    # ------------------------------------------------------------------ data-parallel hooks (Lightning names)
+    def on_before_zero_grad(self, optimizer=None):
+        pass
+
+    def on_after_backward(self):
+        """Lightning calls this right after `loss.backward()`: send the gradient segments backward has not sent itself
+        and make the optimizer's stream wait for the exchange.  A plain loop calls it between backward() and step()."""
+        if self._reducer is not None:
+            if self._reducer.accumulating:
+                self._reducer.skip()          # gradients keep accumulating locally; exchanged after the last micro-batch
+            else:
+                self._reducer.finish()
+
+    def _is_accumulating(self):
+        """True for every micro-batch but the last of an ACCUMULATE_GRAD_BATCHES group: Lightning's loop knows
+        (`_should_accumulate`); a plain loop sets `self.accumulate_now`."""
+        if pl is not None and getattr(self, '_trainer', None) is not None:
+            return bool(self._trainer.fit_loop.epoch_loop._should_accumulate())
+        return bool(self.accumulate_now)
+
+    def configure_ddp(self, *a, **k):   # pragma: no cover
+        raise RuntimeError(_DDP_MSG)
 
     # ------------------------------------------------------------------ optimiser
     def configure_optimizers(self):
@@ -273,4 +345,21 @@ class WorldModelTrainer(_Base):
         else:
             raise ValueError(cfg.SCHEDULER.NAME)
         self._optimizer = optimizer
+        self._attach_reducer(optimizer)
         return [optimizer], [{'scheduler': sched, 'interval': 'step'}]
+
+    def _attach_reducer(self, optimizer):
+        """Data parallelism (reference: Lightning's implicit DDP, train.py:93-98).  When torch.distributed is initialised
+        with more than one rank, the segmented reducer (muvo_amd/parallel.py) is attached here: backward hooks launch one
+        RCCL all-reduce per finished segment on a side stream, `on_after_backward` waits for them, AdamW divides by the
+        world size.  A DistributedDataParallel wrapper around this module would all-reduce a second time (and trip over
+        the 12 never-used `encoder_layer.*` tensors): refuse it."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        from muvo_amd.parallel import SegmentedGradReducer
+        self._reducer = SegmentedGradReducer(self.store)
+        self.model.segment_done = self._reducer.segment_done
+        self.model.dropout_rank = dist.get_rank()
+        optimizer.grad_scale = self._reducer.grad_scale
+        self.register_forward_pre_hook(_refuse_ddp)

@@ -34,8 +34,105 @@ def base_1d_cfg() -> dict:
 
 
 # --------------------------------------------------------------------------- preprocess
-def preprocess(batch: Dict[str, torch.Tensor], cfg: dict) -> Dict[str, torch.Tensor]:
-    """muvo/models/preprocess.py:201-225 (+ prepare_bev_labels :102-186), augmentation off."""
+def _tv_blend(a, b, ratio):
+    """torchvision _blend for float images: clamp(ratio*a + (1-ratio)*b, 0, 1)."""
+    return (ratio * a + (1.0 - ratio) * b).clamp(0, 1.0)
+
+
+def _tv_gray(img):
+    return (0.2989 * img[0] + 0.587 * img[1] + 0.114 * img[2]).unsqueeze(0)
+
+
+def _tv_hue(img, hf):
+    """torchvision adjust_hue on a float (3,H,W) image: RGB -> HSV, h = (h + hf) mod 1, HSV -> RGB."""
+    r, g, b = img[0], img[1], img[2]
+    maxc, minc = img.max(0).values, img.min(0).values
+    eqc = maxc == minc
+    cr = maxc - minc
+    one = torch.ones_like(maxc)
+    sat = cr / torch.where(eqc, one, maxc)
+    div = torch.where(eqc, one, cr)
+    rc, gc, bc = (maxc - r) / div, (maxc - g) / div, (maxc - b) / div
+    h = (maxc == r) * (bc - gc) + ((maxc == g) & (maxc != r)) * (2.0 + rc - bc) + ((maxc != g) & (maxc != r)) * (4.0 + gc - rc)
+    h = torch.fmod(h / 6.0 + 1.0, 1.0)
+    h = (h + hf) % 1.0
+    i = torch.floor(h * 6.0)
+    f = h * 6.0 - i
+    i = i.to(torch.int64) % 6
+    v = maxc
+    p = (v * (1.0 - sat)).clamp(0, 1)
+    q = (v * (1.0 - sat * f)).clamp(0, 1)
+    t = (v * (1.0 - sat * (1.0 - f))).clamp(0, 1)
+    table = torch.stack([torch.stack(c) for c in ((v, q, p, p, t, v), (t, v, v, q, p, p), (p, p, t, v, v, q))])  # (3, 6, H, W)
+    return table.gather(1, i.expand(3, 1, *i.shape)).squeeze(1)
+
+
+def pixel_augmentation(img: torch.Tensor, params: torch.Tensor) -> torch.Tensor:
+    """PixelAugmentation.forward (preprocess.py:316-333) with the random draws as an explicit table: img (b,s,3,H,W) in
+    [0,1] is modified IN PLACE and returned; params (b*s, 16): [0] 0 none / 1 gaussian blur 5x5 / 2 sharpen, [1] sigma |
+    factor, [2] colour jitter on, [3..6] op order (0 brightness 1 contrast 2 saturation 3 hue, 4 = op switched off by the
+    config), [7..10] factors.  Image algorithms: torchvision 0.15.2 (gaussian_blur: reflect padding + 2-D gaussian;
+    adjust_sharpness: blend with the 3x3 [1 1 1; 1 5 1; 1 1 1]/13 smoothing, border pixels kept; ColorJitter ops)."""
+    b, s = img.shape[:2]
+    for f in range(b * s):
+        P = params[f]
+        x = img[f // s, f % s]
+        mode = int(P[0])
+        if mode == 1:
+            t = torch.linspace(-2.0, 2.0, steps=5)
+            k = torch.exp(-0.5 * (t / float(P[1])).pow(2))
+            k = k / k.sum()
+            k2 = (k[:, None] * k[None, :]).expand(3, 1, 5, 5)
+            x = F.conv2d(F.pad(x[None], (2, 2, 2, 2), mode='reflect'), k2, groups=3)[0]
+        elif mode == 2 and x.shape[-1] > 2 and x.shape[-2] > 2:
+            k = torch.ones(3, 3)
+            k[1, 1] = 5.0
+            k = (k / k.sum()).expand(3, 1, 3, 3)
+            smooth = x.clone()
+            smooth[:, 1:-1, 1:-1] = F.conv2d(x[None], k, groups=3)[0]
+            x = _tv_blend(x, smooth, float(P[1]))
+        if int(P[2]):
+            for kk in range(4):
+                op = int(P[3 + kk])
+                if op == 0:
+                    x = _tv_blend(x, torch.zeros_like(x), float(P[7]))
+                elif op == 1:
+                    x = _tv_blend(x, _tv_gray(x).mean(), float(P[8]))
+                elif op == 2:
+                    x = _tv_blend(x, _tv_gray(x), float(P[9]))
+                elif op == 3:
+                    x = _tv_hue(x, float(P[10]))
+        img[f // s, f % s] = x
+    return img
+
+
+def route_augmentation(route: torch.Tensor, params: torch.Tensor) -> torch.Tensor:
+    """RouteAugmentation.forward (preprocess.py:349-365) with explicit draws: route (b,s,3,H,W) in [0,1]; params (b, 8):
+    [0] 0 none / 1 drop / 2 end of route / 3 affine, [1] leading rows zeroed, [2..7] torchvision's inverse affine matrix.
+    Affine = torchvision F.affine(nearest, fill 0): affine grid in normalised coordinates + grid_sample(align_corners=False)."""
+    out = route.clone()
+    b, s, _, H, W = route.shape
+    for i in range(b):
+        mode = int(params[i, 0])
+        if mode == 1:
+            out[i] = 0
+        elif mode == 2:
+            out[i][:, :, :int(params[i, 1])] = 0
+        elif mode == 3:
+            theta = params[i, 2:8].reshape(1, 2, 3).to(route.dtype)
+            base = torch.empty(1, H, W, 3)
+            base[..., 0] = torch.linspace(-W * 0.5 + 0.5, W * 0.5 + 0.5 - 1, steps=W)
+            base[..., 1] = torch.linspace(-H * 0.5 + 0.5, H * 0.5 + 0.5 - 1, steps=H).unsqueeze(-1)
+            base[..., 2] = 1
+            grid = base.view(1, H * W, 3).bmm(theta.transpose(1, 2) / torch.tensor([0.5 * W, 0.5 * H])).view(1, H, W, 2)
+            out[i] = F.grid_sample(route[i], grid.expand(s, H, W, 2), mode='nearest', padding_mode='zeros', align_corners=False)
+    return out
+
+
+def preprocess(batch: Dict[str, torch.Tensor], cfg: dict, pixel_aug=None, route_aug=None) -> Dict[str, torch.Tensor]:
+    """muvo/models/preprocess.py:201-225 (+ prepare_bev_labels :102-186).  pixel_aug / route_aug: the training-time
+    augmentation (preprocess.py:213-214) with its random draws as explicit tables (None = off); it runs after the label
+    pyramids were made and alters `rgb_label_1` (which IS the image) but not `rgb_label_2/4`."""
     out = dict(batch)
     img = batch['image'].float() / 255
     route = batch['route_map'].float() / 255
@@ -121,6 +218,12 @@ def preprocess(batch: Dict[str, torch.Tensor], cfg: dict) -> Dict[str, torch.Ten
         for f in (2, 4):
             prev = F.interpolate(prev.flatten(0, 1).float(), size=(h // f, w // f), mode='nearest').to(seg.dtype).view(b, s, 1, h // f, w // f)
             out[f'range_view_seg_label_{f}'] = prev
+    if pixel_aug is not None:
+        img = img.contiguous()
+        out['rgb_label_1'] = img                 # stays the same tensor as the (augmented) image
+        pixel_augmentation(img, pixel_aug)
+    if route_aug is not None:
+        route = route_augmentation(route, route_aug)
     mean = torch.tensor(cfg['MEAN']).view(3, 1, 1)
     std = torch.tensor(cfg['STD']).view(3, 1, 1)
     out['image'] = (img - mean) / std

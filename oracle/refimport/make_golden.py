@@ -10,6 +10,7 @@ the observed deviations in the fixture.
 Usage: python oracle/refimport/make_golden.py [--b 1 --s 2 --tag b1s2]
 """
 import argparse
+import gc
 import hashlib
 import json
 import os
@@ -113,6 +114,8 @@ def main():
     ap.add_argument('--tag', default=None)
     ap.add_argument('--steps', type=int, default=2)
     ap.add_argument('--skip-oracle', action='store_true')
+    ap.add_argument('--fp64-checkpoint', action='store_true',
+                    help='float64 run: recompute the three decoders in backward (b*s > 4 does not fit 62 GB otherwise)')
     ap.add_argument('--no-fp64', action='store_true', help='skip the float64 run of the reference (gradient noise floor)')
     args = ap.parse_args()
     tag = args.tag or f'b{args.b}s{args.s}'
@@ -141,12 +144,14 @@ def main():
     spec = {k: list(v.shape) for k, v in model.state_dict().items()}
     param_names = [n for n, _ in model.named_parameters()]
     os.makedirs(os.path.join(REPO, 'tests', 'golden'), exist_ok=True)
-    with open(os.path.join(REPO, 'tests', 'golden', 'state_dict_spec.json'), 'w') as f:
-        json.dump({'state_dict': spec, 'parameters': param_names}, f)
+    if tag == 'b1s2':
+        with open(os.path.join(REPO, 'tests', 'golden', 'state_dict_spec.json'), 'w') as f:
+            json.dump({'state_dict': spec, 'parameters': param_names}, f)
 
     # keep a copy of the effective cfg (data, not code)
-    with open(os.path.join(REPO, 'tests', 'golden', 'effective_cfg_base_1d.json'), 'w') as f:
-        json.dump(cfg_dict, f, indent=1, default=list)
+    if tag == 'b1s2':
+        with open(os.path.join(REPO, 'tests', 'golden', 'effective_cfg_base_1d.json'), 'w') as f:
+            json.dump(cfg_dict, f, indent=1, default=list)
 
     opts, scheds = trainer.configure_optimizers()
     opt, sched = opts[0], scheds[0]['scheduler']
@@ -211,6 +216,7 @@ def main():
             am = v1.argmax(dim=2).reshape(-1).to(torch.uint8).clone()
             am[tie.long()] = 0
             samples['voxel_1_near_tie_idx'] = tie.numpy()
+            samples['voxel_1_near_tie_argmax'] = v1.argmax(dim=2).reshape(-1).to(torch.uint8)[tie.long()].numpy()
             rec['voxel_1_near_tie_margin'] = NEAR_TIE
             rec['voxel_1_near_tie_count'] = int(tie.numel())
             rec['voxel_1_argmax_sha256_excl_near_ties'] = hashlib.sha256(
@@ -227,55 +233,6 @@ def main():
                                  'voxel_decoder.conv3.conv2.conv_act.0.weight']:
                 _, smp = tensor_stats(dict(model.named_parameters())[n].grad)
                 samples['grad.' + n] = smp
-            if not args.no_fp64:
-                # The same step of the REAL reference in float64: the truth the fp32 gradients are measured against.
-                # tests compare |hip - ref64| with the reference's own fp32 rounding error |ref32 - ref64| per tensor.
-                t0 = time.time()
-                torch.set_default_dtype(torch.float64)
-                _tensor_float = torch.Tensor.float
-                torch.Tensor.float = lambda self, *a, **k: self.double()   # the reference calls .float() on inputs
-                try:
-                    tr64 = ref_trainer.WorldModelTrainer(cfg_dict)
-                    tr64.train()
-                    tr64.preprocess.eval()
-                    tr64.model.load_state_dict(model.state_dict())
-                    tr64.double()
-                    for m in tr64.model.modules():
-                        if isinstance(m, torch.nn.Dropout):
-                            m.p = 0.0
-                        if isinstance(m, torch.nn.MultiheadAttention):
-                            m.dropout = 0.0
-                    b64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in raw.items()}
-                    with NoisePatch(eps.double(), coin):
-                        out64, _ = tr64.forward(b64)
-                    l64 = tr64.compute_loss(b64, out64)
-                    tot64 = tr64.loss_reducing(l64)
-                    tot64.backward()
-                finally:
-                    torch.set_default_dtype(torch.float32)
-                    torch.Tensor.float = _tensor_float
-                p64 = dict(tr64.model.named_parameters())
-                rec['total_fp64'] = float(tot64.item())
-                rec['losses_fp64'] = {k: float(v.item()) for k, v in l64.items()}
-                gn64, noise = {}, {}
-                for n, p in model.named_parameters():
-                    if p.grad is None:
-                        gn64[n] = None
-                        continue
-                    g64 = p64[n].grad
-                    gn64[n] = float(g64.pow(2).sum().sqrt())
-                    noise[n] = float((p.grad.double() - g64).pow(2).sum().sqrt())   # L2 of the fp32 reference's own error
-                rec['grad_l2_fp64'] = gn64
-                rec['grad_l2_ref32_err'] = noise
-                for key in [k for k in samples if k.startswith('grad.')]:
-                    n = key[5:]
-                    g64 = p64[n].grad.detach().contiguous().view(-1)
-                    stride = max(1, g64.numel() // 1024)
-                    samples['grad64.' + n] = g64[::stride][:1024].clone().numpy()
-                print(f'  fp64 reference fwd+bwd {time.time() - t0:.1f}s total={tot64.item():.9f} '
-                      f'(fp32 total {total.item():.9f})')
-                del tr64, out64, p64
-
         if oracle_model is not None:
             from oracle import muvo_ref
             t0 = time.time()
@@ -297,6 +254,66 @@ def main():
                                               max_abs_out_dev=odev)
             oracle_opt.step()
             oracle_sched.step()
+            del o_total, o_losses, o_out
+        del output, losses, total
+        gc.collect()
+        if step == 0 and not args.no_fp64:
+            # The same step of the REAL reference in float64: the truth the fp32 gradients are measured against.
+            # tests compare |hip - ref64| with the reference's own fp32 rounding error |ref32 - ref64| per tensor.
+            t0 = time.time()
+            torch.set_default_dtype(torch.float64)
+            _tensor_float = torch.Tensor.float
+            torch.Tensor.float = lambda self, *a, **k: self.double()   # the reference calls .float() on inputs
+            try:
+                tr64 = ref_trainer.WorldModelTrainer(cfg_dict)
+                tr64.train()
+                tr64.preprocess.eval()
+                tr64.model.load_state_dict(model.state_dict())
+                tr64.double()
+                for m in tr64.model.modules():
+                    if isinstance(m, torch.nn.Dropout):
+                        m.p = 0.0
+                    if isinstance(m, torch.nn.MultiheadAttention):
+                        m.dropout = 0.0
+                if args.fp64_checkpoint:
+                    # activation memory: the decoders hold most of it (float64: ~6 GB per frame).  Recompute them in
+                    # backward instead (torch.utils.checkpoint around the REAL modules' forward; deterministic CPU
+                    # arithmetic, so the gradients are the same numbers)
+                    from torch.utils.checkpoint import checkpoint
+                    for name in ('rgb_decoder', 'lidar_re', 'voxel_decoder'):
+                        mod = getattr(tr64.model, name)
+                        mod.forward = (lambda x, _f=mod.forward: checkpoint(_f, x, use_reentrant=False))
+                b64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in raw.items()}
+                with NoisePatch(eps.double(), coin):
+                    out64, _ = tr64.forward(b64)
+                l64 = tr64.compute_loss(b64, out64)
+                tot64 = tr64.loss_reducing(l64)
+                tot64.backward()
+            finally:
+                torch.set_default_dtype(torch.float32)
+                torch.Tensor.float = _tensor_float
+            p64 = dict(tr64.model.named_parameters())
+            rec['total_fp64'] = float(tot64.item())
+            rec['losses_fp64'] = {k: float(v.item()) for k, v in l64.items()}
+            gn64, noise = {}, {}
+            for n, p in model.named_parameters():
+                if p.grad is None:
+                    gn64[n] = None
+                    continue
+                g64 = p64[n].grad
+                gn64[n] = float(g64.pow(2).sum().sqrt())
+                noise[n] = float((p.grad.double() - g64).pow(2).sum().sqrt())   # L2 of the fp32 reference's own error
+            rec['grad_l2_fp64'] = gn64
+            rec['grad_l2_ref32_err'] = noise
+            for key in [k for k in samples if k.startswith('grad.')]:
+                n = key[5:]
+                g64 = p64[n].grad.detach().contiguous().view(-1)
+                stride = max(1, g64.numel() // 1024)
+                samples['grad64.' + n] = g64[::stride][:1024].clone().numpy()
+            print(f'  fp64 reference fwd+bwd {time.time() - t0:.1f}s total={tot64.item():.9f} '
+                  f'(fp32 total {rec["total"]:.9f})')
+            del tr64, out64, p64
+
         rec['lr'] = [g['lr'] for g in opt.param_groups]
         opt.step()
         sched.step()

@@ -75,6 +75,7 @@ def test_hip_aux_heads_match_reference(dev):
             assert getattr(getattr(cfg, name), key) == fx['cfg'][name][key], (name, key)
     tr = WorldModelTrainer(cfg.convert_to_dict(), device=dev)
     tr.train()
+    tr.preprocess.augment = False
     assert {k: list(v.shape) for k, v in tr.model.state_dict().items()} == fx['state_dict']
     detinit.fill_state_dict_(tr.model)
     for layer in tr.model.transformer_encoder.layers:

@@ -77,6 +77,7 @@ def _hip_bev_step(dev, arith):
     cfg.MODEL.TRANSFORMER.BEV = True
     tr = WorldModelTrainer(cfg.convert_to_dict(), device=dev)
     tr.train()
+    tr.preprocess.augment = False
     assert {k: list(v.shape) for k, v in tr.model.state_dict().items()} == fx['state_dict']
     bev_intr = tr.model.frustum_pooling.bev_intrinsics.clone()
     detinit.fill_state_dict_(tr.model)

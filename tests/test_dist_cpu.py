@@ -39,7 +39,7 @@ def _worker(rank, world, port, overlap, q):
     pad = torch.ones(store.numel, dtype=torch.bool)
     for o, k in store.offsets.values():
         pad[o:o + k] = False
-    assert [n for n, _, _ in store.segment_ranges] == ['decoders', 'rssm', 'fusion', 'encoders']
+    assert [n for n, _, _ in store.segment_ranges] == ['rgb_decoder', 'rssm', 'fusion', 'image_branch']
     for step in range(2):
         red.begin_step()
         store.zero_grad()
@@ -47,9 +47,11 @@ def _worker(rank, world, port, overlap, q):
             if n in used:
                 p.grad.add_(float(rank + 1) * (step + 1))
         if overlap:
-            red.segment_done('decoders')
+            red.segment_done('policy')   # no such segment in the toy: everything before it in layout order = 'rgb_decoder'
             red.segment_done('fusion')   # implies 'rssm'
+            assert red.launch_log == [('rgb_decoder', True), ('rssm', True), ('fusion', True)]
         red.finish()
+        assert [n for n, _ in red.launch_log] == ['rgb_decoder', 'rssm', 'fusion', 'image_branch']
         expect = float(sum(range(1, world + 1))) * (step + 1)
         assert torch.all(store.flat_grad[~pad] == expect), (store.flat_grad, expect)
         assert torch.all(store.flat_grad[pad] == 0) and torch.all(store.flat_param[pad] == 0)
@@ -71,3 +73,45 @@ def test_segmented_reducer_gloo(overlap):
         p.join(120)
         assert p.exitcode == 0
     assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]
+
+
+def test_optimizer_state_dict_format_cpu():
+    """FusedAdamW.state_dict()/load_state_dict() speak torch.optim.AdamW's format (host logic only: no kernel runs)."""
+    sys.path.insert(0, ROOT)
+    from muvo_amd.optim import FusedAdamW
+    from muvo_amd.param_store import ParamStore
+    torch.manual_seed(0)
+    m = _Toy()
+    store = ParamStore(m)
+    opt = FusedAdamW(store, lr=1e-3, weight_decay=0.01)
+    # groups in the reference's order: 1-D tensors (biases) -> no decay, matrices -> decay; the unused module is listed too
+    assert [len(g['params']) for g in opt.param_groups] == [5, 5]
+    assert opt.state_dict()['state'] == {}
+    opt._step = 3
+    store.exp_avg.uniform_(-1, 1)
+    store.exp_avg_sq.uniform_(0, 1)
+    sd = opt.state_dict()
+    assert len(sd['state']) == 8 and all(float(v['step']) == 3.0 for v in sd['state'].values())   # encoder_layer.*: no state
+    twin = [torch.nn.Parameter(torch.zeros(p.shape)) for g in opt.param_groups for p in g['params']]
+    ref = torch.optim.AdamW([{'params': twin[:5], 'weight_decay': 0.0}, {'params': twin[5:], 'weight_decay': 0.01}], lr=1e-3)
+    ref.load_state_dict(sd)                        # torch accepts it ...
+    back = ref.state_dict()                        # ... and what torch writes loads back
+    m2 = _Toy()
+    store2 = ParamStore(m2)
+    opt2 = FusedAdamW(store2, lr=5e-4, weight_decay=0.01)
+    opt2.load_state_dict(back)
+    assert opt2._step == 3 and opt2.param_groups[0]['lr'] == 1e-3
+    pad = torch.ones(store.numel, dtype=torch.bool)
+    for o, k in store.offsets.values():
+        pad[o:o + k] = False
+    assert torch.equal(store2.exp_avg[~pad], store.exp_avg[~pad]) and torch.equal(store2.exp_avg_sq[~pad], store.exp_avg_sq[~pad])
+    # gradients re-bind to the flat buffer after nn.Module.zero_grad(set_to_none=True); foreign gradient tensors are copied in
+    m.zero_grad(set_to_none=True)
+    assert m.rssm.weight.grad is None
+    m.rssm.weight.grad = torch.full_like(m.rssm.weight, 2.0)
+    store.flat_grad.fill_(7.0)
+    store.settle_grads()
+    o, k = store.offsets['rssm.weight']
+    assert torch.all(store.flat_grad[o:o + k] == 2.0) and m.rssm.weight.grad.data_ptr() == store.flat_grad.data_ptr() + 4 * o
+    o, k = store.offsets['encoder.bias']
+    assert torch.all(store.flat_grad[o:o + k] == 0.0)      # got no gradient since the reset: treated as zero

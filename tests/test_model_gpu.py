@@ -42,6 +42,7 @@ def _run_steps(dev):
     cfg = base_1d_cfg(RECEPTIVE_FIELD=s, FUTURE_HORIZON=0, STEPS=100000)
     tr = WorldModelTrainer(cfg.convert_to_dict(), device=dev)
     tr.train()
+    tr.preprocess.augment = False
     detinit.fill_state_dict_(tr.model)
     for layer in tr.model.transformer_encoder.layers:
         layer.p = 0.0

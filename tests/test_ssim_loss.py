@@ -58,6 +58,7 @@ def test_hip_ssim_loss_step_matches_reference(dev):
     cfg.LOSSES.SSIM = True
     tr = WorldModelTrainer(cfg.convert_to_dict(), device=dev)
     tr.train()
+    tr.preprocess.augment = False
     detinit.fill_state_dict_(tr.model)
     for layer in tr.model.transformer_encoder.layers:
         layer.p = 0.0

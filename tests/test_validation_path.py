@@ -74,7 +74,8 @@ def test_hip_validation_path_matches_reference(dev):
     cfg = base_1d_cfg(RECEPTIVE_FIELD=rf, FUTURE_HORIZON=fh, STEPS=100000)
     assert cfg.PREDICTION.N_SAMPLES == ns
     tr = WorldModelTrainer(cfg.convert_to_dict(), device=dev)
-    detinit.fill_state_dict_(tr.model)
+    tr.preprocess.augment = False   # validation_step calls self.train() like the reference (trainer.py:405), which would
+    detinit.fill_state_dict_(tr.model)  # switch the input augmentation on; the fixture was made without it
     for layer in tr.model.transformer_encoder.layers:
         layer.p = 0.0
     eps, use_prior = make_noise(b, rf + ns * fh, seed=fx['seed'])
@@ -104,7 +105,8 @@ def test_hip_validation_metrics_match_oracle(dev):
     b, rf, fh, ns = fx['b'], fx['rf'], fx['fh'], fx['n_samples']
     cfg = base_1d_cfg(RECEPTIVE_FIELD=rf, FUTURE_HORIZON=fh, STEPS=100000)
     tr = WorldModelTrainer(cfg.convert_to_dict(), device=dev)
-    detinit.fill_state_dict_(tr.model)
+    tr.preprocess.augment = False   # validation_step calls self.train() like the reference (trainer.py:405), which would
+    detinit.fill_state_dict_(tr.model)  # switch the input augmentation on; the fixture was made without it
     for layer in tr.model.transformer_encoder.layers:
         layer.p = 0.0
     eps, use_prior = make_noise(b, rf + ns * fh, seed=fx['seed'])

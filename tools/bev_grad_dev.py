@@ -14,7 +14,7 @@ dev = torch.device('cuda:0')
 b, s = fx['b'], fx['s']
 cfg = base_1d_cfg(RECEPTIVE_FIELD=s, FUTURE_HORIZON=0, STEPS=100000)
 cfg.MODEL.TRANSFORMER.BEV = True
-tr = WorldModelTrainer(cfg.convert_to_dict(), device=dev); tr.train()
+tr = WorldModelTrainer(cfg.convert_to_dict(), device=dev); tr.train(); tr.preprocess.augment = False
 bev_intr = tr.model.frustum_pooling.bev_intrinsics.clone()
 detinit.fill_state_dict_(tr.model)
 tr.model.frustum_pooling.bev_intrinsics.copy_(bev_intr)

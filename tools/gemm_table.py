@@ -10,7 +10,7 @@ dev = torch.device('cuda:0')
 B, S = 2, 10
 cfg = base_1d_cfg(RECEPTIVE_FIELD=6, FUTURE_HORIZON=4, BATCHSIZE=B, STEPS=100000)
 torch.manual_seed(1234)
-tr = WorldModelTrainer(cfg.convert_to_dict(), device=dev); tr.train()
+tr = WorldModelTrainer(cfg.convert_to_dict(), device=dev); tr.train(); tr.preprocess.augment = False
 opts, scheds = tr.configure_optimizers(); opt, sched = opts[0], scheds[0]['scheduler']
 batches = [make_batch(B, S, seed=1234 + k, device=dev) for k in range(2)]
 def step(i):

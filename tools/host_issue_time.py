@@ -11,7 +11,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 cfg = base_1d_cfg(RECEPTIVE_FIELD=max(S - 4, 1), FUTURE_HORIZON=S - max(S - 4, 1), BATCHSIZE=B, STEPS=100000)
 torch.manual_seed(1234)
-tr = WorldModelTrainer(cfg.convert_to_dict(), device=dev); tr.train()
+tr = WorldModelTrainer(cfg.convert_to_dict(), device=dev); tr.train(); tr.preprocess.augment = False
 opts, scheds = tr.configure_optimizers(); opt, sched = opts[0], scheds[0]['scheduler']
 batches = [make_batch(B, S, seed=1234 + k, device=dev) for k in range(2)]
 def step(i):

@@ -16,6 +16,7 @@ cfg = base_1d_cfg(RECEPTIVE_FIELD=6, FUTURE_HORIZON=4, BATCHSIZE=2, STEPS=100000
 torch.manual_seed(1234)
 tr = WorldModelTrainer(cfg.convert_to_dict(), device=dev)
 tr.train()
+tr.preprocess.augment = False
 opts, scheds = tr.configure_optimizers()
 opt, sched = opts[0], scheds[0]['scheduler']
 batches = [make_batch(2, 10, seed=1234 + k, device=dev) for k in range(2)]
