@@ -113,6 +113,12 @@ int muvo_conv_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp_dg
  * dy * act'(y) (y may be NULL with MUVO_ACT_NONE), dbias += its per-channel sums (dbias may be NULL) */
 int muvo_conv_prepare_dy(const muvo_conv_desc* d, const float* y, const float* dy, int act, float slope, void* ws_dy,
                          float* dbias, void* stream);
+/* The operand layout of the bf16x3 kernels on its own: x (N,C,S) fp32 -> ws = [bf16 hi plane | bf16 lo plane] channels-last
+ * (N,S,roundup(C,8)) (+ 16 zero bytes + scratch); optionally multiplied by act'(y) first and with per-channel sums added to
+ * dbias (the backward preamble above without a descriptor).  ws: muvo_split_planes_bytes(N, C, S) bytes. */
+int64_t muvo_split_planes_bytes(int N, int C, int64_t S);
+int muvo_split_planes(const float* x, void* ws, int N, int C, int64_t S, const float* y, int act, float slope, float* dbias,
+                      void* stream);
 /* dw += conv_weight_grad(x, dy) (PyTorch layout); dbias += sum(dy) if non-NULL.
  * dwp_scratch: fwd_floats floats of workspace that must be ALL-ZERO on entry and is left all-zero on return (the split-K
  * partial sums accumulate in it with float atomics; the unpack pass clears what it reads, so no memset is needed per call).  ws_x / ws_dy: see muvo_conv_workspace_bytes (may be NULL
@@ -184,9 +190,11 @@ int muvo_batchsum(const float* x, float* out, int N, int64_t inner, int accumula
 int muvo_nchw_to_tokens(const float* x, const float* pos, const float* temb, int temb_stride, float* tokens, int N, int C,
                         int L, int l0, void* stream);
 int muvo_tokens_to_nchw(const float* tokens, float* x, int N, int C, int L, int l0, void* stream);
-int muvo_maxpool2d_fwd(const float* x, float* y, int32_t* idx, int64_t NC, int H, int W, int OH, int OW, int k, int s, int p,
+/* F.max_pool2d 3x3 s2 p1 (ResNet stem) / 2x2 s2 (DecoderDS, common.py:127-128); idx: one byte per output = position a*k + b of
+ * the (first) maximum inside its window, consumed by the backward pass */
+int muvo_maxpool2d_fwd(const float* x, float* y, uint8_t* idx, int64_t NC, int H, int W, int OH, int OW, int k, int s, int p,
                        void* stream);
-int muvo_maxpool2d_bwd(const float* dy, const int32_t* idx, float* dx, int64_t NC, int H, int W, int OH, int OW, int k, int s,
+int muvo_maxpool2d_bwd(const float* dy, const uint8_t* idx, float* dx, int64_t NC, int H, int W, int OH, int OW, int k, int s,
                        int p, void* stream);
 int muvo_avgpool_fwd(const float* x, float* y, int64_t G, int64_t S, void* stream);
 int muvo_avgpool_bwd(const float* dy, float* dx, int64_t G, int64_t S, void* stream);

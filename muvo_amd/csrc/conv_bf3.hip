@@ -1090,6 +1090,82 @@ nchw_split_nhwc_kernel(const float* __restrict__ in, uint4* __restrict__ out_hi,
     out_hi[2 * ((size_t)gridDim.z * S * Cp >> 3)] = make_uint4(0u, 0u, 0u, 0u);
 }
 
+// Second form of the same pass for S % 4 == 0: a workgroup owns 64 channels x 256 pixels, every lane reads FOUR consecutive
+// pixels of a channel as one 16-byte load (a wave instruction = 1 KB contiguous of one channel row instead of 256 B: four times
+// fewer DRAM pages opened per byte, 16 loads of 16 B in flight per thread).  LDS holds [plane][channel pair][256 pixels]
+// (row stride 258 words: the transposing reads below hit 32 distinct banks per half wave).
+#define SPLIT2_PS 258
+__global__ void __launch_bounds__(256)
+nchw_split_nhwc_v4_kernel(const float* __restrict__ in, uint4* __restrict__ out_hi, uint4* __restrict__ out_lo, int C, int Cp,
+                          long S, const float* __restrict__ yact, int act, float slope, float* __restrict__ dbias) {
+  extern __shared__ unsigned sp_lds[];
+  unsigned* th = sp_lds;
+  unsigned* tl = sp_lds + 32 * SPLIT2_PS;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c0 = blockIdx.y * 64, n = blockIdx.z;
+  const long s0 = (long)blockIdx.x * 256;
+  const float* inn = in + (size_t)n * C * S;
+  const float* yn = yact ? yact + (size_t)n * C * S : nullptr;
+  const long s = s0 + 4 * lane;
+  const bool sin = s < S;                // S % 4 == 0: the four pixels are inside or outside together
+  f32x4 v[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int c = c0 + 2 * (w * 8 + (r >> 1)) + (r & 1);
+    v[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (sin && c < C) v[r] = *(const f32x4*)(inn + (size_t)c * S + s);
+  }
+  if (yn) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = c0 + 2 * (w * 8 + (r >> 1)) + (r & 1);
+      if (sin && c < C) {
+        const f32x4 y = *(const f32x4*)(yn + (size_t)c * S + s);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[r][j] *= act_grad_from_out(y[j], act, slope);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int k = w * 8 + r;
+    unsigned hi[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split2(v[2 * r][j], v[2 * r + 1][j], hi[j], lo[j]);
+    uint2* ph = (uint2*)(th + k * SPLIT2_PS + 4 * lane);
+    uint2* pq = (uint2*)(tl + k * SPLIT2_PS + 4 * lane);
+    ph[0] = make_uint2(hi[0], hi[1]);
+    ph[1] = make_uint2(hi[2], hi[3]);
+    pq[0] = make_uint2(lo[0], lo[1]);
+    pq[1] = make_uint2(lo[2], lo[3]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int item = tid + 256 * r;
+    const int pix = item >> 3, ch = item & 7;
+    const long so = s0 + pix;
+    const int c = c0 + ch * 8;
+    if (so < S && c < Cp) {
+      const unsigned* ph = th + (4 * ch) * SPLIT2_PS + pix;
+      const unsigned* pq = tl + (4 * ch) * SPLIT2_PS + pix;
+      const size_t o = (((size_t)n * S + so) * Cp + c) >> 3;
+      out_hi[o] = make_uint4(ph[0], ph[SPLIT2_PS], ph[2 * SPLIT2_PS], ph[3 * SPLIT2_PS]);
+      out_lo[o] = make_uint4(pq[0], pq[SPLIT2_PS], pq[2 * SPLIT2_PS], pq[3 * SPLIT2_PS]);
+    }
+  }
+  if (dbias) {   // lanes of a wave = 256 pixels of the same 16 channels
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = c0 + 2 * (w * 8 + (r >> 1)) + (r & 1);
+      const float sum = wave_sum(v[r][0] + v[r][1] + v[r][2] + v[r][3]);
+      if (lane == 0 && c < C) atomicAdd(dbias + (size_t)(blockIdx.x % BIAS_REPLICAS) * Cp + c, sum);
+    }
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0)
+    out_hi[2 * ((size_t)gridDim.z * S * Cp >> 3)] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 // dbias[c] += sum over replicas
 __global__ void bias_replica_reduce_kernel(const float* __restrict__ rep, float* __restrict__ dbias, int C, int Cp) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1248,8 +1324,20 @@ int bf3_split_input(const float* x, void* ws, int N, int C, long S, hipStream_t 
       return MUVO_ERR_HIP;
     }
   }
-  dim3 grid(cdiv(cdiv(S, 64), SPLIT_TILES), cdiv(Cp, 64), N);
-  hipLaunchKernelGGL(nchw_split_nhwc_kernel, grid, dim3(256), 0, st, x, hi, lo, C, Cp, S, yact, act, slope, rep);
+  static const int split_v4 = getenv("MUVO_SPLIT_V4") ? atoi(getenv("MUVO_SPLIT_V4")) : 1;
+  if (split_v4 && !yact && S % 4 == 0 && S >= 1024 && ((uintptr_t)x & 15) == 0) {   // 5.5 vs 4.5 TB/s (profiles/r02b_hbm.txt); the fused act'(y) form is faster on the 4-byte kernel
+    static bool attr_set = false;
+    constexpr int lds = 2 * 32 * SPLIT2_PS * 4;
+    if (!attr_set) {
+      hipFuncSetAttribute((const void*)nchw_split_nhwc_v4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr_set = true;
+    }
+    dim3 grid(cdiv(S, 256), cdiv(Cp, 64), N);
+    hipLaunchKernelGGL(nchw_split_nhwc_v4_kernel, grid, dim3(256), lds, st, x, hi, lo, C, Cp, S, yact, act, slope, rep);
+  } else {
+    dim3 grid(cdiv(cdiv(S, 64), SPLIT_TILES), cdiv(Cp, 64), N);
+    hipLaunchKernelGGL(nchw_split_nhwc_kernel, grid, dim3(256), 0, st, x, hi, lo, C, Cp, S, yact, act, slope, rep);
+  }
   if (dbias) hipLaunchKernelGGL(bias_replica_reduce_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, rep, dbias, C, Cp);
   MUVO_CHECK_LAUNCH("nchw_split_nhwc_kernel");
   return MUVO_OK;

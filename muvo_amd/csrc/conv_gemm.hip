@@ -1036,6 +1036,12 @@ int muvo_conv_wgrad(const muvo_conv_desc* d, const float* x, const float* dy, fl
 }
 
 // db[m] += sum_{n,s} dy[n][m][s]
+int64_t muvo_split_planes_bytes(int N, int C, int64_t S) { return bf3_workspace_bytes(N, C, (long)S); }
+int muvo_split_planes(const float* x, void* ws, int N, int C, int64_t S, const float* y, int act, float slope, float* dbias,
+                      void* stream) {
+  MUVO_CHECK_ARG(x && ws && N > 0 && C > 0 && S > 0, "split_planes: bad args");
+  return bf3_split_input(x, ws, N, C, (long)S, (hipStream_t)stream, act == MUVO_ACT_NONE ? nullptr : y, act, slope, dbias);
+}
 int muvo_bias_grad_nchw(const float* dy, float* db, int N, int M, int64_t S, void* stream) {
   MUVO_CHECK_ARG(dy && db && N > 0 && M > 0 && S > 0, "bias_grad_nchw: bad args");
   int chunks = cdiv((long)N * S, 65536);

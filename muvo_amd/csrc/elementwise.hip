@@ -102,51 +102,72 @@ __global__ void __launch_bounds__(256) tokens_to_nchw_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------- pooling
-__global__ void maxpool2d_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int* __restrict__ idx, long NC,
-                                     int H, int W, int OH, int OW, int k, int s, int p) {
-  const long n = NC * OH * OW;
-  GRID_STRIDE(i, n) {
-    const int ow = (int)(i % OW);
-    long r = i / OW;
-    const int oh = (int)(r % OH);
-    const long nc = r / OH;
-    const float* xp = x + nc * H * W;
-    float best = -INFINITY;
-    int bi = -1;
-    for (int a = 0; a < k; ++a) {
-      const int h = oh * s - p + a;
-      if ((unsigned)h >= (unsigned)H) continue;
-      for (int b = 0; b < k; ++b) {
-        const int w = ow * s - p + b;
-        if ((unsigned)w >= (unsigned)W) continue;
-        const float v = xp[h * W + w];
-        if (v > best || bi < 0) { best = v; bi = h * W + w; }   // first max wins (PyTorch semantics)
+// max_pool2d (ResNet stem 3x3 s2 p1, DecoderDS 2x2 s2): the winner of each window is remembered as ONE BYTE (its position
+// a*K + b inside the window; first maximum wins like PyTorch), so the backward pass moves 1 instead of 4 index bytes per
+// output.  Thread = (4 consecutive columns, 1 row); no integer division per element (3-D grid).
+template <int K, int S, int P>
+__global__ void __launch_bounds__(256) maxpool2d_fwd_t_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                              uint8_t* __restrict__ idx, int H, int W, int OH, int OW) {
+  const int ow0 = (blockIdx.x * 64 + threadIdx.x) * 4, oh = blockIdx.y * 4 + threadIdx.y;
+  if (ow0 >= OW || oh >= OH) return;
+  const long nc = blockIdx.z;
+  const float* xp = x + nc * (long)H * W;
+  float best[4];
+  int bi[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { best[e] = -INFINITY; bi[e] = -1; }
+#pragma unroll
+  for (int a = 0; a < K; ++a) {
+    const int h = oh * S - P + a;
+    if ((unsigned)h >= (unsigned)H) continue;
+    const float* row = xp + (long)h * W;
+    constexpr int SPAN = 3 * S + K;                 // columns touched by 4 consecutive windows
+    float v[SPAN];
+    const int w0 = ow0 * S - P;
+#pragma unroll
+    for (int j = 0; j < SPAN; ++j) v[j] = ((unsigned)(w0 + j) < (unsigned)W) ? row[w0 + j] : -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int b = 0; b < K; ++b) {
+        const bool in = (unsigned)(w0 + e * S + b) < (unsigned)W;
+        const float t = v[e * S + b];
+        if (in && (t > best[e] || bi[e] < 0)) { best[e] = t; bi[e] = a * K + b; }
       }
-    }
-    y[i] = best;
-    idx[i] = bi;
   }
+  const long o = (nc * OH + oh) * (long)OW + ow0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (ow0 + e < OW) { y[o + e] = best[e]; idx[o + e] = (uint8_t)bi[e]; }
 }
-__global__ void maxpool2d_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ idx, float* __restrict__ dx,
-                                     long NC, int H, int W, int OH, int OW, int k, int s, int p) {
-  const long n = NC * H * W;
-  GRID_STRIDE(i, n) {
-    const int w = (int)(i % W);
-    long r = i / W;
-    const int h = (int)(r % H);
-    const long nc = r / H;
-    const int me = h * W + w;
-    int oh0 = (h + p - k + s) / s; if (h + p - k + 1 <= 0) oh0 = 0;
-    int ow0 = (w + p - k + s) / s; if (w + p - k + 1 <= 0) ow0 = 0;
-    int oh1 = (h + p) / s; if (oh1 > OH - 1) oh1 = OH - 1;
-    int ow1 = (w + p) / s; if (ow1 > OW - 1) ow1 = OW - 1;
-    float g = 0.f;
-    for (int oh = oh0; oh <= oh1; ++oh)
-      for (int ow = ow0; ow <= ow1; ++ow) {
-        const long o = (nc * OH + oh) * OW + ow;
-        if (idx[o] == me) g += dy[o];
-      }
-    dx[i] = g;
+template <int K, int S, int P>
+__global__ void __launch_bounds__(256) maxpool2d_bwd_t_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                              float* __restrict__ dx, int H, int W, int OH, int OW) {
+  const int w0 = (blockIdx.x * 64 + threadIdx.x) * 4, h = blockIdx.y * 4 + threadIdx.y;
+  if (w0 >= W || h >= H) return;
+  const long nc = blockIdx.z;
+  float g[4] = {0.f, 0.f, 0.f, 0.f};
+  // windows that contain row h: oh with oh*S - P <= h <= oh*S - P + K - 1
+  const int oh_lo = (h + P - K + 1 <= 0) ? 0 : (h + P - K + S) / S, oh_hi = min((h + P) / S, OH - 1);
+  const int ow_lo = (w0 + P - K + 1 <= 0) ? 0 : (w0 + P - K + S) / S, ow_hi = min((w0 + 3 + P) / S, OW - 1);
+  for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+    const int a = h - (oh * S - P);
+    const long ro = (nc * OH + oh) * (long)OW;
+    for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+      const int b0 = w0 - (ow * S - P);            // position of column w0 inside window ow
+      const int win = idx[ro + ow] - a * K;        // winning column offset if the winner lies in row a
+      const float d = dy[ro + ow];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (win == b0 + e && (unsigned)(b0 + e) < (unsigned)K) g[e] += d;
+    }
+  }
+  float* o = dx + (nc * H + h) * (long)W + w0;
+  if (w0 + 3 < W && (((uintptr_t)o) & 15) == 0) {
+    *(float4*)o = make_float4(g[0], g[1], g[2], g[3]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (w0 + e < W) o[e] = g[e];
   }
 }
 // y[g] = mean_s x[g*S + s]; one wave per group
@@ -655,20 +676,25 @@ int muvo_tokens_to_nchw(const float* tokens, float* x, int N, int C, int L, int 
   MUVO_CHECK_LAUNCH("tokens_to_nchw");
   return MUVO_OK;
 }
-int muvo_maxpool2d_fwd(const float* x, float* y, int32_t* idx, int64_t NC, int H, int W, int OH, int OW, int k, int s,
-                       int p, void* stream) {
-  MUVO_CHECK_ARG(x && y && idx && NC > 0 && k > 0 && s > 0 && p >= 0 && p < k, "maxpool2d_fwd: bad args");
-  MUVO_CHECK_ARG(OH == (H + 2 * p - k) / s + 1 && OW == (W + 2 * p - k) / s + 1, "maxpool2d_fwd: bad output size");
-  hipLaunchKernelGGL(maxpool2d_fwd_kernel, dim3(ew_grid(NC * OH * OW)), dim3(256), 0, ST, x, y, idx, (long)NC, H, W, OH, OW,
-                     k, s, p);
+int muvo_maxpool2d_fwd(const float* x, float* y, uint8_t* idx, int64_t NC, int H, int W, int OH, int OW, int k, int s, int p,
+                       void* stream) {
+  MUVO_CHECK_ARG(x && y && idx && NC > 0 && NC <= 2147483647L, "maxpool2d_fwd: bad args");
+  MUVO_CHECK_ARG((k == 3 && s == 2 && p == 1) || (k == 2 && s == 2 && p == 0), "maxpool2d: only 3x3 s2 p1 and 2x2 s2 p0 are on the path");
+  MUVO_CHECK_ARG(OH == (H + 2 * p - k) / s + 1 && OW == (W + 2 * p - k) / s + 1 && cdiv(OH, 4) <= 65535, "maxpool2d_fwd: output size");
+  dim3 grid(cdiv(OW, 256), cdiv(OH, 4), (unsigned)NC), block(64, 4);
+  if (k == 3) hipLaunchKernelGGL((maxpool2d_fwd_t_kernel<3, 2, 1>), grid, block, 0, ST, x, y, idx, H, W, OH, OW);
+  else hipLaunchKernelGGL((maxpool2d_fwd_t_kernel<2, 2, 0>), grid, block, 0, ST, x, y, idx, H, W, OH, OW);
   MUVO_CHECK_LAUNCH("maxpool2d_fwd");
   return MUVO_OK;
 }
-int muvo_maxpool2d_bwd(const float* dy, const int32_t* idx, float* dx, int64_t NC, int H, int W, int OH, int OW, int k,
+int muvo_maxpool2d_bwd(const float* dy, const uint8_t* idx, float* dx, int64_t NC, int H, int W, int OH, int OW, int k,
                        int s, int p, void* stream) {
-  MUVO_CHECK_ARG(dy && dx && idx && NC > 0 && k > 0 && s > 0, "maxpool2d_bwd: bad args");
-  hipLaunchKernelGGL(maxpool2d_bwd_kernel, dim3(ew_grid(NC * H * W)), dim3(256), 0, ST, dy, idx, dx, (long)NC, H, W, OH, OW,
-                     k, s, p);
+  MUVO_CHECK_ARG(dy && dx && idx && NC > 0 && NC <= 2147483647L, "maxpool2d_bwd: bad args");
+  MUVO_CHECK_ARG((k == 3 && s == 2 && p == 1) || (k == 2 && s == 2 && p == 0), "maxpool2d: only 3x3 s2 p1 and 2x2 s2 p0 are on the path");
+  MUVO_CHECK_ARG(cdiv(H, 4) <= 65535, "maxpool2d_bwd: image too tall");
+  dim3 grid(cdiv(W, 256), cdiv(H, 4), (unsigned)NC), block(64, 4);
+  if (k == 3) hipLaunchKernelGGL((maxpool2d_bwd_t_kernel<3, 2, 1>), grid, block, 0, ST, dy, idx, dx, H, W, OH, OW);
+  else hipLaunchKernelGGL((maxpool2d_bwd_t_kernel<2, 2, 0>), grid, block, 0, ST, dy, idx, dx, H, W, OH, OW);
   MUVO_CHECK_LAUNCH("maxpool2d_bwd");
   return MUVO_OK;
 }

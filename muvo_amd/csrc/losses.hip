@@ -82,46 +82,80 @@ __global__ void __launch_bounds__(256) voxel_loss_fwd_kernel(const float* __rest
   constexpr int NCU = CT ? CT : MAXC;     // unrolled class loops
   const int Cc = CT ? CT : C;
   __shared__ double red[4];
-  const long n = F * V;
   float ce = 0.f, wsum = 0.f;
   float P[NCU], Nn[NCU], T[NCU], Q[NCU], R[NCU];
   float gI = 0.f, gA = 0.f, gB = 0.f, gS = 0.f, gR = 0.f;
 #pragma unroll
   for (int c = 0; c < NCU; ++c) { P[c] = 0.f; Nn[c] = 0.f; T[c] = 0.f; Q[c] = 0.f; R[c] = 0.f; }
-  // fp32 thread-local accumulation over <= ~2k voxels per thread (values in [0,1]) then fp64 combine
-  GRID_STRIDE(i, n) {
-    const long f = i / V, v = i - f * V;
-    const float* lp = logits + f * C * V + v;
-    const int t = target[i];
-    float l[NCU];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int c = 0; c < NCU; ++c)
-      if (c < Cc) { l[c] = lp[(long)c * V]; mx = fmaxf(mx, l[c]); }
-    float se = 0.f;
-#pragma unroll
-    for (int c = 0; c < NCU; ++c)
-      if (c < Cc) { l[c] = expf(l[c] - mx); se += l[c]; }
-    const float inv = 1.f / se;
-    const float lse = logf(se) + mx;
-    // cross entropy (target must be a valid class for CE; reference casts the same labels to long)
-    if (t < C) {
-      const float w = class_w ? class_w[t] : 1.f;
-      ce += w * (lse - lp[(long)t * V]);
-      wsum += 1.f;
-    }
-    const bool m = t != 255;
-    if (m) {
+  // grid = (voxel blocks, frames): no 64-bit division per voxel; a thread takes FOUR consecutive voxels per trip (one 16-byte
+  // load per class plane + one 4-byte label load when V % 4 == 0).  fp32 thread-local accumulation over <= ~2k voxels per
+  // thread (values in [0,1]), then fp64 combine.
+  const long f = blockIdx.y;
+  const float* lf = logits + f * C * V;
+  const uint8_t* tf = target + f * V;
+  const bool vec = (V & 3) == 0;
+  const long nq = (V + 3) >> 2;
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nq; q += (long)gridDim.x * 256) {
+    const long v0 = q << 2;
+    float lv[NCU][4];
+    int tv[4];
+    if (vec) {
 #pragma unroll
       for (int c = 0; c < NCU; ++c)
         if (c < Cc) {
-          const float p = l[c] * inv;
-          const float ct = t == c ? 1.f : 0.f;
-          P[c] += p; Nn[c] += p * ct; T[c] += ct; Q[c] += (1.f - p) * (1.f - ct); R[c] += 1.f - ct;
+          const float4 t4 = *(const float4*)(lf + (long)c * V + v0);
+          lv[c][0] = t4.x; lv[c][1] = t4.y; lv[c][2] = t4.z; lv[c][3] = t4.w;
         }
-      const float ep = l[0] * inv, nep = 1.f - ep;
-      const float net = t != 0 ? 1.f : 0.f;
-      gI += net * nep; gA += nep; gB += net; gS += (1.f - net) * ep; gR += 1.f - net;
+      const unsigned t4 = *(const unsigned*)(tf + v0);
+      tv[0] = t4 & 255; tv[1] = (t4 >> 8) & 255; tv[2] = (t4 >> 16) & 255; tv[3] = t4 >> 24;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool in = v0 + e < V;
+        tv[e] = in ? tf[v0 + e] : 0;
+#pragma unroll
+        for (int c = 0; c < NCU; ++c)
+          if (c < Cc) lv[c][e] = in ? lf[(long)c * V + v0 + e] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (!vec && v0 + e >= V) continue;
+      const int t = tv[e];
+      float l[NCU];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int c = 0; c < NCU; ++c)
+        if (c < Cc) { l[c] = lv[c][e]; mx = fmaxf(mx, l[c]); }
+      float lt = 0.f;                       // logit of the target class
+#pragma unroll
+      for (int c = 0; c < NCU; ++c)
+        if (c < Cc && c == t) lt = l[c];
+      float se = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCU; ++c)
+        if (c < Cc) { l[c] = expf(l[c] - mx); se += l[c]; }
+      const float inv = 1.f / se;
+      const float lse = logf(se) + mx;
+      // cross entropy (target must be a valid class for CE; reference casts the same labels to long)
+      if (t < C) {
+        const float w = class_w ? class_w[t] : 1.f;
+        ce += w * (lse - lt);
+        wsum += 1.f;
+      }
+      const bool m = t != 255;
+      if (m) {
+#pragma unroll
+        for (int c = 0; c < NCU; ++c)
+          if (c < Cc) {
+            const float p = l[c] * inv;
+            const float ct = t == c ? 1.f : 0.f;
+            P[c] += p; Nn[c] += p * ct; T[c] += ct; Q[c] += (1.f - p) * (1.f - ct); R[c] += 1.f - ct;
+          }
+        const float ep = l[0] * inv, nep = 1.f - ep;
+        const float net = t != 0 ? 1.f : 0.f;
+        gI += net * nep; gA += nep; gB += net; gS += (1.f - net) * ep; gR += 1.f - net;
+      }
     }
   }
   block_atomic_add_d((double)ce, &stats[0], red);
@@ -196,45 +230,90 @@ __global__ void __launch_bounds__(256) voxel_loss_bwd_kernel(const float* __rest
                                                              float weight) {
   constexpr int NCU = CT ? CT : MAXC;     // unrolled class loops
   const int Cc = CT ? CT : C;
-  const long n = F * V;
   const float gce = gout[0] * weight, gsem = gout[1] * weight, ggeo = gout[2] * weight;
-  GRID_STRIDE(i, n) {
-    const long f = i / V, v = i - f * V;
-    const float* lp = logits + f * C * V + v;
-    float* dp = dlogits + f * C * V + v;
-    const int t = target[i];
-    float p[NCU], g[NCU];
-    float mx = -INFINITY;
+  float ka[NCU], kb[NCU], ks[NCU];
 #pragma unroll
-    for (int c = 0; c < NCU; ++c)
-      if (c < Cc) { p[c] = lp[(long)c * V]; mx = fmaxf(mx, p[c]); }
-    float se = 0.f;
+  for (int c = 0; c < NCU; ++c)
+    if (c < Cc) { ka[c] = coef[1 + 3 * c]; kb[c] = coef[2 + 3 * c]; ks[c] = coef[3 + 3 * c]; }
+  const float g0 = coef[1 + 3 * C], g1 = coef[2 + 3 * C], g2 = coef[3 + 3 * C], inv_n = coef[0];
+  // same thread mapping as the forward pass: (voxel blocks, frames), four consecutive voxels per trip
+  const long f = blockIdx.y;
+  const float* lf = logits + f * C * V;
+  float* df = dlogits + f * C * V;
+  const uint8_t* tf = target + f * V;
+  const bool vec = (V & 3) == 0;
+  const long nq = (V + 3) >> 2;
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nq; q += (long)gridDim.x * 256) {
+    const long v0 = q << 2;
+    float lv[NCU][4];
+    int tv[4];
+    if (vec) {
 #pragma unroll
-    for (int c = 0; c < NCU; ++c)
-      if (c < Cc) { p[c] = expf(p[c] - mx); se += p[c]; }
-    const float inv = 1.f / se;
-    const bool m = t != 255;
-    float dot = 0.f;
-#pragma unroll
-    for (int c = 0; c < NCU; ++c)
-      if (c < Cc) {
-        p[c] *= inv;
-        float gc = 0.f;
-        if (m) {
-          const float ct = t == c ? 1.f : 0.f;
-          gc = gsem * (coef[1 + 3 * c] * ct + coef[2 + 3 * c] + coef[3 + 3 * c] * (1.f - ct));
-          if (c == 0) {
-            const float net = t != 0 ? 1.f : 0.f;
-            gc += ggeo * (coef[1 + 3 * C] * net + coef[2 + 3 * C] + coef[3 + 3 * C] * (1.f - net));
-          }
+      for (int c = 0; c < NCU; ++c)
+        if (c < Cc) {
+          const float4 t4 = *(const float4*)(lf + (long)c * V + v0);
+          lv[c][0] = t4.x; lv[c][1] = t4.y; lv[c][2] = t4.z; lv[c][3] = t4.w;
         }
-        g[c] = gc;
-        dot += gc * p[c];
-      }
-    const float cw = (t < C) ? (class_w ? class_w[t] : 1.f) * gce * coef[0] : 0.f;
+      const unsigned t4 = *(const unsigned*)(tf + v0);
+      tv[0] = t4 & 255; tv[1] = (t4 >> 8) & 255; tv[2] = (t4 >> 16) & 255; tv[3] = t4 >> 24;
+    } else {
 #pragma unroll
-    for (int c = 0; c < NCU; ++c)
-      if (c < Cc) dp[(long)c * V] = p[c] * (g[c] - dot) + cw * (p[c] - (t == c ? 1.f : 0.f));
+      for (int e = 0; e < 4; ++e) {
+        const bool in = v0 + e < V;
+        tv[e] = in ? tf[v0 + e] : 0;
+#pragma unroll
+        for (int c = 0; c < NCU; ++c)
+          if (c < Cc) lv[c][e] = in ? lf[(long)c * V + v0 + e] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int t = tv[e];
+      float p[NCU], g[NCU];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int c = 0; c < NCU; ++c)
+        if (c < Cc) { p[c] = lv[c][e]; mx = fmaxf(mx, p[c]); }
+      float se = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCU; ++c)
+        if (c < Cc) { p[c] = expf(p[c] - mx); se += p[c]; }
+      const float inv = 1.f / se;
+      const bool m = t != 255;
+      float dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCU; ++c)
+        if (c < Cc) {
+          p[c] *= inv;
+          float gc = 0.f;
+          if (m) {
+            const float ct = t == c ? 1.f : 0.f;
+            gc = gsem * (ka[c] * ct + kb[c] + ks[c] * (1.f - ct));
+            if (c == 0) {
+              const float net = t != 0 ? 1.f : 0.f;
+              gc += ggeo * (g0 * net + g1 + g2 * (1.f - net));
+            }
+          }
+          g[c] = gc;
+          dot += gc * p[c];
+        }
+      const float cw = (t < C) ? (class_w ? class_w[t] : 1.f) * gce * inv_n : 0.f;
+#pragma unroll
+      for (int c = 0; c < NCU; ++c)
+        if (c < Cc) lv[c][e] = p[c] * (g[c] - dot) + cw * (p[c] - (t == c ? 1.f : 0.f));
+    }
+    if (vec) {
+#pragma unroll
+      for (int c = 0; c < NCU; ++c)
+        if (c < Cc) *(float4*)(df + (long)c * V + v0) = make_float4(lv[c][0], lv[c][1], lv[c][2], lv[c][3]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (v0 + e < V)
+#pragma unroll
+          for (int c = 0; c < NCU; ++c)
+            if (c < Cc) df[(long)c * V + v0 + e] = lv[c][e];
+    }
   }
 }
 
@@ -401,11 +480,14 @@ int muvo_voxel_loss_fwd(const float* logits, const uint8_t* target, int64_t F, i
   MUVO_CHECK_ARG(logits && target && stats && coef && loss3, "voxel_loss_fwd: null pointer");
   MUVO_CHECK_ARG(F > 0 && V > 0 && C >= 2 && C <= MAXC, "voxel_loss_fwd: C=%d unsupported (2..%d)", C, MAXC);
   hipMemsetAsync(stats, 0, sizeof(double) * (2 + 5 * C + 5), ST);
-  long nb = (F * V + 256L * 8 - 1) / (256L * 8);
+  MUVO_CHECK_ARG(F <= 65535, "voxel_loss_fwd: more than 65535 frames");
+  // per frame: one workgroup per 8192 voxels (32 per thread), at most ~4096 workgroups in all
+  long nbx = (V + 8191) / 8192;
   static const long nb_cap = getenv("MUVO_VOXLOSS_BLOCKS") ? atol(getenv("MUVO_VOXLOSS_BLOCKS")) : 4096;
-  if (nb > nb_cap) nb = nb_cap;
-  if (C == 2) hipLaunchKernelGGL(voxel_loss_fwd_kernel<2>, dim3((int)nb), dim3(256), 0, ST, logits, target, (long)F, C, (long)V, class_w, stats);
-  else hipLaunchKernelGGL(voxel_loss_fwd_kernel<0>, dim3((int)nb), dim3(256), 0, ST, logits, target, (long)F, C, (long)V, class_w, stats);
+  if (nbx * F > nb_cap) nbx = nb_cap / F > 0 ? nb_cap / F : 1;
+  const dim3 grid((unsigned)nbx, (unsigned)F);
+  if (C == 2) hipLaunchKernelGGL(voxel_loss_fwd_kernel<2>, grid, dim3(256), 0, ST, logits, target, (long)F, C, (long)V, class_w, stats);
+  else hipLaunchKernelGGL(voxel_loss_fwd_kernel<0>, grid, dim3(256), 0, ST, logits, target, (long)F, C, (long)V, class_w, stats);
   hipLaunchKernelGGL(voxel_loss_finalize_kernel, dim3(1), dim3(64), 0, ST, stats, C, (double)F * (double)V, weight, loss3, coef);
   MUVO_CHECK_LAUNCH("voxel_loss_fwd");
   return MUVO_OK;
@@ -414,12 +496,16 @@ int muvo_voxel_loss_bwd(const float* logits, const uint8_t* target, float* dlogi
                         const float* class_w, float weight, const float* coef, const float* gout3, void* stream) {
   MUVO_CHECK_ARG(logits && target && dlogits && coef && gout3, "voxel_loss_bwd: null pointer");
   MUVO_CHECK_ARG(C >= 2 && C <= MAXC, "voxel_loss_bwd: bad C");
+  MUVO_CHECK_ARG(F <= 65535, "voxel_loss_bwd: more than 65535 frames");
+  long nbx = (V + 4095) / 4096;
+  if (nbx * F > 8192) nbx = 8192 / F > 0 ? 8192 / F : 1;
+  const dim3 grid((unsigned)nbx, (unsigned)F);
   if (C == 2)
-    hipLaunchKernelGGL(voxel_loss_bwd_kernel<2>, dim3(ew_grid(F * V)), dim3(256), 0, ST, logits, target, dlogits, (long)F, C,
-                       (long)V, class_w, coef, gout3, weight);
+    hipLaunchKernelGGL(voxel_loss_bwd_kernel<2>, grid, dim3(256), 0, ST, logits, target, dlogits, (long)F, C, (long)V, class_w,
+                       coef, gout3, weight);
   else
-    hipLaunchKernelGGL(voxel_loss_bwd_kernel<0>, dim3(ew_grid(F * V)), dim3(256), 0, ST, logits, target, dlogits, (long)F, C,
-                       (long)V, class_w, coef, gout3, weight);
+    hipLaunchKernelGGL(voxel_loss_bwd_kernel<0>, grid, dim3(256), 0, ST, logits, target, dlogits, (long)F, C, (long)V, class_w,
+                       coef, gout3, weight);
   MUVO_CHECK_LAUNCH("voxel_loss_bwd");
   return MUVO_OK;
 }

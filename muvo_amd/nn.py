@@ -80,6 +80,10 @@ class BatchNorm2d(nn.Module):
         ops.flush_bn_counters()          # num_batches_tracked increments are applied lazily, in one fused launch
         super()._save_to_state_dict(destination, prefix, keep_vars)
 
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        ops.flush_bn_counters()          # pending increments belong to the values that are about to be overwritten
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
 
 class LayerNorm(nn.Module):
     def __init__(self, e, eps=1e-5):

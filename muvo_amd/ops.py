@@ -64,6 +64,7 @@ EXPORTS = [
     'muvo_resize_bilinear_bwd', 'muvo_softmax_channel_fwd', 'muvo_softmax_channel_bwd',
     'muvo_range_projection', 'muvo_voxel_grid', 'muvo_seg_ce_fwd', 'muvo_seg_ce_bwd', 'muvo_ssim_maps', 'muvo_ssim_bwd',
     'muvo_instance_labels', 'muvo_pixel_augment', 'muvo_preprocess_route_aug',
+    'muvo_split_planes_bytes', 'muvo_split_planes',
 ]
 
 
@@ -81,6 +82,7 @@ def lib():
                 L.muvo_conv_workspace_bytes.restype = C.c_int64
                 L.muvo_linear_bf16x3_workspace_bytes.restype = C.c_int64
                 L.muvo_pack_table_item_bytes.restype = C.c_int64
+                L.muvo_split_planes_bytes.restype = C.c_int64
                 for name in EXPORTS:
                     getattr(L, name)  # AttributeError if a declared symbol is missing
                 _lib = L
@@ -1060,7 +1062,7 @@ class MaxPool2dFn(torch.autograd.Function):
         n, c, h, w = x.shape
         oh, ow = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
         y = torch.empty(n, c, oh, ow, device=x.device, dtype=torch.float32)
-        idx = torch.empty(n, c, oh, ow, device=x.device, dtype=torch.int32)
+        idx = torch.empty(n, c, oh, ow, device=x.device, dtype=torch.uint8)
         _ck(lib().muvo_maxpool2d_fwd(_f(x), _f(y), _p(idx), _i64(n * c), h, w, oh, ow, k, s, p, _st()))
         ctx.dims = (n, c, h, w, oh, ow, k, s, p)
         ctx.save_for_backward(idx)

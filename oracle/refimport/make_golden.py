@@ -257,7 +257,14 @@ def main():
             del o_total, o_losses, o_out
         del output, losses, total
         gc.collect()
+        try:                      # hand the freed float32 activations back to the OS before the float64 run
+            import ctypes
+            ctypes.CDLL('libc.so.6').malloc_trim(0)
+        except OSError:
+            pass
         if step == 0 and not args.no_fp64:
+            import resource
+            print(f'  peak RSS before the fp64 run {resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2**20:.1f} GB')
             # The same step of the REAL reference in float64: the truth the fp32 gradients are measured against.
             # tests compare |hip - ref64| with the reference's own fp32 rounding error |ref32 - ref64| per tensor.
             t0 = time.time()
@@ -276,13 +283,24 @@ def main():
                     if isinstance(m, torch.nn.MultiheadAttention):
                         m.dropout = 0.0
                 if args.fp64_checkpoint:
+                    # float64 convolutions on CPU take torch's im2col path, whose column buffer is
+                    # taps * Cin * voxels * 8 B PER FRAME (8 GB for the 16->8 Conv3d at 192x192x64): feed the convolution
+                    # modules one frame at a time (a convolution is independent per batch element)
+                    def per_frame(fwd):
+                        return lambda x: torch.cat([fwd(x[i:i + 1]) for i in range(x.shape[0])], 0) if x.shape[0] > 1 else fwd(x)
+                    for m in tr64.model.modules():
+                        if isinstance(m, (torch.nn.Conv3d, torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+                            m.forward = per_frame(m.forward)
                     # activation memory: the decoders hold most of it (float64: ~6 GB per frame).  Recompute them in
                     # backward instead (torch.utils.checkpoint around the REAL modules' forward; deterministic CPU
                     # arithmetic, so the gradients are the same numbers)
                     from torch.utils.checkpoint import checkpoint
-                    for name in ('rgb_decoder', 'lidar_re', 'voxel_decoder'):
-                        mod = getattr(tr64.model, name)
-                        mod.forward = (lambda x, _f=mod.forward: checkpoint(_f, x, use_reentrant=False))
+                    vd = tr64.model.voxel_decoder
+                    mods = [tr64.model.rgb_decoder, tr64.model.lidar_re, tr64.model.encoder, tr64.model.range_view_encoder,
+                            tr64.model.feat_decoder, tr64.model.range_view_decoder,
+                            vd.first_conv, *vd.middle_conv, vd.conv1, vd.conv2, vd.conv3]
+                    for mod in mods:     # (the voxel decoder block by block: its top level alone is ~2.6 GB per frame)
+                        mod.forward = (lambda *a, _f=mod.forward: checkpoint(_f, *a, use_reentrant=False))
                 b64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in raw.items()}
                 with NoisePatch(eps.double(), coin):
                     out64, _ = tr64.forward(b64)
@@ -310,6 +328,8 @@ def main():
                 g64 = p64[n].grad.detach().contiguous().view(-1)
                 stride = max(1, g64.numel() // 1024)
                 samples['grad64.' + n] = g64[::stride][:1024].clone().numpy()
+            import resource
+            print(f'  peak RSS so far {resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2**20:.1f} GB')
             print(f'  fp64 reference fwd+bwd {time.time() - t0:.1f}s total={tot64.item():.9f} '
                   f'(fp32 total {rec["total"]:.9f})')
             del tr64, out64, p64

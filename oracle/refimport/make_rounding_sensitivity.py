@@ -5,7 +5,7 @@ L1-sign decisions that flip under such a perturbation move the gradients by far 
 per-parameter L2 distance between the two gradients is the floor below which a gradient comparison says nothing about the
 implementation.  Writes tests/golden/base1d_b1s2_rounding.json (data only).
 
-Usage: python oracle/refimport/make_rounding_sensitivity.py
+Usage: python oracle/refimport/make_rounding_sensitivity.py [b1s2|b2s4]
 """
 import json
 import os
@@ -26,7 +26,8 @@ REL = 4e-6
 
 
 def main():
-    fx = json.load(open(os.path.join(REPO, 'tests', 'golden', 'base1d_b1s2.json')))
+    tag = sys.argv[1] if len(sys.argv) > 1 else 'b1s2'
+    fx = json.load(open(os.path.join(REPO, 'tests', 'golden', f'base1d_{tag}.json')))
     b, s, seed = fx['b'], fx['s'], fx['seed']
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -75,9 +76,9 @@ def main():
           f'relative gradient change: median {sorted(rel.values())[len(rel) // 2]:.2e}, max {max(rel.values()):.2e}')
     for n, v in sorted(rel.items(), key=lambda kv: -kv[1])[:10]:
         print(f'   {n:60s} {v:.2e}')
-    with open(os.path.join(REPO, 'tests', 'golden', 'base1d_b1s2_rounding.json'), 'w') as f:
+    with open(os.path.join(REPO, 'tests', 'golden', f'base1d_{tag}_rounding.json'), 'w') as f:
         json.dump(out, f)
-    print('wrote tests/golden/base1d_b1s2_rounding.json')
+    print(f'wrote tests/golden/base1d_{tag}_rounding.json')
 
 
 if __name__ == '__main__':

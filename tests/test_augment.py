@@ -98,7 +98,8 @@ def test_hip_augmentation_matches_reference(dev):
     b, s = fx['b'], fx['s']
     for f in range(b * s):
         same = torch.equal(plain['image'][f // s, f % s], out['image'][f // s, f % s])
-        assert same == (pix[f, 0] == 0 and pix[f, 2] == 0), f
+        if pix[f, 0] == 0 and pix[f, 2] == 0:      # (the converse need not hold: a blur with sigma ~0.1 changes nothing)
+            assert same, f
     for i in range(b):
         assert torch.equal(plain['route_map'][i], out['route_map'][i]) == (route[i, 0] == 0), i
 

@@ -151,9 +151,14 @@ def test_lightning_like_loop(dev):
             loss.backward()
             tr.on_after_backward()
             base = tr.store.flat_grad.data_ptr()
-            for p in tr.store.params:                       # the kernels re-bound every gradient to its flat slot
-                assert p.grad is not None and p.grad.data_ptr() == base + 4 * tr.store._off[id(p)]
+            # the kernels re-bound the gradients they write to their flat slots; a parameter that gets its gradient from
+            # autograd itself (the voxel decoder's constant tensor is an autograd INPUT) now holds a tensor of its own ...
+            foreign = [n for n, p in tr.model.named_parameters() if p.grad is not None and id(p) in tr.store.used_ids
+                       and p.grad.data_ptr() != base + 4 * tr.store._off[id(p)]]
+            assert foreign == ([] if step == 0 else ['voxel_decoder.constant_tensor']), foreign
             optimizer.step()
+            for p in tr.store.params:                       # ... which step() copied into the slot and re-bound
+                assert p.grad is not None and p.grad.data_ptr() == base + 4 * tr.store._off[id(p)]
             sched.step()
             tr._global_step += 1
             assert _rel(loss.item(), g['total']) < (1e-3 if step == 0 else 2e-3)
@@ -192,8 +197,13 @@ def test_optimizer_checkpoint_roundtrip(dev):
     ref_opt = torch.optim.AdamW([{'params': twin[:277], 'weight_decay': 0.0}, {'params': twin[277:], 'weight_decay': 0.01}], lr=1e-4)
     ref_opt.load_state_dict({'state': {k: {kk: vv.cpu() for kk, vv in v.items()} for k, v in ck['opt']['state'].items()},
                              'param_groups': ck['opt']['param_groups']})
+    before = {n: p.detach().clone() for n, p in tr.model.named_parameters()}
     one_step(tr, opt, sched, 1)
     want = {n: p.detach().clone() for n, p in tr.model.named_parameters()}
+    upd = sum(float((want[n] - before[n]).double().pow(2).sum()) for n in want) ** 0.5
+
+    def rel(a, b):
+        return float((a.double() - b.double()).norm() / b.double().norm())
 
     tr2 = _trainer(dev, 2)
     tr2.model.load_state_dict(ck['model'], strict=True)
@@ -203,10 +213,13 @@ def test_optimizer_checkpoint_roundtrip(dev):
     sched2.load_state_dict(ck['sched'])
     assert opt2._step == 1 and float(tr2.store.exp_avg.abs().sum()) > 0
     one_step(tr2, opt2, sched2, 1)
-    worst = 0.0
-    for n, p in tr2.model.named_parameters():
-        worst = max(worst, float((p.detach() - want[n]).abs().max() / want[n].abs().max().clamp_min(1e-12)))
-    assert worst < 2e-6, worst     # split-K float atomics: last-digit differences between two identical runs
+    # the moments are linear in the gradients: the resumed run reproduces them up to the run-to-run noise of the split-K
+    # float atomics; the parameters move by lr * m/sqrt(v), which amplifies that noise where a gradient is ~0, so they are
+    # compared as a whole against the size of the step
+    assert opt2._step == opt._step == 2
+    assert rel(tr2.store.exp_avg, tr.store.exp_avg) < 1e-4 and rel(tr2.store.exp_avg_sq, tr.store.exp_avg_sq) < 1e-4
+    dev2 = sum(float((p.detach() - want[n]).double().pow(2).sum()) for n, p in tr2.model.named_parameters()) ** 0.5
+    assert dev2 < 0.02 * upd, (dev2, upd)
 
     # a resumed run WITHOUT the optimizer state takes a visibly different step (what ADVICE r1 flagged)
     tr3 = _trainer(dev, 2)
@@ -214,5 +227,6 @@ def test_optimizer_checkpoint_roundtrip(dev):
     opts3, scheds3 = tr3.configure_optimizers()
     scheds3[0]['scheduler'].load_state_dict(ck['sched'])
     one_step(tr3, opts3[0], scheds3[0]['scheduler'], 1)
-    diff = max(float((p.detach() - want[n]).abs().max()) for n, p in tr3.model.named_parameters())
-    assert diff > 1e-6
+    assert rel(tr3.store.exp_avg, tr.store.exp_avg) > 0.3
+    dev3 = sum(float((p.detach() - want[n]).double().pow(2).sum()) for n, p in tr3.model.named_parameters()) ** 0.5
+    assert dev3 > 5 * dev2

@@ -442,15 +442,18 @@ def test_tokens_roundtrip(dev):
 def test_pooling_and_upsample(dev):
     from muvo_amd import ops
     torch.manual_seed(7)
-    x = torch.randn(2, 5, 13, 18)
-    for k, s, p in ((3, 2, 1), (2, 2, 0)):
+    shapes = {'plain': torch.randn(2, 5, 13, 18), 'ties': (torch.randn(2, 3, 33, 70) * 2).round() / 2,   # many equal maxima
+              'wide': torch.randn(1, 2, 64, 1024), 'tiny': torch.randn(3, 2, 2, 2)}
+    for name, (k, s, p) in [(n_, c_) for n_ in shapes for c_ in ((3, 2, 1), (2, 2, 0))]:
+        x = shapes[name]
         xg, xc = x.to(dev).requires_grad_(True), x.clone().requires_grad_(True)
         y, yr = ops.max_pool2d(xg, k, s, p), F.max_pool2d(xc, k, s, p)
         _close(y, yr, rtol=0, atol=0, name='maxpool fwd')
         g = torch.randn_like(yr)
         yr.backward(g)
         y.backward(g.to(dev))
-        _close(xg.grad, xc.grad, name='maxpool bwd')
+        _close(xg.grad, xc.grad, rtol=0, atol=0, name=f'maxpool bwd {name} k{k}')
+    x = shapes['plain']
     xg, xc = x.to(dev).requires_grad_(True), x.clone().requires_grad_(True)
     y, yr = ops.global_avg_pool(xg), xc.mean(dim=(-1, -2))
     _close(y, yr, name='avgpool')
@@ -642,3 +645,39 @@ def test_conv_strided_dgrad_uses_one_arithmetic_for_all_phases(dev):
         _close(m.bias.grad, b.grad, rtol=5e-4, name='dbias')
     finally:
         ops.set_conv_mode(old, min_gflop=-1.0)
+
+
+@pytest.mark.parametrize('n,c,s', [(2, 70, 520), (2, 70, 521), (1, 8, 256), (3, 128, 1028), (1, 3, 300)])
+def test_split_planes(dev, n, c, s):
+    """The bf16x3 operand layout (muvo_split_planes): hi = bf16(x) (round to nearest even), lo = bf16(x - hi), channels-last with
+    the channel count padded to 8 (zeros) — bit-exact; both kernel forms (S % 4 == 0 takes the 16-byte-load form); the
+    backward-preamble variant multiplies by act'(y) first and adds per-channel sums to dbias."""
+    import ctypes as C
+    from muvo_amd import ops
+    L = ops.lib()
+    torch.manual_seed(n * 1000 + c + s)
+    x = torch.randn(n, c, s, device=dev) * 3
+    cp = (c + 7) // 8 * 8
+
+    def run(xin, y=None, act=ops.ACT_NONE, slope=0.0, dbias=None):
+        ws = torch.zeros((L.muvo_split_planes_bytes(n, c, C.c_int64(s)) + 3) // 4, device=dev, dtype=torch.float32)
+        ops._ck(L.muvo_split_planes(ops._f(xin), ops._p(ws), n, c, C.c_int64(s), ops._f(y), act, C.c_float(slope), ops._f(dbias), ops._st()))
+        planes = ws.view(torch.int16)[:2 * n * s * cp].view(2, n, s, cp)
+        return planes[0].view(torch.bfloat16).float(), planes[1].view(torch.bfloat16).float()
+
+    def ref(v):
+        hi = v.to(torch.bfloat16).float()
+        lo = (v - hi).to(torch.bfloat16).float()
+        pad = lambda t: torch.nn.functional.pad(t.permute(0, 2, 1), (0, cp - c))
+        return pad(hi), pad(lo)
+
+    hi, lo = run(x)
+    rhi, rlo = ref(x)
+    assert torch.equal(hi, rhi) and torch.equal(lo, rlo)
+    y = torch.randn(n, c, s, device=dev)
+    db = torch.ones(c, device=dev)
+    hi, lo = run(x, torch.nn.functional.leaky_relu(y, 0.2), ops.ACT_LEAKY, 0.2, db)
+    z = x * torch.where(y > 0, torch.ones_like(y), torch.full_like(y, 0.2))
+    rhi, rlo = ref(z)
+    assert torch.equal(hi, rhi) and torch.equal(lo, rlo)
+    assert torch.allclose(db, 1 + z.sum((0, 2)), rtol=1e-4, atol=1e-3)

@@ -1,6 +1,8 @@
 """-m gpu: the full HIP training step (preprocess -> forward -> 21 losses -> backward -> fused AdamW, through the
-C ABI) against the golden fixture generated from the REAL reference (tests/golden/base1d_b1s2*.{json,npz},
-oracle/refimport/make_golden.py).  Tolerance: 1e-3 relative fp32 (BASELINE.json north_star); voxel argmax bit-exact.  Every test runs twice: on the exact
+C ABI) against the golden fixtures generated from the REAL reference (tests/golden/base1d_{b1s2,b2s4}*.{json,npz},
+oracle/refimport/make_golden.py): batch 1 x 2 frames, and batch 2 x 4 frames whose RSSM takes the "feed the PRIOR sample
+forward" branch (transition.py:118-124) at t = 2, so that branch shapes the later time steps and BPTT runs over three
+transitions.  Plus the BASELINE workload itself (batch 2 x 10 frames) through size-independent properties.  Tolerance: 1e-3 relative fp32 (BASELINE.json north_star); voxel argmax bit-exact.  Every test runs twice: on the exact
 fp32 MFMA kernels ('f32') and on the library's default arithmetic policy ('policy': bf16x3 split products for most
 convolutions).  The gradient bars of the 'policy' run add the REAL reference's own gradient change under a 4e-6 relative
 perturbation of its convolution outputs (tests/golden/base1d_b1s2_rounding.json,
@@ -17,27 +19,30 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), 'golden')
 
 
-@pytest.fixture(scope='module', params=['f32', 'policy'])
+@pytest.fixture(scope='module', params=['b1s2-f32', 'b1s2-policy', 'b2s4-f32', 'b2s4-policy'])
 def run(dev, request):
     from muvo_amd import ops
+    tag, mode = request.param.split('-')
     old = ops.get_conv_mode()
-    ops.set_conv_mode(ops.CONV_F32 if request.param == 'f32' else ops.CONV_BF16X3, min_gflop=-1.0)
+    ops.set_conv_mode(ops.CONV_F32 if mode == 'f32' else ops.CONV_BF16X3, min_gflop=-1.0)
     try:
-        fx, smp, recs = _run_steps(dev)
+        fx, smp, recs = _run_steps(dev, tag)
     finally:
         ops.set_conv_mode(old, min_gflop=-1.0)
-    rounding = json.load(open(os.path.join(GOLD, 'base1d_b1s2_rounding.json'))) if request.param == 'policy' else None
-    fx = dict(fx, rounding=rounding)
+    rounding = json.load(open(os.path.join(GOLD, f'base1d_{tag}_rounding.json'))) if mode == 'policy' else None
+    fx = dict(fx, rounding=rounding, mode=mode)
+    if tag == 'b2s4':      # the fixture exists to exercise the prior-sample branch in the middle of the sequence
+        assert any(fx['use_prior'][1:-1]), fx['use_prior']
     return fx, smp, recs
 
 
-def _run_steps(dev):
+def _run_steps(dev, tag='b1s2'):
     from muvo_amd.config import base_1d_cfg
     from muvo_amd.data.synthetic import make_batch, make_noise
     from muvo_amd.trainer import WorldModelTrainer
     from muvo_amd.utils import detinit
-    fx = json.load(open(os.path.join(GOLD, 'base1d_b1s2.json')))
-    smp = np.load(os.path.join(GOLD, 'base1d_b1s2_samples.npz'))
+    fx = json.load(open(os.path.join(GOLD, f'base1d_{tag}.json')))
+    smp = np.load(os.path.join(GOLD, f'base1d_{tag}_samples.npz'))
     b, s, seed = fx['b'], fx['s'], fx['seed']
     cfg = base_1d_cfg(RECEPTIVE_FIELD=s, FUTURE_HORIZON=0, STEPS=100000)
     tr = WorldModelTrainer(cfg.convert_to_dict(), device=dev)
@@ -125,6 +130,18 @@ def test_voxel_argmax_bit_exact(run):
     masked[tie] = 0
     digest = hashlib.sha256(np.packbits(masked.numpy().astype(bool)).tobytes()).hexdigest()
     assert digest == g['voxel_1_argmax_sha256_excl_near_ties']
+    # of the near-tie voxels (reference margin < 2e-3), how many actually decide differently from the reference's fp32 run
+    flips = int((am[tie] != torch.from_numpy(smp['voxel_1_near_tie_argmax'])).sum())
+    frac = flips / max(tie.numel(), 1)
+    print(f'voxel argmax [{fx["tag"]} {fx["mode"]}]: {flips} of {tie.numel()} near-tie voxels flip '
+          f'({flips / am.numel():.2e} of all {am.numel()} voxels)')
+    os.makedirs(os.path.join(os.path.dirname(GOLD), '..', 'gpurun_out'), exist_ok=True)
+    with open(os.path.join(os.path.dirname(GOLD), '..', 'gpurun_out', 'argmax_flips.txt'), 'a') as f:
+        f.write(f'{fx["tag"]} {fx["mode"]}: {flips} of {tie.numel()} near-tie voxels flip; {am.numel()} voxels\n')
+    assert frac <= (0.02 if fx['mode'] == 'f32' else 0.10), (flips, tie.numel())
+    if flips == 0:          # then the whole argmax is bit-identical to the reference's
+        full = hashlib.sha256(np.packbits(am.numpy().astype(bool)).tobytes()).hexdigest()
+        assert full == g['voxel_1_argmax_sha256']
 
 
 def test_gradients_match_reference(run):
@@ -182,3 +199,75 @@ def test_adamw_steps_match_reference(run):
             if _rel(a_got, a_ref) > 1e-5 or abs(s_got - s_ref) > 1e-5 * max(a_ref, 1.0):
                 bad.append((n, s_got, s_ref, a_got, a_ref))
         assert not bad, f'step {step}: {len(bad)} parameter checksums off, first {bad[:3]}'
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the BASELINE workload (configs[1]: base_1d, batch 2 x seq_len 10, full sizes) through size-independent properties
+def test_full_size_step_properties(dev):
+    """batch 2 x 10 frames, the library's default arithmetic, dropout off, explicit RSSM noise: (i) 21 finite losses;
+    (ii) two runs from the same state agree to 1e-5 on every loss (split-K float atomics are the only nondeterminism);
+    (iii) every loss equals the CPU oracle's loss FUNCTIONS applied to this run's own outputs within 1e-3 (the loss kernels
+    at full size: 18.9 M voxels x 20 frames, masked-mean spatial losses, KL); (iv) every BatchNorm moved its running
+    buffers and counted one batch; (v) all 440 used gradients are finite and non-zero, the 12 never-used tensors have none;
+    (vi) AdamW changes every used parameter, leaves the unused ones alone."""
+    from muvo_amd.config import base_1d_cfg
+    from muvo_amd.data.synthetic import make_batch, make_noise
+    from muvo_amd.trainer import WorldModelTrainer
+    from muvo_amd.utils import detinit
+    from oracle import muvo_ref as R
+    b, s, seed = 2, 10, 1234
+    cfg = base_1d_cfg(RECEPTIVE_FIELD=6, FUTURE_HORIZON=4, STEPS=100000)
+    tr = WorldModelTrainer(cfg.convert_to_dict(), device=dev)
+    tr.train()
+    tr.preprocess.augment = False
+    detinit.fill_state_dict_(tr.model)
+    for layer in tr.model.transformer_encoder.layers:
+        layer.p = 0.0
+    opt = tr.configure_optimizers()[0][0]
+    eps, use_prior = make_noise(b, s, seed=seed)
+    use_prior[4] = True                       # make sure the prior-sample branch is taken mid-sequence
+    eps = eps.to(dev)
+    bn = [m for m in tr.model.modules() if hasattr(m, 'running_mean')]
+    assert len(bn) == 76
+    before = {k: v.clone() for k, v in tr.model.state_dict().items()}
+    runs = []
+    for _ in range(2):
+        tr.model.load_state_dict(before)
+        opt.zero_grad()
+        batch = make_batch(b, s, seed=seed, device=dev)
+        losses, output, _, _ = tr.shared_step(batch, mode='train', noise=eps, use_prior=use_prior)
+        tr.loss_reducing(losses).backward()
+        runs.append({k: v.item() for k, v in losses.items()})
+    assert len(runs[0]) == 21 and all(np.isfinite(v) and v > 0 for v in runs[0].values()), runs[0]
+    for k in runs[0]:
+        assert abs(runs[0][k] - runs[1][k]) <= 1e-5 * abs(runs[0][k]), (k, runs[0][k], runs[1][k])
+    # (iii) the oracle's loss functions on this run's outputs
+    cpu_out = {k: v.detach().cpu() for k, v in output.items() if torch.is_tensor(v)}
+    for grp in ('prior', 'posterior'):
+        cpu_out[grp] = {k: v.detach().cpu() for k, v in output[grp].items()}
+    cpu_batch = {k: v.detach().cpu() for k, v in batch.items() if torch.is_tensor(v)}
+    ref = R.compute_losses(cpu_batch, cpu_out, R.base_1d_cfg())
+    assert set(ref) == set(runs[1])
+    for k, v in ref.items():
+        assert abs(runs[1][k] - float(v)) <= 1e-3 * abs(float(v)), (k, runs[1][k], float(v))
+    # (iv) BatchNorm buffers
+    after = tr.model.state_dict()
+    for name in after:
+        if name.endswith('num_batches_tracked'):
+            assert int(after[name]) == int(before[name]) + 1, name
+        elif name.endswith('running_mean') or name.endswith('running_var'):
+            assert not torch.equal(after[name], before[name]), name
+    # (v) gradients
+    n_used = 0
+    for n, p in tr.model.named_parameters():
+        if n.startswith('encoder_layer.'):
+            assert p.grad is None, n
+            continue
+        n_used += 1
+        assert torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0, n
+    assert n_used == 440
+    # (vi) optimizer
+    snap = {n: p.detach().clone() for n, p in tr.model.named_parameters()}
+    opt.step()
+    for n, p in tr.model.named_parameters():
+        assert torch.equal(p, snap[n]) == n.startswith('encoder_layer.'), n
