@@ -206,6 +206,18 @@ int muvo_preprocess_image(const uint8_t* img, float* label, float* norm, int64_t
                           int CH, int CW, const float* mean3, const float* std3, void* stream);
 int muvo_preprocess_route(const uint8_t* img, float* norm, int64_t NC, int C, int H, int W, int OH, int OW,
                           const float* mean3, const float* std3, void* stream);
+/* Fused multi-head self-attention core of nn.TransformerEncoderLayer (muvo/models/mile.py:96-101,558), csrc/attention.hip:
+ * qkv (L, N, 3*H*DH) packed in-projection (q | k | v along the last axis, heads contiguous inside each), out (L, N, H*DH) =
+ * dropout(softmax(q k^T / sqrt(DH))) v per (n, head), lse (N*H, L) row log-sum-exp saved for the backward pass; K and V of a
+ * head live in LDS, the L x L matrices never reach HBM.  p / seed: attention-probability dropout, mask index
+ * ((n*H + h)*L + query)*L + key (same as muvo_softmax_dropout_*).  muvo_attention_supported: DH in {16,32,48,64}, L <= 384
+ * and 2 * roundup(L,16) * (DH+4) * 4 bytes (+ 8 * roundup(L,16)) <= 160 KB of LDS; otherwise use the unfused entry points.
+ * muvo_attention_bwd writes all of dqkv (dq, dk, dv) — no atomics, deterministic. */
+int muvo_attention_supported(int L, int DH);
+int muvo_attention_fwd(const float* qkv, float* out, float* lse, int L, int N, int H, int DH, float p, uint64_t seed,
+                       void* stream);
+int muvo_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int L, int N, int H,
+                       int DH, float p, uint64_t seed, void* stream);
 /* Training-time augmentation inside PreProcess.forward (muvo/models/preprocess.py:45-48,213-214; PixelAugmentation :295-333,
  * RouteAugmentation :336-367; torchvision 0.15.2 tensor algorithms).  The random draws are explicit inputs.
  * muvo_pixel_augment: img (F,3,H,W) in [0,1] (the cropped image = rgb_label_1) is augmented IN PLACE, norm (F,3,H,W) receives

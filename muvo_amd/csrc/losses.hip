@@ -158,21 +158,26 @@ __global__ void __launch_bounds__(256) voxel_loss_fwd_kernel(const float* __rest
       }
     }
   }
-  block_atomic_add_d((double)ce, &stats[0], red);
-  block_atomic_add_d((double)wsum, &stats[1], red);
-  for (int c = 0; c < Cc; ++c) {
-    block_atomic_add_d((double)P[c], &stats[2 + 5 * c + 0], red);
-    block_atomic_add_d((double)Nn[c], &stats[2 + 5 * c + 1], red);
-    block_atomic_add_d((double)T[c], &stats[2 + 5 * c + 2], red);
-    block_atomic_add_d((double)Q[c], &stats[2 + 5 * c + 3], red);
-    block_atomic_add_d((double)R[c], &stats[2 + 5 * c + 4], red);
-  }
-  double* gs = stats + 2 + 5 * C;
-  block_atomic_add_d((double)gI, &gs[0], red);
-  block_atomic_add_d((double)gA, &gs[1], red);
-  block_atomic_add_d((double)gB, &gs[2], red);
-  block_atomic_add_d((double)gS, &gs[3], red);
-  block_atomic_add_d((double)gR, &gs[4], red);
+  // ONE workgroup reduction for all 2 + 5C + 5 sums (they are contiguous in `stats`): wave shuffles, one barrier, then lanes
+  // 0..NV-1 of wave 0 issue their atomics side by side (17 separate barrier + atomic rounds per workgroup, times ~4000
+  // workgroups hammering the same 17 addresses, had made this pass atomic-bound: 522 us for 0.43 GB)
+  constexpr int NVMAX = 2 + 5 * NCU + 5;
+  __shared__ double redm[NVMAX][4];
+  const int NV = 2 + 5 * Cc + 5;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  auto put = [&](int i, float v) {
+    const double d = wave_sum_d((double)v);
+    if (lane == 0) redm[i][w] = d;
+  };
+  put(0, ce);
+  put(1, wsum);
+#pragma unroll
+  for (int c = 0; c < NCU; ++c)
+    if (c < Cc) { put(2 + 5 * c, P[c]); put(3 + 5 * c, Nn[c]); put(4 + 5 * c, T[c]); put(5 + 5 * c, Q[c]); put(6 + 5 * c, R[c]); }
+  put(2 + 5 * Cc, gI); put(3 + 5 * Cc, gA); put(4 + 5 * Cc, gB); put(5 + 5 * Cc, gS); put(6 + 5 * Cc, gR);
+  __syncthreads();
+  if ((int)threadIdx.x < NV) atomicAdd(&stats[threadIdx.x], redm[threadIdx.x][0] + redm[threadIdx.x][1] + redm[threadIdx.x][2] + redm[threadIdx.x][3]);
+  (void)red;
 }
 
 // BCE(x, 1) = -max(log x, -100) (torch clamps the log)
@@ -481,9 +486,9 @@ int muvo_voxel_loss_fwd(const float* logits, const uint8_t* target, int64_t F, i
   MUVO_CHECK_ARG(F > 0 && V > 0 && C >= 2 && C <= MAXC, "voxel_loss_fwd: C=%d unsupported (2..%d)", C, MAXC);
   hipMemsetAsync(stats, 0, sizeof(double) * (2 + 5 * C + 5), ST);
   MUVO_CHECK_ARG(F <= 65535, "voxel_loss_fwd: more than 65535 frames");
-  // per frame: one workgroup per 8192 voxels (32 per thread), at most ~4096 workgroups in all
+  // per frame: one workgroup per 8192 voxels (32 per thread), at most ~1280 workgroups in all (5 per CU)
   long nbx = (V + 8191) / 8192;
-  static const long nb_cap = getenv("MUVO_VOXLOSS_BLOCKS") ? atol(getenv("MUVO_VOXLOSS_BLOCKS")) : 4096;
+  static const long nb_cap = getenv("MUVO_VOXLOSS_BLOCKS") ? atol(getenv("MUVO_VOXLOSS_BLOCKS")) : 1280;
   if (nbx * F > nb_cap) nbx = nb_cap / F > 0 ? nb_cap / F : 1;
   const dim3 grid((unsigned)nbx, (unsigned)F);
   if (C == 2) hipLaunchKernelGGL(voxel_loss_fwd_kernel<2>, grid, dim3(256), 0, ST, logits, target, (long)F, C, (long)V, class_w, stats);

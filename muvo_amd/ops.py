@@ -64,7 +64,7 @@ EXPORTS = [
     'muvo_resize_bilinear_bwd', 'muvo_softmax_channel_fwd', 'muvo_softmax_channel_bwd',
     'muvo_range_projection', 'muvo_voxel_grid', 'muvo_seg_ce_fwd', 'muvo_seg_ce_bwd', 'muvo_ssim_maps', 'muvo_ssim_bwd',
     'muvo_instance_labels', 'muvo_pixel_augment', 'muvo_preprocess_route_aug',
-    'muvo_split_planes_bytes', 'muvo_split_planes',
+    'muvo_split_planes_bytes', 'muvo_split_planes', 'muvo_attention_supported', 'muvo_attention_fwd', 'muvo_attention_bwd',
 ]
 
 
@@ -1196,7 +1196,39 @@ class AttentionFn(torch.autograd.Function):
         return dqkv, None, None, None
 
 
+class FlashAttentionFn(torch.autograd.Function):
+    """The same attention core as ONE kernel forward and two backward (csrc/attention.hip): K / V of a head staged in LDS,
+    softmax over register-resident score tiles with wave shuffles, no L x L tensor in HBM; saves only the row log-sum-exp."""
+
+    @staticmethod
+    def forward(ctx, qkv, nheads, p, seed):
+        qkv = qkv.contiguous()
+        l, n, e3 = qkv.shape
+        e = e3 // 3
+        o = torch.empty(l, n, e, device=qkv.device, dtype=torch.float32)
+        lse = torch.empty(n * nheads, l, device=qkv.device, dtype=torch.float32)
+        _ck(lib().muvo_attention_fwd(_f(qkv), _f(o), _f(lse), l, n, nheads, e // nheads, _fl(p), C.c_uint64(seed), _st()))
+        ctx.dims = (l, n, nheads, e // nheads, p, seed)
+        ctx.save_for_backward(qkv, o, lse)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, o, lse = ctx.saved_tensors
+        l, n, nheads, dh, p, seed = ctx.dims
+        dqkv = torch.empty_like(qkv)
+        _ck(lib().muvo_attention_bwd(_f(qkv), _f(o), _f(do.contiguous()), _f(lse), _f(dqkv), l, n, nheads, dh, _fl(p),
+                                     C.c_uint64(seed), _st()))
+        return dqkv, None, None, None
+
+
+FLASH_ATTENTION = os.environ.get('MUVO_FLASH_ATTN', '1') != '0'
+
+
 def attention(qkv, nheads, p, seed):
+    l, _, e3 = qkv.shape
+    if FLASH_ATTENTION and lib().muvo_attention_supported(l, e3 // 3 // nheads):
+        return FlashAttentionFn.apply(qkv, nheads, p, seed)
     return AttentionFn.apply(qkv, nheads, p, seed)
 
 

@@ -217,9 +217,11 @@ def test_optimizer_checkpoint_roundtrip(dev):
     # float atomics; the parameters move by lr * m/sqrt(v), which amplifies that noise where a gradient is ~0, so they are
     # compared as a whole against the size of the step
     assert opt2._step == opt._step == 2
-    assert rel(tr2.store.exp_avg, tr.store.exp_avg) < 1e-4 and rel(tr2.store.exp_avg_sq, tr.store.exp_avg_sq) < 1e-4
+    # (two identical runs of one step differ by ~1e-3 relative L2 in the gradients: L1-sign / ReLU decisions flip with the
+    # summation order of the float atomics, tools/grad_repeat.py)
+    assert rel(tr2.store.exp_avg, tr.store.exp_avg) < 5e-3 and rel(tr2.store.exp_avg_sq, tr.store.exp_avg_sq) < 1e-2
     dev2 = sum(float((p.detach() - want[n]).double().pow(2).sum()) for n, p in tr2.model.named_parameters()) ** 0.5
-    assert dev2 < 0.02 * upd, (dev2, upd)
+    assert dev2 < 0.05 * upd, (dev2, upd)
 
     # a resumed run WITHOUT the optimizer state takes a visibly different step (what ADVICE r1 flagged)
     tr3 = _trainer(dev, 2)

@@ -370,10 +370,10 @@ def test_conv_lrelu_adain_fused_backward(dev):
     _close(sg.grad, sc.grad, rtol=5e-4, name='dstyle')
 
 
-def test_transformer_layer(dev):
+@pytest.mark.parametrize('l,n,e', [(70, 3, 96), (324, 2, 384)])    # head dim 12: unfused attention; 48: the fused kernel
+def test_transformer_layer(dev, l, n, e):
     from muvo_amd import nn as hnn
     torch.manual_seed(5)
-    l, n, e = 70, 3, 96
     with torch.device(dev):
         layer = hnn.TransformerEncoderLayer(e, 8, dim_ff=160, dropout=0.0)
     ref = torch.nn.TransformerEncoderLayer(e, 8, dim_feedforward=160, dropout=0.0)
@@ -681,3 +681,38 @@ def test_split_planes(dev, n, c, s):
     rhi, rlo = ref(z)
     assert torch.equal(hi, rhi) and torch.equal(lo, rlo)
     assert torch.allclose(db, 1 + z.sum((0, 2)), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize('l,n,heads,dh', [(324, 3, 8, 48), (70, 2, 4, 16), (33, 1, 2, 64), (16, 2, 1, 32), (384, 1, 2, 48), (1, 1, 1, 16)])
+def test_flash_attention(dev, l, n, heads, dh):
+    """csrc/attention.hip against (i) a plain PyTorch fp32 attention (no dropout) and (ii) the unfused GEMM + softmax_dropout +
+    GEMM path with the same dropout seed (same mask index convention): output and all three input gradients."""
+    from muvo_amd import ops
+    assert ops.lib().muvo_attention_supported(l, dh) == 1
+    torch.manual_seed(l * 7 + dh)
+    e = heads * dh
+    qkv = torch.randn(l, n, 3 * e, device=dev)
+    g = torch.randn(l, n, e, device=dev)
+
+    def run(fn, p, seed):
+        x = qkv.clone().requires_grad_(True)
+        o = fn(x, heads, p, seed)
+        o.backward(g)
+        return o.detach(), x.grad
+
+    o, dq = run(ops.FlashAttentionFn.apply, 0.0, 0)
+    x = qkv.clone().requires_grad_(True)
+    q, k, v = (t.reshape(l, n, heads, dh).permute(1, 2, 0, 3) for t in x.split(e, dim=-1))
+    att = torch.softmax(q @ k.transpose(-1, -2) / dh ** 0.5, dim=-1) @ v          # (n, heads, l, dh)
+    ref = att.permute(2, 0, 1, 3).reshape(l, n, e)
+    ref.backward(g)
+    _close(o, ref, rtol=2e-5, name='flash attention fwd')
+    _close(dq, x.grad, rtol=1e-4, name='flash attention dqkv')
+    o2, dq2 = run(ops.FlashAttentionFn.apply, 0.0, 0)
+    assert torch.equal(o, o2) and torch.equal(dq, dq2)                            # no atomics: bit-reproducible
+    for p, seed in ((0.1, 77), (0.5, 123456789)):
+        of, df = run(ops.FlashAttentionFn.apply, p, seed)
+        ou, du = run(ops.AttentionFn.apply, p, seed)
+        _close(of, ou, rtol=2e-5, name=f'flash vs unfused fwd p={p}')
+        _close(df, du, rtol=1e-4, name=f'flash vs unfused dqkv p={p}')
+        assert not torch.allclose(of, o)                                          # the mask does something

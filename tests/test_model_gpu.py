@@ -30,7 +30,7 @@ def run(dev, request):
     finally:
         ops.set_conv_mode(old, min_gflop=-1.0)
     rounding = json.load(open(os.path.join(GOLD, f'base1d_{tag}_rounding.json'))) if mode == 'policy' else None
-    fx = dict(fx, rounding=rounding, mode=mode)
+    fx = dict(fx, rounding=rounding, mode=mode, tag=tag)
     if tag == 'b2s4':      # the fixture exists to exercise the prior-sample branch in the middle of the sequence
         assert any(fx['use_prior'][1:-1]), fx['use_prior']
     return fx, smp, recs
@@ -115,33 +115,43 @@ def test_outputs_match_reference(run):
 
 
 def test_voxel_argmax_bit_exact(run):
-    """Bit-exact argmax on every voxel whose reference decision margin exceeds fp32 summation-order noise (2e-3);
-    the fixture lists the near-tie voxels (a few thousand of 4.7 M) which may flip."""
+    """argmax(voxel_1) against the reference's, voxel by voxel (tests/golden/base1d_<tag>_argmax.npz: the full packed argmax
+    and the classes of its top-2 logit margin).  Exact fp32 MFMA: bit-exact on every voxel whose reference margin is at
+    least 2e-3 (fp32 summation-order noise on logits of magnitude 10-27), and only a small fraction of the near-ties may
+    flip.  Default arithmetic (bf16x3 split products, ~5e-6 relative per contraction): bit-exact beyond a margin of 1e-2
+    (4e-4 of the logit range).  The counts are printed and written to gpurun_out/argmax_flips.txt."""
     fx, smp, recs = run
     g = fx['steps'][0]
+    ref = np.load(os.path.join(GOLD, f'base1d_{fx["tag"]}_argmax.npz'))
     v = recs[0]['output']['voxel_1']
-    am = v.argmax(dim=2).reshape(-1).to(torch.uint8).cpu()
-    tie = torch.from_numpy(smp['voxel_1_near_tie_idx']).long()
-    assert tie.numel() == g['voxel_1_near_tie_count'] and tie.numel() < 0.01 * am.numel()
-    full_pops = am.view(-1, am.numel() // (fx['b'] * fx['s'])).sum(1).tolist()
-    for got, ref in zip(full_pops, g['voxel_1_argmax_popcounts']):
-        assert abs(got - ref) <= tie.numel(), (full_pops, g['voxel_1_argmax_popcounts'])
-    masked = am.clone()
-    masked[tie] = 0
-    digest = hashlib.sha256(np.packbits(masked.numpy().astype(bool)).tobytes()).hexdigest()
-    assert digest == g['voxel_1_argmax_sha256_excl_near_ties']
-    # of the near-tie voxels (reference margin < 2e-3), how many actually decide differently from the reference's fp32 run
-    flips = int((am[tie] != torch.from_numpy(smp['voxel_1_near_tie_argmax'])).sum())
-    frac = flips / max(tie.numel(), 1)
-    print(f'voxel argmax [{fx["tag"]} {fx["mode"]}]: {flips} of {tie.numel()} near-tie voxels flip '
-          f'({flips / am.numel():.2e} of all {am.numel()} voxels)')
+    am = v.argmax(dim=2).reshape(-1).to(torch.uint8).cpu().numpy().astype(bool)
+    n = am.size
+    ref_am = np.unpackbits(ref['argmax_bits'])[:n].astype(bool)
+    assert hashlib.sha256(np.packbits(ref_am).tobytes()).hexdigest() == g['voxel_1_argmax_sha256']
+    flip = am != ref_am
+    classes = {k: np.unpackbits(ref[f'margin_lt_{k}_bits'])[:n].astype(bool) for k in ('2e-3', '1e-2', '5e-2')}
+    assert int(classes['2e-3'].sum()) == g['voxel_1_near_tie_count']
+    inside = {k: int((flip & m).sum()) for k, m in classes.items()}
+    total = int(flip.sum())
+    line = (f'{fx["tag"]} {fx["mode"]}: {total} of {n} voxels decide differently from the reference ({total / n:.2e}); by reference '
+            f'margin: {inside["2e-3"]} of {int(classes["2e-3"].sum())} below 2e-3, {inside["1e-2"] - inside["2e-3"]} in [2e-3, 1e-2), '
+            f'{inside["5e-2"] - inside["1e-2"]} in [1e-2, 5e-2), {total - inside["5e-2"]} above')
+    print(line)
     os.makedirs(os.path.join(os.path.dirname(GOLD), '..', 'gpurun_out'), exist_ok=True)
     with open(os.path.join(os.path.dirname(GOLD), '..', 'gpurun_out', 'argmax_flips.txt'), 'a') as f:
-        f.write(f'{fx["tag"]} {fx["mode"]}: {flips} of {tie.numel()} near-tie voxels flip; {am.numel()} voxels\n')
-    assert frac <= (0.02 if fx['mode'] == 'f32' else 0.10), (flips, tie.numel())
-    if flips == 0:          # then the whole argmax is bit-identical to the reference's
-        full = hashlib.sha256(np.packbits(am.numpy().astype(bool)).tobytes()).hexdigest()
-        assert full == g['voxel_1_argmax_sha256']
+        f.write(line + '\n')
+    if fx['mode'] == 'f32':
+        assert total == inside['2e-3'], line                       # bit-exact wherever the reference margin is >= 2e-3
+        assert inside['2e-3'] <= 0.02 * classes['2e-3'].sum(), line
+        masked = am.copy()
+        masked[classes['2e-3']] = False                             # the digest the round-1 fixture carries
+        assert hashlib.sha256(np.packbits(masked).tobytes()).hexdigest() == g['voxel_1_argmax_sha256_excl_near_ties']
+    else:
+        assert total == inside['1e-2'], line                       # bit-exact wherever the reference margin is >= 1e-2
+        assert total <= 2e-4 * n, line
+    pops = am.reshape(fx['b'] * fx['s'], -1).sum(1).tolist()
+    for got, want in zip(pops, g['voxel_1_argmax_popcounts']):
+        assert abs(got - want) <= total, (pops, g['voxel_1_argmax_popcounts'])
 
 
 def test_gradients_match_reference(run):
@@ -184,7 +194,7 @@ def test_gradients_match_reference(run):
             tol = max(2e-2 * ref.abs().max().item(), 6.0 * noise, 1e-12)
             tol_l2 = max(5e-3 * ref.norm().item(), 6.0 * noise_l2, 1e-12)
             if rnd:   # the reference's own response to bf16x3-sized rounding, scaled to the strided sample
-                tol = max(tol, 2.0 * rnd['grad_max_err'][n])
+                tol = max(tol, 3.0 * rnd['grad_max_err'][n])     # (one random perturbation sample: its maximum is itself noisy)
                 tol_l2 = max(tol_l2, 3.0 * rnd['grad_l2_err'][n] * (ref.numel() / t.numel()) ** 0.5)
             assert err <= tol, f'{n}: max err {err:.3e} > tol {tol:.3e} (reference fp32 noise {noise:.3e})'
             assert err_l2 <= tol_l2, f'{n}: L2 err {err_l2:.3e} > tol {tol_l2:.3e} (reference fp32 noise {noise_l2:.3e})'
