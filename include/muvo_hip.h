@@ -218,6 +218,32 @@ int muvo_attention_fwd(const float* qkv, float* out, float* lse, int L, int N, i
                        void* stream);
 int muvo_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int L, int N, int H,
                        int DH, float p, uint64_t seed, void* stream);
+/* The whole recurrent state-space model (muvo/models/transition.py:76-173) as two persistent kernels (csrc/rssm.hip): one
+ * workgroup per CU walks the T time steps, 4 grid barriers per step; B <= 4 sequences, T <= 64, H/S/E/A multiples of 4.
+ * weights[18] (PyTorch [out][in] layouts): pre_gru_net.0.{weight,bias}, recurrent_model.{weight_ih,weight_hh,bias_ih,bias_hh},
+ *   prior_action_module.0.{weight,bias}, posterior_action_module.0.{weight,bias}, prior.module.0.{weight,bias},
+ *   prior.module.2.{weight,bias}, posterior.module.0.{weight,bias}, posterior.module.2.{weight,bias}.
+ * emb (B,T,E), act (B,T,AD), noise (B,T,2,S) [prior, posterior draws]; use_prior_mask bit t: step t+1 continues from the PRIOR
+ *   sample of step t (transition.py:118-124), else from the posterior sample.
+ * out7 (B,T,.): hidden state h (H) — shared by the prior and posterior dicts —, prior mu, sigma, sample, posterior mu, sigma,
+ *   sample (S).  keep12 (B,T,.), written for the backward pass: h_prev (H), z_prev (S), a_prev (AD), u (H), gi (3H), gh (3H),
+ *   x_prior (H+A), x_post (H+E+A), y1_prior (H+A), y1_post (H+E+A), mls_prior (2S), mls_post (2S).
+ * muvo_rssm_backward: kept5 = {h_prev, gi, gh, mls_prior, mls_post}; upstream7 = gradients of out7 (NULL = none);
+ *   grads10 (B,T,.) written: d_emb (E), dmls_prior, dmls_post (2S), dy1_prior (H+A), dy1_post (H+E+A), dgi, dgh (3H), du (H),
+ *   dla_prior, dla_post (A) — the weight gradients are dW = dY^T X over the B*T rows (caller: one skinny GEMM per weight):
+ *   W_post2: dmls_post x y1_post; W_post0: dy1_post x x_post; W_prior2: dmls_prior x y1_prior; W_prior0: dy1_prior x x_prior;
+ *   W_ih: dgi x u; W_hh: dgh x h_prev; W_pre: du x z_prev; action modules: dla x a_prev; biases: column sums of the dY.
+ *   wt_scratch: muvo_rssm_transposed_floats() floats (the transposed weights are rebuilt by every call); scratch:
+ *   muvo_rssm_scratch_floats() floats; barrier_word: 4 bytes of device memory. */
+int muvo_rssm_supported(int B, int T, int H, int S, int E, int A, int AD);
+int64_t muvo_rssm_transposed_floats(int H, int S, int E, int A);
+int64_t muvo_rssm_scratch_floats(int B, int H, int S, int E, int A);
+int muvo_rssm_forward(int B, int T, int H, int S, int E, int A, int AD, const float* const* weights, const float* emb,
+                      const float* act, const float* noise, uint64_t use_prior_mask, float* const* out7, float* const* keep12,
+                      uint32_t* barrier_word, float min_std, void* stream);
+int muvo_rssm_backward(int B, int T, int H, int S, int E, int A, int AD, const float* const* weights, float* wt_scratch,
+                       const float* noise, uint64_t use_prior_mask, const float* const* kept5, const float* const* upstream7,
+                       float* const* grads10, float* scratch, uint32_t* barrier_word, void* stream);
 /* Training-time augmentation inside PreProcess.forward (muvo/models/preprocess.py:45-48,213-214; PixelAugmentation :295-333,
  * RouteAugmentation :336-367; torchvision 0.15.2 tensor algorithms).  The random draws are explicit inputs.
  * muvo_pixel_augment: img (F,3,H,W) in [0,1] (the cropped image = rgb_label_1) is augmented IN PLACE, norm (F,3,H,W) receives

@@ -49,6 +49,12 @@ class RSSM(nn.Module):
         if use_prior is None:
             use_prior = [bool(self.training and self.use_dropout and torch.rand(1).item() < self.dropout_probability
                               and t > 0) for t in range(s)]
+        if use_sample and not self.active_inference and ops.rssm_fused_supported(
+                b, s, self.hidden_state_dim, self.state_dim, self.embedding_dim, self.action_latent_dim, self.action_dim):
+            # the whole time loop as one persistent kernel (csrc/rssm.hip); the hidden state is one tensor for both dicts
+            h, p_mu, p_sigma, p_sample, q_mu, q_sigma, q_sample = ops.rssm_fused(input_embedding, action, noise, self, use_prior)
+            return {'prior': {'hidden_state': h, 'sample': p_sample, 'mu': p_mu, 'sigma': p_sigma},
+                    'posterior': {'hidden_state': h, 'sample': q_sample, 'mu': q_mu, 'sigma': q_sigma}}
         h_t = torch.zeros(b, self.hidden_state_dim, device=dev)
         sample_t = torch.zeros(b, self.state_dim, device=dev)
         zeros_a = torch.zeros(b, self.action_dim, device=dev)

@@ -65,6 +65,7 @@ EXPORTS = [
     'muvo_range_projection', 'muvo_voxel_grid', 'muvo_seg_ce_fwd', 'muvo_seg_ce_bwd', 'muvo_ssim_maps', 'muvo_ssim_bwd',
     'muvo_instance_labels', 'muvo_pixel_augment', 'muvo_preprocess_route_aug',
     'muvo_split_planes_bytes', 'muvo_split_planes', 'muvo_attention_supported', 'muvo_attention_fwd', 'muvo_attention_bwd',
+    'muvo_rssm_supported', 'muvo_rssm_transposed_floats', 'muvo_rssm_scratch_floats', 'muvo_rssm_forward', 'muvo_rssm_backward',
 ]
 
 
@@ -83,6 +84,8 @@ def lib():
                 L.muvo_linear_bf16x3_workspace_bytes.restype = C.c_int64
                 L.muvo_pack_table_item_bytes.restype = C.c_int64
                 L.muvo_split_planes_bytes.restype = C.c_int64
+                L.muvo_rssm_transposed_floats.restype = C.c_int64
+                L.muvo_rssm_scratch_floats.restype = C.c_int64
                 for name in EXPORTS:
                     getattr(L, name)  # AttributeError if a declared symbol is missing
                 _lib = L
@@ -1298,6 +1301,90 @@ class RSSMSampleFn(torch.autograd.Function):
 
 def rssm_sample(mls, eps, min_std=0.1):
     return RSSMSampleFn.apply(mls, eps, min_std)
+
+
+def _ptr_table(tensors):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        if t is not None:
+            assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32
+            arr[i] = t.data_ptr()
+    return arr
+
+
+def rssm_weights(rssm):
+    """The 18 parameter tensors in the order of include/muvo_hip.h: muvo_rssm_forward."""
+    return [rssm.pre_gru_net[0].weight, rssm.pre_gru_net[0].bias, rssm.recurrent_model.weight_ih, rssm.recurrent_model.weight_hh,
+            rssm.recurrent_model.bias_ih, rssm.recurrent_model.bias_hh, rssm.prior_action_module[0].weight,
+            rssm.prior_action_module[0].bias, rssm.posterior_action_module[0].weight, rssm.posterior_action_module[0].bias,
+            rssm.prior.module[0].weight, rssm.prior.module[0].bias, rssm.prior.module[2].weight, rssm.prior.module[2].bias,
+            rssm.posterior.module[0].weight, rssm.posterior.module[0].bias, rssm.posterior.module[2].weight,
+            rssm.posterior.module[2].bias]
+
+
+class RSSMFusedFn(torch.autograd.Function):
+    """RSSM.forward (transition.py:76-127) for a whole sequence: one persistent kernel forward, one backward (csrc/rssm.hip),
+    then one skinny GEMM per weight for dW = dY^T X over the b*T rows."""
+
+    @staticmethod
+    def forward(ctx, emb, act, noise, rssm, mask):
+        emb, act, noise = emb.contiguous(), act.contiguous(), noise.contiguous()
+        B, T, E = emb.shape
+        AD, H, S, A = act.shape[-1], rssm.hidden_state_dim, rssm.state_dim, rssm.action_latent_dim
+        dev = emb.device
+        new = lambda n: torch.empty(B, T, n, device=dev, dtype=torch.float32)
+        out = [new(H)] + [new(S) for _ in range(6)]
+        keep = [new(n) for n in (H, S, AD, H, 3 * H, 3 * H, H + A, H + E + A, H + A, H + E + A, 2 * S, 2 * S)]
+        bar = scratch('rssm_bar', 4, dev, torch.int32)
+        w = rssm_weights(rssm)
+        _ck(lib().muvo_rssm_forward(B, T, H, S, E, A, AD, _ptr_table(w), _f(emb), _f(act), _f(noise), C.c_uint64(mask),
+                                    _ptr_table(out), _ptr_table(keep), _p(bar), _fl(rssm.prior.min_std), _st()))
+        ctx.rssm, ctx.mask, ctx.dims = rssm, mask, (B, T, H, S, E, A, AD)
+        ctx.save_for_backward(noise, *keep)
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *gout):
+        noise, hprev, zprev, aprev, u, gi, gh, xp, xq, y1p, y1q, mls_p, mls_q = ctx.saved_tensors
+        B, T, H, S, E, A, AD = ctx.dims
+        rssm = ctx.rssm
+        dev = noise.device
+        L = lib()
+        gout = [None if g is None else g.contiguous() for g in gout]
+        new = lambda n: torch.empty(B, T, n, device=dev, dtype=torch.float32)
+        d_emb = new(E)
+        dmls_p, dmls_q, dy1p, dy1q, dgi, dgh, du, dla_p, dla_q = (new(n) for n in (2 * S, 2 * S, H + A, H + E + A, 3 * H, 3 * H, H, A, A))
+        wt = scratch('rssm_wt', L.muvo_rssm_transposed_floats(H, S, E, A), dev)
+        sc = scratch('rssm_scratch', L.muvo_rssm_scratch_floats(B, H, S, E, A), dev)
+        bar = scratch('rssm_bar', 4, dev, torch.int32)
+        w = rssm_weights(rssm)
+        _ck(L.muvo_rssm_backward(B, T, H, S, E, A, AD, _ptr_table(w), _f(wt), _f(noise), C.c_uint64(ctx.mask),
+                                 _ptr_table([hprev, gi, gh, mls_p, mls_q]), _ptr_table(gout),
+                                 _ptr_table([d_emb, dmls_p, dmls_q, dy1p, dy1q, dgi, dgh, du, dla_p, dla_q]), _f(sc), _p(bar), _st()))
+        rows = B * T
+        for dz, x, wi in ((du, zprev, 0), (dgi, u, 2), (dgh, hprev, 3), (dla_p, aprev, 6), (dla_q, aprev, 8), (dy1p, xp, 10),
+                          (dmls_p, y1p, 12), (dy1q, xq, 14), (dmls_q, y1q, 16)):
+            weight = w[wi]
+            out_f, in_f = weight.shape
+            if weight.requires_grad:
+                gemm(dz, x, grad_of(weight), out_f, in_f, rows, 1, out_f, in_f, 1, in_f, mode=1)
+        for dz, bi in ((du, 1), (dgi, 4), (dgh, 5), (dla_p, 7), (dla_q, 9), (dy1p, 11), (dmls_p, 13), (dy1q, 15), (dmls_q, 17)):
+            if w[bi].requires_grad:
+                n = w[bi].numel()
+                _ck(L.muvo_colsum_acc(_f(dz), _f(grad_of(w[bi])), _i64(rows), _i64(n), _i64(n), _st()))
+        return d_emb, None, None, None, None
+
+
+FUSED_RSSM = os.environ.get('MUVO_FUSED_RSSM', '1') != '0'
+
+
+def rssm_fused_supported(B, T, H, S, E, A, AD):
+    return FUSED_RSSM and bool(lib().muvo_rssm_supported(B, T, H, S, E, A, AD))
+
+
+def rssm_fused(emb, act, noise, rssm, use_prior):
+    mask = sum(1 << t for t, f in enumerate(use_prior) if f)
+    return RSSMFusedFn.apply(emb, act, noise, rssm, mask)
 
 
 # ================================================================================================ preprocess (no grad)

@@ -716,3 +716,56 @@ def test_flash_attention(dev, l, n, heads, dh):
         _close(of, ou, rtol=2e-5, name=f'flash vs unfused fwd p={p}')
         _close(df, du, rtol=1e-4, name=f'flash vs unfused dqkv p={p}')
         assert not torch.allclose(of, o)                                          # the mask does something
+
+
+@pytest.mark.parametrize('b,t,dims', [(2, 5, (64, 32, 32, 8)), (1, 3, (64, 32, 32, 8)), (4, 4, (128, 64, 32, 16)), (2, 10, (1024, 512, 512, 64))])
+def test_fused_rssm(dev, b, t, dims):
+    """The persistent RSSM kernels (csrc/rssm.hip) against the oracle's RSSM (plain torch on CPU; transition.py:76-173) and
+    against the unfused per-op path of the same module: all eight outputs, the gradient w.r.t. the embedding and all 18
+    parameter gradients, with the prior-sample branch taken mid-sequence and at the end, upstream gradients on every output."""
+    from muvo_amd import ops
+    from muvo_amd.models.transition import RSSM
+    from oracle import muvo_ref as R
+    H, S, E, A = dims
+    torch.manual_seed(b * 100 + t + H)
+    with torch.device(dev):
+        m = RSSM(embedding_dim=E, action_dim=2, hidden_state_dim=H, state_dim=S, action_latent_dim=A, receptive_field=t,
+                 use_dropout=True, dropout_probability=0.15)
+    m.train()
+    ref = R.RSSM(E, 2, H, S, A)
+    ref.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    emb, act = torch.randn(b, t, E), torch.rand(b, t, 2) * 2 - 1
+    noise = torch.randn(b, t, 2, S)
+    use_prior = [bool(i in (1, t - 1) and i > 0) for i in range(t)]
+    keys = [(g, k) for g in ('prior', 'posterior') for k in ('hidden_state', 'sample', 'mu', 'sigma')]
+    ups = {gk: torch.randn(b, t, H if gk[1] == 'hidden_state' else S) for gk in keys}
+
+    def run(fused):
+        ops.FUSED_RSSM = fused
+        for p in m.parameters():
+            p.grad = torch.zeros_like(p)
+        e = emb.to(dev).requires_grad_(True)
+        out = m(e, act.to(dev), noise=noise.to(dev), use_prior=use_prior)
+        sum((out[g][k] * ups[(g, k)].to(dev)).sum() for g, k in keys).backward()
+        return out, e.grad, {n: p.grad.clone() for n, p in m.named_parameters()}
+
+    assert ops.rssm_fused_supported(b, t, H, S, E, A, 2)
+    try:
+        out_f, de_f, gw_f = run(True)
+        out_u, de_u, gw_u = run(False)
+    finally:
+        ops.FUSED_RSSM = True
+    ec = emb.clone().requires_grad_(True)
+    pri, pos = ref(ec, act, noise, use_prior)
+    out_r = {'prior': pri, 'posterior': pos}
+    sum((out_r[g][k] * ups[(g, k)]).sum() for g, k in keys).backward()
+    tol = dict(rtol=2e-4, atol=2e-5) if H < 512 else dict(rtol=1e-3, atol=1e-4)
+    for g, k in keys:
+        _close(out_f[g][k], out_r[g][k], name=f'fused rssm {g}.{k}', **tol)
+        _close(out_f[g][k], out_u[g][k], name=f'fused vs unfused {g}.{k}', **tol)
+    _close(de_f, ec.grad, name='fused rssm d_embedding', **tol)
+    _close(de_f, de_u, name='fused vs unfused d_embedding', **tol)
+    refp = dict(ref.named_parameters())
+    for n in gw_f:
+        _close(gw_f[n], refp[n].grad, name=f'fused rssm grad {n}', **tol)
+        _close(gw_f[n], gw_u[n], name=f'fused vs unfused grad {n}', **tol)
