@@ -51,16 +51,23 @@ struct RssmBwdArgs {
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
 
-// all workgroups are resident (grid = number of CUs, one workgroup each): counter barrier with agent-scope release/acquire
+// Data that one workgroup writes and another reads across a grid barrier moves through agent-scope relaxed atomics (32-bit
+// loads / stores that are coherent across the 8 XCDs by themselves), so the barrier needs NO L2 write-back / invalidate:
+// a device-scope fence per wave cost ~90 us per barrier here (512 buffer_wbl2 + buffer_inv per XCD), 3.9 ms per sequence.
+__device__ __forceinline__ void coh_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float coh_load(const float* p) {
+  return __hip_atomic_load(const_cast<float*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// all workgroups are resident (grid = number of CUs, one workgroup each): counter barrier.  Every wave first waits until its
+// own (write-through) stores are acknowledged, the workgroup barrier collects the waves, one thread signs in and spins.
 __device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned target) {
-  __threadfence();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    atomicAdd(bar, 1u);
-    while (__atomic_load_n(bar, __ATOMIC_RELAXED) < target) __builtin_amdgcn_s_sleep(2);
+    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
   }
   __syncthreads();
-  __threadfence();
 }
 
 // NR weight rows (each K floats, 16-byte aligned, K % 4 == 0) dotted with the B input vectors xs[r*ldx + k] in LDS
@@ -72,17 +79,26 @@ __device__ __forceinline__ void wave_dots(const float* const (&w)[NR], const flo
   for (int q = 0; q < NR; ++q)
 #pragma unroll
     for (int r = 0; r < RSSM_BM; ++r) acc[q][r] = 0.f;
-  for (int k = 4 * lane; k < K; k += 256) {
-    f32x4 wv[NR];
+  for (int k0 = 4 * lane; k0 < K; k0 += 1024) {
+    f32x4 wv[4][NR];
 #pragma unroll
-    for (int q = 0; q < NR; ++q) wv[q] = *(const f32x4*)(w[q] + k);
+    for (int u = 0; u < 4; ++u)                 // up to 4 x NR independent 16-byte loads in flight per lane
 #pragma unroll
-    for (int r = 0; r < RSSM_BM; ++r)
-      if (r < B) {
-        const f32x4 xv = *(const f32x4*)(xs + r * ldx + k);
+      for (int q = 0; q < NR; ++q) {
+        wv[u][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (k0 + 256 * u < K) wv[u][q] = __builtin_nontemporal_load((const f32x4*)(w[q] + k0 + 256 * u));
+      }
 #pragma unroll
-        for (int q = 0; q < NR; ++q)
-          acc[q][r] += (wv[q][0] * xv[0] + wv[q][1] * xv[1]) + (wv[q][2] * xv[2] + wv[q][3] * xv[3]);
+    for (int u = 0; u < 4; ++u)
+      if (k0 + 256 * u < K) {
+#pragma unroll
+        for (int r = 0; r < RSSM_BM; ++r)
+          if (r < B) {
+            const f32x4 xv = *(const f32x4*)(xs + r * ldx + k0 + 256 * u);
+#pragma unroll
+            for (int q = 0; q < NR; ++q)
+              acc[q][r] += (wv[u][q][0] * xv[0] + wv[u][q][1] * xv[1]) + (wv[u][q][2] * xv[2] + wv[u][q][3] * xv[3]);
+          }
       }
   }
 #pragma unroll
@@ -103,7 +119,7 @@ __device__ __forceinline__ float pick(const float (&a)[RSSM_BM], int lane) {
 __device__ __forceinline__ void lds_load(float* dst, const float* __restrict__ src, int B, int n, long src_ld) {
   for (int i = threadIdx.x; i < B * n; i += RSSM_THREADS) {
     const int b = i / n, j = i - b * n;
-    dst[i] = src ? src[(long)b * src_ld + j] : 0.f;
+    dst[i] = src ? coh_load(src + (long)b * src_ld + j) : 0.f;
   }
 }
 
@@ -136,25 +152,25 @@ __global__ void __launch_bounds__(RSSM_THREADS) rssm_fwd_kernel(const RssmFwdArg
         const float* const wr[1] = {a.w.w_pre + (long)o * S};
         float acc[1][RSSM_BM];
         wave_dots<1>(wr, xa, S, S, B, acc);
-        if (lane < B) a.u[((long)lane * T + t) * H + o] = pick(acc[0], lane) + a.w.b_pre[o];
+        if (lane < B) coh_store(&a.u[((long)lane * T + t) * H + o], pick(acc[0], lane) + a.w.b_pre[o]);
       } else if (o < 4 * H) {
         const int oo = o - H;
         const float* const wr[1] = {a.w.w_hh + (long)oo * H};
         float acc[1][RSSM_BM];
         wave_dots<1>(wr, hs, H, H, B, acc);
-        if (lane < B) a.gh[((long)lane * T + t) * 3 * H + oo] = pick(acc[0], lane) + a.w.b_hh[oo];
+        if (lane < B) coh_store(&a.gh[((long)lane * T + t) * 3 * H + oo], pick(acc[0], lane) + a.w.b_hh[oo]);
       } else if (lane < B) {
         const int oo = o - 4 * H, post = oo >= A, j = post ? oo - A : oo;
         const float* wj = (post ? a.w.w_qa : a.w.w_pa) + (long)j * AD;
         float v = (post ? a.w.b_qa : a.w.b_pa)[j];
         for (int k = 0; k < AD; ++k) v += wj[k] * as[lane * AD + k];
-        if (post) a.xq[((long)lane * T + t) * HQ + H + E + j] = v;
-        else a.xp[((long)lane * T + t) * HP + H + j] = v;
+        if (post) coh_store(&a.xq[((long)lane * T + t) * HQ + H + E + j], v);
+        else coh_store(&a.xp[((long)lane * T + t) * HP + H + j], v);
       }
     }
     for (long i = gtid; i < (long)B * E; i += gthreads) {      // the embedding slice of the posterior input
       const int b = (int)(i / E), e = (int)(i - (long)b * E);
-      a.xq[((long)b * T + t) * HQ + H + e] = a.emb[((long)b * T + t) * E + e];
+      coh_store(&a.xq[((long)b * T + t) * HQ + H + e], a.emb[((long)b * T + t) * E + e]);
     }
     target += gridDim.x;
     grid_barrier(a.bar, target);
@@ -169,13 +185,13 @@ __global__ void __launch_bounds__(RSSM_THREADS) rssm_fwd_kernel(const RssmFwdArg
         const long base = ((long)lane * T + t) * 3 * H;
         const float ir = pick(acc[0], lane) + a.w.b_ih[j], iz = pick(acc[1], lane) + a.w.b_ih[H + j], in_ = pick(acc[2], lane) + a.w.b_ih[2 * H + j];
         a.gi[base + j] = ir; a.gi[base + H + j] = iz; a.gi[base + 2 * H + j] = in_;
-        const float r = sigm(ir + a.gh[base + j]);
-        const float z = sigm(iz + a.gh[base + H + j]);
-        const float nn = tanhf(in_ + r * a.gh[base + 2 * H + j]);
+        const float r = sigm(ir + coh_load(&a.gh[base + j]));
+        const float z = sigm(iz + coh_load(&a.gh[base + H + j]));
+        const float nn = tanhf(in_ + r * coh_load(&a.gh[base + 2 * H + j]));
         const float hn = (1.f - z) * nn + z * hs[lane * H + j];
-        a.h[((long)lane * T + t) * H + j] = hn;
-        a.xp[((long)lane * T + t) * HP + j] = hn;
-        a.xq[((long)lane * T + t) * HQ + j] = hn;
+        coh_store(&a.h[((long)lane * T + t) * H + j], hn);
+        coh_store(&a.xp[((long)lane * T + t) * HP + j], hn);
+        coh_store(&a.xq[((long)lane * T + t) * HQ + j], hn);
       }
     }
     target += gridDim.x;
@@ -189,12 +205,12 @@ __global__ void __launch_bounds__(RSSM_THREADS) rssm_fwd_kernel(const RssmFwdArg
       if (o < HP) {
         const float* const wr[1] = {a.w.w_p0 + (long)o * HP};
         wave_dots<1>(wr, xb, HP, HP, B, acc);
-        if (lane < B) a.y1p[((long)lane * T + t) * HP + o] = pick(acc[0], lane) + a.w.b_p0[o];
+        if (lane < B) coh_store(&a.y1p[((long)lane * T + t) * HP + o], pick(acc[0], lane) + a.w.b_p0[o]);
       } else {
         const int oo = o - HP;
         const float* const wr[1] = {a.w.w_q0 + (long)oo * HQ};
         wave_dots<1>(wr, xa, HQ, HQ, B, acc);
-        if (lane < B) a.y1q[((long)lane * T + t) * HQ + oo] = pick(acc[0], lane) + a.w.b_q0[oo];
+        if (lane < B) coh_store(&a.y1q[((long)lane * T + t) * HQ + oo], pick(acc[0], lane) + a.w.b_q0[oo]);
       }
     }
     target += gridDim.x;
@@ -221,7 +237,7 @@ __global__ void __launch_bounds__(RSSM_THREADS) rssm_fwd_kernel(const RssmFwdArg
         const float e = a.noise[(bt * 2 + post) * S + j];
         (post ? a.mu_q : a.mu_p)[bt * S + j] = m;
         (post ? a.sg_q : a.sg_p)[bt * S + j] = sg;
-        (post ? a.z_q : a.z_p)[bt * S + j] = m + sg * e;
+        coh_store(&(post ? a.z_q : a.z_p)[bt * S + j], m + sg * e);
       }
     }
     target += gridDim.x;
@@ -252,7 +268,7 @@ __global__ void __launch_bounds__(RSSM_THREADS) rssm_bwd_kernel(const RssmBwdArg
       const float* gsg = post ? a.g_sg_q : a.g_sg_p;
       const float* gz = post ? a.g_z_q : a.g_z_p;
       float dz = gz ? gz[bt * S + j] : 0.f;
-      if (has_carry && (up != (bool)post)) dz += a.dz_carry[b * S + j];
+      if (has_carry && (up != (bool)post)) dz += coh_load(&a.dz_carry[b * S + j]);
       const float s = sigm(mls[bt * 2 * S + S + j] * 0.5f);
       const float e = a.noise[(bt * 2 + post) * S + j];
       const float dmu = (gmu ? gmu[bt * S + j] : 0.f) + dz;
@@ -272,12 +288,12 @@ __global__ void __launch_bounds__(RSSM_THREADS) rssm_bwd_kernel(const RssmBwdArg
       if (o < HP) {
         const float* const wr[1] = {a.wt.w_p2 + (long)o * 2 * S};
         wave_dots<1>(wr, xb, 2 * S, 2 * S, B, acc);
-        if (lane < B) a.dy1p[((long)lane * T + t) * HP + o] = pick(acc[0], lane);
+        if (lane < B) coh_store(&a.dy1p[((long)lane * T + t) * HP + o], pick(acc[0], lane));
       } else {
         const int oo = o - HP;
         const float* const wr[1] = {a.wt.w_q2 + (long)oo * 2 * S};
         wave_dots<1>(wr, xa, 2 * S, 2 * S, B, acc);
-        if (lane < B) a.dy1q[((long)lane * T + t) * HQ + oo] = pick(acc[0], lane);
+        if (lane < B) coh_store(&a.dy1q[((long)lane * T + t) * HQ + oo], pick(acc[0], lane));
       }
     }
     target += gridDim.x;
@@ -292,7 +308,7 @@ __global__ void __launch_bounds__(RSSM_THREADS) rssm_bwd_kernel(const RssmBwdArg
         const float* const wr[1] = {a.wt.w_p0 + (long)o * HP};
         wave_dots<1>(wr, xb, HP, HP, B, acc);
         if (lane < B) {
-          a.dxp[lane * HP + o] = pick(acc[0], lane);
+          coh_store(&a.dxp[lane * HP + o], pick(acc[0], lane));
           if (o >= H) a.dla_p[((long)lane * T + t) * A + (o - H)] = pick(acc[0], lane);
         }
       } else {
@@ -300,7 +316,7 @@ __global__ void __launch_bounds__(RSSM_THREADS) rssm_bwd_kernel(const RssmBwdArg
         const float* const wr[1] = {a.wt.w_q0 + (long)oo * HQ};
         wave_dots<1>(wr, xa, HQ, HQ, B, acc);
         if (lane < B) {
-          a.dxq[lane * HQ + oo] = pick(acc[0], lane);
+          coh_store(&a.dxq[lane * HQ + oo], pick(acc[0], lane));
           if (oo >= H + E) a.dla_q[((long)lane * T + t) * A + (oo - H - E)] = pick(acc[0], lane);
           else if (oo >= H) a.d_emb[((long)lane * T + t) * E + (oo - H)] = pick(acc[0], lane);
         }
@@ -314,8 +330,8 @@ __global__ void __launch_bounds__(RSSM_THREADS) rssm_bwd_kernel(const RssmBwdArg
     for (int i = tid; i < B * H; i += RSSM_THREADS) {
       const int b = i / H, j = i - b * H;
       const long bt = (long)b * T + t, base = bt * 3 * H;
-      float g = (a.g_h ? a.g_h[bt * H + j] : 0.f) + a.dxp[b * HP + j] + a.dxq[b * HQ + j];
-      if (has_carry) g += carry_in[i];
+      float g = (a.g_h ? a.g_h[bt * H + j] : 0.f) + coh_load(&a.dxp[b * HP + j]) + coh_load(&a.dxq[b * HQ + j]);
+      if (has_carry) g += coh_load(&carry_in[i]);
       const float ghn = a.gh[base + 2 * H + j];
       const float r = sigm(a.gi[base + j] + a.gh[base + j]);
       const float z = sigm(a.gi[base + H + j] + a.gh[base + H + j]);
@@ -339,12 +355,12 @@ __global__ void __launch_bounds__(RSSM_THREADS) rssm_bwd_kernel(const RssmBwdArg
       if (o < H) {
         const float* const wr[1] = {a.wt.w_ih + (long)o * 3 * H};
         wave_dots<1>(wr, xa, 3 * H, 3 * H, B, acc);
-        if (lane < B) a.du[((long)lane * T + t) * H + o] = pick(acc[0], lane);
+        if (lane < B) coh_store(&a.du[((long)lane * T + t) * H + o], pick(acc[0], lane));
       } else {
         const int oo = o - H;
         const float* const wr[1] = {a.wt.w_hh + (long)oo * 3 * H};
         wave_dots<1>(wr, xb, 3 * H, 3 * H, B, acc);
-        if (lane < B) carry_out[lane * H + oo] = pick(acc[0], lane) + dd[lane * H + oo];
+        if (lane < B) coh_store(&carry_out[lane * H + oo], pick(acc[0], lane) + dd[lane * H + oo]);
       }
     }
     target += gridDim.x;
@@ -356,7 +372,7 @@ __global__ void __launch_bounds__(RSSM_THREADS) rssm_bwd_kernel(const RssmBwdArg
       const float* const wr[1] = {a.wt.w_pre + (long)o * H};
       float acc[1][RSSM_BM];
       wave_dots<1>(wr, xa, H, H, B, acc);
-      if (lane < B) a.dz_carry[lane * S + o] = pick(acc[0], lane);
+      if (lane < B) coh_store(&a.dz_carry[lane * S + o], pick(acc[0], lane));
     }
     target += gridDim.x;
     grid_barrier(a.bar, target);
