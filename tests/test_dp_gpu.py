@@ -69,7 +69,10 @@ def test_two_rank_step_matches_reference(dev, conv_mode):
                 assert _rel(tr.last_losses[k].item(), v) < tol, (step, rank, k)
         if step == 0:
             bad = []
-            tol_rel = 3e-3 if conv_mode == 'f32' else 3e-2     # policy: bf16x3 rounding flips ReLU/L1-sign decisions
+            # f32: 5e-3 (the norms at the end of the backward chain carry the reference's own fp32 noise, up to 2e-3: see
+            # test_model_gpu.test_gradients_match_reference for the per-tensor bars); policy: bf16x3 rounding flips ReLU / L1-sign
+            # decisions
+            tol_rel = 5e-3 if conv_mode == 'f32' else 3e-2
             for n, ref in g['avg_grad_l2'].items():
                 p = dict(tr.model.named_parameters())[n]
                 if ref is None:
