@@ -109,6 +109,10 @@ int muvo_conv_forward(const muvo_conv_desc* d, const float* x, const float* wp_f
  * planes of dy (written by muvo_conv_prepare_dy), dy itself is then not read by the bf16x3 path */
 int muvo_conv_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp_dgrad, float* dx, void* ws, int ws_valid,
                     void* stream);
+/* dx += conv_data_grad(dy, w) for the 1x1 output heads (muvo_conv_kernel_family(d, 1) == 3; RGBHead / LidarReHead / VoxelSemHead,
+ * common.py:274-303,354-367): the head hangs off a decoder trunk, dx already holds the gradient that came back through the
+ * trunk, so no separate add pass over the feature map is needed */
+int muvo_conv_dgrad_accumulate(const muvo_conv_desc* d, const float* dy, const float* wp_dgrad, float* dx, void* stream);
 /* backward preamble when muvo_conv_kernel_family(d, 1) == muvo_conv_kernel_family(d, 2) == 1: ws_dy <- split planes of
  * dy * act'(y) (y may be NULL with MUVO_ACT_NONE), dbias += its per-channel sums (dbias may be NULL) */
 int muvo_conv_prepare_dy(const muvo_conv_desc* d, const float* y, const float* dy, int act, float slope, void* ws_dy,

@@ -936,6 +936,14 @@ int muvo_conv_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp_dg
   return run_phases(pl.dgr, pl.ndgr, dy, wp_dgrad, nullptr, dx, MUVO_ACT_NONE, 0.f, ws, (hipStream_t)stream, ws_valid != 0);
 }
 
+int muvo_conv_dgrad_accumulate(const muvo_conv_desc* d, const float* dy, const float* wp_dgrad, float* dx, void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  MUVO_CHECK_ARG(dy && wp_dgrad && dx, "conv_dgrad_accumulate: null pointer");
+  MUVO_CHECK_ARG(pw_applicable(d), "conv_dgrad_accumulate: only the 1x1 head kernels (muvo_conv_kernel_family == 3) accumulate");
+  return pw_dgrad_acc(d, dy, wp_dgrad, dx, (hipStream_t)stream);
+}
+
 // Backward preamble for layers whose dgrad AND wgrad run on the bf16x3 kernels: one pass over (y, dy) writes the
 // channels-last split planes of dz = dy * act'(y) into ws_dy (muvo_conv_workspace_bytes(d, 1) bytes) and adds the bias
 // gradient sum(dz) to dbias — instead of an activation-gradient pass, a split pass and a bias-gradient pass.

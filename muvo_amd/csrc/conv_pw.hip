@@ -47,7 +47,9 @@ __global__ void __launch_bounds__(256) pw_fwd_kernel(const float* __restrict__ i
   }
 }
 
-template <int CO>
+// ACC: din += W^T dout (the head is a side branch of a decoder trunk: the gradient that came back through the trunk is
+// already in din, so autograd needs no separate add pass over the full feature map)
+template <int CO, bool ACC>
 __global__ void __launch_bounds__(256) pw_dgrad_kernel(const float* __restrict__ dout, const float* __restrict__ w,
                                                        float* __restrict__ din, int Cin, long S4) {
   extern __shared__ float s_w[];
@@ -63,6 +65,7 @@ __global__ void __launch_bounds__(256) pw_dgrad_kernel(const float* __restrict__
 #pragma unroll 4
     for (int ci = 0; ci < Cin; ++ci) {
       float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ACC) r = din_n[(size_t)ci * S4 + p];
 #pragma unroll
       for (int co = 0; co < CO; ++co) {
         const float ww = s_w[co * Cin + ci];
@@ -150,7 +153,9 @@ static int pw_run(int op, const muvo_conv_desc* d, const float* a, const float* 
   if (op == 0) {
     hipLaunchKernelGGL((pw_fwd_kernel<CO>), dim3(gx, d->N), dim3(256), lds, st, a, w, bias, o0, d->Cin, S4, act, slope);
   } else if (op == 1) {
-    hipLaunchKernelGGL((pw_dgrad_kernel<CO>), dim3(gx, d->N), dim3(256), lds, st, a, w, o0, d->Cin, S4);
+    hipLaunchKernelGGL((pw_dgrad_kernel<CO, false>), dim3(gx, d->N), dim3(256), lds, st, a, w, o0, d->Cin, S4);
+  } else if (op == 3) {
+    hipLaunchKernelGGL((pw_dgrad_kernel<CO, true>), dim3(gx, d->N), dim3(256), lds, st, a, w, o0, d->Cin, S4);
   } else {
     const int cgroups = cdiv(d->Cin, 8);
     int chunks = cdiv(2048, (long)cgroups * d->N);
@@ -180,6 +185,9 @@ int pw_forward(const muvo_conv_desc* d, const float* x, const float* w, const fl
 }
 int pw_dgrad(const muvo_conv_desc* d, const float* dy, const float* w, float* dx, hipStream_t st) {
   return pw_dispatch(1, d, dy, nullptr, w, nullptr, dx, nullptr, MUVO_ACT_NONE, 0.f, st);
+}
+int pw_dgrad_acc(const muvo_conv_desc* d, const float* dy, const float* w, float* dx, hipStream_t st) {
+  return pw_dispatch(3, d, dy, nullptr, w, nullptr, dx, nullptr, MUVO_ACT_NONE, 0.f, st);
 }
 int pw_wgrad(const muvo_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias, hipStream_t st) {
   return pw_dispatch(2, d, x, dy, nullptr, nullptr, dw, dbias, MUVO_ACT_NONE, 0.f, st);

@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(256) moments_kernel(const float* __restrict__ 
 }
 
 // two-term backward reductions per group: s1 = sum(dz), s2 = sum(dz * xhat)
-// mask_mode: 0 none, 1 mask = y > 0 (y given), 2 mask = (xhat*gamma+beta) > 0
+// mask_mode: 0 none, 1 mask = y > 0 (y given), 2 mask = bn(x) > 0 recomputed with the forward kernel's expression x*sc + sh
 __global__ void __launch_bounds__(256) bwd_moments_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                           const float* __restrict__ dy, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(256) bwd_moments_kernel(const float* __restric
         const float xh = (xs[e] - mu) * rs;
         float d = dd[e];
         if (mask_mode == 1) d = ys[e] > 0.f ? d : 0.f;
-        else if (mask_mode == 2) d = (xh * ga + be) > 0.f ? d : 0.f;
+        else if (mask_mode == 2) d = (xs[e] * (rs * ga) + (be - mu * (rs * ga))) > 0.f ? d : 0.f;   /* the forward's own expression: same sign bit */
         s += d;
         q += d * xh;
       }
@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(256) bwd_moments_kernel(const float* __restric
       const float xh = (x[xidx] - mu) * rs;
       float d = dy[idx];
       if (mask_mode == 1) d = y[idx] > 0.f ? d : 0.f;
-      else if (mask_mode == 2) d = (xh * ga + be) > 0.f ? d : 0.f;
+      else if (mask_mode == 2) d = (x[xidx] * (rs * ga) + (be - mu * (rs * ga))) > 0.f ? d : 0.f;   /* the forward's own expression: same sign bit */
       s += d;
       q += d * xh;
       if (++k == 64) { ds += s; dq += q; s = 0.f; q = 0.f; k = 0; }
@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
     const float xh = (x[e] - mu) * rs;
     float d = dy[e];
     if (mask_mode == 1) d = y[e] > 0.f ? d : 0.f;
-    else if (mask_mode == 2) d = (xh * ga + beta[c]) > 0.f ? d : 0.f;
+    else if (mask_mode == 2) d = (x[e] * (rs * ga) + (beta[c] - mu * (rs * ga))) > 0.f ? d : 0.f;
     if (dres) dres[e] = d;
     dx[e] = ga * rs * (d - m1 - xh * m2);
   }
@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_vec_kernel(const float* __re
       const float xh = (xs[e] - mu) * rs;
       float d = dd[e];
       if (mask_mode == 1) d = ys[e] > 0.f ? d : 0.f;
-      else if (mask_mode == 2) d = (xh * ga + be) > 0.f ? d : 0.f;
+      else if (mask_mode == 2) d = (xs[e] * (rs * ga) + (be - mu * (rs * ga))) > 0.f ? d : 0.f;   /* the forward's own expression: same sign bit */
       dm[e] = d;
       o[e] = ga * rs * (d - m1 - xh * m2);
     }

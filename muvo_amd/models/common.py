@@ -224,6 +224,13 @@ class _Head(nn.Module):
     def forward(self, x):
         return {f'{self._key}_{self.downsample_factor}': getattr(self, self._attr)[0](x)}
 
+    def branch(self, x):
+        """(x, outputs) for a head that reads a feature map the trunk goes on using: its backward accumulates the head's
+        data gradient into the trunk's (ops.HeadBranchFn)."""
+        m = getattr(self, self._attr)[0]
+        x, y = ops.head_branch(x, m.weight, m.bias, m.geom, m._packed)
+        return x, {f'{self._key}_{self.downsample_factor}': y}
+
 
 def RGBHead(in_channels, n_classes, downsample_factor):
     return _Head('rgb_head', 'rgb', hnn.Conv2d(in_channels, n_classes, 1, 1, 0), downsample_factor)
@@ -271,9 +278,9 @@ class VoxelDecoder1(nn.Module):
         for module in self.middle_conv:
             x = module(x, w)
         x = self.conv1(x, w)
-        output_4 = self.head_4(x)
+        x, output_4 = self.head_4.branch(x)
         x = self.conv2(x, w)
-        output_2 = self.head_2(x)
+        x, output_2 = self.head_2.branch(x)
         x = self.conv3(x, w)
         output_1 = self.head_1(x)
         return {**output_4, **output_2, **output_1}
@@ -344,9 +351,9 @@ class ConvDecoder(nn.Module):
         for i in (2, 4, 6):
             x = self.pre_transpose_conv[i](x, act=ops.ACT_ELU)
         x = self.trans_conv1[0](x, act=ops.ACT_ELU)
-        output_4 = self.head_4(x)
+        x, output_4 = self.head_4.branch(x)
         x = self.trans_conv2[0](x, act=ops.ACT_ELU)
-        output_2 = self.head_2(x)
+        x, output_2 = self.head_2.branch(x)
         x = self.trans_conv3[0](x, act=ops.ACT_ELU)
         output_1 = self.head_1(x)
         return {**output_4, **output_2, **output_1}

@@ -65,7 +65,7 @@ EXPORTS = [
     'muvo_range_projection', 'muvo_voxel_grid', 'muvo_seg_ce_fwd', 'muvo_seg_ce_bwd', 'muvo_ssim_maps', 'muvo_ssim_bwd',
     'muvo_instance_labels', 'muvo_pixel_augment', 'muvo_preprocess_route_aug',
     'muvo_split_planes_bytes', 'muvo_split_planes', 'muvo_attention_supported', 'muvo_attention_fwd', 'muvo_attention_bwd',
-    'muvo_rssm_supported', 'muvo_rssm_transposed_floats', 'muvo_rssm_scratch_floats', 'muvo_rssm_forward', 'muvo_rssm_backward',
+    'muvo_conv_dgrad_accumulate', 'muvo_rssm_supported', 'muvo_rssm_transposed_floats', 'muvo_rssm_scratch_floats', 'muvo_rssm_forward', 'muvo_rssm_backward',
 ]
 
 
@@ -724,6 +724,62 @@ def conv(x, weight, bias, geom, packed, act=ACT_NONE, slope=0.0, act_bwd_fused=F
     return ConvFn.apply(x, weight, bias, geom, packed, act, slope, act_bwd_fused)
 
 
+class HeadBranchFn(torch.autograd.Function):
+    """x -> (x, head(x)) for a 1x1 output head that hangs off a decoder trunk (ConvDecoder / VoxelDecoder1: head_4 and head_2
+    read the feature map that also feeds the next stage, common.py:520-545,608-632).  Forward is the plain head convolution.
+    Backward: the trunk's gradient arrives as the gradient of the first output; the head's data gradient is ACCUMULATED into
+    that tensor by the kernel (muvo_conv_dgrad_accumulate) instead of autograd adding two full feature maps in a separate
+    pass (3 x 681 MB at the rgb 1/2-scale level)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, geom, packed):
+        y = ConvFn.forward(ctx, x, weight, bias, geom, packed, ACT_NONE, 0.0)
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, gx, gy):
+        x, _ = ctx.saved_tensors
+        geom, packed, weight, bias = ctx.geom, ctx.packed, ctx.weight, ctx.bias
+        if gy is None:
+            return gx, None, None, None, None
+        d, out_sz, ff, df = geom.plan(x.shape[0], ctx.in_sz)
+        L = lib()
+        gy = gy.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if packed.dgr is None or packed.dgr.numel() < df:
+                packed.dgr = torch.empty(df, device=x.device, dtype=torch.float32)
+                packed.dgr_key = None
+            k, pkey = _wkey(weight), (ctx.in_sz, _plan_epoch[0])
+            if packed.dgr_key != k or packed.dgr_plan != pkey:
+                _ck(L.muvo_conv_pack_weights(C.byref(d), _f(weight), None, _f(packed.dgr), _st()))
+                packed.dgr_key, packed.dgr_plan = k, pkey
+            if gx is not None and gx.is_contiguous():
+                dx = gx            # a fresh tensor made by the trunk's backward for this one consumer: accumulated in place
+                _ck(L.muvo_conv_dgrad_accumulate(C.byref(d), _f(gy), _f(packed.dgr), _f(dx), _st()))
+            else:
+                dx = torch.empty_like(x)
+                _ck(L.muvo_conv_dgrad(C.byref(d), _f(gy), _f(packed.dgr), _f(dx), None, 0, _st()))
+                if gx is not None:
+                    dx = dx + gx
+        if weight.requires_grad:
+            ws = scratch_zeroed('wgrad', ff, x.device)
+            _ck(L.muvo_conv_wgrad(C.byref(d), _f(x), _f(gy), _f(ws), _f(grad_of(weight)), _f(grad_of(bias)) if bias is not None else None,
+                                  None, None, 0, _st()))
+        return dx, None, None, None, None
+
+
+def head_branch(x, weight, bias, geom, packed):
+    """(x, head(x)); fused backward when the head runs on the 1x1 head kernels, plain conv otherwise."""
+    n = x.shape[0]
+    in_sz = tuple(x.shape[2:]) if geom.nd == 3 else (1,) + tuple(x.shape[2:])
+    geom.plan(n, in_sz)
+    fam = geom.family[(n, in_sz, _plan_epoch[0])]
+    if fam[0] == 3 and fam[1] == 3 and fam[2] == 3 and x.requires_grad and torch.is_grad_enabled():
+        return HeadBranchFn.apply(x, weight, bias, geom, packed)
+    return x, conv(x, weight, bias, geom, packed)
+
+
 # ================================================================================================ norms
 class BNActFn(torch.autograd.Function):
     """Train-mode BatchNorm2d + optional residual + ReLU.  res_mode 1: relu(bn(x)+res); 2: relu(bn(x))+res."""
@@ -747,7 +803,9 @@ class BNActFn(torch.autograd.Function):
                                     _fl(bn.momentum), res_mode if residual is not None else 0, int(relu), _st()))
         _BN_PENDING.append(bn)           # num_batches_tracked += 1, applied in one fused launch (flush_bn_counters)
         ctx.bn, ctx.dims = bn, (n, c, s)
-        ctx.mask_mode = 0 if not relu else (2 if (residual is not None and res_mode == 2) else 1)
+        # ReLU mask in backward: recomputed from x (mode 2: y is neither saved nor re-read) unless the ReLU sits AFTER the
+        # residual add (res_mode 1), where only y knows the sign
+        ctx.mask_mode = 0 if not relu else (1 if (residual is not None and res_mode == 1) else 2)
         ctx.has_res, ctx.res_mode = residual is not None, res_mode
         ctx.save_for_backward(x, y if ctx.mask_mode == 1 else None, mean, rstd)
         return y
