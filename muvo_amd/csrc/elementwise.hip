@@ -391,6 +391,61 @@ __global__ void __launch_bounds__(256) upsample3d_x2_bwd_vec_kernel(const float*
   *xp = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
 
+// The same adjoint with every fine element fetched from HBM once: a workgroup owns the whole (h, w) plane of one (n, c) and
+// WALKS along d.  A thread keeps the (w, h)-reduced contributions P_a of the last two fine planes in registers; coarse plane
+// d = 0.25 P_{2d-1} + 0.75 P_{2d} + 0.75 P_{2d+1} + 0.25 P_{2d+2} needs only the two new planes per step (the gather form
+// above reads each fine row four times over and ran at 1.85 TB/s).  block = (W/4, H) threads, grid = (d segments, N*C).
+__device__ __forceinline__ float4 up2_plane_contrib(const float* __restrict__ plane, int OH, int OW, int h, int j, const float (&wb)[4],
+                                                    int W, bool left, bool right) {
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int ib = 0; ib < 4; ++ib) {
+    if (wb[ib] == 0.f) continue;
+    const float* row = plane + (long)(2 * h - 1 + ib) * OW + 8 * j;
+    const float4 m0 = *(const float4*)row, m1 = *(const float4*)(row + 4);
+    const float gl = left ? row[-1] : 0.f, gr = right ? row[8] : 0.f;
+    const float g[10] = {gl, m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w, gr};
+    float r[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int w = 4 * j + e;
+      const float w1 = w > 0 ? 0.75f : 1.f, w2 = w < W - 1 ? 0.75f : 1.f;
+      r[e] = wb[ib] * ((0.25f * g[2 * e] + w1 * g[2 * e + 1]) + (w2 * g[2 * e + 2] + 0.25f * g[2 * e + 3]));
+    }
+    acc.x += r[0]; acc.y += r[1]; acc.z += r[2]; acc.w += r[3];
+  }
+  return acc;
+}
+__global__ void __launch_bounds__(1024) upsample3d_x2_bwd_walk_kernel(const float* __restrict__ dy, float* __restrict__ dx, int D,
+                                                                     int H, int W, int dseg) {
+  const int OH = 2 * H, OW = 2 * W;
+  const int j = threadIdx.x, h = threadIdx.y;
+  const long nc = blockIdx.y;
+  const int d0 = blockIdx.x * dseg, d1 = min(d0 + dseg, D);
+  float wb[4];
+  up2_bwd_weights(h, H, wb);
+  const bool left = j > 0, right = 8 * j + 8 < OW;
+  const float* gp = dy + nc * (2L * D) * OH * OW;
+  const long ps = (long)OH * OW;
+  auto contrib = [&](int a) -> float4 {
+    if (a < 0 || a >= 2 * D) return make_float4(0.f, 0.f, 0.f, 0.f);
+    return up2_plane_contrib(gp + (long)a * ps, OH, OW, h, j, wb, W, left, right);
+  };
+  float4 pm1 = contrib(2 * d0 - 1), p0 = contrib(2 * d0);
+  for (int d = d0; d < d1; ++d) {
+    const float4 p1 = contrib(2 * d + 1), p2 = contrib(2 * d + 2);
+    float wa[4];
+    up2_bwd_weights(d, D, wa);
+    float4 o;
+    o.x = (wa[0] * pm1.x + wa[1] * p0.x) + (wa[2] * p1.x + wa[3] * p2.x);
+    o.y = (wa[0] * pm1.y + wa[1] * p0.y) + (wa[2] * p1.y + wa[3] * p2.y);
+    o.z = (wa[0] * pm1.z + wa[1] * p0.z) + (wa[2] * p1.z + wa[3] * p2.z);
+    o.w = (wa[0] * pm1.w + wa[1] * p0.w) + (wa[2] * p1.w + wa[3] * p2.w);
+    *((float4*)(dx + ((nc * D + d) * H + h) * (long)W) + j) = o;
+    pm1 = p1; p0 = p2;
+  }
+}
+
 // ------------------------------------------------------------------------------------ preprocess
 // u8 (NC, H, W) -> crop (top,left,CH,CW) -> /255 -> label ; (label-mean[c])/std[c] -> normalised
 __global__ void preprocess_image_kernel(const uint8_t* __restrict__ img, float* __restrict__ label,
@@ -731,6 +786,16 @@ int muvo_upsample3d_x2_fwd(const float* x, float* y, int64_t NC, int D, int H, i
 }
 int muvo_upsample3d_x2_bwd(const float* dy, float* dx, int64_t NC, int D, int H, int W, void* stream) {
   MUVO_CHECK_ARG(dy && dx && NC > 0 && D > 0 && H > 0 && W > 0, "upsample3d_bwd: bad args");
+  static const int walk = getenv("MUVO_UPSAMPLE_WALK") ? atoi(getenv("MUVO_UPSAMPLE_WALK")) : 1;
+  if (walk && W % 4 == 0 && (W / 4) * H <= 1024 && (W / 4) * H >= 128 && NC <= 65535 && (((uintptr_t)dy | (uintptr_t)dx) & 15) == 0) {
+    // enough workgroups to fill the chip: split the d range (each segment recomputes its two lead-in planes)
+    int segs = 1;
+    while ((long)NC * segs < 1024 && segs * 8 <= D) segs *= 2;
+    const int dseg = cdiv(D, segs);
+    hipLaunchKernelGGL(upsample3d_x2_bwd_walk_kernel, dim3(cdiv(D, dseg), (unsigned)NC), dim3(W / 4, H), 0, ST, dy, dx, D, H, W, dseg);
+    MUVO_CHECK_LAUNCH("upsample3d_bwd_walk");
+    return MUVO_OK;
+  }
   if (W % 4 == 0 && D <= 65535 && NC <= 65535) {
     dim3 grid(cdiv((long)H * (W / 4), 256), D, (unsigned)NC);
     hipLaunchKernelGGL(upsample3d_x2_bwd_vec_kernel, grid, dim3(256), 0, ST, dy, dx, D, H, W);

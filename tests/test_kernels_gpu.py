@@ -462,7 +462,8 @@ def test_pooling_and_upsample(dev):
     y.backward(g.to(dev))
     _close(xg.grad, xc.grad, name='avgpool bwd')
     # vectorised (W % 4 == 0 / even) + scalar; W = 4, 8, 32: eight outputs per lane with neighbour columns from adjacent lanes
-    for shape in ((2, 3, 3, 5, 2), (2, 3, 3, 5, 8), (1, 2, 4, 6, 4), (1, 1, 2, 3, 5), (1, 2, 3, 37, 32), (1, 1, 2, 3, 12), (1, 1, 6, 8, 12), (2, 1, 2, 2, 4)):
+    for shape in ((2, 3, 3, 5, 2), (2, 3, 3, 5, 8), (1, 2, 4, 6, 4), (1, 1, 2, 3, 5), (1, 2, 3, 37, 32), (1, 1, 2, 3, 12), (1, 1, 6, 8, 12), (2, 1, 2, 2, 4),
+                  (2, 3, 9, 32, 16), (1, 2, 17, 96, 32), (1, 1, 1, 48, 16)):      # the last three: the d-walking backward kernel
         v = torch.randn(*shape)
         vg, vc = v.to(dev).requires_grad_(True), v.clone().requires_grad_(True)
         y = ops.upsample3d_x2(vg)
