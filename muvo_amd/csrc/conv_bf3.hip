@@ -1012,65 +1012,6 @@ __global__ void __launch_bounds__(256) bf3_unpack_wgrad_kernel(const ConvPhase g
   }
 }
 
-// The same unpack through an LDS tile: the scratch is read (and cleared) in its own order — rows of 64 consecutive c — and the
-// weight gradient is updated in the PyTorch layout's order (taps innermost), so both sides move whole cache lines; no
-// integer division per element.  Tile = all T taps x (all merge groups) x MT rows x 64 columns.
-//   regular conv   (wsm > wsc):  dw[m][c][q]            q = tap_w[t]
-//   transposed conv (wsc > wsm): dw[c][co][q]           q = tap_wm[grp][t] (merged sub-pixel phases) or tap_w[t]
-__global__ void __launch_bounds__(256) bf3_unpack_wgrad_tiled_kernel(const ConvPhase g, float* __restrict__ wg,
-                                                                     float* __restrict__ dw, int MT, int KK) {
-  constexpr int CT = 64, CS = CT + 1;
-  extern __shared__ float tl[];                       // [T][nmerge][MT][CS]
-  __shared__ short inv[MAX_TAPS * 8];                 // weight tap q -> grp * T + t, or -1
-  const int T = g.T, NG = g.nmerge, Msub = g.Msub, M = g.M, C = g.C;
-  const int c0 = blockIdx.x * CT, r0 = blockIdx.y * MT;
-  const int mrows = min(MT, Msub - r0), ccols = min(CT, C - c0);
-  for (int i = threadIdx.x; i < KK; i += 256) inv[i] = -1;
-  __syncthreads();
-  for (int i = threadIdx.x; i < NG * T; i += 256) {
-    const int grp = i / T, t = i - grp * T;
-    const int q = NG > 1 ? g.tap_wm[grp][t] : g.tap_w[t];
-    if (q >= 0 && q < KK) inv[q] = (short)i;
-  }
-  float* base = wg + g.wp_off;
-  const int rows = T * NG * mrows;                    // LDS rows to fill, CT floats each
-  for (int i = threadIdx.x; i < rows * CT; i += 256) {
-    const int ci = i & (CT - 1), rr = i >> 6;
-    const int mi = rr % mrows, gt = rr / mrows;       // gt = t * NG + grp
-    const int grp = gt % NG, t = gt / NG;
-    float v = 0.f;
-    if (ci < ccols) {
-      float* src = base + ((size_t)t * M + grp * Msub + r0 + mi) * C + c0 + ci;
-      v = *src;
-      *src = 0.f;
-    }
-    tl[((t * NG + grp) * MT + mi) * CS + ci] = v;
-  }
-  __syncthreads();
-  const bool m_major = g.wsm > g.wsc;
-  if (m_major) {            // run of ccols * KK consecutive floats per row m
-    const int per = ccols * KK;
-    for (int i = threadIdx.x; i < mrows * per; i += 256) {
-      const int mi = i / per, r = i - mi * per, ci = r / KK, q = r - ci * KK;
-      const int gt = inv[q];
-      if (gt >= 0) {
-        const int grp = gt / T, t = gt - grp * T;
-        dw[(size_t)(r0 + mi) * g.wsm + (size_t)(c0 + ci) * g.wsc + q] += tl[((t * NG + grp) * MT + mi) * CS + ci];
-      }
-    }
-  } else {                  // run of mrows * KK consecutive floats per column c
-    const int per = mrows * KK;
-    for (int i = threadIdx.x; i < ccols * per; i += 256) {
-      const int ci = i / per, r = i - ci * per, mi = r / KK, q = r - mi * KK;
-      const int gt = inv[q];
-      if (gt >= 0) {
-        const int grp = gt / T, t = gt - grp * T;
-        dw[(size_t)(r0 + mi) * g.wsm + (size_t)(c0 + ci) * g.wsc + q] += tl[((t * NG + grp) * MT + mi) * CS + ci];
-      }
-    }
-  }
-}
-
 // fp32 NCHW [N][C][S] -> bf16 hi / lo planes, channels-last [N][S][Cp] (Cp = roundup(C, 8), zero padded).
 // Tile = 64 pixels x 64 channels through LDS: reads coalesced along pixels (each lane takes two adjacent channels of its
 // pixel so it stores one packed dword), writes one full 128-byte line per pixel and plane.  LDS rows are 33 dwords, which
@@ -1588,24 +1529,6 @@ int bf3_wgrad_phase(const ConvPhase& g, const void* ws_x, int Cin_total, const v
                                    : bf3_wgrad_launch<64, 64, 1, 2, 2>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st);
   if (rc) return rc;
   const long total = (long)g.M * g.C * g.T;
-  static const int tiled = getenv("MUVO_UNPACK_TILED") ? atoi(getenv("MUVO_UNPACK_TILED")) : 1;
-  const long KK = g.wsm < g.wsc ? g.wsm : g.wsc;     // taps per (m, c) pair in the PyTorch weight
-  const int NG = g.nmerge > 1 ? g.nmerge : 1;
-  if (tiled && KK >= 1 && KK <= MAX_TAPS * 8 && KK * NG >= g.T && g.C >= 16 && (NG == 1 || g.M == NG * g.Msub)) {
-    const int Msub = NG > 1 ? g.Msub : g.M;
-    int MT = (int)(8192 / ((long)g.T * NG * 65));     // <= 32 KB of LDS
-    if (MT > 16) MT = 16;
-    if (MT > Msub) MT = Msub;
-    if (MT >= 1) {
-      ConvPhase gg = g;
-      gg.nmerge = NG; gg.Msub = Msub;
-      const size_t lds = sizeof(float) * (size_t)g.T * NG * MT * 65;
-      hipLaunchKernelGGL(bf3_unpack_wgrad_tiled_kernel, dim3(cdiv(g.C, 64), cdiv(Msub, MT)), dim3(256), lds, st, gg, wg, dw, MT,
-                         (int)KK);
-      MUVO_CHECK_LAUNCH("bf3_unpack_wgrad_tiled_kernel");
-      return MUVO_OK;
-    }
-  }
   hipLaunchKernelGGL(bf3_unpack_wgrad_kernel, dim3(ew_grid(total)), dim3(256), 0, st, g, wg, dw);
   MUVO_CHECK_LAUNCH("bf3_unpack_wgrad_kernel");
   return MUVO_OK;

@@ -953,10 +953,9 @@ static int vox_blocks_target(int wgrad) {
   return wgrad ? w : f;
 }
 
-template <int CK, int Z>
-static int launch_vox_bf3(const muvo_conv_desc* d, int Cin, int Cout, const float* in, const float* wp, const float* bias,
-                          float* out, int act, float slope, hipStream_t st, int cin_total = 0, int accum = 0) {
-  constexpr int TY = 8;
+template <int CK, int Z, int TY>
+static int launch_vox_bf3_ty(const muvo_conv_desc* d, int Cin, int Cout, const float* in, const float* wp, const float* bias,
+                             float* out, int act, float slope, hipStream_t st, int cin_total, int accum) {
   VoxArgs a;
   a.N = d->N; a.Cin = Cin; a.Cout = Cout; a.X = d->in_sz[0]; a.Y = d->in_sz[1];
   a.ytiles = cdiv(a.Y, TY);
@@ -980,6 +979,16 @@ static int launch_vox_bf3(const muvo_conv_desc* d, int Cin, int Cout, const floa
                      slope, xseg, accum);
   MUVO_CHECK_LAUNCH("vox_bf3_kernel");
   return MUVO_OK;
+}
+
+// TY = 4 rows per workgroup halves the LDS ring (76 KB for 16 channels x Z = 64): two workgroups share a CU, so the MFMA phase
+// of one overlaps the staging / LDS phase of the other (MUVO_VOX_TY, default from the r02 A/B: profiles/r02_vox_ty.txt)
+template <int CK, int Z>
+static int launch_vox_bf3(const muvo_conv_desc* d, int Cin, int Cout, const float* in, const float* wp, const float* bias,
+                          float* out, int act, float slope, hipStream_t st, int cin_total = 0, int accum = 0) {
+  static const int ty = getenv("MUVO_VOX_TY") ? atoi(getenv("MUVO_VOX_TY")) : 8;
+  if (ty == 4) return launch_vox_bf3_ty<CK, Z, 4>(d, Cin, Cout, in, wp, bias, out, act, slope, st, cin_total, accum);
+  return launch_vox_bf3_ty<CK, Z, 8>(d, Cin, Cout, in, wp, bias, out, act, slope, st, cin_total, accum);
 }
 
 template <int Z, int CK>
