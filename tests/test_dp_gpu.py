@@ -235,3 +235,78 @@ def test_optimizer_checkpoint_roundtrip(dev):
     assert rel(tr3.store.exp_avg, tr.store.exp_avg) > 0.3
     dev3 = sum(float((p.detach() - want[n]).double().pow(2).sum()) for n, p in tr3.model.named_parameters()) ** 0.5
     assert dev3 > 5 * dev2
+
+
+def _dp_rank(rank, world, port, q):
+    """One data-parallel rank of the REAL trainer on cuda:0 (both ranks share the GPU; the collective is gloo, which moves the
+    CUDA gradient segments through the host — slow, but every line of the product's DP wiring runs: configure_optimizers
+    attaches the reducer, backward hooks send the segments on the side stream, on_after_backward joins, AdamW scales by 1/2)."""
+    import sys
+    sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), '..')))
+    import torch.distributed as dist
+    from muvo_amd import ops
+    from muvo_amd.data.synthetic import make_batch, make_noise
+    try:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        dev = torch.device('cuda:0')
+        torch.cuda.set_device(dev)
+        ops.set_conv_mode(ops.CONV_F32, min_gflop=-1.0)
+        fx = json.load(open(os.path.join(GOLD, 'base1d_dp2_b1s2.json')))
+        b, s, seed = fx['b'], fx['s'], fx['seed']
+        tr = _trainer(dev, s)
+        opts, scheds = tr.configure_optimizers()
+        opt, sched = opts[0], scheds[0]['scheduler']
+        red = tr._reducer
+        assert red is not None and red.world == world and opt.grad_scale == 1.0 / world and tr.model.dropout_rank == rank
+        eps, use_prior = make_noise(b, s, seed=seed + 10 * rank)
+        res = {'rank': rank, 'losses': [], 'bad': [], 'hooks': []}
+        for step, g in enumerate(fx['steps']):
+            opt.zero_grad()
+            total = tr.training_step(make_batch(b, s, seed=seed + 10 * rank + step, device=dev), step, noise=eps.to(dev), use_prior=use_prior)
+            total.backward()
+            tr.on_after_backward()
+            res['hooks'].append(list(red.launch_log))
+            opt.step()
+            sched.step()
+            res['losses'].append((total.item(), g['ranks'][rank]['total']))
+            for n, (s_ref, a_ref) in g['param_checksums_after_step'].items():
+                d = dict(tr.model.named_parameters())[n].detach().double()
+                if abs(d.abs().sum().item() - a_ref) > 1e-5 * a_ref + 4 * max(g['lr']) * (step + 1):      # (two noise-level sign flips, see test_model_gpu)
+                    res['bad'].append((step, n, d.abs().sum().item(), a_ref))
+        flat = tr.store.flat_param.double()
+        res['digest'] = [flat.sum().item(), flat.abs().sum().item(), flat.pow(2).sum().item()]
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put(res)
+    except Exception as e:       # noqa: BLE001
+        import traceback
+        q.put({'rank': rank, 'error': traceback.format_exc()})
+        raise e
+
+
+def test_two_processes_share_the_gpu(dev):
+    """'a 2-process test that DP gradients equal ...'.  Two processes, world size 2, real model, two optimizer steps:
+    each rank's loss equals the reference's loss on ITS batch, the parameters after every step equal the reference's (which
+    averaged the two ranks' gradients), both ranks end bit-identical, and 7 of the 8 segments were sent from backward hooks."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29800 + os.getpid() % 150
+    procs = [ctx.Process(target=_dp_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+    for r in out:
+        assert 'error' not in r, r.get('error')
+    out.sort(key=lambda r: r['rank'])
+    for r in out:
+        for got, want in r['losses']:
+            assert _rel(got, want) < 2e-3, r['losses']
+        assert not r['bad'], r['bad'][:3]
+        for log in r['hooks']:
+            assert [n for n, _ in log] == ['voxel_decoder', 'lidar_re', 'rgb_decoder', 'policy', 'rssm', 'fusion', 'lidar_branch', 'image_branch']
+            assert [h for _, h in log] == [True] * 7 + [False]
+    assert out[0]['digest'] == out[1]['digest'], (out[0]['digest'], out[1]['digest'])
