@@ -229,14 +229,17 @@ def main():
                 out['roofline']['share_of_conv_time'] = dom_s / max(conv_s, 1e-12)
             # HBM-side bytes per launch of the dominant class: PMC counters cannot be read from inside this process, so the
             # figure comes from the committed rocprofv3 --pmc passes over this same command (tools/pmc_step.sh)
-            tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01w_hbm_traffic.json')
-            if out['roofline'] is not None and os.path.exists(tf):
+            import glob
+            files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r*_hbm_traffic.json')))
+            if out['roofline'] is not None and files:
+                tf = files[-1]                       # the latest round's measurement
                 pm = json.load(open(tf))
                 for cname, c in pm['classes'].items():
                     if ops.KERNEL_NAMES.get(cname) == out['roofline']['kernel']:
                         out['roofline']['traffic'] = c['hbm_bytes_per_launch']
                         out['roofline']['traffic_unit'] = 'bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, includes Infinity-Cache hits)'
-                        out['roofline']['traffic_source'] = 'profiles/r01w_hbm_traffic.json (tools/pmc_step.sh)'
+                        out['roofline']['traffic_source'] = f'profiles/{os.path.basename(tf)} (tools/pmc_step.sh)'
+                        out['roofline']['traffic_over_algorithmic'] = c['hbm_bytes_per_launch'] / max(out['roofline']['algorithmic_bytes'], 1.0)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(usable_cores())
         print(json.dumps(out), flush=True)

@@ -85,3 +85,28 @@ def test_oracle_gradients_match_reference(oracle_run):
         else:
             got = float(p.grad.double().pow(2).sum().sqrt())
             assert abs(got - g[n]) <= 1e-3 * g[n] + 1e-9, (n, got, g[n])
+
+
+def test_oracle_losses_b2s4_prior_branch():
+    """The second reference fixture (batch 2 x 4 frames, the RSSM continues from the PRIOR sample after t = 2): the oracle's 21
+    losses, forward only (the generator already compared losses, outputs, gradients and two optimizer steps of the oracle with
+    the reference on this batch: fixture key oracle_vs_reference)."""
+    from muvo_amd.data.synthetic import make_batch, make_noise
+    from muvo_amd.utils import detinit
+    from oracle import muvo_ref as R
+    fx = json.load(open(os.path.join(GOLD, 'base1d_b2s4.json')))
+    assert fx['use_prior'] == [False, False, True, False]
+    assert fx['steps'][0]['oracle_vs_reference']['max_rel_loss_dev'] < 1e-6
+    assert fx['steps'][0]['oracle_vs_reference']['max_rel_grad_dev'] < 1e-4
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    model = R.MileRef()
+    detinit.fill_state_dict_(model)
+    model.train()
+    model.set_dropout(0.0)
+    eps, use_prior = make_noise(fx['b'], fx['s'], seed=fx['seed'])
+    with torch.no_grad():
+        total, losses, _, _ = R.training_step(model, make_batch(fx['b'], fx['s'], seed=fx['seed']), eps, use_prior)
+    g = fx['steps'][0]
+    for k, v in g['losses'].items():
+        assert abs(float(losses[k]) - v) <= 2e-5 * max(abs(v), 1e-6), (k, float(losses[k]), v)
+    assert abs(float(total) - g['total']) < 2e-5 * g['total']
