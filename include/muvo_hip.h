@@ -109,6 +109,16 @@ int muvo_conv_forward(const muvo_conv_desc* d, const float* x, const float* wp_f
  * planes of dy (written by muvo_conv_prepare_dy), dy itself is then not read by the bf16x3 path */
 int muvo_conv_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp_dgrad, float* dx, void* ws, int ws_valid,
                     void* stream);
+/* muvo_conv_forward that also accumulates, per (n, output channel), the sum and the sum of squares of the ACTIVATED output into
+ * moments[N][Cout][2] (doubles, all-zero on entry): the statistics of the instance norm that follows the convolution
+ * (ConvInstanceNorm3d, common.py:190-202), taken from the epilogue registers instead of a pass over the output tensor.  Only
+ * the bf16x3 voxel kernels (muvo_conv_kernel_family(d, 0) == 4) do this: ask muvo_conv_forward_moments_supported first.
+ * muvo_adain_fwd_moments consumes such a buffer (and leaves it all-zero). */
+int muvo_conv_forward_moments_supported(const muvo_conv_desc* d);
+int muvo_conv_forward_moments(const muvo_conv_desc* d, const float* x, const float* wp_fwd, const float* bias, float* y, int act,
+                              float slope, double* moments, void* stream);
+int muvo_adain_fwd_moments(const float* x, const float* style, float* y, float* save_mean, float* save_rstd, double* moments,
+                           int N, int C, int64_t S, float eps, void* stream);
 /* dx += conv_data_grad(dy, w) for the 1x1 output heads (muvo_conv_kernel_family(d, 1) == 3; RGBHead / LidarReHead / VoxelSemHead,
  * common.py:274-303,354-367): the head hangs off a decoder trunk, dx already holds the gradient that came back through the
  * trunk, so no separate add pass over the feature map is needed */

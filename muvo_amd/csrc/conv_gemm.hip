@@ -925,6 +925,20 @@ int muvo_conv_forward(const muvo_conv_desc* d, const float* x, const float* wp_f
   return run_phases(pl.fwd, pl.nfwd, x, wp_fwd, bias, y, act, slope, ws, (hipStream_t)stream);
 }
 
+int muvo_conv_forward_moments_supported(const muvo_conv_desc* d) {
+  if (check_desc(d)) return 0;
+  return (!pw_applicable(d) && vox_fwd_ok(d) && vox_uses_bf3(d, 0)) ? 1 : 0;
+}
+int muvo_conv_forward_moments(const muvo_conv_desc* d, const float* x, const float* wp_fwd, const float* bias, float* y, int act,
+                              float slope, double* moments, void* stream) {
+  ConvPlan pl;
+  int rc = build_plan(d, &pl);
+  if (rc) return rc;
+  MUVO_CHECK_ARG(x && wp_fwd && y && moments, "conv_forward_moments: null pointer");
+  MUVO_CHECK_ARG(muvo_conv_forward_moments_supported(d), "conv_forward_moments: only the bf16x3 voxel kernels produce output moments");
+  return vox_forward(d, x, wp_fwd, bias, y, act, slope, (hipStream_t)stream, true, moments);
+}
+
 int muvo_conv_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp_dgrad, float* dx, void* ws, int ws_valid,
                     void* stream) {
   ConvPlan pl;

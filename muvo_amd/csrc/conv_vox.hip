@@ -25,6 +25,7 @@ struct VoxArgs {
   int ytiles, xgroups;
   int XYZ;           // X*Y*Z
   long sN_in, sN_out;  // batch strides (floats)
+  double* moments;     // optional (bf16x3 forward kernels): [N][Cout][2] += (sum, sum of squares) of the activated output
 };
 
 __device__ __forceinline__ float dpp_wave_shr1(float v) {  // lane l <- lane l-1, lane 0 <- 0
@@ -441,6 +442,7 @@ vox_bf3_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* __re
 
   // this lane's B-fragment geometry per k-step: tap -> (dx, dy, dz), channel group
   const int v = lane & 15, g = lane >> 4;
+  float msum[4] = {0.f, 0.f, 0.f, 0.f}, msq[4] = {0.f, 0.f, 0.f, 0.f};
   int fdx[NSTEP], foff[NSTEP];       // dx in {-1, 0, 1}; uint4 offset inside a plane (hi part) for tile 0
 #pragma unroll
   for (int s = 0; s < NSTEP; ++s) {
@@ -486,12 +488,35 @@ vox_bf3_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* __re
             float r = acc[i];
             if (accum) r += ob[(long)co * a.XYZ];      // second half of a 32-channel reduction: add the first pass
             if (bias) r += bias[co];
-            ob[(long)co * a.XYZ] = act_apply(r, act, slope);
+            r = act_apply(r, act, slope);
+            ob[(long)co * a.XYZ] = r;
+            msum[i] += r;
+            msq[i] += r * r;
           }
         }
       }
     }
     __syncthreads();     // everybody is done with plane x-1's slot before the next step overwrites it
+  }
+  // instance-norm statistics of what was just written (the AdaIN that follows, common.py:227-246, would otherwise re-read
+  // the whole output): lanes of a 16-lane group = 16 z of the same channels, waves = rows; one double atomic per channel,
+  // statistic and workgroup
+  if (a.moments) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { msum[i] += __shfl_xor(msum[i], o, 64); msq[i] += __shfl_xor(msq[i], o, 64); }
+    float* red = (float*)vsm;                  // the ring is free after the loop's last barrier
+    if (v == 0)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { red[((wave * 4 + g) * 4 + i) * 2] = msum[i]; red[((wave * 4 + g) * 4 + i) * 2 + 1] = msq[i]; }
+    __syncthreads();
+    if (tid < 32) {
+      const int c = tid >> 1, k = tid & 1;
+      double t = 0.0;
+      for (int w = 0; w < TY; ++w) t += (double)red[((w * 4 + (c >> 2)) * 4 + (c & 3)) * 2 + k];
+      if (co0 + c < a.Cout) atomicAdd(&a.moments[((long)n * a.Cout + co0 + c) * 2 + k], t);
+    }
   }
 }
 
@@ -772,6 +797,7 @@ vox_bf3_2row_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4*
     }
   };
   const int v = lane & 15, g = lane >> 4;
+  float msum[4] = {0.f, 0.f, 0.f, 0.f}, msq[4] = {0.f, 0.f, 0.f, 0.f};
   int fdx[NSTEP], foff[NSTEP];
 #pragma unroll
   for (int s = 0; s < NSTEP; ++s) {
@@ -811,11 +837,34 @@ vox_bf3_2row_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4*
         for (int i = 0; i < 4; ++i) {
           float r = acc[i];
           if (bias) r += bias[cb + i];
-          ob[(long)(cb + i) * a.XYZ] = act_apply(r, act, slope);
+          r = act_apply(r, act, slope);
+          ob[(long)(cb + i) * a.XYZ] = r;
+          msum[i] += r;
+          msq[i] += r * r;
         }
       }
     }
     __syncthreads();
+  }
+  if (a.moments) {     // as in vox_bf3_kernel; lanes g and g ^ 2 hold the same channels of the wave's two rows
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { msum[i] += __shfl_xor(msum[i], o, 64); msq[i] += __shfl_xor(msq[i], o, 64); }
+      msum[i] += __shfl_xor(msum[i], 32, 64);
+      msq[i] += __shfl_xor(msq[i], 32, 64);
+    }
+    float* red = (float*)vsm;
+    if (v == 0 && g < 2)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { red[((wave * 2 + g) * 4 + i) * 2] = msum[i]; red[((wave * 2 + g) * 4 + i) * 2 + 1] = msq[i]; }
+    __syncthreads();
+    if (tid < 16) {
+      const int c = tid >> 1, k = tid & 1;
+      double t = 0.0;
+      for (int w = 0; w < NT / 64; ++w) t += (double)red[((w * 2 + (c >> 2)) * 4 + (c & 3)) * 2 + k];
+      atomicAdd(&a.moments[((long)n * 8 + c) * 2 + k], t);
+    }
   }
 }
 
@@ -930,7 +979,7 @@ int vox_pack(const muvo_conv_desc* d, const float* w, float* wp, int dgrad, hipS
 template <int CQ, int TY, int Z>
 static int launch_vox_conv(const muvo_conv_desc* d, int Cin, int Cout, const float* in, const float* wp, const float* bias,
                            float* out, int act, float slope, hipStream_t st) {
-  VoxArgs a;
+  VoxArgs a{};
   a.N = d->N; a.Cin = Cin; a.Cout = Cout; a.X = d->in_sz[0]; a.Y = d->in_sz[1];
   a.ytiles = cdiv(a.Y, TY);
   a.xgroups = cdiv(a.X, 64 / Z);
@@ -955,8 +1004,9 @@ static int vox_blocks_target(int wgrad) {
 
 template <int CK, int Z, int TY>
 static int launch_vox_bf3_ty(const muvo_conv_desc* d, int Cin, int Cout, const float* in, const float* wp, const float* bias,
-                             float* out, int act, float slope, hipStream_t st, int cin_total, int accum) {
-  VoxArgs a;
+                             float* out, int act, float slope, hipStream_t st, int cin_total, int accum, double* moments) {
+  VoxArgs a{};
+  a.moments = moments;
   a.N = d->N; a.Cin = Cin; a.Cout = Cout; a.X = d->in_sz[0]; a.Y = d->in_sz[1];
   a.ytiles = cdiv(a.Y, TY);
   a.xgroups = 0;
@@ -985,17 +1035,19 @@ static int launch_vox_bf3_ty(const muvo_conv_desc* d, int Cin, int Cout, const f
 // of one overlaps the staging / LDS phase of the other (MUVO_VOX_TY, default from the r02 A/B: profiles/r02_vox_ty.txt)
 template <int CK, int Z>
 static int launch_vox_bf3(const muvo_conv_desc* d, int Cin, int Cout, const float* in, const float* wp, const float* bias,
-                          float* out, int act, float slope, hipStream_t st, int cin_total = 0, int accum = 0) {
+                          float* out, int act, float slope, hipStream_t st, int cin_total = 0, int accum = 0,
+                          double* moments = nullptr) {
   static const int ty = getenv("MUVO_VOX_TY") ? atoi(getenv("MUVO_VOX_TY")) : 8;
-  if (ty == 4) return launch_vox_bf3_ty<CK, Z, 4>(d, Cin, Cout, in, wp, bias, out, act, slope, st, cin_total, accum);
-  return launch_vox_bf3_ty<CK, Z, 8>(d, Cin, Cout, in, wp, bias, out, act, slope, st, cin_total, accum);
+  if (ty == 4) return launch_vox_bf3_ty<CK, Z, 4>(d, Cin, Cout, in, wp, bias, out, act, slope, st, cin_total, accum, moments);
+  return launch_vox_bf3_ty<CK, Z, 8>(d, Cin, Cout, in, wp, bias, out, act, slope, st, cin_total, accum, moments);
 }
 
 template <int Z, int CK>
 static int launch_vox_bf3_2row(const muvo_conv_desc* d, const float* in, const float* wp, const float* bias, float* out, int act,
-                               float slope, hipStream_t st) {
+                               float slope, hipStream_t st, double* moments) {
   constexpr int TY = CK == 16 ? 8 : 16;
-  VoxArgs a;
+  VoxArgs a{};
+  a.moments = moments;
   a.N = d->N; a.Cin = CK; a.Cout = 8; a.X = d->in_sz[0]; a.Y = d->in_sz[1];
   a.ytiles = cdiv(a.Y, TY);
   a.xgroups = 0;
@@ -1020,13 +1072,14 @@ static int launch_vox_bf3_2row(const muvo_conv_desc* d, const float* in, const f
 }
 
 static int vox_conv_dispatch(const muvo_conv_desc* d, int Cin, int Cout, const float* in, const float* wp, const float* bias,
-                             float* out, int act, float slope, hipStream_t st, bool bf3) {
+                             float* out, int act, float slope, hipStream_t st, bool bf3, double* moments = nullptr) {
+  if (moments && !bf3) { muvo_set_error("vox_conv: output moments need the bf16x3 kernels"); return MUVO_ERR_INVALID_ARG; }
   const int Z = d->in_sz[2];
   if (bf3 && vox_bf3_two_rows(Cin, Cout)) {
-    if (Cin == 8) return Z == 64 ? launch_vox_bf3_2row<64, 8>(d, in, wp, bias, out, act, slope, st)
-                                 : launch_vox_bf3_2row<32, 8>(d, in, wp, bias, out, act, slope, st);
-    return Z == 64 ? launch_vox_bf3_2row<64, 16>(d, in, wp, bias, out, act, slope, st)
-                   : launch_vox_bf3_2row<32, 16>(d, in, wp, bias, out, act, slope, st);
+    if (Cin == 8) return Z == 64 ? launch_vox_bf3_2row<64, 8>(d, in, wp, bias, out, act, slope, st, moments)
+                                 : launch_vox_bf3_2row<32, 8>(d, in, wp, bias, out, act, slope, st, moments);
+    return Z == 64 ? launch_vox_bf3_2row<64, 16>(d, in, wp, bias, out, act, slope, st, moments)
+                   : launch_vox_bf3_2row<32, 16>(d, in, wp, bias, out, act, slope, st, moments);
   }
   if (bf3 && Cin == 32) {
     // two accumulating passes over 16 reduction channels each; bias and activation ride on the second
@@ -1035,14 +1088,14 @@ static int vox_conv_dispatch(const muvo_conv_desc* d, int Cin, int Cout, const f
     int rc = Z == 64 ? launch_vox_bf3<16, 64>(d, 16, Cout, in, wp, nullptr, out, MUVO_ACT_NONE, 0.f, st, 32, 0)
                      : launch_vox_bf3<16, 32>(d, 16, Cout, in, wp, nullptr, out, MUVO_ACT_NONE, 0.f, st, 32, 0);
     if (rc) return rc;
-    return Z == 64 ? launch_vox_bf3<16, 64>(d, 16, Cout, in + 16 * XYZ, wp2, bias, out, act, slope, st, 32, 1)
-                   : launch_vox_bf3<16, 32>(d, 16, Cout, in + 16 * XYZ, wp2, bias, out, act, slope, st, 32, 1);
+    return Z == 64 ? launch_vox_bf3<16, 64>(d, 16, Cout, in + 16 * XYZ, wp2, bias, out, act, slope, st, 32, 1, moments)
+                   : launch_vox_bf3<16, 32>(d, 16, Cout, in + 16 * XYZ, wp2, bias, out, act, slope, st, 32, 1, moments);
   }
   if (bf3) {
-    if (Cin == 16 && Z == 64) return launch_vox_bf3<16, 64>(d, Cin, Cout, in, wp, bias, out, act, slope, st);
-    if (Cin == 16 && Z == 32) return launch_vox_bf3<16, 32>(d, Cin, Cout, in, wp, bias, out, act, slope, st);
-    if (Cin == 8 && Z == 64) return launch_vox_bf3<8, 64>(d, Cin, Cout, in, wp, bias, out, act, slope, st);
-    if (Cin == 8 && Z == 32) return launch_vox_bf3<8, 32>(d, Cin, Cout, in, wp, bias, out, act, slope, st);
+    if (Cin == 16 && Z == 64) return launch_vox_bf3<16, 64>(d, Cin, Cout, in, wp, bias, out, act, slope, st, 0, 0, moments);
+    if (Cin == 16 && Z == 32) return launch_vox_bf3<16, 32>(d, Cin, Cout, in, wp, bias, out, act, slope, st, 0, 0, moments);
+    if (Cin == 8 && Z == 64) return launch_vox_bf3<8, 64>(d, Cin, Cout, in, wp, bias, out, act, slope, st, 0, 0, moments);
+    if (Cin == 8 && Z == 32) return launch_vox_bf3<8, 32>(d, Cin, Cout, in, wp, bias, out, act, slope, st, 0, 0, moments);
   }
   if (Cout == 8 && Z == 64) return launch_vox_conv<2, 6, 64>(d, Cin, Cout, in, wp, bias, out, act, slope, st);
   if (Cout == 8 && Z == 32) return launch_vox_conv<2, 6, 32>(d, Cin, Cout, in, wp, bias, out, act, slope, st);
@@ -1053,8 +1106,8 @@ static int vox_conv_dispatch(const muvo_conv_desc* d, int Cin, int Cout, const f
 }
 
 int vox_forward(const muvo_conv_desc* d, const float* x, const float* wp, const float* bias, float* y, int act, float slope,
-                hipStream_t st, bool bf3) {
-  return vox_conv_dispatch(d, d->Cin, d->Cout, x, wp, bias, y, act, slope, st, bf3);
+                hipStream_t st, bool bf3, double* moments) {
+  return vox_conv_dispatch(d, d->Cin, d->Cout, x, wp, bias, y, act, slope, st, bf3, moments);
 }
 int vox_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp, float* dx, hipStream_t st, bool bf3) {
   return vox_conv_dispatch(d, d->Cout, d->Cin, dy, wp, nullptr, dx, MUVO_ACT_NONE, 0.f, st, bf3);
@@ -1064,7 +1117,7 @@ template <int RQB, int CQR, int Z, int TYB>
 static int launch_vox_wgrad(const muvo_conv_desc* d, const float* x, const float* dz, float* dw, float* dbias,
                             hipStream_t st) {
   constexpr int CQB = 2;
-  VoxArgs a;
+  VoxArgs a{};
   a.N = d->N; a.Cin = d->Cin; a.Cout = d->Cout; a.X = d->in_sz[0]; a.Y = d->in_sz[1];
   a.ytiles = cdiv(a.Y, TYB);
   a.xgroups = 0;
@@ -1098,7 +1151,7 @@ static int launch_vox_bf3_wgrad(const muvo_conv_desc* d, const float* x, const f
   constexpr int ZH = Z / 32, WROWS = 8 / ZH, ROWS = WROWS + 2;
   constexpr size_t lds = (size_t)3 * 2 * CI * (ROWS * (Z + 16) * 2 + 16) + (size_t)2 * 2 * 16 * (WROWS * Z * 2 + 16) + 64;
   static_assert(lds >= (CI == 16 ? 27 : 15) * 256 * 4, "the reduction reuses the rings");
-  VoxArgs a;
+  VoxArgs a{};
   a.N = d->N; a.Cin = d->Cin; a.Cout = d->Cout; a.X = d->in_sz[0]; a.Y = d->in_sz[1];
   a.ytiles = cdiv(a.Y, WROWS);
   a.xgroups = 0;

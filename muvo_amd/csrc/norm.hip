@@ -523,6 +523,27 @@ extern "C" int muvo_adain_fwd(const float* x, const float* style, float* y, floa
   return MUVO_OK;
 }
 
+// the same with the (sum, sum of squares) per (n, c) already accumulated by the producing convolution's epilogue
+// (muvo_conv_forward_moments): no statistics pass over x.  `moments` is left all-zero for the next use.
+extern "C" int muvo_adain_fwd_moments(const float* x, const float* style, float* y, float* save_mean, float* save_rstd,
+                                      double* moments, int N, int C, int64_t S, float eps, void* stream) {
+  MUVO_CHECK_ARG(x && style && y && save_mean && save_rstd && moments && N > 0 && C > 0 && S > 0, "adain_fwd_moments: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  const int G = N * C;
+  hipLaunchKernelGGL(in_finalize_kernel, dim3(cdiv(G, 64)), dim3(64), 0, st, moments, save_mean, save_rstd, G, (double)S, eps);
+  const long total = (long)G * S;
+  if (S % 4 == 0 && S >= 1024 && G <= 65535 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+    int gx = cdiv(S / 4, 256 * 4);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(adain_apply_vec_kernel, dim3(gx, G), dim3(256), 0, st, x, save_mean, save_rstd, style, y, C, (long)S,
+                       (long)C * S);
+  } else
+    hipLaunchKernelGGL(adain_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, st, x, save_mean, save_rstd, style, y, C,
+                       (long)S, (long)C * S, total);
+  MUVO_CHECK_LAUNCH("adain_fwd_moments");
+  return MUVO_OK;
+}
+
 // dx: (N,C,S) always dense (caller reduces over batch when the input was broadcast); dstyle: (N, 2C) overwritten
 extern "C" int muvo_adain_bwd(const float* x, const float* style, const float* dy, const float* save_mean,
                               const float* save_rstd, float* dx, float* dstyle, double* ws, int N, int C, int64_t S,

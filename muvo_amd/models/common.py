@@ -91,8 +91,8 @@ class AdaptiveInstanceNorm3d(nn.Module):
         self.epsilon = epsilon
         self.latent_affine = hnn.Linear(latent_n_channels, 2 * out_channels)
 
-    def forward(self, x, style, pre_act=ops.ACT_NONE, pre_slope=0.0):
-        return ops.adain(x, self.latent_affine(style), self.epsilon, style.shape[0], pre_act, pre_slope)
+    def forward(self, x, style, pre_act=ops.ACT_NONE, pre_slope=0.0, moments=None):
+        return ops.adain(x, self.latent_affine(style), self.epsilon, style.shape[0], pre_act, pre_slope, moments)
 
 
 class ConvInstanceNorm3d(nn.Module):
@@ -103,8 +103,10 @@ class ConvInstanceNorm3d(nn.Module):
 
     def forward(self, x, w):
         # LeakyReLU is fused into the conv epilogue; its derivative is chained inside the AdaIN backward kernel
-        x = self.conv_act[0](x, act=ops.ACT_LEAKY, slope=0.2, act_bwd_fused=True)
-        return self.adaptive_norm(x, w, pre_act=ops.ACT_LEAKY, pre_slope=0.2)
+        # (top two levels, bf16x3 voxel kernels: the conv epilogue also delivers the instance-norm statistics of its output)
+        moments = ops.conv_moments_buffer(x, self.conv_act[0].geom)
+        x = self.conv_act[0](x, act=ops.ACT_LEAKY, slope=0.2, act_bwd_fused=True, moments=moments)
+        return self.adaptive_norm(x, w, pre_act=ops.ACT_LEAKY, pre_slope=0.2, moments=moments)
 
 
 class AdaptiveInstanceNorm(nn.Module):

@@ -65,7 +65,8 @@ EXPORTS = [
     'muvo_range_projection', 'muvo_voxel_grid', 'muvo_seg_ce_fwd', 'muvo_seg_ce_bwd', 'muvo_ssim_maps', 'muvo_ssim_bwd',
     'muvo_instance_labels', 'muvo_pixel_augment', 'muvo_preprocess_route_aug',
     'muvo_split_planes_bytes', 'muvo_split_planes', 'muvo_attention_supported', 'muvo_attention_fwd', 'muvo_attention_bwd',
-    'muvo_conv_dgrad_accumulate', 'muvo_rssm_supported', 'muvo_rssm_transposed_floats', 'muvo_rssm_scratch_floats', 'muvo_rssm_forward', 'muvo_rssm_backward',
+    'muvo_conv_dgrad_accumulate', 'muvo_conv_forward_moments_supported', 'muvo_conv_forward_moments', 'muvo_adain_fwd_moments',
+    'muvo_rssm_supported', 'muvo_rssm_transposed_floats', 'muvo_rssm_scratch_floats', 'muvo_rssm_forward', 'muvo_rssm_backward',
 ]
 
 
@@ -604,7 +605,7 @@ _KEEP_WS = os.environ.get('MUVO_KEEP_WS', '1') != '0'
 
 class ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, geom, packed, act, slope, act_bwd_fused=False):
+    def forward(ctx, x, weight, bias, geom, packed, act, slope, act_bwd_fused=False, moments=None):
         x = x.contiguous()
         ctx.act_bwd_fused = act_bwd_fused
         n = x.shape[0]
@@ -637,7 +638,10 @@ class ConvFn(torch.autograd.Function):
         else:
             ws = scratch('conv_ws', (wsb[0] + 3) // 4, x.device) if wsb[0] else None
         ctx.ws_x = ws if keep_ws else None
-        _ck(L.muvo_conv_forward(C.byref(d), _f(x), _f(packed.fwd), _f(bias), _f(y), act, _fl(slope), _p(ws), _st()))
+        if moments is not None:     # instance-norm statistics of y from the epilogue registers (voxel bf16x3 kernels)
+            _ck(L.muvo_conv_forward_moments(C.byref(d), _f(x), _f(packed.fwd), _f(bias), _f(y), act, _fl(slope), _p(moments), _st()))
+        else:
+            _ck(L.muvo_conv_forward(C.byref(d), _f(x), _f(packed.fwd), _f(bias), _f(y), act, _fl(slope), _p(ws), _st()))
         if kt is not None:
             e1.record()
         ctx.geom, ctx.packed, ctx.act, ctx.slope = geom, packed, act, slope
@@ -717,11 +721,35 @@ class ConvFn(torch.autograd.Function):
                                   flags, _st()))
             if kt is not None:
                 e1.record()
-        return dx, None, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None, None
 
 
-def conv(x, weight, bias, geom, packed, act=ACT_NONE, slope=0.0, act_bwd_fused=False):
-    return ConvFn.apply(x, weight, bias, geom, packed, act, slope, act_bwd_fused)
+def conv(x, weight, bias, geom, packed, act=ACT_NONE, slope=0.0, act_bwd_fused=False, moments=None):
+    return ConvFn.apply(x, weight, bias, geom, packed, act, slope, act_bwd_fused, moments)
+
+
+CONV_MOMENTS = os.environ.get('MUVO_CONV_MOMENTS', '1') != '0'
+
+
+def conv_moments_buffer(x, geom):
+    """A zeroed (N, Cout, 2) float64 buffer if the convolution `geom` on input x can deliver the instance-norm statistics of
+    its output from its epilogue (muvo_conv_forward_moments), else None.  The buffer is per layer and stays all-zero between
+    uses (muvo_adain_fwd_moments clears it)."""
+    if not CONV_MOMENTS:
+        return None
+    n = x.shape[0]
+    in_sz = tuple(x.shape[2:]) if geom.nd == 3 else (1,) + tuple(x.shape[2:])
+    d = geom.plan(n, in_sz)[0]
+    key = ('moments', n, in_sz, _plan_epoch[0])
+    ok = geom.family.get(key)
+    if ok is None:
+        ok = geom.family[key] = bool(lib().muvo_conv_forward_moments_supported(C.byref(d)))
+    if not ok:
+        return None
+    buf = geom.__dict__.get('_moments')
+    if buf is None or buf.shape[0] != n or buf.device != x.device:
+        buf = geom._moments = torch.zeros(n, geom.cout, 2, device=x.device, dtype=torch.float64)
+    return buf
 
 
 class HeadBranchFn(torch.autograd.Function):
@@ -856,7 +884,7 @@ class AdaINFn(torch.autograd.Function):
     """AdaptiveInstanceNorm3d. x: (N,C,D,H,W) or a broadcast (C,D,H,W) parameter; style: (N, 2C)."""
 
     @staticmethod
-    def forward(ctx, x, style, eps, n_batch, pre_act=ACT_NONE, pre_slope=0.0):
+    def forward(ctx, x, style, eps, n_batch, pre_act=ACT_NONE, pre_slope=0.0, moments=None):
         x = x.contiguous()
         style = style.contiguous()
         bcast = x.dim() == 4
@@ -867,9 +895,12 @@ class AdaINFn(torch.autograd.Function):
         y = torch.empty((n, c) + tuple(x.shape[-3:]), device=x.device, dtype=torch.float32)
         mean = torch.empty(n * c, device=x.device, dtype=torch.float32)
         rstd = torch.empty(n * c, device=x.device, dtype=torch.float32)
-        ws = torch.empty(2 * n * c, device=x.device, dtype=torch.float64)
-        _ck(lib().muvo_adain_fwd(_f(x), _f(style), _f(y), _f(mean), _f(rstd), _p(ws), n, c, _i64(s),
-                                 _i64(0 if bcast else c * s), _fl(eps), _st()))
+        if moments is not None and not bcast:   # statistics already accumulated by the producing convolution's epilogue
+            _ck(lib().muvo_adain_fwd_moments(_f(x), _f(style), _f(y), _f(mean), _f(rstd), _p(moments), n, c, _i64(s), _fl(eps), _st()))
+        else:
+            ws = torch.empty(2 * n * c, device=x.device, dtype=torch.float64)
+            _ck(lib().muvo_adain_fwd(_f(x), _f(style), _f(y), _f(mean), _f(rstd), _p(ws), n, c, _i64(s),
+                                     _i64(0 if bcast else c * s), _fl(eps), _st()))
         ctx.dims = (n, c, s, bcast)
         ctx.save_for_backward(x, style, mean, rstd)
         return y
@@ -889,13 +920,13 @@ class AdaINFn(torch.autograd.Function):
             _ck(lib().muvo_batchsum(_f(dxf), _f(dx), n, _i64(c * s), 0, _st()))
         else:
             dx = dxf
-        return dx, dstyle, None, None, None, None
+        return dx, dstyle, None, None, None, None, None
 
 
-def adain(x, style, eps, n_batch, pre_act=ACT_NONE, pre_slope=0.0):
+def adain(x, style, eps, n_batch, pre_act=ACT_NONE, pre_slope=0.0, moments=None):
     """pre_act: x is the output of that activation and the producer's backward does NOT apply its derivative (the
     AdaIN backward kernel chains it); pair with conv(..., act_bwd_fused=True)."""
-    return AdaINFn.apply(x, style, eps, n_batch, pre_act, pre_slope)
+    return AdaINFn.apply(x, style, eps, n_batch, pre_act, pre_slope, moments)
 
 
 class AddDropoutLNFn(torch.autograd.Function):
