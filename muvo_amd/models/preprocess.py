@@ -25,6 +25,9 @@ class PreProcess(nn.Module):
             raise NotImplementedError('EVAL.RESOLUTION.ENABLED (preprocess.py:209-210: antialiased down-scaling of the input '
                                       'for evaluation) is outside the training hot path (SURVEY.md §8)')
         self._pins, self._pin_i = {}, 0
+        # state_dict parity with the reference module (preprocess.py:42-43); the kernels take the values as scalars
+        self.register_buffer('image_mean', torch.tensor(self.mean).unsqueeze(1).unsqueeze(1))
+        self.register_buffer('image_std', torch.tensor(self.std).unsqueeze(1).unsqueeze(1))
         self.augment = True     # False: no augmentation even in training mode (parity runs against augmentation-free fixtures)
 
     def _to_device(self, table, device):

@@ -272,8 +272,10 @@ class WorldModelTrainer(_Base):
             print('ACTIVE INFERENCE ACTIVATED')
             print('!' * 50)
             self.model.rssm.active_inference = True
-        if self._optimizer is not None:
-            self.model.seed_epoch = self._optimizer._step
+        if self._optimizer is not None and self.model.seed_epoch != self._optimizer._step + 1:
+            # dropout seeds = f(rank, optimizer step, micro-batch within the step): reproducible across a checkpoint resume
+            self.model.seed_epoch = self._optimizer._step + 1
+            self.model._step_seed = 0
         if self._reducer is not None:
             self._reducer.accumulating = self._is_accumulating()
             self._reducer.begin_step()

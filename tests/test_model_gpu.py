@@ -288,3 +288,55 @@ def test_full_size_step_properties(dev):
     opt.step()
     for n, p in tr.model.named_parameters():
         assert torch.equal(p, snap[n]) == n.startswith('encoder_layer.'), n
+
+
+@pytest.mark.parametrize('mode', ['f32', 'policy'])
+def test_loss_curve_matches_reference(dev, mode):
+    """Eight optimizer steps of the REAL reference (tests/golden/base1d_b1s2_curve.json: make_golden.py --steps 8, a new batch
+    every step, OneCycleLR running) against the HIP step: every one of the 21 loss terms at every step, and the parameters after
+    the last step.  The trajectories separate slowly (each step feeds the previous step's rounding differences through
+    Adam's g/|g|): the bar is 1e-3 on the first step and grows by 1e-3 per step; the measured deviations are written to
+    gpurun_out/loss_curve.txt."""
+    from muvo_amd import ops
+    from muvo_amd.config import base_1d_cfg
+    from muvo_amd.data.synthetic import make_batch, make_noise
+    from muvo_amd.trainer import WorldModelTrainer
+    from muvo_amd.utils import detinit
+    fx = json.load(open(os.path.join(GOLD, 'base1d_b1s2_curve.json')))
+    b, s, seed = fx['b'], fx['s'], fx['seed']
+    assert len(fx['steps']) == 8
+    old = ops.get_conv_mode()
+    ops.set_conv_mode(ops.CONV_F32 if mode == 'f32' else ops.CONV_BF16X3, min_gflop=-1.0)
+    try:
+        tr = WorldModelTrainer(base_1d_cfg(RECEPTIVE_FIELD=s, FUTURE_HORIZON=0, STEPS=100000).convert_to_dict(), device=dev)
+        tr.train()
+        tr.preprocess.augment = False
+        detinit.fill_state_dict_(tr.model)
+        for layer in tr.model.transformer_encoder.layers:
+            layer.p = 0.0
+        opts, scheds = tr.configure_optimizers()
+        opt, sched = opts[0], scheds[0]['scheduler']
+        eps, use_prior = make_noise(b, s, seed=seed)
+        eps = eps.to(dev)
+        lines, worst = [], []
+        for step, g in enumerate(fx['steps']):
+            opt.zero_grad()
+            total = tr.training_step(make_batch(b, s, seed=seed + step, device=dev), step, noise=eps, use_prior=use_prior)
+            total.backward()
+            opt.step()
+            sched.step()
+            dev_k = {k: _rel(tr.last_losses[k].item(), v) for k, v in g['losses'].items()}
+            w = max(dev_k, key=dev_k.get)
+            worst.append(dev_k[w])
+            lines.append(f'{mode} step {step}: total {total.item():.6f} vs {g["total"]:.6f} (rel {_rel(total.item(), g["total"]):.2e}); '
+                         f'worst term {w} {dev_k[w]:.2e}')
+        with open(os.path.join(os.path.dirname(GOLD), '..', 'gpurun_out', 'loss_curve.txt'), 'a') as f:
+            f.write('\\n'.join(lines) + '\\n')
+        print('\\n'.join(lines))
+        for step, wv in enumerate(worst):
+            assert wv < 1e-3 * (step + 1), lines[step]
+        bad = [n for n, (s_ref, a_ref) in fx['steps'][-1]['param_checksums_after_step'].items()
+               if abs(dict(tr.model.named_parameters())[n].detach().double().abs().sum().item() - a_ref) > 1e-4 * a_ref + 8 * 1e-4]
+        assert not bad, bad[:5]
+    finally:
+        ops.set_conv_mode(old, min_gflop=-1.0)
