@@ -49,13 +49,16 @@ def load_checkpoint(module, optimizer, scheduler, path):
     return int(ck['global_step'])
 
 
-def fit(cfg, device, steps=None, resume=None, log=None, seed=1234, batch_fn=None):
-    """The training loop; returns (module, list of per-step loss dicts as floats)."""
+def fit(cfg, device, steps=None, resume=None, log=None, seed=1234, batch_fn=None, setup=None):
+    """The training loop; returns (module, list of per-step loss dicts as floats).  batch_fn(micro_index) / setup(module):
+    hooks for tests (own batches, e.g. switching dropout off)."""
     import torch.distributed as dist
     rank = dist.get_rank() if dist.is_initialized() else 0
     torch.manual_seed(seed)
     module = WorldModelTrainer(cfg.convert_to_dict(), device=device)
     module.train()
+    if setup is not None:
+        setup(module)
     opts, scheds = module.configure_optimizers()
     optimizer, scheduler = opts[0], scheds[0]['scheduler']
     torch.manual_seed(seed + 7919 * rank)         # data-dependent randomness (RSSM noise, augmentation) differs per rank
@@ -84,7 +87,7 @@ def fit(cfg, device, steps=None, resume=None, log=None, seed=1234, batch_fn=None
         global_step += 1
         module._global_step = global_step
         if log is not None or global_step % max(1, cfg.LOGGING_INTERVAL) == 0 or global_step == steps:
-            rec = {k: float(v) for k, v in module.logged.items()}
+            rec = {k: float(v.detach()) for k, v in module.logged.items()}
             rec['step'], rec['lr'] = global_step, optimizer.param_groups[0]['lr']
             history.append(rec)
             if rank == 0:

@@ -331,8 +331,8 @@ def test_loss_curve_matches_reference(dev, mode):
             lines.append(f'{mode} step {step}: total {total.item():.6f} vs {g["total"]:.6f} (rel {_rel(total.item(), g["total"]):.2e}); '
                          f'worst term {w} {dev_k[w]:.2e}')
         with open(os.path.join(os.path.dirname(GOLD), '..', 'gpurun_out', 'loss_curve.txt'), 'a') as f:
-            f.write('\\n'.join(lines) + '\\n')
-        print('\\n'.join(lines))
+            f.write('\n'.join(lines) + '\n')
+        print('\n'.join(lines))
         for step, wv in enumerate(worst):
             assert wv < 1e-3 * (step + 1), lines[step]
         bad = [n for n, (s_ref, a_ref) in fx['steps'][-1]['param_checksums_after_step'].items()
