@@ -24,26 +24,58 @@ __global__ void __launch_bounds__(256) spatial_loss_fwd_kernel(const float* __re
                                                                const float* __restrict__ target, long F, int Ct, long HW,
                                                                int c0, int c1, int norm, float ignore,
                                                                double* __restrict__ stats) {
-  __shared__ double red[4];
-  const long n = F * HW;
+  // grid = (pixel blocks, frames): no 64-bit division per pixel, four consecutive pixels per trip (16-byte loads when
+  // HW % 4 == 0), ONE workgroup reduction for both sums (few hundred workgroups: the two atomics are not contended)
+  __shared__ double red[2][4];
+  const long f = blockIdx.y;
+  const float* pf = pred + f * Ct * HW;
+  const float* tf = target + f * Ct * HW;
+  const bool vec = (HW & 3) == 0;
+  const long nq = (HW + 3) >> 2;
   float s = 0.f, cnt = 0.f;
   double ds = 0.0;
   int k = 0;
-  GRID_STRIDE(i, n) {
-    const long f = i / HW, p = i - f * HW;
-    const long base = f * Ct * HW + p;
-    if (target[base + (long)c0 * HW] != ignore) {
-      cnt += 1.f;
-      for (int c = c0; c < c1; ++c) {
-        const float d = pred[base + (long)c * HW] - target[base + (long)c * HW];
-        s += norm == 1 ? fabsf(d) : d * d;
-      }
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nq; q += (long)gridDim.x * 256) {
+    const long p0 = q << 2;
+    float m[4];
+    if (vec) {
+      const float4 t4 = *(const float4*)(tf + (long)c0 * HW + p0);
+      m[0] = t4.x; m[1] = t4.y; m[2] = t4.z; m[3] = t4.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m[e] = p0 + e < HW ? tf[(long)c0 * HW + p0 + e] : ignore;
     }
-    if (++k == 32) { ds += s; s = 0.f; k = 0; }
+    bool on[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { on[e] = m[e] != ignore && (vec || p0 + e < HW); cnt += on[e] ? 1.f : 0.f; }
+    for (int c = c0; c < c1; ++c) {
+      float pv[4], tv[4];
+      if (vec) {
+        const float4 a4 = *(const float4*)(pf + (long)c * HW + p0), b4 = *(const float4*)(tf + (long)c * HW + p0);
+        pv[0] = a4.x; pv[1] = a4.y; pv[2] = a4.z; pv[3] = a4.w; tv[0] = b4.x; tv[1] = b4.y; tv[2] = b4.z; tv[3] = b4.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool in = p0 + e < HW;
+          pv[e] = in ? pf[(long)c * HW + p0 + e] : 0.f;
+          tv[e] = in ? tf[(long)c * HW + p0 + e] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (on[e]) {
+          const float d = pv[e] - tv[e];
+          s += norm == 1 ? fabsf(d) : d * d;
+        }
+    }
+    if (++k == 8) { ds += s; s = 0.f; k = 0; }
   }
   ds += s;
-  block_atomic_add_d(ds, &stats[0], red);
-  block_atomic_add_d((double)cnt, &stats[1], red);
+  const double d0 = wave_sum_d(ds), d1 = wave_sum_d((double)cnt);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) { red[0][w] = d0; red[1][w] = d1; }
+  __syncthreads();
+  if (threadIdx.x < 2) atomicAdd(&stats[threadIdx.x], red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
 __global__ void spatial_loss_finalize_kernel(const double* __restrict__ stats, float* __restrict__ loss, float weight) {
   if (threadIdx.x == 0 && blockIdx.x == 0) loss[0] = stats[1] > 0.0 ? (float)(weight * stats[0] / stats[1]) : 0.f;
@@ -464,8 +496,11 @@ int muvo_spatial_loss_fwd(const float* pred, const float* target, int64_t F, int
   MUVO_CHECK_ARG(pred && target && stats2 && loss, "spatial_loss_fwd: null pointer");
   MUVO_CHECK_ARG(F > 0 && HW > 0 && 0 <= c0 && c0 < c1 && c1 <= Ct && (norm == 1 || norm == 2), "spatial_loss_fwd: bad args");
   hipMemsetAsync(stats2, 0, 2 * sizeof(double), ST);
-  hipLaunchKernelGGL(spatial_loss_fwd_kernel, dim3(ew_grid(F * HW)), dim3(256), 0, ST, pred, target, (long)F, Ct, (long)HW, c0,
-                     c1, norm, ignore, stats2);
+  MUVO_CHECK_ARG(F <= 65535, "spatial_loss_fwd: more than 65535 frames");
+  long nbx = (HW / 4 + 1023) / 1024;             // ~4 trips of 4 pixels per thread
+  if (nbx * F > 1024) nbx = 1024 / F > 0 ? 1024 / F : 1;
+  hipLaunchKernelGGL(spatial_loss_fwd_kernel, dim3((unsigned)nbx, (unsigned)F), dim3(256), 0, ST, pred, target, (long)F, Ct, (long)HW,
+                     c0, c1, norm, ignore, stats2);
   hipLaunchKernelGGL(spatial_loss_finalize_kernel, dim3(1), dim3(64), 0, ST, stats2, loss, weight);
   MUVO_CHECK_LAUNCH("spatial_loss_fwd");
   return MUVO_OK;

@@ -53,8 +53,13 @@ def test_gradient_accumulation_equals_big_batch_gradient(dev, tmp_path, monkeypa
     from muvo_amd import ops, train
     from muvo_amd.data.synthetic import make_batch
     monkeypatch.chdir(tmp_path)
-    monkeypatch.setattr(torch, 'randn', lambda *shape, **kw: torch.full(shape, 0.3, **kw))
-    monkeypatch.setattr(torch, 'rand', lambda *shape, **kw: torch.full(shape, 0.9, **kw))
+    def const(value):
+        def f(*shape, **kw):
+            shape = tuple(shape[0]) if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)) else shape
+            return torch.full(shape, value, **kw)
+        return f
+    monkeypatch.setattr(torch, 'randn', const(0.3))
+    monkeypatch.setattr(torch, 'rand', const(0.9))
 
     def no_dropout(m):
         for layer in m.model.transformer_encoder.layers:
