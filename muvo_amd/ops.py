@@ -17,7 +17,7 @@ import weakref
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, 'libmuvo_hip.so')
+_LIB_PATH = os.environ.get('MUVO_HIP_LIB') or os.path.join(_HERE, 'libmuvo_hip.so')   # MUVO_HIP_LIB: A/B builds on the GPU box
 _lib = None
 _lock = threading.Lock()
 
