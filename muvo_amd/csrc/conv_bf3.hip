@@ -51,29 +51,6 @@ __device__ __forceinline__ void dma16(const uint4* g, uint4* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
-// The twelve MFMAs of one K step of a 2x2 wave tile (three split products x four accumulator tiles).  MUVO_MFMA_GRAY orders
-// them so that consecutive instructions share one operand (hh: (0,0) (0,1) (1,1) (1,0), then only B flips to its lo plane: hl
-// (1,1) (1,0) (0,0) (0,1), then lh (1,0) (1,1) (0,1) (0,0)) and no accumulator is used by two neighbouring instructions; the
-// default order walks the tiles and issues the three products of a tile back to back (both operands change on 8 of 12
-// transitions).  The big launches are limited by board power (all-zero operands run 25 % faster): an experiment on operand toggling.
-#ifdef MUVO_MFMA_GRAY
-#define BF3_MFMA_2X2(AH, AL, BH, BL, ACC)                                                   \
-  do {                                                                                      \
-    ACC[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH[0], BH[0], ACC[0][0], 0, 0, 0);  \
-    ACC[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH[0], BH[1], ACC[0][1], 0, 0, 0);  \
-    ACC[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH[1], BH[1], ACC[1][1], 0, 0, 0);  \
-    ACC[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH[1], BH[0], ACC[1][0], 0, 0, 0);  \
-    ACC[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH[1], BL[1], ACC[1][1], 0, 0, 0);  \
-    ACC[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH[1], BL[0], ACC[1][0], 0, 0, 0);  \
-    ACC[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH[0], BL[0], ACC[0][0], 0, 0, 0);  \
-    ACC[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AH[0], BL[1], ACC[0][1], 0, 0, 0);  \
-    ACC[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AL[1], BH[0], ACC[1][0], 0, 0, 0);  \
-    ACC[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AL[1], BH[1], ACC[1][1], 0, 0, 0);  \
-    ACC[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AL[0], BH[1], ACC[0][1], 0, 0, 0);  \
-    ACC[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AL[0], BH[0], ACC[0][0], 0, 0, 0);  \
-  } while (0)
-#endif
-
 // Activation operand: xs = bf16 hi plane, xs + plane_u4 = lo plane, each [N][ID][IH][IW][Cp] (channels-last, written by
 // nchw_split_nhwc_kernel), so 8 consecutive k of one pixel are 16 contiguous bytes and both operands are staged by
 // LDS-DMA with no register round trip and no conversion work in this kernel.
@@ -593,21 +570,14 @@ conv_bf3_k16_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-#ifdef MUVO_MFMA_GRAY
-    if constexpr (TM == 2 && TN == 2) {
-      BF3_MFMA_2X2(ah, al, bh, bl, acc);
-    } else
-#endif
-    {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-        }
-    }
+      for (int j = 0; j < TN; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     stage = stage == 2 ? 0 : stage + 1;
@@ -796,9 +766,6 @@ conv_bf3_wgrad_kernel(const ConvPhase g, const uint4* __restrict__ xs, long xpla
         bh[i] = tr_read8(Bh + o + lane_off0, Bh + o + lane_off1);
         bl[i] = tr_read8(Bl + o + lane_off0, Bl + o + lane_off1);
       }
-#ifdef MUVO_MFMA_GRAY
-      BF3_MFMA_2X2(ah, al, bh, bl, acc);
-#else
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -807,7 +774,6 @@ conv_bf3_wgrad_kernel(const ConvPhase g, const uint4* __restrict__ xs, long xpla
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
-#endif
     }
     stage = stage == 2 ? 0 : stage + 1;
   }
