@@ -1,6 +1,8 @@
 #!/bin/bash
 # HBM traffic of one layer (GPU box): FETCH_SIZE and WRITE_SIZE in separate passes, as /opt/skills/guides/MI355X_MICROARCH.md
 # prescribes.  usage: tools/pmc_hbm.sh <tag> <layer_bench args...>
+set -uo pipefail
+: ${GRAFT_REPO_ROOT:?}
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

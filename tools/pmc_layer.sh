@@ -1,6 +1,8 @@
 #!/bin/bash
 # PMC passes over tools/layer_bench.py for one layer/mode (GPU box).  usage: tools/pmc_layer.sh <tag> <layer_bench args...>
 # Writes gpurun_out/pmc_<tag>_pass{1,2,3}/ (rocpd databases); summarise with tools/rocpd_pmc.py.
+set -uo pipefail
+: ${GRAFT_REPO_ROOT:?}
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
