@@ -746,9 +746,10 @@ def conv_moments_buffer(x, geom):
         ok = geom.family[key] = bool(lib().muvo_conv_forward_moments_supported(C.byref(d)))
     if not ok:
         return None
-    buf = geom.__dict__.get('_moments')
-    if buf is None or buf.shape[0] != n or buf.device != x.device:
-        buf = geom._moments = torch.zeros(n, geom.cout, 2, device=x.device, dtype=torch.float64)
+    cache = geom.__dict__.setdefault('_moments', {})       # one zeroed buffer per batch size (training / validation / imagination)
+    buf = cache.get((n, x.device))
+    if buf is None:
+        buf = cache[(n, x.device)] = torch.zeros(n, geom.cout, 2, device=x.device, dtype=torch.float64)
     return buf
 
 
