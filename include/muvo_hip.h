@@ -119,6 +119,17 @@ int muvo_conv_forward_moments(const muvo_conv_desc* d, const float* x, const flo
                               float slope, double* moments, void* stream);
 int muvo_adain_fwd_moments(const float* x, const float* style, float* y, float* save_mean, float* save_rstd, double* moments,
                            int N, int C, int64_t S, float eps, void* stream);
+/* Last stage of VoxelDecoder1 fused (common.py:541-545 + VoxelSemHead :354-367): AdaIN of the last convolution's output x
+ * (N,C,S) followed by the 1x1x1 class head (head_w (CO,C), head_b (CO)) -> logits (N,CO,S).  The normalised tensor is never
+ * written; backward recomputes it and forms dy = head_w^T dlogits on the fly.  `moments`: the (sum, sum of squares) buffer of
+ * muvo_conv_forward_moments (cleared).  muvo_adain_head_bwd: dx (N,C,S) (incl. the LeakyReLU derivative of the producing
+ * convolution, as muvo_adain_bwd), dstyle (N,2C) overwritten, dhead_w / dhead_b accumulated; ws: 2*N*C doubles. */
+int muvo_adain_head_supported(int C, int CO, int64_t S);
+int muvo_adain_head_fwd(const float* x, const float* style, float* save_mean, float* save_rstd, double* moments, const float* head_w,
+                        const float* head_b, float* logits, int N, int C, int CO, int64_t S, float eps, void* stream);
+int muvo_adain_head_bwd(const float* x, const float* style, const float* save_mean, const float* save_rstd, const float* head_w,
+                        const float* dlogits, float* dx, float* dstyle, float* dhead_w, float* dhead_b, double* ws, int N, int C,
+                        int CO, int64_t S, int act, float slope, void* stream);
 /* dx += conv_data_grad(dy, w) for the 1x1 output heads (muvo_conv_kernel_family(d, 1) == 3; RGBHead / LidarReHead / VoxelSemHead,
  * common.py:274-303,354-367): the head hangs off a decoder trunk, dx already holds the gradient that came back through the
  * trunk, so no separate add pass over the feature map is needed */

@@ -544,6 +544,238 @@ extern "C" int muvo_adain_fwd_moments(const float* x, const float* style, float*
   return MUVO_OK;
 }
 
+// ================================================================================================
+// Last stage of VoxelDecoder1 (common.py:541-545): AdaIN of the last 3x3x3 convolution, then the 1x1x1 class head
+// (VoxelSemHead :354-367).  The normalised tensor (8 channels x 2.36 M voxels x 20 frames = 1.5 GB) has ONE consumer, the head,
+// so it is never written: forward reads the convolution output once and writes the logits; backward recomputes it, and forms
+// dy = W^T dlogits on the fly in both of its passes (statistics + head weight gradient; apply) instead of a head data-gradient
+// pass that writes dy and two passes that read it back.  Thread = 4 consecutive voxels x all C channels.
+//   y_c = st_c ((x_c - mu_c) rs_c) + sh_c        logit_o = b_o + sum_c W[o][c] y_c      (operation order of the unfused kernels)
+// ================================================================================================
+template <int C, int CO>
+__global__ void __launch_bounds__(256) adain_head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, const float* __restrict__ style,
+                                                             const float* __restrict__ wh, const float* __restrict__ bh,
+                                                             float* __restrict__ logits, long S) {
+  const long n = blockIdx.y, S4 = S >> 2;
+  float st[C], sh[C], mu[C], rs[C], w[CO][C], b[CO];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    st[c] = style[n * 2 * C + c]; sh[c] = style[n * 2 * C + C + c]; mu[c] = mean[n * C + c]; rs[c] = rstd[n * C + c];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) w[o][c] = wh[o * C + c];
+  }
+#pragma unroll
+  for (int o = 0; o < CO; ++o) b[o] = bh ? bh[o] : 0.f;
+  const float4* xp = reinterpret_cast<const float4*>(x + n * C * S);
+  float4* lp = reinterpret_cast<float4*>(logits + n * CO * S);
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < S4; i += (long)gridDim.x * 256) {
+    float4 acc[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) acc[o] = make_float4(b[o], b[o], b[o], b[o]);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float4 v = xp[(long)c * S4 + i];
+      const float4 y = make_float4(st[c] * ((v.x - mu[c]) * rs[c]) + sh[c], st[c] * ((v.y - mu[c]) * rs[c]) + sh[c],
+                                   st[c] * ((v.z - mu[c]) * rs[c]) + sh[c], st[c] * ((v.w - mu[c]) * rs[c]) + sh[c]);
+#pragma unroll
+      for (int o = 0; o < CO; ++o) {
+        acc[o].x += w[o][c] * y.x; acc[o].y += w[o][c] * y.y; acc[o].z += w[o][c] * y.z; acc[o].w += w[o][c] * y.w;
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < CO; ++o) lp[(long)o * S4 + i] = acc[o];
+  }
+}
+
+// backward pass 1: per (n, c) sums of dy and dy * xhat (dy = W^T dlogits), head weight / bias gradient
+template <int C, int CO>
+__global__ void __launch_bounds__(256) adain_head_bwd_stats_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                                   const float* __restrict__ rstd, const float* __restrict__ style,
+                                                                   const float* __restrict__ wh, const float* __restrict__ dl,
+                                                                   double* __restrict__ sums, double* __restrict__ hsum, long S) {
+  constexpr int NV = 2 * C + CO * C + CO;
+  __shared__ float red[4][NV];
+  const long n = blockIdx.y, S4 = S >> 2;
+  float st[C], sh[C], mu[C], rs[C], w[CO][C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    st[c] = style[n * 2 * C + c]; sh[c] = style[n * 2 * C + C + c]; mu[c] = mean[n * C + c]; rs[c] = rstd[n * C + c];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) w[o][c] = wh[o * C + c];
+  }
+  float s1[C], s2[C], gw[CO][C], gb[CO];
+#pragma unroll
+  for (int c = 0; c < C; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
+#pragma unroll
+  for (int o = 0; o < CO; ++o) { gb[o] = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) gw[o][c] = 0.f; }
+  const float4* xp = reinterpret_cast<const float4*>(x + n * C * S);
+  const float4* gp = reinterpret_cast<const float4*>(dl + n * CO * S);
+  // <= 4096 voxels per thread block trip count keeps the fp32 partial sums short (same budget as bwd_moments_kernel)
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < S4; i += (long)gridDim.x * 256) {
+    float4 g[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) { g[o] = gp[(long)o * S4 + i]; gb[o] += (g[o].x + g[o].y) + (g[o].z + g[o].w); }
+    float ge[CO][4];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) { ge[o][0] = g[o].x; ge[o][1] = g[o].y; ge[o][2] = g[o].z; ge[o][3] = g[o].w; }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float4 v = xp[(long)c * S4 + i];
+      const float xs[4] = {v.x, v.y, v.z, v.w};
+      float dy[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int o = 0; o < CO; ++o)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dy[e] += w[o][c] * ge[o][e];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (xs[e] - mu[c]) * rs[c];
+        s1[c] += dy[e];
+        s2[c] += dy[e] * xh;
+        const float y = st[c] * xh + sh[c];
+#pragma unroll
+        for (int o = 0; o < CO; ++o) gw[o][c] += ge[o][e] * y;
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const float a = wave_sum(s1[c]), b2 = wave_sum(s2[c]);
+    if (lane == 0) { red[wave][2 * c] = a; red[wave][2 * c + 1] = b2; }
+#pragma unroll
+    for (int o = 0; o < CO; ++o) {
+      const float t = wave_sum(gw[o][c]);
+      if (lane == 0) red[wave][2 * C + o * C + c] = t;
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < CO; ++o) {
+    const float t = wave_sum(gb[o]);
+    if (lane == 0) red[wave][2 * C + CO * C + o] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    const int k = threadIdx.x;
+    const float t = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+    if (k < 2 * C) atomicAdd(&sums[2 * (n * C) + k], (double)t);         // [n][c][2]: k = 2 c + which
+    else atomicAdd(&hsum[n * (CO * C + CO) + (k - 2 * C)], (double)t);  // per frame: <= gridDim.x adds per address
+  }
+}
+// dW_head[o][c] += sum over frames, db_head[o] likewise; clears the partials
+__global__ void adain_head_finalize_kernel(double* __restrict__ hsum, float* __restrict__ dwh, float* __restrict__ dbh, int N, int nw,
+                                           int nb) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nw + nb) return;
+  double t = 0.0;
+  for (int n = 0; n < N; ++n) { t += hsum[(long)n * (nw + nb) + k]; hsum[(long)n * (nw + nb) + k] = 0.0; }
+  if (k < nw) dwh[k] += (float)t;
+  else if (dbh) dbh[k - nw] += (float)t;
+}
+
+// backward pass 2: dx = st rs (dy - m1 - xhat m2) act'(x)
+template <int C, int CO>
+__global__ void __launch_bounds__(256) adain_head_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                                   const float* __restrict__ rstd, const float* __restrict__ style,
+                                                                   const float* __restrict__ wh, const float* __restrict__ dl,
+                                                                   const double* __restrict__ fin, float* __restrict__ dx, long S,
+                                                                   int act, float slope) {
+  const long n = blockIdx.y, S4 = S >> 2;
+  float st[C], mu[C], rs[C], m1[C], m2[C], w[CO][C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    st[c] = style[n * 2 * C + c]; mu[c] = mean[n * C + c]; rs[c] = rstd[n * C + c];
+    m1[c] = (float)(fin[2 * (n * C + c)] / (double)S); m2[c] = (float)(fin[2 * (n * C + c) + 1] / (double)S);
+#pragma unroll
+    for (int o = 0; o < CO; ++o) w[o][c] = wh[o * C + c];
+  }
+  const float4* xp = reinterpret_cast<const float4*>(x + n * C * S);
+  const float4* gp = reinterpret_cast<const float4*>(dl + n * CO * S);
+  float4* op = reinterpret_cast<float4*>(dx + n * C * S);
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < S4; i += (long)gridDim.x * 256) {
+    float4 g[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) g[o] = gp[(long)o * S4 + i];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float4 v = xp[(long)c * S4 + i];
+      const float xs[4] = {v.x, v.y, v.z, v.w};
+      float dy[4] = {0.f, 0.f, 0.f, 0.f}, o4[4];
+#pragma unroll
+      for (int o = 0; o < CO; ++o) {
+        dy[0] += w[o][c] * g[o].x; dy[1] += w[o][c] * g[o].y; dy[2] += w[o][c] * g[o].z; dy[3] += w[o][c] * g[o].w;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (xs[e] - mu[c]) * rs[c];
+        o4[e] = st[c] * rs[c] * (dy[e] - m1[c] - xh * m2[c]) * act_grad_from_out(xs[e], act, slope);
+      }
+      op[(long)c * S4 + i] = make_float4(o4[0], o4[1], o4[2], o4[3]);
+    }
+  }
+}
+
+template <int C, int CO>
+static int adain_head_run(int which, const float* x, const float* style, float* mean, float* rstd, double* moments, const float* wh,
+                          const float* bh, float* logits, const float* dl, float* dx, float* dstyle, float* dwh, float* dbh,
+                          double* ws, int N, long S, float eps, int act, float slope, hipStream_t st) {
+  const int G = N * C;
+  const long S4 = S >> 2;
+  if (which == 0) {
+    hipLaunchKernelGGL(in_finalize_kernel, dim3(cdiv(G, 64)), dim3(64), 0, st, moments, mean, rstd, G, (double)S, eps);
+    int gx = cdiv(S4, 256 * 4);
+    if (gx > 128) gx = 128;
+    hipLaunchKernelGGL((adain_head_fwd_kernel<C, CO>), dim3(gx, N), dim3(256), 0, st, x, (const float*)mean, (const float*)rstd, style,
+                       wh, bh, logits, S);
+  } else {
+    double* sums = norm_sums(2 * (size_t)G + (size_t)N * (CO * C + CO));
+    if (!sums) { muvo_set_error("adain_head_bwd: cannot allocate the statistics buffer"); return MUVO_ERR_HIP; }
+    double* hsum = sums + 2 * (size_t)G;
+    int gx = cdiv(S4, 1024);                 // 4096 voxels per workgroup
+    if (gx > 128) gx = 128;
+    hipLaunchKernelGGL((adain_head_bwd_stats_kernel<C, CO>), dim3(gx, N), dim3(256), 0, st, x, (const float*)mean, (const float*)rstd,
+                       style, wh, dl, sums, hsum, S);
+    hipLaunchKernelGGL(adain_bwd_finalize_kernel, dim3(cdiv(G, 64)), dim3(64), 0, st, sums, ws, dstyle, N, C);
+    hipLaunchKernelGGL(adain_head_finalize_kernel, dim3(1), dim3(64), 0, st, hsum, dwh, dbh, N, CO * C, CO);
+    gx = cdiv(S4, 256 * 4);
+    if (gx > 128) gx = 128;
+    hipLaunchKernelGGL((adain_head_bwd_apply_kernel<C, CO>), dim3(gx, N), dim3(256), 0, st, x, (const float*)mean, (const float*)rstd,
+                       style, wh, dl, (const double*)ws, dx, S, act, slope);
+  }
+  return MUVO_OK;
+}
+
+extern "C" int muvo_adain_head_supported(int C, int CO, int64_t S) {
+  return (C == 8 && CO == 2 && S % 4 == 0 && S >= 1024) ? 1 : 0;
+}
+extern "C" int muvo_adain_head_fwd(const float* x, const float* style, float* save_mean, float* save_rstd, double* moments,
+                                   const float* head_w, const float* head_b, float* logits, int N, int C, int CO, int64_t S,
+                                   float eps, void* stream) {
+  MUVO_CHECK_ARG(x && style && save_mean && save_rstd && moments && head_w && logits && N > 0 && N <= 65535, "adain_head_fwd: bad args");
+  MUVO_CHECK_ARG(muvo_adain_head_supported(C, CO, S) && (((uintptr_t)x | (uintptr_t)logits) & 15) == 0, "adain_head_fwd: shape");
+  const int rc = adain_head_run<8, 2>(0, x, style, save_mean, save_rstd, moments, head_w, head_b, logits, nullptr, nullptr, nullptr,
+                                      nullptr, nullptr, nullptr, N, (long)S, eps, 0, 0.f, (hipStream_t)stream);
+  if (rc) return rc;
+  MUVO_CHECK_LAUNCH("adain_head_fwd");
+  return MUVO_OK;
+}
+extern "C" int muvo_adain_head_bwd(const float* x, const float* style, const float* save_mean, const float* save_rstd,
+                                   const float* head_w, const float* dlogits, float* dx, float* dstyle, float* dhead_w,
+                                   float* dhead_b, double* ws, int N, int C, int CO, int64_t S, int act, float slope, void* stream) {
+  MUVO_CHECK_ARG(x && style && save_mean && save_rstd && head_w && dlogits && dx && dstyle && dhead_w && ws && N > 0 && N <= 65535,
+                 "adain_head_bwd: bad args");
+  MUVO_CHECK_ARG(muvo_adain_head_supported(C, CO, S) && (((uintptr_t)x | (uintptr_t)dlogits | (uintptr_t)dx) & 15) == 0,
+                 "adain_head_bwd: shape");
+  const int rc = adain_head_run<8, 2>(1, x, style, (float*)save_mean, (float*)save_rstd, nullptr, head_w, nullptr, nullptr, dlogits, dx,
+                                      dstyle, dhead_w, dhead_b, ws, N, (long)S, 0.f, act, slope, (hipStream_t)stream);
+  if (rc) return rc;
+  MUVO_CHECK_LAUNCH("adain_head_bwd");
+  return MUVO_OK;
+}
+
 // dx: (N,C,S) always dense (caller reduces over batch when the input was broadcast); dstyle: (N, 2C) overwritten
 extern "C" int muvo_adain_bwd(const float* x, const float* style, const float* dy, const float* save_mean,
                               const float* save_rstd, float* dx, float* dstyle, double* ws, int N, int C, int64_t S,

@@ -108,6 +108,16 @@ class ConvInstanceNorm3d(nn.Module):
         x = self.conv_act[0](x, act=ops.ACT_LEAKY, slope=0.2, act_bwd_fused=True, moments=moments)
         return self.adaptive_norm(x, w, pre_act=ops.ACT_LEAKY, pre_slope=0.2, moments=moments)
 
+    def forward_with_head(self, x, w, head_conv):
+        """This layer followed by a 1x1x1 head that is the ONLY consumer of its output (VoxelDecoder1's last stage): returns
+        the head's logits; the normalised tensor is never materialised when the fused kernels apply (ops.AdaINHeadFn)."""
+        moments = ops.conv_moments_buffer(x, self.conv_act[0].geom)
+        x = self.conv_act[0](x, act=ops.ACT_LEAKY, slope=0.2, act_bwd_fused=True, moments=moments)
+        if ops.adain_head_supported(x, head_conv.weight, moments):
+            an = self.adaptive_norm
+            return ops.adain_head(x, an.latent_affine(w), head_conv.weight, head_conv.bias, an.epsilon, moments, ops.ACT_LEAKY, 0.2)
+        return head_conv(self.adaptive_norm(x, w, pre_act=ops.ACT_LEAKY, pre_slope=0.2, moments=moments))
+
 
 class AdaptiveInstanceNorm(nn.Module):
     """common.py:205-224 (2-D): the 3-D kernel with a unit depth."""
@@ -208,9 +218,11 @@ class DecoderBlock3d(nn.Module):
         self.conv1 = ConvInstanceNorm3d(in_channels, out_channels, latent_n_channels)
         self.conv2 = ConvInstanceNorm3d(out_channels, out_channels, latent_n_channels)
 
-    def forward(self, x, w):
+    def forward(self, x, w, head_conv=None):
         if self.upsample:
             x = ops.upsample3d_x2(x)
+        if head_conv is not None:
+            return self.conv2.forward_with_head(self.conv1(x, w), w, head_conv)
         return self.conv2(self.conv1(x, w), w)
 
 
@@ -283,8 +295,9 @@ class VoxelDecoder1(nn.Module):
         x, output_4 = self.head_4.branch(x)
         x = self.conv2(x, w)
         x, output_2 = self.head_2.branch(x)
-        x = self.conv3(x, w)
-        output_1 = self.head_1(x)
+        # last stage: the block's output feeds the head only -> AdaIN + head fused (the 1.5 GB normalised tensor is not written)
+        h1 = self.head_1
+        output_1 = {f'{h1._key}_{h1.downsample_factor}': self.conv3(x, w, head_conv=getattr(h1, h1._attr)[0])}
         return {**output_4, **output_2, **output_1}
 
 

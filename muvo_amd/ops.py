@@ -66,6 +66,7 @@ EXPORTS = [
     'muvo_instance_labels', 'muvo_pixel_augment', 'muvo_preprocess_route_aug',
     'muvo_split_planes_bytes', 'muvo_split_planes', 'muvo_attention_supported', 'muvo_attention_fwd', 'muvo_attention_bwd',
     'muvo_conv_dgrad_accumulate', 'muvo_conv_forward_moments_supported', 'muvo_conv_forward_moments', 'muvo_adain_fwd_moments',
+    'muvo_adain_head_supported', 'muvo_adain_head_fwd', 'muvo_adain_head_bwd',
     'muvo_rssm_supported', 'muvo_rssm_transposed_floats', 'muvo_rssm_scratch_floats', 'muvo_rssm_forward', 'muvo_rssm_backward',
 ]
 
@@ -928,6 +929,56 @@ def adain(x, style, eps, n_batch, pre_act=ACT_NONE, pre_slope=0.0, moments=None)
     """pre_act: x is the output of that activation and the producer's backward does NOT apply its derivative (the
     AdaIN backward kernel chains it); pair with conv(..., act_bwd_fused=True)."""
     return AdaINFn.apply(x, style, eps, n_batch, pre_act, pre_slope, moments)
+
+
+class AdaINHeadFn(torch.autograd.Function):
+    """AdaIN of the last voxel-decoder convolution + the 1x1x1 class head in one pass each way (csrc/norm.hip:
+    adain_head_*): x (N,C,D,H,W) is the convolution output (LeakyReLU applied, its derivative chained here), `moments` its
+    per-(n,c) sums from the convolution epilogue.  The normalised tensor never exists in HBM."""
+
+    @staticmethod
+    def forward(ctx, x, style, head_w, head_b, eps, moments, pre_act, pre_slope):
+        x, style = x.contiguous(), style.contiguous()
+        n, c = x.shape[:2]
+        s = x.numel() // (n * c)
+        co = head_w.shape[0]
+        logits = torch.empty((n, co) + tuple(x.shape[2:]), device=x.device, dtype=torch.float32)
+        mean = torch.empty(n * c, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(n * c, device=x.device, dtype=torch.float32)
+        _ck(lib().muvo_adain_head_fwd(_f(x), _f(style), _f(mean), _f(rstd), _p(moments), _f(head_w.contiguous().view(co, c)),
+                                      _f(head_b), _f(logits), n, c, co, _i64(s), _fl(eps), _st()))
+        ctx.dims, ctx.pre = (n, c, co, s), (pre_act, pre_slope)
+        ctx.head_w, ctx.head_b = head_w, head_b
+        ctx.save_for_backward(x, style, mean, rstd)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dl):
+        x, style, mean, rstd = ctx.saved_tensors
+        n, c, co, s = ctx.dims
+        head_w, head_b = ctx.head_w, ctx.head_b
+        dl = dl.contiguous()
+        dx = torch.empty_like(x)
+        dstyle = torch.empty_like(style)
+        ws = torch.empty(2 * n * c, device=x.device, dtype=torch.float64)
+        _ck(lib().muvo_adain_head_bwd(_f(x), _f(style), _f(mean), _f(rstd), _f(head_w.contiguous().view(co, c)), _f(dl), _f(dx),
+                                      _f(dstyle), _f(grad_of(head_w)), _f(grad_of(head_b)) if head_b is not None else None, _p(ws),
+                                      n, c, co, _i64(s), ctx.pre[0], _fl(ctx.pre[1]), _st()))
+        return dx, dstyle, None, None, None, None, None, None
+
+
+ADAIN_HEAD = os.environ.get('MUVO_ADAIN_HEAD', '1') != '0'
+
+
+def adain_head_supported(x, head_w, moments):
+    if not ADAIN_HEAD or moments is None or x.dim() != 5:
+        return False
+    n, c = x.shape[:2]
+    return bool(lib().muvo_adain_head_supported(c, head_w.shape[0], _i64(x.numel() // (n * c)))) and n <= 65535
+
+
+def adain_head(x, style, head_w, head_b, eps, moments, pre_act=ACT_NONE, pre_slope=0.0):
+    return AdaINHeadFn.apply(x, style, head_w, head_b, eps, moments, pre_act, pre_slope)
 
 
 class AddDropoutLNFn(torch.autograd.Function):
