@@ -370,6 +370,43 @@ def test_conv_lrelu_adain_fused_backward(dev):
     _close(sg.grad, sc.grad, rtol=5e-4, name='dstyle')
 
 
+@pytest.mark.parametrize('pre', [False, True])
+def test_adain_head_fused(dev, pre):
+    """AdaIN + 1x1x1 class head in one pass (VoxelDecoder1's last stage, common.py:541-545 + :354-367): logits, the data /
+    style gradients and the head's weight / bias gradients against the plain PyTorch composition; `pre`: the LeakyReLU
+    derivative of the producing convolution chained inside the backward."""
+    from muvo_amd import ops
+    torch.manual_seed(21)
+    n, c, co, shape = 3, 8, 2, (8, 12, 16)
+    assert ops.lib().muvo_adain_head_supported(c, co, 8 * 12 * 16)
+    z = torch.randn(n, c, *shape) + 0.3
+    x = F.leaky_relu(z, 0.2) if pre else z
+    style = torch.randn(n, 2 * c)
+    hw, hb = torch.randn(co, c, 1, 1, 1) * 0.3, torch.randn(co)
+    xg, sg = x.to(dev).requires_grad_(True), style.to(dev).requires_grad_(True)
+    hwg, hbg = torch.nn.Parameter(hw.to(dev)), torch.nn.Parameter(hb.to(dev))
+    hwg.grad, hbg.grad = torch.full_like(hwg, 0.5), torch.full_like(hbg, -0.25)       # the kernels ACCUMULATE into these
+    xd = xg.detach().double()
+    moments = torch.stack([xd.sum(dim=(2, 3, 4)), (xd * xd).sum(dim=(2, 3, 4))], dim=-1).contiguous()
+    y = ops.adain_head(xg, sg, hwg, hbg, 1e-8, moments, ops.ACT_LEAKY if pre else ops.ACT_NONE, 0.2)
+    assert float(moments.abs().max()) == 0.0                                           # handed back cleared
+    zc, sc = z.clone().requires_grad_(True), style.clone().requires_grad_(True)
+    hwc, hbc = hw.clone().requires_grad_(True), hb.clone().requires_grad_(True)
+    h = F.leaky_relu(zc, 0.2) if pre else zc
+    hm = h - h.mean(dim=(-1, -2, -3), keepdim=True)
+    a = sc[:, :c, None, None, None] * (hm / torch.sqrt((hm ** 2).mean(dim=(-1, -2, -3), keepdim=True) + 1e-8)) + \
+        sc[:, c:, None, None, None]
+    yr = F.conv3d(a, hwc, hbc)
+    _close(y, yr, name='logits')
+    g = torch.randn_like(yr)
+    yr.backward(g)
+    y.backward(g.to(dev))
+    _close(xg.grad, zc.grad, rtol=5e-4, name='dx')
+    _close(sg.grad, sc.grad, rtol=5e-4, name='dstyle')
+    _close(hwg.grad - 0.5, hwc.grad, rtol=5e-4, atol=1e-3, name='dhead_w')
+    _close(hbg.grad + 0.25, hbc.grad, rtol=5e-4, atol=1e-3, name='dhead_b')
+
+
 @pytest.mark.parametrize('l,n,e', [(70, 3, 96), (324, 2, 384)])    # head dim 12: unfused attention; 48: the fused kernel
 def test_transformer_layer(dev, l, n, e):
     from muvo_amd import nn as hnn
