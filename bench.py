@@ -227,6 +227,19 @@ def main():
                 conv_s = sum(c['seconds'] for c in out['kernel_classes'].values())
                 dom_s = sum(c['seconds'] for k, c in out['kernel_classes'].items() if k.split(':')[0] == dominant)
                 out['roofline']['share_of_conv_time'] = dom_s / max(conv_s, 1e-12)
+            if out['roofline'] is not None:
+                # clock probe of the dominant kernel (workgroup 0 of the most recent eight-wave launch, include/muvo_hip.h):
+                # the class runs power-limited below the 2.4 GHz the peak is quoted at
+                import ctypes
+                mhz, usk = ctypes.c_double(0.0), ctypes.c_double(0.0)
+                if ops.lib().muvo_bf3_loop_clock(ctypes.byref(mhz), ctypes.byref(usk)) == 0 and mhz.value > 0:
+                    r = out['roofline']
+                    r['shader_clock_mhz_under_load'] = mhz.value
+                    r['peak_at_that_clock'] = r['peak'] * mhz.value / 2400.0
+                    r['frac_at_that_clock'] = r['achieved'] / r['peak_at_that_clock']
+                    # one K step of a workgroup = 24 MFMA 32x32x16 (8 passes = 32 clocks each) per wave, two waves per SIMD
+                    r['k_loop_mfma_busy'] = 24 * 32 * 2 / (usk.value * mhz.value)
+                    r['clock_note'] = 'shader clock and time per K step measured by workgroup 0 of the last eight-wave launch (s_memtime / s_memrealtime)'
             # HBM-side bytes per launch of the dominant class: PMC counters cannot be read from inside this process, so the
             # figure comes from the committed rocprofv3 --pmc passes over this same command (tools/pmc_step.sh)
             import glob

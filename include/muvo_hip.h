@@ -119,6 +119,10 @@ int muvo_conv_forward_moments(const muvo_conv_desc* d, const float* x, const flo
                               float slope, double* moments, void* stream);
 int muvo_adain_fwd_moments(const float* x, const float* style, float* y, float* save_mean, float* save_rstd, double* moments,
                            int N, int C, int64_t S, float eps, void* stream);
+/* Clock probe of the dominant kernel class (eight-wave bf16x3 implicit-GEMM tiles): shader clock (MHz) and wall time per
+ * K step (32 deep, 24 MFMA 32x32x16 per wave) that workgroup 0 of the most recent launch measured over its K loop.  The
+ * kernels run power-limited well below the 2.4 GHz the dense MFMA peak is quoted at; bench.py reports both. */
+int muvo_bf3_loop_clock(double* shader_mhz, double* us_per_k_step);
 /* Last stage of VoxelDecoder1 fused (common.py:541-545 + VoxelSemHead :354-367): AdaIN of the last convolution's output x
  * (N,C,S) followed by the 1x1x1 class head (head_w (CO,C), head_b (CO)) -> logits (N,CO,S).  The normalised tensor is never
  * written; backward recomputes it and forms dy = head_w^T dlogits on the fly.  `moments`: the (sum, sum of squares) buffer of

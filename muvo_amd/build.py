@@ -9,7 +9,28 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libmuvo_hip.so')
 SOURCES = ['abi.hip', 'conv_gemm.hip', 'conv_vox.hip', 'conv_pw.hip', 'conv_bf3.hip', 'gemm.hip', 'norm.hip', 'elementwise.hip', 'losses.hip', 'metrics.hip', 'bev.hip', 'input.hip', 'augment.hip', 'attention.hip', 'rssm.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-munsafe-fp-atomics', '-Wno-unused-result', '-Wno-unused-value',
-         '-ffp-contract=off']
+         '-ffp-contract=off', '-Rpass-analysis=kernel-resource-usage']
+# Kernels allowed to use scratch memory (bytes per lane).  Everything else must stay in registers: a kernel that silently
+# picks up scratch (an argument struct captured by reference and copied to the stack, register spills after a small edit)
+# loses tens of microseconds per workgroup launch — the build fails instead.
+SCRATCH_ALLOWED = {'rssm_fwd_kernel': 128, 'rssm_bwd_kernel': 128}
+
+
+def _check_resources(src, stderr):
+    """Parses hipcc's kernel-resource-usage remarks: returns [(kernel, scratch bytes, spilled VGPRs)] of offenders."""
+    import re
+    bad, name = [], None
+    for line in stderr.splitlines():
+        m = re.search(r'remark: Function Name: (\S+)', line)
+        if m:
+            name = m.group(1)
+            continue
+        m = re.search(r'remark:\s+ScratchSize \[bytes/lane\]: (\d+)', line)
+        if m and name and int(m.group(1)) > 0:
+            short = next((k for k in SCRATCH_ALLOWED if k in name), None)
+            if short is None or int(m.group(1)) > SCRATCH_ALLOWED[short]:
+                bad.append((name, int(m.group(1))))
+    return bad
 
 
 def _stale(out, deps):
@@ -38,8 +59,16 @@ def build(force=False, verbose=True):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f'hipcc failed:\n{r.stdout}\n{r.stderr}')
-        if verbose and r.stderr.strip():
-            print(r.stderr)
+        bad = _check_resources(cmd[-3], r.stderr)
+        if bad:
+            if os.path.exists(cmd[-1]) and cmd[-2] == '-o':
+                os.remove(cmd[-1])
+            raise RuntimeError('kernels use scratch memory (see muvo_amd/build.py SCRATCH_ALLOWED): ' +
+                               ', '.join(f'{n}: {b} B/lane' for n, b in bad))
+        rest = '\n'.join(l for l in r.stderr.splitlines() if 'kernel-resource-usage' not in l and not l.lstrip().startswith(('|', '^')) and
+                         not (l.strip()[:1].isdigit() and ' | ' in l))
+        if verbose and rest.strip():
+            print(rest)
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     if jobs or force or not os.path.exists(LIB):

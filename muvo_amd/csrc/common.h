@@ -55,6 +55,42 @@ __device__ __forceinline__ float act_apply(float v, int act, float slope) {
     default: return v;
   }
 }
+// Compile-time form + dispatcher.  A kernel epilogue with dozens of unrolled stores must not carry the runtime switch per
+// element: every copy inlines the expm1f / tanhf / expf bodies, the 64-store epilogue of the convolution tiles became ~150 KB
+// of mostly skipped code and ran instruction-fetch bound (19 us of a 65-us tile, tools/bf3_stamps.py).  act_dispatch runs the
+// caller's whole loop once, instantiated for the (uniform) activation.
+template <int ACT>
+__device__ __forceinline__ float act_apply_c(float v, float slope) {
+  if constexpr (ACT == MUVO_ACT_RELU) return v > 0.f ? v : 0.f;
+  else if constexpr (ACT == MUVO_ACT_LEAKY) return v > 0.f ? v : v * slope;
+  else if constexpr (ACT == MUVO_ACT_ELU) return v > 0.f ? v : expm1f(v);
+  else if constexpr (ACT == MUVO_ACT_TANH) return tanhf(v);
+  else if constexpr (ACT == MUVO_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+  else return v;
+}
+template <int ACT> struct ActTag { static constexpr int value = ACT; };
+template <class F>
+__device__ __forceinline__ void act_dispatch(int act, F&& f) {
+  switch (act) {
+    case MUVO_ACT_RELU: f(ActTag<MUVO_ACT_RELU>{}); break;
+    case MUVO_ACT_LEAKY: f(ActTag<MUVO_ACT_LEAKY>{}); break;
+    case MUVO_ACT_ELU: f(ActTag<MUVO_ACT_ELU>{}); break;
+    case MUVO_ACT_TANH: f(ActTag<MUVO_ACT_TANH>{}); break;
+    case MUVO_ACT_SIGMOID: f(ActTag<MUVO_ACT_SIGMOID>{}); break;
+    default: f(ActTag<MUVO_ACT_NONE>{}); break;
+  }
+}
+// the same for epilogues written as function templates (a lambda that captures a kernel's by-value argument struct by
+// reference makes the compiler copy the struct to scratch memory): F is a function-like macro taking the activation constant
+#define MUVO_ACT_SWITCH(act, F)                      \
+  switch (act) {                                     \
+    case MUVO_ACT_RELU: F(MUVO_ACT_RELU); break;     \
+    case MUVO_ACT_LEAKY: F(MUVO_ACT_LEAKY); break;   \
+    case MUVO_ACT_ELU: F(MUVO_ACT_ELU); break;       \
+    case MUVO_ACT_TANH: F(MUVO_ACT_TANH); break;     \
+    case MUVO_ACT_SIGMOID: F(MUVO_ACT_SIGMOID); break; \
+    default: F(MUVO_ACT_NONE); break;                \
+  }
 // derivative expressed through the OUTPUT y = act(x)
 __device__ __forceinline__ float act_grad_from_out(float y, int act, float slope) {
   switch (act) {

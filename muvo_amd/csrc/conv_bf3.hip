@@ -21,6 +21,30 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// K-loop clock probe of the eight-wave forward / data-gradient kernel (written by workgroup 0 of every launch)
+__device__ unsigned long long g_bf3_clock[3];
+extern "C" int muvo_bf3_loop_clock(double* shader_mhz, double* us_per_k_step) {
+  unsigned long long h[3] = {0, 0, 0};
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_bf3_clock), sizeof(h)) != hipSuccess) return MUVO_ERR_HIP;
+  if (h[1] == 0 || h[2] == 0) { *shader_mhz = 0.0; *us_per_k_step = 0.0; return MUVO_OK; }
+  *shader_mhz = (double)h[0] / ((double)h[1] / 100.0);
+  *us_per_k_step = (double)h[1] / 100.0 / (double)h[2];
+  return MUVO_OK;
+}
+
+#ifdef MUVO_BF3_STAMPS
+// diagnostic build (tools/ab_build.sh "-DMUVO_BF3_STAMPS"): wave 0 of every workgroup of conv_bf3_kernel records where it
+// ran and when it passed setup / prologue / K loop / epilogue (100 MHz wall clock), read back by tools/bf3_stamps.py
+__device__ unsigned long long g_bf3_stamps[8 * 16384];
+#define BF3_STAMP(slot)                                                                      \
+  if (threadIdx.x == 0 && blockIdx.x < 16384) g_bf3_stamps[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime()
+extern "C" int muvo_debug_bf3_stamps(unsigned long long* host_out, int n_u64) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_bf3_stamps), sizeof(unsigned long long) * n_u64) == hipSuccess ? 0 : 1;
+}
+#else
+#define BF3_STAMP(slot)
+#endif
+
 // two floats -> packed bf16 hi pair and bf16 lo pair (RNE both)
 __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) {
   const bf16x2 h = __builtin_convertvector((f32x2){x0, x1}, bf16x2);
@@ -75,6 +99,11 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
+  BF3_STAMP(0);
+#ifdef MUVO_BF3_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < 16384)
+    g_bf3_stamps[blockIdx.x * 8 + 5] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492);
+#endif
 
   // 1-D grid, pixel tiles fastest, XCD-swizzled: one XCD works through consecutive pixel tiles of one m-tile
   const int gx = (g.npix + BN - 1) / BN;
@@ -119,6 +148,7 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
   // The per-tap input offset comes from a small LDS table so that the loop holds no scalar memory loads (their
   // out-of-order return would force full lgkmcnt(0) waits in front of the fragment reads).
   int* taptab = (int*)(smem + NST * STAGE);
+  float* sbias = (float*)(taptab + 64) + wave * (32 * TM);     // this wave's bias rows (epilogue, conv_plan.h)
   for (int tt = tid; tt < g.T; tt += 64 * NW) {
     const int d = g.tap_d[tt];
     taptab[tt] = (((((d >> 16) & 255) - 128) * g.IH + ((d >> 8) & 255) - 128) * g.IW + (d & 255) - 128) * cp8;
@@ -245,6 +275,7 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
   using par0 = std::integral_constant<int, 0>;
   using par1 = std::integral_constant<int, 1>;
   __syncthreads();                       // tap table
+  BF3_STAMP(1);
   bstate(0);
 #pragma unroll
   for (int q = 0; q < DMA_PER_STEP; ++q) gload_piece(par0{}, 0, q);
@@ -260,6 +291,10 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
   for (int q = 0; q < DMA_PER_STEP; ++q) gload_piece(par0{}, 2, q);
   bstate(3);
   __syncthreads();
+  BF3_STAMP(2);
+  // clock probe: workgroup 0 reports shader-clock ticks and 100-MHz wall-clock ticks of its K loop (muvo_bf3_loop_clock);
+  // the eight-wave kernels run power-limited far below the 2.4 GHz the MFMA peak is quoted at
+  const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
   if constexpr (NST == 3) {
     // Ping-pong schedule: the waves of a workgroup form two groups (one wave per SIMD each) that run half a step out
     // of phase.  While one group issues nothing but its 24 MFMAs of a step, the other does all memory work of its next
@@ -361,256 +396,23 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
     }
   }
 
-  // epilogue: bias + activation, coalesced along pixels (MFMA column = lane & 31); merged phases: row group -> residue
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int pj = bx * BN + wn * (TN * 32) + j * 32 + (lane & 31);
-    if (pj >= g.npix) continue;
-    int nn, jz, jy, jx;
-    decode_pix(g, pj, nn, jz, jy, jx);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int mb = m_tile + wm * (TM * 32) + i * 32;
-      const int grp = g.nmerge > 1 ? mb / g.Msub : 0;
-      const int mo = mb - grp * g.Msub;
-      const size_t obase = (size_t)nn * g.out_sN +
-                           ((size_t)(jz * g.os[0] + g.mop[grp][0]) * g.OH + (jy * g.os[1] + g.mop[grp][1])) * g.OW +
-                           (jx * g.os[2] + g.mop[grp][2]);
-      if (g.out_sC == 1) {   // (uniform) token-major output of a Linear layer, M % 4 == 0: four consecutive rows per store
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int m = mo + 8 * q + 4 * (lane >> 5);
-          if (m < g.M) {
-            float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-            if (bias) { v.x += bias[m]; v.y += bias[m + 1]; v.z += bias[m + 2]; v.w += bias[m + 3]; }
-            v.x = act_apply(v.x, act, slope); v.y = act_apply(v.y, act, slope);
-            v.z = act_apply(v.z, act, slope); v.w = act_apply(v.w, act, slope);
-            *reinterpret_cast<float4*>(out + obase + m) = v;
-          }
-        }
-        continue;
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int m = mo + rr;
-        if (mb + rr < g.M && m < g.Msub) {
-          float v = acc[i][j][r];
-          if (bias) v += bias[m];
-          out[obase + (size_t)m * g.out_sC] = act_apply(v, act, slope);
-        }
-      }
-    }
+  // epilogue, instantiated per activation (conv_plan.h)
+  BF3_STAMP(3);
+  if (NST == 3 && blockIdx.x == 0 && threadIdx.x == 0) {
+    g_bf3_clock[0] = __builtin_amdgcn_s_memtime() - clk0;
+    g_bf3_clock[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+    g_bf3_clock[2] = (unsigned long long)nk;
   }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Wide variant of conv_bf3_kernel for phases with many rows and pixels: 256 x 256 tile, eight waves of 128 x 64
-// (TM x TN = 4 x 2 MFMA tiles), K step = 16 (one MFMA k-slice), same ping-pong schedule with three 32-KB stages.
-// Per MFMA it moves 0.55x the LDS bytes of the 64 x 64 wave tile (12 fragment reads feed 24 MFMAs; 32 KB of stage
-// writes per 16 k of a 256 x 256 tile), which is what bounds the narrow kernel.
-// A stage: A [plane][chunk (2)][BM rows], B [plane][BN pixels][2 chunks ^ ((pixel >> 3) & 1)].
-// B loads: lane = 2 * pixel + chunk (32 contiguous bytes per pixel and plane), wave w stages pixels [32 w, +32) of both
-// planes; A loads: 1 KB of consecutive rows per instruction, wave w stages (plane, chunk, 64-row group) = 2w, 2w + 1.
-// ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN>
-__global__ void __launch_bounds__(64 * WM * WN)
-conv_bf3_k16_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, const uint4* __restrict__ wp,
-                    const float* __restrict__ bias, float* __restrict__ out, int act, float slope) {
-  constexpr int NW = WM * WN, TM = BM / (WM * 32), TN = BN / (WN * 32);
-  static_assert(NW == 8 && BN == 32 * NW, "two groups of four waves; one 32-pixel B group per wave");
-  constexpr int STAGE = 4 * (BM + BN);            // uint4 per stage
-  constexpr int RG = BM / 64;
-  constexpr int APW = 4 * RG / NW, BPW = 2, DPS = APW + BPW;
-  static_assert(APW * NW == 4 * RG, "A load roles must tile");
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  extern __shared__ uint4 smem[];                 // 3 stages + tap table
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  const int gx = (g.npix + BN - 1) / BN;
-  const int wg = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int bx = wg % gx, by = wg / gx;
-  const int m_tile = by * BM;
-  const uint4* wpb = wp + g.wp_off / 4 + m_tile;
-  const int nk = g.Kp >> 4;                       // K steps of 16
-  const int cp8 = g.Cp >> 3;
-
-  // this lane's pixel (B loads) and its tap validity mask
-  const int pl = wave * 32 + (lane >> 1);
-  int pixoff;
-  unsigned long long vmask = 0ull;
-  {
-    const int p = bx * BN + pl;
-    const bool pvalid = p < g.npix;
-    int n, iz, iy, ix;
-    decode_pix(g, pvalid ? p : 0, n, iz, iy, ix);
-    const int z0 = iz * g.is[0] + g.ib[0], y0 = iy * g.is[1] + g.ib[1], x0 = ix * g.is[2] + g.ib[2];
-    pixoff = (((n * g.ID + z0) * g.IH + y0) * g.IW + x0) * cp8;
-    for (int tt = 0; tt < g.T; ++tt) {
-      const int d = g.tap_d[tt];
-      const int z = z0 + ((d >> 16) & 255) - 128, y = y0 + ((d >> 8) & 255) - 128, x = x0 + (d & 255) - 128;
-      const bool ok = pvalid && (unsigned)z < (unsigned)g.ID && (unsigned)y < (unsigned)g.IH && (unsigned)x < (unsigned)g.IW;
-      vmask |= (unsigned long long)ok << tt;
-    }
-  }
-  int* taptab = (int*)(smem + 3 * STAGE);
-  for (int tt = tid; tt < g.T; tt += 64 * NW) {
-    const int d = g.tap_d[tt];
-    taptab[tt] = (((((d >> 16) & 255) - 128) * g.IH + ((d >> 8) & 255) - 128) * g.IW + (d & 255) - 128) * cp8;
-  }
-  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)wpb, 0, (int)(((long)(g.Kp >> 5) * 8 * g.Mp - m_tile) * 16), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)xs, 0, (int)(2 * plane_u4 * 16), 0x00020000);
-  constexpr int OOB = 0x7ffffff0;
-
-  // B source state of the next step to load (calls are sequential in the step index)
-  int b_uoff = 0; unsigned long long b_bit = 0ull; bool b_tval = false;
-  const bool tap_inner = bf3_tap_inner(g);
-  int ti_t = 0, ti_half = 0, ti_grp = 0;
-  auto bstate = [&](int s) {
-    if (tap_inner) {      // K order (32-channel group, tap, half of the group): chunk = group * 4 + half * 2 + (lane & 1)
-      const int c8 = ti_grp * 4 + ti_half * 2 + (lane & 1);
-      b_uoff = taptab[ti_t] + c8;
-      b_bit = 1ull << ti_t;
-      b_tval = c8 < cp8;
-      if (++ti_half == 2) { ti_half = 0; if (++ti_t == g.T) { ti_t = 0; ++ti_grp; } }
-      return;
-    }
-    const int k0 = s * 16 + (lane & 1) * 8;
-    const int t = (int)(((unsigned long long)(unsigned)k0 * g.cp_magic) >> 32);
-    const int c8 = (k0 - t * g.Cp) >> 3;
-    const int tc = t < g.T ? t : 0;
-    b_uoff = taptab[tc] + c8;
-    b_bit = 1ull << tc;
-    b_tval = t < g.T;
-  };
-  u32x4 R[DPS];
-  auto gload_piece = [&](int s, int q) {
-    if (q < APW) {
-      const int a = wave * APW + q;               // (plane * 2 + ch) * RG + rg
-      const int pc = a / RG, rg = a % RG, plane = pc >> 1, ch = pc & 1;
-      const int k32 = s >> 1, c4 = (s & 1) * 2 + ch;
-      R[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, lane * 16, ((k32 * 8 + plane * 4 + c4) * g.Mp + rg * 64) * 16, 0));
-    } else {
-      const int plane = q - APW;
-      const bool ok = b_tval && (vmask & b_bit);
-      const int off = ok ? (pixoff + b_uoff + plane * (int)plane_u4) * 16 : OOB;
-      R[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
-    }
-  };
-  auto lstore_piece = [&](int stage, int q) {
-    uint4* S = smem + stage * STAGE;
-    if (q < APW) {
-      const int a = wave * APW + q;
-      const int pc = a / RG, rg = a % RG;
-      *(u32x4*)(S + pc * BM + rg * 64 + lane) = R[q];
-    } else {
-      *(u32x4*)(S + 4 * BM + (q - APW) * 2 * BN + pl * 2 + ((lane & 1) ^ ((pl >> 3) & 1))) = R[q];
-    }
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
-  const int fragA = (lane >> 5) * BM + wm * (TM * 32) + (lane & 31);
-  const int fragB = 4 * BM + (wn * (TN * 32) + (lane & 31)) * 2 + ((lane >> 5) ^ ((lane >> 3) & 1));
-  auto read_piece = [&](int stage, int w) {       // w: 0 .. 2 TM - 1 = A (i, plane), then B (j, plane)
-    const uint4* S = smem + stage * STAGE;
-    if (w < 2 * TM) {
-      const int i = w >> 1;
-      if (w & 1) al[i] = __builtin_bit_cast(bf16x8, S[fragA + 2 * BM + i * 32]);
-      else ah[i] = __builtin_bit_cast(bf16x8, S[fragA + i * 32]);
-    } else {
-      const int j = (w - 2 * TM) >> 1;
-      if (w & 1) bl[j] = __builtin_bit_cast(bf16x8, S[fragB + 2 * BN + j * 64]);
-      else bh[j] = __builtin_bit_cast(bf16x8, S[fragB + j * 64]);
-    }
-  };
-
-  __syncthreads();                                // tap table
-#pragma unroll
-  for (int pre = 0; pre < 2; ++pre) {
-    bstate(pre);
-#pragma unroll
-    for (int q = 0; q < DPS; ++q) gload_piece(pre, q);
-#pragma unroll
-    for (int q = 0; q < DPS; ++q) lstore_piece(pre, q);
-  }
-  bstate(2);
-#pragma unroll
-  for (int q = 0; q < DPS; ++q) gload_piece(2, q);
-  bstate(3);
-  __syncthreads();
-  const int grp = wave / (NW / 2);
-  if (grp == 1) __builtin_amdgcn_s_barrier();
-  int stage = 0;
-  for (int s = 0; s < nk; ++s) {
-    const int wstage = stage == 0 ? 2 : stage - 1;
-#pragma unroll
-    for (int q = 0; q < DPS; ++q) lstore_piece(wstage, q);          // step s + 2
-    __builtin_amdgcn_sched_barrier(0);
-    constexpr int NRD = 2 * (TM + TN);
-    constexpr int RPL = (NRD + DPS - 1) / DPS;
-#pragma unroll
-    for (int q = 0; q < DPS; ++q) {
-      gload_piece(s + 3, q);
-#pragma unroll
-      for (int u = 0; u < RPL; ++u)
-        if (q * RPL + u < NRD) read_piece(stage, q * RPL + u);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    bstate(s + 4);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-      }
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    stage = stage == 2 ? 0 : stage + 1;
-  }
-  if (grp == 0) __builtin_amdgcn_s_barrier();
-
-  // epilogue: bias + activation, coalesced along pixels (MFMA column = lane & 31); merged phases: row group -> residue
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int pj = bx * BN + wn * (TN * 32) + j * 32 + (lane & 31);
-    if (pj >= g.npix) continue;
-    int nn, jz, jy, jx;
-    decode_pix(g, pj, nn, jz, jy, jx);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int mb = m_tile + wm * (TM * 32) + i * 32;
-      const int grpm = g.nmerge > 1 ? mb / g.Msub : 0;
-      const int mo = mb - grpm * g.Msub;
-      const size_t obase = (size_t)nn * g.out_sN +
-                           ((size_t)(jz * g.os[0] + g.mop[grpm][0]) * g.OH + (jy * g.os[1] + g.mop[grpm][1])) * g.OW +
-                           (jx * g.os[2] + g.mop[grpm][2]);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int m = mo + rr;
-        if (mb + rr < g.M && m < g.Msub) {
-          float v = acc[i][j][r];
-          if (bias) v += bias[m];
-          out[obase + (size_t)m * g.out_sC] = act_apply(v, act, slope);
-        }
-      }
-    }
-  }
+#ifdef MUVO_BF3_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < 16384) g_bf3_stamps[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime() - clk0;
+#endif
+#define BF3_STORE(ACT) conv_tile_store<ACT, true>(g, acc, bias, out, slope, 1, bx * BN, m_tile, wm, wn, lane, sbias)
+  MUVO_ACT_SWITCH(act, BF3_STORE)
+  BF3_STAMP(4);
+#if defined(MUVO_BF3_STAMPS) && MUVO_BF3_STAMPS == 2
+  __builtin_amdgcn_s_waitcnt(0);         // all stores of this wave acknowledged
+  BF3_STAMP(6);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1371,7 +1173,7 @@ int bf3_split_rows(const float* x, void* ws, long rows, int C, hipStream_t st) {
 template <int BM, int BN, int WM, int WN, int BKC, int NST>
 static int bf3_launch(const ConvPhase& g, const void* ws, const float* wp, const float* bias, float* out, int act,
                       float slope, hipStream_t st) {
-  constexpr size_t lds = (size_t)NST * 2 * BKC * (BM + BN) * 16 + 256;   // stages + tap table
+  constexpr size_t lds = (size_t)NST * 2 * BKC * (BM + BN) * 16 + 256 + 4 * BM * WN;   // stages + tap table + bias rows per wave
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   static const uint4* zero16 = nullptr;
@@ -1389,27 +1191,6 @@ static int bf3_launch(const ConvPhase& g, const void* ws, const float* wp, const
   hipLaunchKernelGGL((conv_bf3_kernel<BM, BN, WM, WN, BKC, NST>), grid, dim3(64 * WM * WN), lds, st, g, (const uint4*)ws, plane_u4,
                      (const uint4*)wp, bias, out, act, slope, zero16);
   MUVO_CHECK_LAUNCH("conv_bf3_kernel");
-  return MUVO_OK;
-}
-
-template <int BM, int BN, int WM, int WN>
-static int bf3_launch_k16(const ConvPhase& g, const void* ws, const float* wp, const float* bias, float* out, int act,
-                          float slope, hipStream_t st) {
-  constexpr size_t lds = (size_t)3 * 4 * (BM + BN) * 16 + 256;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv_bf3_k16_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess) {
-      muvo_set_error("conv_bf3_k16: kernel attribute setup failed");
-      return MUVO_ERR_HIP;
-    }
-    attr_set = true;
-  }
-  const long plane_u4 = (long)g.N * g.ID * g.IH * g.IW * (g.Cp / 8);
-  dim3 grid(cdiv(g.npix, BN) * cdiv(g.M, BM), 1, 1);
-  hipLaunchKernelGGL((conv_bf3_k16_kernel<BM, BN, WM, WN>), grid, dim3(64 * WM * WN), lds, st, g, (const uint4*)ws, plane_u4,
-                     (const uint4*)wp, bias, out, act, slope);
-  MUVO_CHECK_LAUNCH("conv_bf3_k16_kernel");
   return MUVO_OK;
 }
 
@@ -1432,7 +1213,6 @@ int bf3_launch_fwd_phase(const ConvPhase& g, const void* ws, const float* wp, co
     if (g.M > 128) return bf3_launch<256, 128, 4, 2, 4, 2>(g, ws, wp, bias, out, act, slope, st);
     if (g.M > 64) return bf3_launch<128, 256, 2, 4, 4, 2>(g, ws, wp, bias, out, act, slope, st);
   }
-  if (variant == 16 && g.M > 128 && g.npix >= 256 * 256) return bf3_launch_k16<256, 256, 2, 4>(g, ws, wp, bias, out, act, slope, st);
   // Launches whose eight-wave tiles (one 147 KB workgroup per CU) would cover less than half of the 256 CUs, and all
   // 64-row launches, use the four-wave 64x128 tile: 49 KB of LDS, three workgroups per CU.  Measured per layer
   // (profiles/r01q_tile_choice.txt): 64x128 beats 64x256 (one workgroup per CU) by 1.4-1.6x on every 64-row layer and

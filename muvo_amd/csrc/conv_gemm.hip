@@ -40,6 +40,7 @@ conv_fwd_kernel(const ConvPhase g, const float* __restrict__ in, const float* __
 
   __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA + LDB)];
   __shared__ int s_tap[MAX_TAPS];
+  __shared__ float s_bias[4][32 * TM];          // per wave: bias of its rows, staged by the epilogue (conv_plan.h)
   float* As0 = smem;
   float* Bs0 = smem + 2 * BK * LDA;
 
@@ -149,37 +150,10 @@ conv_fwd_kernel(const ConvPhase g, const float* __restrict__ in, const float* __
   }
   if (ksplit > 1 && kt0 >= nk) return;
 
-  // ---- epilogue: bias + activation, coalesced along pixels (MFMA column = lane&31)
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int pj = blockIdx.x * BN + wn * (TN * 32) + j * 32 + (lane & 31);
-    if (pj >= g.npix) continue;
-    int nn, jz, jy, jx;
-    decode_pix(g, pj, nn, jz, jy, jx);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int mb = m_tile + wm * (TM * 32) + i * 32;   // 32-row tile: inside one merged group (Msub % 32 == 0)
-      const int grp = g.nmerge > 1 ? mb / g.Msub : 0;
-      const int mo = mb - grp * g.Msub;
-      const size_t obase = (size_t)nn * g.out_sN +
-                           ((size_t)(jz * g.os[0] + g.mop[grp][0]) * g.OH + (jy * g.os[1] + g.mop[grp][1])) * g.OW +
-                           (jx * g.os[2] + g.mop[grp][2]);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int m = mo + rr;
-        if (mb + rr < g.M && m < g.Msub) {
-          float v = acc[i][j][r];
-          if (ksplit > 1) {
-            atomicAdd(out + obase + (size_t)m * g.out_sC, v);
-          } else {
-            if (bias) v += bias[m];
-            out[obase + (size_t)m * g.out_sC] = act_apply(v, act, slope);
-          }
-        }
-      }
-    }
-  }
+  // ---- epilogue, instantiated per activation (see act_dispatch in common.h)
+#define CONV_FWD_STORE(ACT) conv_tile_store<ACT, false>(g, acc, bias, out, slope, ksplit, blockIdx.x * BN, m_tile, wm, wn, lane, s_bias[wave])
+  MUVO_ACT_SWITCH(ksplit > 1 ? MUVO_ACT_NONE : act, CONV_FWD_STORE)
+#undef CONV_FWD_STORE
 }
 
 // y[n][m][s] = act(y + bias[m]) in place (finishing pass of split-K launches)

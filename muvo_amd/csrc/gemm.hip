@@ -31,7 +31,7 @@ struct TileLoader {
   static constexpr int BK = 16;
   static constexpr int EPT = BMN * BK / 256;  // elements per thread
   // returns registers
-  __device__ static void load(const float* __restrict__ base, long s_mn, long s_k, int mn0, int mn_lim, int k0,
+  __device__ static __forceinline__ void load(const float* __restrict__ base, long s_mn, long s_k, int mn0, int mn_lim, int k0,
                               int k_lim, int tid, float (&reg)[EPT]) {
     if (LAY == 0) {
       constexpr int KG = 256 / BMN, KPT = BK / KG;
@@ -57,7 +57,7 @@ struct TileLoader {
       }
     }
   }
-  __device__ static void store(float* __restrict__ tile, int ld, int tid, const float (&reg)[EPT]) {
+  __device__ static __forceinline__ void store(float* __restrict__ tile, int ld, int tid, const float (&reg)[EPT]) {
     if (LAY == 0) {
       constexpr int KG = 256 / BMN, KPT = BK / KG;
       const int ml = tid % BMN, kg = tid / BMN;
@@ -70,6 +70,31 @@ struct TileLoader {
     }
   }
 };
+
+// epilogue of gemm_kernel for one (compile-time) activation
+template <int ACT, int TM, int TN, class V>
+__device__ __forceinline__ void gemm_store(const V (&acc)[TM][TN], float* __restrict__ Cb, int m0, int n0, int wm, int wn, int lane,
+                                           int gM, int gN, long scm, float alpha, float slope, int mode,
+                                           const float* __restrict__ gbias, int bias_div) {
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * (TN * 32) + j * 32 + (lane & 31);
+    if (n >= gN) continue;
+    const float bv = gbias ? gbias[n / bias_div] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < gM) {
+          float* dst = Cb + (long)m * scm + n;
+          const float v = alpha * acc[i][j][r];
+          if (mode == 1) atomicAdd(dst, v);
+          else *dst = act_apply_c<ACT>(v + bv, slope);
+        }
+      }
+  }
+}
 
 template <int BM, int BN, int WM, int WN, int ALAY, int BLAY>
 __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g, const float* __restrict__ A,
@@ -144,24 +169,9 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g, const float
   }
   if (kt0 >= kt1 && g.mode == 1) return;
 
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * (TN * 32) + j * 32 + (lane & 31);
-    if (n >= g.N) continue;
-    const float bv = g.bias ? g.bias[n / g.bias_div] : 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m < g.M) {
-          float* dst = Cb + (long)m * g.scm + n;
-          const float v = g.alpha * acc[i][j][r];
-          if (g.mode == 1) atomicAdd(dst, v);
-          else *dst = act_apply(v + bv, g.act, g.slope);
-        }
-      }
-  }
+#define GEMM_STORE(ACT) gemm_store<ACT, TM, TN>(acc, Cb, m0, n0, wm, wn, lane, g.M, g.N, g.scm, g.alpha, g.slope, g.mode, g.bias, g.bias_div)
+  MUVO_ACT_SWITCH(g.mode == 1 ? MUVO_ACT_NONE : g.act, GEMM_STORE)
+#undef GEMM_STORE
 }
 
 // ------------------------------------------------------------------------------------------------

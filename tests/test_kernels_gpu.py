@@ -74,11 +74,37 @@ def conv_mode(request):
 
 @pytest.mark.parametrize('case', CONV_CASES, ids=[str(i) for i in range(len(CONV_CASES))])
 def test_conv_family(dev, case, conv_mode):
+    _check_conv(dev, case, 3)
+
+
+# Shapes with more eight-wave tiles than CUs (several rounds of 147-KB workgroups per CU).  256x128 tiles (M > 128), 128x256 tiles
+# (64 < M <= 128), merged ConvTranspose phases (M = 4 Cout), a channel count that is no multiple of 32 (taps outermost in K),
+# ragged last tiles.  (Smooth activations only: with ~10^7 outputs some pre-activations land within the bf16x3 error of the
+# kink of ReLU / LeakyReLU, and the derivative mask of those elements then differs from the CPU reference's.)
+MANY_TILE_CASES = [
+    (2, False, 64, 160, 3, 1, 1, 0, (160, 168), True, 3),     # 630 tiles of 256x128, K = 576
+    (2, False, 48, 96, 3, 1, 1, 0, (150, 181), True, 0),      # 319 tiles of 128x256, Cp = 48
+    (2, True, 64, 64, 6, 2, 2, 0, (120, 97), True, 3),        # merged phases: M = 256, 273 tiles; dgrad: stride-2 conv
+    (2, False, 160, 64, 3, 1, 1, 0, (100, 131), False, 0),    # dgrad runs the 256x128 tiles (M = 160)
+]
+
+
+@pytest.mark.parametrize('case', MANY_TILE_CASES, ids=[str(i) for i in range(len(MANY_TILE_CASES))])
+def test_conv_many_eight_wave_tiles(dev, case):
+    from muvo_amd import ops
+    old = ops.get_conv_mode()
+    ops.set_conv_mode(ops.CONV_BF16X3, min_gflop=0.0)
+    try:
+        _check_conv(dev, case, 3)
+    finally:
+        ops.set_conv_mode(old, min_gflop=-1.0)
+
+
+def _check_conv(dev, case, n):
     from muvo_amd import nn as hnn
     from muvo_amd import ops
     nd, transposed, cin, cout, k, stride, pad, out_pad, in_sz, bias, act = case
     torch.manual_seed(0)
-    n = 3
     with torch.device(dev):
         if nd == 3:
             m = hnn.Conv3d(cin, cout, k, stride, pad, bias=bias)
