@@ -362,6 +362,23 @@ typedef __bf16 vbf16x8 __attribute__((ext_vector_type(8)));
 typedef float vf32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned vu32x4 __attribute__((ext_vector_type(4)));
 
+// none / ReLU / LeakyReLU without a branch (the per-element switch of act_apply, with the expm1f / tanhf / expf bodies inlined
+// at each of the 16 stores of a plane, made the hot loop tens of KB of code)
+__device__ __forceinline__ float vox_act_simple(float v, int act, float slope) {
+  const float neg = act == MUVO_ACT_RELU ? 0.f : v * slope;
+  return (act == MUVO_ACT_NONE || v > 0.f) ? v : neg;
+}
+
+// As many out-of-range (discarded) buffer stores as one plane step issues, placed after the staged loads of the prologue.
+// The wait in front of the first LDS write of a plane step needs the loads issued one step earlier; the compiler derives its
+// vmcnt from the path with the FEWEST younger operations, and on loop entry that would be zero — the steady-state wait then
+// included the acknowledgement of all 16 stores of the previous plane (one HBM write round trip per plane).
+template <int N>
+__device__ __forceinline__ void vox_dummy_stores(__amdgpu_buffer_rsrc_t rs) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) __builtin_amdgcn_raw_buffer_store_b32(0u, rs, 0x7fffff00u + 32u * k, 0, 0);   // distinct and not contiguous: neither merged nor vectorised
+}
+
 __device__ __forceinline__ void vox_split2(float a, float b, unsigned& hi, unsigned& lo) {
   // two fp32 -> packed bf16 pairs: hi = RNE(x), lo = RNE(x - hi)
   auto rne = [](float x) -> unsigned {
@@ -375,7 +392,9 @@ __device__ __forceinline__ void vox_split2(float a, float b, unsigned& hi, unsig
   lo = rne(ra) | (rne(rb) << 16);
 }
 
-template <int CK, int Z, int TY>
+// GENERIC: the variant with the accumulating second pass of a 32-channel reduction and / or an activation beyond
+// none / ReLU / LeakyReLU; the plain variant keeps the plane loop free of conditional memory operations (see "Output side").
+template <int CK, int Z, int TY, bool GENERIC>
 __global__ void __launch_bounds__(64 * TY)
 vox_bf3_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* __restrict__ wp, const float* __restrict__ bias,
                float* __restrict__ out, int act, float slope, int xseg, int accum) {
@@ -443,6 +462,17 @@ vox_bf3_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* __re
   // this lane's B-fragment geometry per k-step: tap -> (dx, dy, dz), channel group
   const int v = lane & 15, g = lane >> 4;
   float msum[4] = {0.f, 0.f, 0.f, 0.f}, msq[4] = {0.f, 0.f, 0.f, 0.f};
+  // Output side.  (1) The bias of this lane's four channels is loaded once, here: a bias load inside the plane loop waits —
+  // vmcnt counts loads and stores in issue order — for the acknowledgement of every store issued before it.  (2) Results
+  // leave through UNCONDITIONAL buffer stores whose offset is pushed out of range for rows / channels that do not exist:
+  // behind `if (gy < Y)` the number of stores in flight is unknown to the compiler, and the wait for the staged loads of
+  // the next plane (issued before them) became vmcnt(0), i.e. one HBM write round trip per plane.
+  float bv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bv[i] = (bias != nullptr && co0 + 4 * g + i < a.Cout) ? bias[co0 + 4 * g + i] : 0.f;
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (long)n * a.sN_out), 0,
+                                                                          (int)((long)a.Cout * a.XYZ * 4), 0x00020000);
+
   int fdx[NSTEP], foff[NSTEP];       // dx in {-1, 0, 1}; uint4 offset inside a plane (hi part) for tile 0
 #pragma unroll
   for (int s = 0; s < NSTEP; ++s) {
@@ -457,6 +487,7 @@ vox_bf3_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* __re
   stage_load(xs - 1); stage_store((xs - 1 + 3) % 3);
   stage_load(xs); stage_store(xs % 3);
   stage_load(xs + 1);
+  vox_dummy_stores<4 * ZT>(rs_out);
   __syncthreads();
   for (int x = xs; x < xe; ++x) {
     // plane x+1 (loaded during the previous step) -> LDS; its slot was last read while computing plane x-2
@@ -479,21 +510,23 @@ vox_bf3_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* __re
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], bl, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], bh, acc, 0, 0, 0);
       }
-      if (gy < a.Y) {
-        float* ob = out + (long)n * a.sN_out + (long)x * YZ + (long)gy * Z + zt * 16 + v;
+      const unsigned ooff = (unsigned)(((long)x * YZ + (long)gy * Z + zt * 16 + v) * 4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int co = co0 + 4 * g + i;
-          if (co < a.Cout) {
-            float r = acc[i];
-            if (accum) r += ob[(long)co * a.XYZ];      // second half of a 32-channel reduction: add the first pass
-            if (bias) r += bias[co];
-            r = act_apply(r, act, slope);
-            ob[(long)co * a.XYZ] = r;
-            msum[i] += r;
-            msq[i] += r * r;
-          }
+      for (int i = 0; i < 4; ++i) {
+        const int co = co0 + 4 * g + i;
+        const bool ok = gy < a.Y && co < a.Cout;
+        const unsigned off = ok ? ooff + (unsigned)co * xyz4 : 0x7fffff00u;
+        float r = acc[i] + bv[i];
+        if constexpr (GENERIC) {
+          if (accum) r += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_out, off, 0, 0));   // second half of a 32-channel reduction
+          r = act_apply(r, act, slope);
+        } else {
+          r = vox_act_simple(r, act, slope);
         }
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), rs_out, off, 0, 0);
+        r = ok ? r : 0.f;
+        msum[i] += r;
+        msq[i] += r * r;
       }
     }
     __syncthreads();     // everybody is done with plane x-1's slot before the next step overwrites it
@@ -738,7 +771,7 @@ vox_bf3_wgrad_kernel(const VoxArgs a, const float* __restrict__ x, const float* 
 // reads per 2 x 16 voxels instead of 42 and 28.  Workgroup = 8 waves x 2 rows = 16 output rows.
 // Packed weights (vox_bf3_pack2_kernel): step s, lane (m = lane & 15, g = lane >> 4): super tap 4 s + g.
 // ------------------------------------------------------------------------------------------------
-template <int Z, int CK>
+template <int Z, int CK, bool GENERIC>
 __global__ void __launch_bounds__(CK == 16 ? 256 : 512)
 vox_bf3_2row_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* __restrict__ wp, const float* __restrict__ bias,
                     float* __restrict__ out, int act, float slope, int xseg) {
@@ -798,6 +831,12 @@ vox_bf3_2row_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4*
   };
   const int v = lane & 15, g = lane >> 4;
   float msum[4] = {0.f, 0.f, 0.f, 0.f}, msq[4] = {0.f, 0.f, 0.f, 0.f};
+  // output side as in vox_bf3_kernel: bias in registers, unconditional buffer stores (out-of-range offset for missing rows)
+  float bv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bv[i] = bias != nullptr ? bias[4 * (g & 1) + i] : 0.f;
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (long)n * a.sN_out), 0,
+                                                                          (int)(8L * a.XYZ * 4), 0x00020000);
   int fdx[NSTEP], foff[NSTEP];
 #pragma unroll
   for (int s = 0; s < NSTEP; ++s) {
@@ -809,6 +848,7 @@ vox_bf3_2row_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4*
   stage_load(xs - 1); stage_store((xs - 1 + 3) % 3);
   stage_load(xs); stage_store(xs % 3);
   stage_load(xs + 1);
+  vox_dummy_stores<4 * ZT>(rs_out);
   __syncthreads();
   for (int x = xs; x < xe; ++x) {
     stage_store((x + 1) % 3);
@@ -831,17 +871,16 @@ vox_bf3_2row_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4*
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], bl, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], bh, acc, 0, 0, 0);
       }
-      if (gy < a.Y) {
-        float* ob = out + (long)n * a.sN_out + (long)x * YZ + (long)gy * Z + zt * 16 + v;
+      const bool ok = gy < a.Y;
+      const unsigned ooff = (unsigned)(((long)x * YZ + (long)gy * Z + zt * 16 + v) * 4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float r = acc[i];
-          if (bias) r += bias[cb + i];
-          r = act_apply(r, act, slope);
-          ob[(long)(cb + i) * a.XYZ] = r;
-          msum[i] += r;
-          msq[i] += r * r;
-        }
+      for (int i = 0; i < 4; ++i) {
+        float r = acc[i] + bv[i];
+        r = GENERIC ? act_apply(r, act, slope) : vox_act_simple(r, act, slope);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), rs_out, ok ? ooff + (unsigned)(cb + i) * xyz4 : 0x7fffff00u, 0, 0);
+        r = ok ? r : 0.f;
+        msum[i] += r;
+        msq[i] += r * r;
       }
     }
     __syncthreads();
@@ -927,7 +966,8 @@ static bool vox_geometry_ok(const muvo_conv_desc* d) {
   const int Z = d->in_sz[2];
   if (Z != 64 && Z != 32) return false;
   if (d->Cin % 4 || d->Cout % 4) return false;
-  if ((long)d->in_sz[0] * d->in_sz[1] * Z * (long)(d->Cin > d->Cout ? d->Cin : d->Cout) >= (1l << 31)) return false;
+  // one sample's tensor is addressed through a buffer descriptor with 32-bit byte offsets (0x7fffff00 = "out of range")
+  if ((long)d->in_sz[0] * d->in_sz[1] * Z * (long)(d->Cin > d->Cout ? d->Cin : d->Cout) * 4 >= 0x7fffff00l) return false;
   return true;
 }
 bool vox_fwd_applicable(const muvo_conv_desc* d) {
@@ -1018,27 +1058,28 @@ static int launch_vox_bf3_ty(const muvo_conv_desc* d, int Cin, int Cout, const f
   constexpr size_t lds = (size_t)3 * 2 * (CK / 8) * (TY + 2) * (Z + 2) * 16;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)vox_bf3_kernel<CK, Z, TY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)vox_bf3_kernel<CK, Z, TY, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)vox_bf3_kernel<CK, Z, TY, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       muvo_set_error("vox_bf3: cannot raise the dynamic LDS limit to %zu bytes", lds);
       return MUVO_ERR_HIP;
     }
     attr_set = true;
   }
   const long blocks = (long)a.N * a.ytiles * cdiv(a.X, xseg);
-  hipLaunchKernelGGL((vox_bf3_kernel<CK, Z, TY>), dim3((unsigned)blocks, cdiv(Cout, 16)), dim3(64 * TY), lds, st, a, in, (const vu32x4*)wp, bias, out, act,
-                     slope, xseg, accum);
+  const dim3 grid((unsigned)blocks, cdiv(Cout, 16));
+  if (accum || act > MUVO_ACT_LEAKY)
+    hipLaunchKernelGGL((vox_bf3_kernel<CK, Z, TY, true>), grid, dim3(64 * TY), lds, st, a, in, (const vu32x4*)wp, bias, out, act, slope, xseg, accum);
+  else
+    hipLaunchKernelGGL((vox_bf3_kernel<CK, Z, TY, false>), grid, dim3(64 * TY), lds, st, a, in, (const vu32x4*)wp, bias, out, act, slope, xseg, 0);
   MUVO_CHECK_LAUNCH("vox_bf3_kernel");
   return MUVO_OK;
 }
 
-// TY = 4 rows per workgroup halves the LDS ring (76 KB for 16 channels x Z = 64): two workgroups share a CU, so the MFMA phase
-// of one overlaps the staging / LDS phase of the other (MUVO_VOX_TY, default from the r02 A/B: profiles/r02_vox_ty.txt)
 template <int CK, int Z>
 static int launch_vox_bf3(const muvo_conv_desc* d, int Cin, int Cout, const float* in, const float* wp, const float* bias,
                           float* out, int act, float slope, hipStream_t st, int cin_total = 0, int accum = 0,
                           double* moments = nullptr) {
-  static const int ty = getenv("MUVO_VOX_TY") ? atoi(getenv("MUVO_VOX_TY")) : 8;
-  if (ty == 4) return launch_vox_bf3_ty<CK, Z, 4>(d, Cin, Cout, in, wp, bias, out, act, slope, st, cin_total, accum, moments);
+  // (four rows per workgroup — half the LDS ring, two workgroups per CU — measured no better: profiles/r02l_vox_rows_per_workgroup.txt)
   return launch_vox_bf3_ty<CK, Z, 8>(d, Cin, Cout, in, wp, bias, out, act, slope, st, cin_total, accum, moments);
 }
 
@@ -1059,14 +1100,18 @@ static int launch_vox_bf3_2row(const muvo_conv_desc* d, const float* in, const f
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)vox_bf3_2row_kernel<Z, CK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)vox_bf3_2row_kernel<Z, CK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)vox_bf3_2row_kernel<Z, CK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       muvo_set_error("vox_bf3_2row: cannot raise the dynamic LDS limit to %zu bytes", lds);
       return MUVO_ERR_HIP;
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((vox_bf3_2row_kernel<Z, CK>), dim3((unsigned)((long)a.N * a.ytiles * cdiv(a.X, xseg))), dim3(32 * TY), lds, st, a, in,
-                     (const vu32x4*)wp, bias, out, act, slope, xseg);
+  const dim3 grid((unsigned)((long)a.N * a.ytiles * cdiv(a.X, xseg)));
+  if (act > MUVO_ACT_LEAKY)
+    hipLaunchKernelGGL((vox_bf3_2row_kernel<Z, CK, true>), grid, dim3(32 * TY), lds, st, a, in, (const vu32x4*)wp, bias, out, act, slope, xseg);
+  else
+    hipLaunchKernelGGL((vox_bf3_2row_kernel<Z, CK, false>), grid, dim3(32 * TY), lds, st, a, in, (const vu32x4*)wp, bias, out, act, slope, xseg);
   MUVO_CHECK_LAUNCH("vox_bf3_2row_kernel");
   return MUVO_OK;
 }
