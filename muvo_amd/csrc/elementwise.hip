@@ -344,6 +344,55 @@ __global__ void __launch_bounds__(256) upsample3d_x2_fwd_vec8_kernel(const float
   __builtin_nontemporal_store((nt_f4){o[4], o[5], o[6], o[7]}, (nt_f4*)yp + 1);
 }
 
+// A 2 x 2 block of output (depth, row) positions per lane, ONE output float4 per position: lane = (row block ph, output float4
+// f).  Outputs od = 2 pd - 1 and 2 pd read the SAME two input planes (pd - 1, pd, clamped) with weights (0.75, 0.25) and
+// (0.25, 0.75), and likewise for rows: four float4 loads feed four float4 stores, and every store instruction of a wave
+// writes whole 256-byte output rows.  In the eight-outputs kernel above a lane's two float4 leave in two instructions that
+// each cover every other 16 bytes of a row: 3.0 TB/s; this kernel: 5.4 TB/s on the 3-GB top level (a plain fill: 6.9).
+// Output columns 4 f .. 4 f + 3 come from input columns 2 f - 1 .. 2 f + 2: the lane pair (f, f ^ 1) loads the same aligned
+// input float4 f >> 1 and takes the one missing column from its neighbour lane.  Blocks pd = 0 .. D, ph = 0 .. H; the
+// positions that fall outside the output are skipped.
+__global__ void __launch_bounds__(256) upsample3d_x2_fwd_row_kernel(const float* __restrict__ x, float* __restrict__ y, int D,
+                                                                    int H, int W) {
+  const int OH = 2 * H, OW = 2 * W, OQ = W / 2;      // output float4 per row
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const bool live = idx < (H + 1) * OQ;
+  const int ph = live ? idx / OQ : 0, f = live ? idx - ph * OQ : 0;
+  const int pd = blockIdx.y;
+  const long nc = blockIdx.z;
+  const int d0 = pd > 0 ? pd - 1 : 0, d1 = pd < D ? pd : D - 1;
+  const int h0 = ph > 0 ? ph - 1 : 0, h1 = ph < H ? ph : H - 1;
+  const float* xp = x + nc * D * H * W + 4 * (f >> 1);
+  const float4 r00 = *(const float4*)(xp + (d0 * H + h0) * W), r01 = *(const float4*)(xp + (d0 * H + h1) * W);
+  const float4 r10 = *(const float4*)(xp + (d1 * H + h0) * W), r11 = *(const float4*)(xp + (d1 * H + h1) * W);
+  typedef float nt_f4 __attribute__((ext_vector_type(4)));
+  const bool odd = f & 1;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {              // od = 2 pd - 1 + a
+    const float wd0 = a ? 0.25f : 0.75f, wd1 = 1.f - wd0;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {            // oh = 2 ph - 1 + b
+      const float wh0 = b ? 0.25f : 0.75f, wh1 = 1.f - wh0;
+      const float w00 = wd0 * wh0, w01 = wd0 * wh1, w10 = wd1 * wh0, w11 = wd1 * wh1;
+      const float cx = w00 * r00.x + w01 * r01.x + w10 * r10.x + w11 * r11.x;
+      const float cy = w00 * r00.y + w01 * r01.y + w10 * r10.y + w11 * r11.y;
+      const float cz = w00 * r00.z + w01 * r01.z + w10 * r10.z + w11 * r11.z;
+      const float cw = w00 * r00.w + w01 * r01.w + w10 * r10.w + w11 * r11.w;
+      const float lft = __shfl_up(cw, 1), rgt = __shfl_down(cx, 1);     // lane f - 1 holds input float4 (f - 1) >> 1, lane f + 1: (f + 1) >> 1
+      const float q0 = odd ? cy : (f > 0 ? lft : cx);
+      const float q1 = odd ? cz : cx;
+      const float q2 = odd ? cw : cy;
+      const float q3 = odd ? (f < OQ - 1 ? rgt : cw) : cz;
+      const int od = 2 * pd - 1 + a, oh = 2 * ph - 1 + b;
+      if (live && od >= 0 && od < 2 * D && oh >= 0 && oh < OH) {
+        float4* yp = (float4*)(y + ((nc * (2 * D) + od) * OH + oh) * (long)OW) + f;
+        __builtin_nontemporal_store((nt_f4){0.25f * q0 + 0.75f * q1, 0.75f * q1 + 0.25f * q2, 0.25f * q1 + 0.75f * q2, 0.75f * q2 + 0.25f * q3},
+                                    (nt_f4*)yp);
+      }
+    }
+  }
+}
+
 // weights with which input index i (of n) receives output indices 2i-1 .. 2i+2 (out-of-range outputs get 0)
 __device__ __forceinline__ void up2_bwd_weights(int i, int n, float (&w)[4]) {
   w[0] = i > 0 ? 0.25f : 0.f;
@@ -442,6 +491,53 @@ __global__ void __launch_bounds__(1024) upsample3d_x2_bwd_walk_kernel(const floa
     o.z = (wa[0] * pm1.z + wa[1] * p0.z) + (wa[2] * p1.z + wa[3] * p2.z);
     o.w = (wa[0] * pm1.w + wa[1] * p0.w) + (wa[2] * p1.w + wa[3] * p2.w);
     *((float4*)(dx + ((nc * D + d) * H + h) * (long)W) + j) = o;
+    pm1 = p1; p0 = p2;
+  }
+}
+
+// The walking adjoint with one FINE float4 per lane and row: lane = (coarse row h, fine float4 f), so a load instruction of a
+// wave reads whole 256-byte fine rows (above: two float4 with a 32-byte stride plus two scalar neighbours per lane) and the
+// coarse result leaves as a float2 per lane, i.e. whole coarse rows per store instruction.  Fine columns 4 f .. 4 f + 3 feed
+// the coarse columns 2 f and 2 f + 1; the two missing fine neighbours (4 f - 1, 4 f + 4) come from the adjacent lanes.
+// 256 threads = 256 / (W / 2) coarse rows; grid = (row groups, d segments, N * C).
+__global__ void __launch_bounds__(256) upsample3d_x2_bwd_row_kernel(const float* __restrict__ dy, float* __restrict__ dx, int D,
+                                                                    int H, int W, int dseg) {
+  const int OH = 2 * H, OW = 2 * W, OQ = W / 2;
+  const int f = threadIdx.x % OQ;
+  const int hr = blockIdx.x * (256 / OQ) + threadIdx.x / OQ;
+  const bool live = hr < H;
+  const int h = live ? hr : H - 1;
+  const long nc = blockIdx.z;
+  const int d0 = blockIdx.y * dseg, d1 = min(d0 + dseg, D);
+  float wb[4];
+  up2_bwd_weights(h, H, wb);
+  const float w1a = f > 0 ? 0.75f : 1.f, w2b = 2 * f + 1 < W - 1 ? 0.75f : 1.f, w2a = 2 * f < W - 1 ? 0.75f : 1.f;
+  const float* gp = dy + nc * (2L * D) * OH * OW + 4 * f;
+  const long ps = (long)OH * OW;
+  auto contrib = [&](int a) -> float2 {
+    float2 acc = make_float2(0.f, 0.f);
+    if (a < 0 || a >= 2 * D) return acc;       // (uniform)
+    const float* plane = gp + (long)a * ps;
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib) {
+      if (wb[ib] == 0.f) continue;             // the row does not exist (uniform within a row of lanes)
+      const float4 g = *(const float4*)(plane + (long)(2 * h - 1 + ib) * OW);
+      const float lft = __shfl_up(g.w, 1), rgt = __shfl_down(g.x, 1);
+      const float gl = f > 0 ? lft : 0.f, gr = f < OQ - 1 ? rgt : 0.f;
+      acc.x += wb[ib] * ((0.25f * gl + w1a * g.x) + (w2a * g.y + 0.25f * g.z));
+      acc.y += wb[ib] * ((0.25f * g.y + 0.75f * g.z) + (w2b * g.w + 0.25f * gr));
+    }
+    return acc;
+  };
+  float2 pm1 = contrib(2 * d0 - 1), p0 = contrib(2 * d0);
+  for (int d = d0; d < d1; ++d) {
+    const float2 p1 = contrib(2 * d + 1), p2 = contrib(2 * d + 2);
+    float wa[4];
+    up2_bwd_weights(d, D, wa);
+    float2 o;
+    o.x = (wa[0] * pm1.x + wa[1] * p0.x) + (wa[2] * p1.x + wa[3] * p2.x);
+    o.y = (wa[0] * pm1.y + wa[1] * p0.y) + (wa[2] * p1.y + wa[3] * p2.y);
+    if (live) *((float2*)(dx + ((nc * D + d) * H + h) * (long)W) + f) = o;
     pm1 = p1; p0 = p2;
   }
 }
@@ -768,6 +864,13 @@ int muvo_avgpool_bwd(const float* dy, float* dx, int64_t G, int64_t S, void* str
 int muvo_upsample3d_x2_fwd(const float* x, float* y, int64_t NC, int D, int H, int W, void* stream) {
   MUVO_CHECK_ARG(x && y && NC > 0 && D > 0 && H > 0 && W > 0, "upsample3d_fwd: bad args");
   const int q8 = W / 4;
+  const int oq = W / 2;                     // output float4 per row
+  if (W % 4 == 0 && oq <= 64 && (oq & (oq - 1)) == 0 && D + 1 <= 65535 && NC <= 65535) {
+    dim3 grid(cdiv((long)(H + 1) * oq, 256), D + 1, (unsigned)NC);
+    hipLaunchKernelGGL(upsample3d_x2_fwd_row_kernel, grid, dim3(256), 0, ST, x, y, D, H, W);
+    MUVO_CHECK_LAUNCH("upsample3d_fwd_row");
+    return MUVO_OK;
+  }
   if (W % 4 == 0 && q8 <= 64 && (q8 & (q8 - 1)) == 0 && 2 * D <= 65535 && NC <= 65535) {
     dim3 grid(cdiv((long)2 * H * q8, 256), 2 * D, (unsigned)NC);
     hipLaunchKernelGGL(upsample3d_x2_fwd_vec8_kernel, grid, dim3(256), 0, ST, x, y, D, H, W);
@@ -786,7 +889,17 @@ int muvo_upsample3d_x2_fwd(const float* x, float* y, int64_t NC, int D, int H, i
 }
 int muvo_upsample3d_x2_bwd(const float* dy, float* dx, int64_t NC, int D, int H, int W, void* stream) {
   MUVO_CHECK_ARG(dy && dx && NC > 0 && D > 0 && H > 0 && W > 0, "upsample3d_bwd: bad args");
-  static const int walk = getenv("MUVO_UPSAMPLE_WALK") ? atoi(getenv("MUVO_UPSAMPLE_WALK")) : 1;
+  static const int walk = getenv("MUVO_UPSAMPLE_WALK") ? atoi(getenv("MUVO_UPSAMPLE_WALK")) : 2;
+  const int oq = W / 2;
+  if (walk == 2 && W % 4 == 0 && oq <= 64 && (oq & (oq - 1)) == 0 && NC <= 65535 && (((uintptr_t)dy | (uintptr_t)dx) & 15) == 0) {
+    const int rgroups = cdiv(H, 256 / oq);
+    int segs = 1;
+    while ((long)NC * rgroups * segs < 4096 && segs * 16 <= D) segs *= 2;
+    const int dseg = cdiv(D, segs);
+    hipLaunchKernelGGL(upsample3d_x2_bwd_row_kernel, dim3(rgroups, cdiv(D, dseg), (unsigned)NC), dim3(256), 0, ST, dy, dx, D, H, W, dseg);
+    MUVO_CHECK_LAUNCH("upsample3d_bwd_row");
+    return MUVO_OK;
+  }
   if (walk && W % 4 == 0 && (W / 4) * H <= 1024 && (W / 4) * H >= 128 && NC <= 65535 && (((uintptr_t)dy | (uintptr_t)dx) & 15) == 0) {
     // enough workgroups to fill the chip: split the d range (each segment recomputes its two lead-in planes)
     int segs = 1;
