@@ -42,9 +42,19 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ x
   const long r0 = blockIdx.y * per;
   long r1 = r0 + per;
   if (r1 > rows) r1 = rows;
+  // eight independent loads per pass (the plain `s += x[..]` loop ran one dependent L2 round trip per row: 19 us for the bias
+  // gradient of a 6500-row token matrix)
   float s = 0.f;
-  if (c < cols)
-    for (long r = r0 + rl; r < r1; r += 4) s += x[r * ld + c];
+  if (c < cols) {
+    long r = r0 + rl;
+    for (; r + 28 < r1; r += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = x[(r + 4 * u) * ld + c];
+      s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    for (; r < r1; r += 4) s += x[r * ld + c];
+  }
   red[rl][cl] = s;
   __syncthreads();
   if (rl == 0 && c < cols) atomicAdd(&out[c], red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
@@ -801,8 +811,8 @@ int muvo_copy2d(const float* src, float* dst, int64_t rows, int64_t cols, int64_
 }
 int muvo_colsum_acc(const float* x, float* out, int64_t rows, int64_t cols, int64_t ld, void* stream) {
   MUVO_CHECK_ARG(x && out && rows > 0 && cols > 0 && ld >= cols, "colsum: bad args");
-  int chunks = cdiv(rows, 256);
-  if (chunks > 128) chunks = 128;
+  int chunks = cdiv(rows, 64);           // 16 rows per lane: enough workgroups to cover the chip even for 384 columns
+  if (chunks > 1024) chunks = 1024;
   hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 64), chunks), dim3(256), 0, ST, x, out, (long)rows, (long)cols, (long)ld);
   MUVO_CHECK_LAUNCH("colsum");
   return MUVO_OK;

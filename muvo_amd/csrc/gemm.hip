@@ -222,11 +222,12 @@ __global__ void __launch_bounds__(256) gemm_skinny_kcontig_kernel(const GemmArgs
 // from HBM exactly once and A is re-read from L2 once per four columns (the two-column kernel above re-read it per column
 // pair and made several passes over the weight for M > 8).
 template <int RM>
-__global__ void __launch_bounds__(512) gemm_skinny_kvec_kernel(const GemmArgs g, const float* __restrict__ A,
+__global__ void __launch_bounds__(512, 2) gemm_skinny_kvec_kernel(const GemmArgs g, const float* __restrict__ A,
                                                                const float* __restrict__ B, float* __restrict__ C) {
   // eight waves x two k chunks x four columns of float4 in flight per workgroup: a cold 68 MB weight needs ~8 MB of
   // outstanding loads to approach HBM speed (HBM latency x bandwidth)
   __shared__ float red[8][RM][4];
+  __shared__ float tr[8][64 * 33];         // per wave: 64 lanes x (up to) 32 values, row stride 33 floats (conflict-free columns)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n0 = blockIdx.x * 4;
   float acc[RM][4];
@@ -235,35 +236,62 @@ __global__ void __launch_bounds__(512) gemm_skinny_kvec_kernel(const GemmArgs g,
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[r][c] = 0.f;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // Every load below is UNCONDITIONAL (clamped address, the weight of a missing second half zeroed afterwards; rows past M
+  // repeat row M - 1 and are never stored).  Behind `has2 ? load : 0` / `if (r < M)` each row's loads sat in their own
+  // basic block with their own wait: 24 sequential L2 round trips, 27 us for the smallest Linear of the model.
+  const int mlast = g.M - 1;
   for (int k = (wave * 64 + lane) * 4; k < g.K; k += 4096) {
-    const int k2 = k + 2048;
-    const bool has2 = k2 < g.K;
+    const bool has2 = k + 2048 < g.K;
+    const int k2 = has2 ? k + 2048 : k;
     float4 w[2][4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const float* bp = B + (long)(n0 + c < g.N ? n0 + c : n0) * g.sbn;
       w[0][c] = *reinterpret_cast<const float4*>(bp + k);
-      w[1][c] = has2 ? *reinterpret_cast<const float4*>(bp + k2) : zero4;
+      const float4 t = *reinterpret_cast<const float4*>(bp + k2);
+      w[1][c] = has2 ? t : zero4;
     }
+    // rows in groups of four: eight float4 of A in flight, then their FMAs (all RM rows at once would need 2 RM float4)
 #pragma unroll
-    for (int r = 0; r < RM; ++r) {
-      if (r < g.M) {   // wave-uniform
-        const float4 a0 = *reinterpret_cast<const float4*>(A + (long)r * g.sam + k);
-        const float4 a1 = has2 ? *reinterpret_cast<const float4*>(A + (long)r * g.sam + k2) : zero4;
+    for (int rg = 0; rg < RM; rg += 4) {
+      float4 a0[4], a1[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float* ar = A + (long)(rg + q < mlast ? rg + q : mlast) * g.sam;
+        a0[q] = *reinterpret_cast<const float4*>(ar + k);
+        a1[q] = *reinterpret_cast<const float4*>(ar + k2);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-          acc[r][c] += a0.x * w[0][c].x + a0.y * w[0][c].y + a0.z * w[0][c].z + a0.w * w[0][c].w +
-                       a1.x * w[1][c].x + a1.y * w[1][c].y + a1.z * w[1][c].z + a1.w * w[1][c].w;
-      }
+          acc[rg + q][c] += a0[q].x * w[0][c].x + a0[q].y * w[0][c].y + a0[q].z * w[0][c].z + a0[q].w * w[0][c].w +
+                            a1[q].x * w[1][c].x + a1[q].y * w[1][c].y + a1[q].z * w[1][c].z + a1[q].w * w[1][c].w;
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
+  // Lane reduction of the RM x 4 partial sums through an LDS transpose: every lane writes a chunk of its values as one row,
+  // lane j then adds up column j.  (wave_sum per value is a chain of six dependent cross-lane shuffles; 96 of them in a row
+  // took 20 us — every Linear with <= 24 rows paid that, whatever its size.)
+  constexpr int NV = RM * 4, CH = NV < 32 ? NV : 32;
+  static_assert(NV % CH == 0, "chunks must tile");
+  float* trw = tr[wave];
 #pragma unroll
-  for (int r = 0; r < RM; ++r)
+  for (int c0 = 0; c0 < NV; c0 += CH) {
+    if (c0) __syncthreads();
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float sum = wave_sum(acc[r][c]);
-      if (lane == 0) red[wave][r][c] = sum;
+    for (int v = 0; v < CH; ++v) trw[lane * 33 + v] = acc[(c0 + v) >> 2][(c0 + v) & 3];
+    __syncthreads();
+    if (lane < CH) {
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+      for (int l = 0; l < 64; l += 4) {
+        s0 += trw[l * 33 + lane]; s1 += trw[(l + 1) * 33 + lane];
+        s2 += trw[(l + 2) * 33 + lane]; s3 += trw[(l + 3) * 33 + lane];
+      }
+      red[wave][(c0 + lane) >> 2][(c0 + lane) & 3] = (s0 + s1) + (s2 + s3);
     }
+  }
   __syncthreads();
   for (int i = threadIdx.x; i < RM * 4; i += 512) {
     const int r = i >> 2, c = i & 3;
@@ -277,31 +305,52 @@ __global__ void __launch_bounds__(512) gemm_skinny_kvec_kernel(const GemmArgs g,
   }
 }
 
-// B n-contiguous (data gradient of nn.Linear: B(k,n) = W[k][n]).  Lanes along n (coalesced weight rows); the four waves of
-// a workgroup and the KS workgroups of grid.y split k.  KS > 1: partial sums are added into the pre-zeroed C with float
-// atomics (only offered without bias/activation).
+// B n-contiguous (data gradient of nn.Linear: B(k,n) = W[k][n]).  Lanes along n (coalesced weight rows); the workgroup
+// walks its k range (grid.y = KS splits) in chunks of 128: the A rows of the chunk are staged in LDS once (zero past M / K),
+// each of the four waves takes 32 k of the chunk, four k per pass: four weight loads in flight, the wave-uniform A operands
+// come as one broadcast 16-byte LDS read per row.  (A from global memory meant a scalar load per row and k with a wait per
+// basic block; the 68-MB Linear of the model ran at 0.5 TB/s.)  KS > 1: partial sums are added into the pre-zeroed C with
+// float atomics (only offered without bias/activation).
 template <int RM>
 __global__ void __launch_bounds__(256) gemm_skinny_ncontig_kernel(const GemmArgs g, const float* __restrict__ A,
                                                                   const float* __restrict__ B, float* __restrict__ C, int KS) {
+  constexpr int KC = 128;
   __shared__ float red[4][RM][64];
+  __shared__ __attribute__((aligned(16))) float sA[RM][KC];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + lane;
   const bool nok = n < g.N;
-  const int kper = (g.K + 4 * KS - 1) / (4 * KS);
-  const int k0 = (blockIdx.y * 4 + wave) * kper;
-  int k1 = k0 + kper;
-  if (k1 > g.K) k1 = g.K;
+  const int nc = nok ? n : g.N - 1;
+  const int kper = ((g.K + KS - 1) / KS + KC - 1) / KC * KC;       // k range of this workgroup: whole chunks
+  const int kbeg = blockIdx.y * kper;
+  int kend = kbeg + kper;
+  if (kend > g.K) kend = g.K;
   for (int r0 = 0; r0 < g.M; r0 += RM) {
     float acc[RM];
 #pragma unroll
     for (int r = 0; r < RM; ++r) acc[r] = 0.f;
-#pragma unroll 4
-    for (int k = k0; k < k1; ++k) {
-      const float w = nok ? B[(long)k * g.sbk + (long)n * g.sbn] : 0.f;
+    for (int kc = kbeg; kc < kend; kc += KC) {
+      __syncthreads();                                             // the previous chunk has been consumed
+      for (int i = threadIdx.x; i < RM * KC; i += 256) {
+        const int r = i / KC, kk = i - r * KC;
+        const bool ok = r0 + r < g.M && kc + kk < kend;
+        const float v = A[(long)(ok ? r0 + r : 0) * g.sam + (long)(ok ? kc + kk : 0) * g.sak];     // unconditional load
+        sA[r][kk] = ok ? v : 0.f;
+      }
+      __syncthreads();
+#pragma unroll 2
+      for (int kk = wave * 32; kk < wave * 32 + 32; kk += 4) {
+        float w[4];
 #pragma unroll
-      for (int r = 0; r < RM; ++r) {
-        const float a = (r0 + r < g.M) ? A[(long)(r0 + r) * g.sam + (long)k * g.sak] : 0.f;  // wave-uniform address
-        acc[r] += a * w;
+        for (int u = 0; u < 4; ++u) {
+          const int k = kc + kk + u;
+          w[u] = B[(long)(k < g.K ? k : g.K - 1) * g.sbk + (long)nc * g.sbn];      // past kend: multiplied by the zeros in sA
+        }
+#pragma unroll
+        for (int r = 0; r < RM; ++r) {
+          const float4 a = *reinterpret_cast<const float4*>(&sA[r][kk]);
+          acc[r] += (a.x * w[0] + a.y * w[1]) + (a.z * w[2] + a.w * w[3]);
+        }
       }
     }
     __syncthreads();
@@ -340,6 +389,10 @@ extern "C" int muvo_gemm(const muvo_gemm_desc* d, const float* A, const float* B
   MUVO_CHECK_ARG(d->B1 > 0 && d->B2 > 0, "gemm: bad batch sizes");
   MUVO_CHECK_ARG(d->mode == 0 || d->mode == 1, "gemm: mode must be 0 (store) or 1 (atomic add)");
   MUVO_CHECK_ARG(!(d->mode == 1 && (bias || d->act != MUVO_ACT_NONE)), "gemm: bias/act not allowed in accumulate mode");
+  static const bool log_calls = getenv("MUVO_GEMM_LOG") != nullptr;      // diagnostic: one line per call
+  if (log_calls)
+    fprintf(stderr, "muvo_gemm M=%d N=%d K=%d nb=%d mode=%d sam=%ld sak=%ld sbk=%ld sbn=%ld act=%d bias=%d\n", d->M, d->N, d->K,
+            d->B1 * d->B2, d->mode, (long)d->sam, (long)d->sak, (long)d->sbk, (long)d->sbn, d->act, bias != nullptr);
   GemmArgs g;
   g.M = d->M; g.N = d->N; g.K = d->K;
   g.sam = d->sam; g.sak = d->sak; g.sbk = d->sbk; g.sbn = d->sbn; g.scm = d->scm;
@@ -353,15 +406,15 @@ extern "C" int muvo_gemm(const muvo_gemm_desc* d, const float* A, const float* B
                     d->sam % 4 == 0 && d->sbn % 4 == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0;
   if (d->M <= 32 && d->mode == 0 && nb == 1 && ((d->N >= 64 && d->K >= 16) || kvec)) {
     g.ksplit = 1;
-    const bool vec = d->sbk == 1 && d->sak == 1 && d->K % 4 == 0 && d->sam % 4 == 0 && d->sbn % 4 == 0 &&
+    // (the k-vector kernel holds M x 4 accumulators per lane: up to 24 rows; 25..32 rows take the k-contiguous kernel)
+    const bool vec = d->M <= 24 && d->sbk == 1 && d->sak == 1 && d->K % 4 == 0 && d->sam % 4 == 0 && d->sbn % 4 == 0 &&
                      (((uintptr_t)A | (uintptr_t)B) & 15) == 0;
     if (vec) {
       const dim3 grid(cdiv(d->N, 4));
       if (d->M <= 4) hipLaunchKernelGGL((gemm_skinny_kvec_kernel<4>), grid, dim3(512), 0, st, g, A, B, C);
       else if (d->M <= 8) hipLaunchKernelGGL((gemm_skinny_kvec_kernel<8>), grid, dim3(512), 0, st, g, A, B, C);
       else if (d->M <= 16) hipLaunchKernelGGL((gemm_skinny_kvec_kernel<16>), grid, dim3(512), 0, st, g, A, B, C);
-      else if (d->M <= 24) hipLaunchKernelGGL((gemm_skinny_kvec_kernel<24>), grid, dim3(512), 0, st, g, A, B, C);
-      else hipLaunchKernelGGL((gemm_skinny_kvec_kernel<32>), grid, dim3(512), 0, st, g, A, B, C);
+      else hipLaunchKernelGGL((gemm_skinny_kvec_kernel<24>), grid, dim3(512), 0, st, g, A, B, C);
     } else if (d->sbk == 1) {
       const int blocks = cdiv(d->N, 8);
       if (d->M <= 4) hipLaunchKernelGGL((gemm_skinny_kcontig_kernel<4>), dim3(blocks), dim3(256), 0, st, g, A, B, C);
@@ -380,7 +433,8 @@ extern "C" int muvo_gemm(const muvo_gemm_desc* d, const float* A, const float* B
         return MUVO_ERR_HIP;
       }
       if (d->M <= 4) hipLaunchKernelGGL((gemm_skinny_ncontig_kernel<4>), dim3(blocks, ks), dim3(256), 0, st, g, A, B, C, ks);
-      else hipLaunchKernelGGL((gemm_skinny_ncontig_kernel<8>), dim3(blocks, ks), dim3(256), 0, st, g, A, B, C, ks);
+      else if (d->M <= 8) hipLaunchKernelGGL((gemm_skinny_ncontig_kernel<8>), dim3(blocks, ks), dim3(256), 0, st, g, A, B, C, ks);
+      else hipLaunchKernelGGL((gemm_skinny_ncontig_kernel<24>), dim3(blocks, ks), dim3(256), 0, st, g, A, B, C, ks);   // the 20 frame rows of a step in one pass
     }
     MUVO_CHECK_LAUNCH("gemm_skinny_kernel");
     return MUVO_OK;

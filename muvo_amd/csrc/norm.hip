@@ -406,6 +406,15 @@ __global__ void __launch_bounds__(256) adain_apply_kernel(const float* __restric
   }
 }
 
+#define VEC_U 4
+// grid.x of the float4 apply kernels: one pass of VEC_U float4 per lane (MUVO_NORM_GX_CAP: A/B switch for the old capped grids)
+static int vec_gx(long S4) {
+  static const long cap = getenv("MUVO_NORM_GX_CAP") ? atol(getenv("MUVO_NORM_GX_CAP")) : (1l << 22);
+  long gx = cdiv(S4, 256l * VEC_U);
+  if (gx > cap) gx = cap;
+  return (int)(gx < 1 ? 1 : gx);
+}
+
 // float4 variants of the AdaIN apply kernels (S % 4 == 0, 16-byte aligned tensors): grid = (chunks, N*C); a workgroup stays
 // inside one (n, c) instance, so the per-instance scalars are loaded once and there is no index division per element.
 __global__ void __launch_bounds__(256) adain_apply_vec_kernel(const float* __restrict__ x, const float* __restrict__ mean,
@@ -419,11 +428,20 @@ __global__ void __launch_bounds__(256) adain_apply_vec_kernel(const float* __res
   const float4* xp = reinterpret_cast<const float4*>(x + n * x_bs + (long)c * S);
   float4* yp = reinterpret_cast<float4*>(y + g * S);
   const long S4 = S >> 2;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < S4; i += (long)gridDim.x * 256) {
-    const float4 v = xp[i];
-    // same operation order as the scalar kernel: style * ((x - mean) * rstd) + bias
-    yp[i] = make_float4(st * ((v.x - mu) * rs) + sh, st * ((v.y - mu) * rs) + sh, st * ((v.z - mu) * rs) + sh,
-                        st * ((v.w - mu) * rs) + sh);
+  // VEC_U float4 per lane and pass, all loads issued before the first store (a load behind a store of the same wave waits for
+  // that store's acknowledgement: vmcnt is in issue order), grid sized so that a workgroup normally makes one pass
+  for (long i0 = blockIdx.x * (256L * VEC_U) + threadIdx.x; i0 < S4; i0 += (long)gridDim.x * 256 * VEC_U) {
+    float4 v[VEC_U];
+#pragma unroll
+    for (int u = 0; u < VEC_U; ++u) { const long i = i0 + 256 * u; v[u] = xp[i < S4 ? i : S4 - 1]; }
+#pragma unroll
+    for (int u = 0; u < VEC_U; ++u) {
+      const long i = i0 + 256 * u;
+      // same operation order as the scalar kernel: style * ((x - mean) * rstd) + bias
+      if (i < S4)
+        yp[i] = make_float4(st * ((v[u].x - mu) * rs) + sh, st * ((v[u].y - mu) * rs) + sh, st * ((v[u].z - mu) * rs) + sh,
+                            st * ((v[u].w - mu) * rs) + sh);
+    }
   }
 }
 
@@ -476,16 +494,26 @@ __global__ void __launch_bounds__(256) adain_bwd_apply_vec_kernel(const float* _
   const float4* gp = reinterpret_cast<const float4*>(dy + g * S);
   float4* op = reinterpret_cast<float4*>(dx + g * S);
   const long S4 = S >> 2;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < S4; i += (long)gridDim.x * 256) {
-    const float4 xv = xp[i], dv = gp[i];
-    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
-    float o[4];
+  for (long i0 = blockIdx.x * (256L * VEC_U) + threadIdx.x; i0 < S4; i0 += (long)gridDim.x * 256 * VEC_U) {
+    float4 xv[VEC_U], dv[VEC_U];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float xh = (xs[e] - mu) * rs;
-      o[e] = st * rs * (dd[e] - m1 - xh * m2) * act_grad_from_out(xs[e], act, slope);
+    for (int u = 0; u < VEC_U; ++u) {
+      const long i = i0 + 256 * u, ic = i < S4 ? i : S4 - 1;
+      xv[u] = xp[ic];
+      dv[u] = gp[ic];
     }
-    op[i] = make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+    for (int u = 0; u < VEC_U; ++u) {
+      const long i = i0 + 256 * u;
+      const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w}, dd[4] = {dv[u].x, dv[u].y, dv[u].z, dv[u].w};
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (xs[e] - mu) * rs;
+        o[e] = st * rs * (dd[e] - m1 - xh * m2) * act_grad_from_out(xs[e], act, slope);
+      }
+      if (i < S4) op[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
   }
 }
 
@@ -512,8 +540,7 @@ extern "C" int muvo_adain_fwd(const float* x, const float* style, float* y, floa
   hipLaunchKernelGGL(in_finalize_kernel, dim3(cdiv(G, 64)), dim3(64), 0, st, sums, save_mean, save_rstd, G, (double)S, eps);
   const long total = (long)G * S;
   if (S % 4 == 0 && S >= 1024 && G <= 65535 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
-    int gx = cdiv(S / 4, 256 * 4);
-    if (gx > 64) gx = 64;
+    const int gx = vec_gx(S / 4);
     hipLaunchKernelGGL(adain_apply_vec_kernel, dim3(gx, G), dim3(256), 0, st, x, save_mean, save_rstd, style, y, C, (long)S,
                        (long)x_batch_stride);
   } else
@@ -533,8 +560,7 @@ extern "C" int muvo_adain_fwd_moments(const float* x, const float* style, float*
   hipLaunchKernelGGL(in_finalize_kernel, dim3(cdiv(G, 64)), dim3(64), 0, st, moments, save_mean, save_rstd, G, (double)S, eps);
   const long total = (long)G * S;
   if (S % 4 == 0 && S >= 1024 && G <= 65535 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
-    int gx = cdiv(S / 4, 256 * 4);
-    if (gx > 64) gx = 64;
+    const int gx = vec_gx(S / 4);
     hipLaunchKernelGGL(adain_apply_vec_kernel, dim3(gx, G), dim3(256), 0, st, x, save_mean, save_rstd, style, y, C, (long)S,
                        (long)C * S);
   } else
@@ -803,8 +829,7 @@ extern "C" int muvo_adain_bwd(const float* x, const float* style, const float* d
   hipLaunchKernelGGL(adain_bwd_finalize_kernel, dim3(cdiv(G, 64)), dim3(64), 0, st, sums, ws, dstyle, N, C);
   const long total = (long)G * S;
   if (S % 4 == 0 && S >= 1024 && G <= 65535 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0) {
-    int gx = cdiv(S / 4, 256 * 4);
-    if (gx > 64) gx = 64;
+    const int gx = vec_gx(S / 4);
     hipLaunchKernelGGL(adain_bwd_apply_vec_kernel, dim3(gx, G), dim3(256), 0, st, x, dy, save_mean, save_rstd, style, ws, dx, C,
                        (long)S, (long)x_batch_stride, act, slope);
   } else
@@ -881,20 +906,27 @@ __global__ void __launch_bounds__(256) add_dropout_ln_bwd_kernel(const float* __
     const float mu = mean[row], rs = rstd[row];
     float d[MAXV], xh[MAXV];
     float s1 = 0.f, s2 = 0.f;
+    // unconditional loads (index clamped, value masked): behind `if (e < E)` every k had its own basic block and its own
+    // wait, i.e. MAXV sequential memory round trips per row
+    float gv[MAXV], zv[MAXV], gm[MAXV];
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) {
-      const int e = lane + 64 * k;
-      d[k] = 0.f; xh[k] = 0.f;
-      if (e < E) {
-        const long idx = (long)row * E + e;
-        const float g = dy[idx];
-        xh[k] = (z[idx] - mu) * rs;
-        ag[k] += g * xh[k];
-        ab[k] += g;
-        d[k] = g * gamma[e];
-        s1 += d[k];
-        s2 += d[k] * xh[k];
-      }
+      const int e = lane + 64 * k, ec = e < E ? e : 0;
+      const long idx = (long)row * E + ec;
+      gv[k] = dy[idx];
+      zv[k] = z[idx];
+      gm[k] = gamma[ec];
+    }
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const bool ok = lane + 64 * k < E;
+      const float g = ok ? gv[k] : 0.f;
+      xh[k] = ok ? (zv[k] - mu) * rs : 0.f;
+      ag[k] += g * xh[k];
+      ab[k] += g;
+      d[k] = g * gm[k];
+      s1 += d[k];
+      s2 += d[k] * xh[k];
     }
     s1 = wave_sum(s1) / E;
     s2 = wave_sum(s2) / E;
@@ -937,7 +969,7 @@ extern "C" int muvo_add_dropout_layernorm_bwd(const float* dy, const float* z, c
                                               int rows, int E, float p, uint64_t seed, void* stream) {
   MUVO_CHECK_ARG(dy && z && mean && rstd && gamma && dx && dgamma && dbeta, "layernorm_bwd: null pointer");
   MUVO_CHECK_ARG(rows > 0 && E > 0 && E <= 512, "layernorm_bwd: E=%d unsupported (max 512)", E);
-  const int rpb = 32;
+  const int rpb = 16;       // four rows per wave; 6500 token rows -> 407 workgroups
   hipLaunchKernelGGL((add_dropout_ln_bwd_kernel<8>), dim3(cdiv(rows, rpb)), dim3(256), 2 * E * sizeof(float),
                      (hipStream_t)stream, dy, z, mean, rstd, gamma, dx, da, dgamma, dbeta, rows, E, rpb, p, seed);
   MUVO_CHECK_LAUNCH("layernorm_bwd");
