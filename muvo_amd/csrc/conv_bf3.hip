@@ -38,6 +38,10 @@ extern "C" int muvo_bf3_loop_clock(double* shader_mhz, double* us_per_k_step) {
 __device__ unsigned long long g_bf3_stamps[8 * 16384];
 #define BF3_STAMP(slot)                                                                      \
   if (threadIdx.x == 0 && blockIdx.x < 16384) g_bf3_stamps[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime()
+extern "C" int muvo_debug_bf3_stamps_reset() {
+  void* p = nullptr;
+  return hipGetSymbolAddress(&p, HIP_SYMBOL(g_bf3_stamps)) == hipSuccess && hipMemset(p, 0, sizeof(unsigned long long) * 8 * 16384) == hipSuccess ? 0 : 1;
+}
 extern "C" int muvo_debug_bf3_stamps(unsigned long long* host_out, int n_u64) {
   return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_bf3_stamps), sizeof(unsigned long long) * n_u64) == hipSuccess ? 0 : 1;
 }

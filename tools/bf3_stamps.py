@@ -17,8 +17,10 @@ L.muvo_debug_bf3_stamps.argtypes = [C.c_void_p, C.c_int]
 LAYERS = [('convT 128->64 in 160x416', lambda: hnn.ConvTranspose2d(128, 64, 6, 2, 2), (20, 128, 160, 416)),
           ('convT 256->128 in 80x208', lambda: hnn.ConvTranspose2d(256, 128, 6, 2, 2), (20, 256, 80, 208)),
           ('convT 512->256 in 40x104', lambda: hnn.ConvTranspose2d(512, 256, 6, 2, 2), (20, 512, 40, 104))]
-NK = {'convT 128->64 in 160x416': 36, 'convT 256->128 in 80x208': 72, 'convT 512->256 in 40x104': 144}
-for name, make, shape in LAYERS[:1]:
+LAYERS.append(('conv 64->64 3x3 in 80x208 (four-wave 64x128 tile)', lambda: hnn.Conv2d(64, 64, 3, 1, 1), (20, 64, 80, 208)))
+LAYERS.append(('conv 128->128 3x3 in 40x104', lambda: hnn.Conv2d(128, 128, 3, 1, 1), (20, 128, 40, 104)))
+NK = {LAYERS[0][0]: 36, LAYERS[1][0]: 72, LAYERS[2][0]: 144, LAYERS[3][0]: 18, LAYERS[4][0]: 36}
+for name, make, shape in LAYERS:
     torch.manual_seed(0)
     with torch.device(dev):
         m = make()
@@ -27,6 +29,7 @@ for name, make, shape in LAYERS[:1]:
         for _ in range(3):
             y = m(x)
         torch.cuda.synchronize()
+        assert L.muvo_debug_bf3_stamps_reset() == 0
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); y = m(x); b.record()
         torch.cuda.synchronize()
