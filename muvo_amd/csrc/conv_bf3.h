@@ -11,7 +11,9 @@ long bf3_workspace_bytes(int N, int C, long S);
 int bf3_split_input(const float* x, void* ws, int N, int C, long S, hipStream_t st, const float* yact = nullptr, int act = 0,
                     float slope = 0.f, float* dbias = nullptr);
 int bf3_launch_fwd_phase(const ConvPhase& g, const void* ws, const float* wp, const float* bias, float* out, int act,
-                         float slope, hipStream_t st);
+                         float slope, hipStream_t st, int ksplit = 1);
+// split-K factor the caller should use for this phase (1: none; > 1: zero the output first, finish bias / activation after)
+int bf3_fwd_ksplit(const ConvPhase& g);
 // weight gradient of one forward-form phase on the split planes (ws_x: planes of x with Cin_total channels, ws_dz: planes
 // of dy with Cout_total channels); wg = zeroed scratch, g.wp_off = float offset of the phase's [T][M][C] slab in it
 int bf3_wgrad_phase(const ConvPhase& g, const void* ws_x, int Cin_total, const void* ws_dz, int Cout_total, float* wg,

@@ -90,7 +90,7 @@ template <int BM, int BN, int WM, int WN, int BKC, int NST>
 __global__ void __launch_bounds__(64 * WM * WN)
 conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, const uint4* __restrict__ wp,
                 const float* __restrict__ bias, float* __restrict__ out, int act, float slope,
-                const uint4* __restrict__ zero16) {
+                const uint4* __restrict__ zero16, int ksplit) {
   constexpr int BK = 8 * BKC, NW = WM * WN;       // BKC = 8-channel chunks per K step (4: BK = 32, 2: BK = 16)
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   constexpr int STAGE = 2 * BKC * (BM + BN);      // uint4 per stage: A [plane][chunk][BM] then B [plane][BN pixels][4 chunks]
@@ -145,6 +145,11 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
   const int m_tile = by * BM;
   const uint4* wpb = wp + g.wp_off / 4 + m_tile;   // wp_off is in floats; one uint4 = 8 bf16 = 4 floats
   const int nk = g.Kp / BK;
+  // split-K (grid.y = ksplit > 1; few-pixel / long-K layers): this workgroup reduces K steps [kt0, kt1) and adds its partial
+  // tile into the pre-zeroed output (bias / activation in the caller's finishing pass, as for the fp32 kernel)
+  const int sps = (nk + ksplit - 1) / ksplit;
+  const int kt0 = blockIdx.y * sps, kt1 = kt0 + sps < nk ? kt0 + sps : nk;
+  if (kt0 >= kt1) return;                  // (uniform)
 
   // Staging: plain 16-byte global loads into registers, written to LDS one step later (ds_write_b128).  Measured on this
   // chip (tools/microbench/mfma_lds.hip) the register round trip sustains the MFMA rate far better than LDS-DMA
@@ -175,7 +180,7 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
   // is never waited for where it is issued)
   int b_uoff = 0; unsigned long long b_bit = 0ull; bool b_tval = false;
   const bool tap_inner = bf3_tap_inner(g);
-  int ti_t = 0, ti_c8 = lane & 3;         // tap-inner order: tap and chunk of the NEXT bstate call (calls are sequential in kt)
+  int ti_t = kt0 % g.T, ti_c8 = (lane & 3) + 4 * (kt0 / g.T);   // tap-inner order: tap and chunk of the NEXT bstate call (calls are sequential in kt)
   auto bstate = [&](int kt) {
     if (tap_inner) {
       b_uoff = taptab[ti_t] + ti_c8;
@@ -280,20 +285,20 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
   using par1 = std::integral_constant<int, 1>;
   __syncthreads();                       // tap table
   BF3_STAMP(1);
-  bstate(0);
+  bstate(kt0);
 #pragma unroll
-  for (int q = 0; q < DMA_PER_STEP; ++q) gload_piece(par0{}, 0, q);
+  for (int q = 0; q < DMA_PER_STEP; ++q) gload_piece(par0{}, kt0, q);
 #pragma unroll
   for (int q = 0; q < DMA_PER_STEP; ++q) lstore_piece(par0{}, 0, q);
-  bstate(1);
+  bstate(kt0 + 1);
 #pragma unroll
-  for (int q = 0; q < DMA_PER_STEP; ++q) gload_piece(par1{}, 1, q);
+  for (int q = 0; q < DMA_PER_STEP; ++q) gload_piece(par1{}, kt0 + 1, q);
 #pragma unroll
   for (int q = 0; q < DMA_PER_STEP; ++q) lstore_piece(par1{}, 1, q);
-  bstate(2);
+  bstate(kt0 + 2);
 #pragma unroll
-  for (int q = 0; q < DMA_PER_STEP; ++q) gload_piece(par0{}, 2, q);
-  bstate(3);
+  for (int q = 0; q < DMA_PER_STEP; ++q) gload_piece(par0{}, kt0 + 2, q);
+  bstate(kt0 + 3);
   __syncthreads();
   BF3_STAMP(2);
   // clock probe: workgroup 0 reports shader-clock ticks and 100-MHz wall-clock ticks of its K loop (muvo_bf3_loop_clock);
@@ -312,7 +317,7 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
     const int grp = wave / (NW / 2);
     if (grp == 1) __builtin_amdgcn_s_barrier();
     int stage = 0;
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kt0; kt < kt1; ++kt) {
       // stage writes first (R is free again once they are issued), then the buffer loads of step kt+3 spread between
       // the fragment reads so that the address path and the LDS work at the same time
       const int wstage = stage == 0 ? 2 : stage - 1;          // (stage + 2) % 3
@@ -394,9 +399,9 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
       // compiler from putting a full lgkmcnt(0) between the F1 requests and MFMA(F0) at the top of the next step
       __builtin_amdgcn_s_waitcnt(0xC07F);
     };
-    for (int kt = 0; kt < nk; kt += 2) {
+    for (int kt = kt0; kt < kt1; kt += 2) {
       step(par0{}, kt);
-      if (kt + 1 < nk) step(par1{}, kt + 1);    // (uniform) only the last pair of an odd K loop skips it
+      if (kt + 1 < kt1) step(par1{}, kt + 1);   // (uniform) only the last pair of an odd K range skips it
     }
   }
 
@@ -410,8 +415,8 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
 #ifdef MUVO_BF3_STAMPS
   if (threadIdx.x == 0 && blockIdx.x < 16384) g_bf3_stamps[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime() - clk0;
 #endif
-#define BF3_STORE(ACT) conv_tile_store<ACT, true>(g, acc, bias, out, slope, 1, bx * BN, m_tile, wm, wn, lane, sbias)
-  MUVO_ACT_SWITCH(act, BF3_STORE)
+#define BF3_STORE(ACT) conv_tile_store<ACT, true>(g, acc, bias, out, slope, ksplit, bx * BN, m_tile, wm, wn, lane, sbias)
+  MUVO_ACT_SWITCH(ksplit > 1 ? MUVO_ACT_NONE : act, BF3_STORE)
   BF3_STAMP(4);
 #if defined(MUVO_BF3_STAMPS) && MUVO_BF3_STAMPS == 2
   __builtin_amdgcn_s_waitcnt(0);         // all stores of this wave acknowledged
@@ -973,12 +978,30 @@ nchw_split_nhwc_v4_kernel(const float* __restrict__ in, uint4* __restrict__ out_
 }
 
 // dbias[c] += sum over replicas
-__global__ void bias_replica_reduce_kernel(const float* __restrict__ rep, float* __restrict__ dbias, int C, int Cp) {
+// (clears what it reads: the library-owned replica buffer stays all-zero between uses, no memset launch per backward pass)
+__global__ void bias_replica_reduce_kernel(float* __restrict__ rep, float* __restrict__ dbias, int C, int Cp) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  if (c >= Cp) return;
   float s = 0.f;
-  for (int r = 0; r < BIAS_REPLICAS; ++r) s += rep[(size_t)r * Cp + c];
-  dbias[c] += s;
+  for (int r = 0; r < BIAS_REPLICAS; ++r) { s += rep[(size_t)r * Cp + c]; rep[(size_t)r * Cp + c] = 0.f; }
+  if (c < C) dbias[c] += s;
+}
+
+// BIAS_REPLICAS x Cp floats, zero on allocation and left zero by bias_replica_reduce_kernel (all users run on one stream)
+static float* bias_replica_buffer(int Cp) {
+  static float* buf = nullptr;
+  static size_t cap = 0;
+  const size_t need = (size_t)BIAS_REPLICAS * Cp;
+  if (need > cap) {
+    if (buf) { hipDeviceSynchronize(); hipFree(buf); buf = nullptr; }
+    const size_t n = need < 65536 ? 65536 : need;
+    if (hipMalloc((void**)&buf, n * sizeof(float)) != hipSuccess || hipMemset(buf, 0, n * sizeof(float)) != hipSuccess) {
+      buf = nullptr; cap = 0;
+      return nullptr;
+    }
+    cap = n;
+  }
+  return buf;
 }
 
 __device__ uint4 g_zero16 = {0u, 0u, 0u, 0u};
@@ -1124,9 +1147,9 @@ int bf3_split_input(const float* x, void* ws, int N, int C, long S, hipStream_t 
   uint4* lo = hi + (size_t)N * S * Cp / 8;
   float* rep = nullptr;
   if (dbias) {
-    rep = (float*)((char*)ws + (size_t)N * S * Cp * 4 + 16);
-    if (hipMemsetAsync(rep, 0, sizeof(float) * BIAS_REPLICAS * Cp, st) != hipSuccess) {
-      muvo_set_error("bf3_split_input: memset failed");
+    rep = bias_replica_buffer(Cp);
+    if (rep == nullptr) {
+      muvo_set_error("bf3_split_input: cannot allocate the bias partial-sum buffer");
       return MUVO_ERR_HIP;
     }
   }
@@ -1144,7 +1167,7 @@ int bf3_split_input(const float* x, void* ws, int N, int C, long S, hipStream_t 
     dim3 grid(cdiv(cdiv(S, 64), SPLIT_TILES), cdiv(Cp, 64), N);
     hipLaunchKernelGGL(nchw_split_nhwc_kernel, grid, dim3(256), 0, st, x, hi, lo, C, Cp, S, yact, act, slope, rep);
   }
-  if (dbias) hipLaunchKernelGGL(bias_replica_reduce_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, rep, dbias, C, Cp);
+  if (dbias) hipLaunchKernelGGL(bias_replica_reduce_kernel, dim3(cdiv(Cp, 64)), dim3(64), 0, st, rep, dbias, C, Cp);
   MUVO_CHECK_LAUNCH("nchw_split_nhwc_kernel");
   return MUVO_OK;
 }
@@ -1176,7 +1199,7 @@ int bf3_split_rows(const float* x, void* ws, long rows, int C, hipStream_t st) {
 
 template <int BM, int BN, int WM, int WN, int BKC, int NST>
 static int bf3_launch(const ConvPhase& g, const void* ws, const float* wp, const float* bias, float* out, int act,
-                      float slope, hipStream_t st) {
+                      float slope, hipStream_t st, int ksplit = 1) {
   constexpr size_t lds = (size_t)NST * 2 * BKC * (BM + BN) * 16 + 256 + 4 * BM * WN;   // stages + tap table + bias rows per wave
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
@@ -1191,9 +1214,9 @@ static int bf3_launch(const ConvPhase& g, const void* ws, const float* wp, const
     attr_set = true;
   }
   const long plane_u4 = (long)g.N * g.ID * g.IH * g.IW * (g.Cp / 8);
-  dim3 grid(cdiv(g.npix, BN) * cdiv(g.M, BM), 1, 1);
+  dim3 grid(cdiv(g.npix, BN) * cdiv(g.M, BM), ksplit, 1);
   hipLaunchKernelGGL((conv_bf3_kernel<BM, BN, WM, WN, BKC, NST>), grid, dim3(64 * WM * WN), lds, st, g, (const uint4*)ws, plane_u4,
-                     (const uint4*)wp, bias, out, act, slope, zero16);
+                     (const uint4*)wp, bias, out, act, slope, zero16, ksplit);
   MUVO_CHECK_LAUNCH("conv_bf3_kernel");
   return MUVO_OK;
 }
@@ -1207,9 +1230,25 @@ bool bf3_fwd_uses_pp(const ConvPhase& g) {
 }
 bool bf3_wgrad_uses_pp(const ConvPhase& g) { return g.M > 128 || (g.M > 64 && g.C > 64); }
 
+// Split-K factor of a forward-type launch: layers with few result pixels and a long reduction (ResNet stage 4 at 5 x 13,
+// the range-view stage at 2 x 32: 512 channels x 9 taps) have too few 64 x 128 tiles to fill the chip; their K range is cut
+// into >= 16-step pieces until ~512 workgroups exist.  The caller zeroes the output and runs the bias / activation pass.
+int bf3_fwd_ksplit(const ConvPhase& g) {
+  if (g.npix <= 0 || bf3_fwd_uses_pp(g)) return 1;
+  static const int tgt = getenv("MUVO_BF3_KSPLIT_BLOCKS") ? atoi(getenv("MUVO_BF3_KSPLIT_BLOCKS")) : 512;
+  static const int min_steps = getenv("MUVO_BF3_KSPLIT_MIN_STEPS") ? atoi(getenv("MUVO_BF3_KSPLIT_MIN_STEPS")) : 16;
+  const long tiles = (long)cdiv(g.npix, 128) * cdiv(g.M, 64);
+  const int nk = g.Kp / 32;
+  if (tiles >= 192 || nk < 2 * min_steps) return 1;
+  int ks = cdiv(tgt, tiles);
+  if (ks > nk / min_steps) ks = nk / min_steps;
+  return ks < 1 ? 1 : ks;
+}
+
 int bf3_launch_fwd_phase(const ConvPhase& g, const void* ws, const float* wp, const float* bias, float* out, int act,
-                         float slope, hipStream_t st) {
+                         float slope, hipStream_t st, int ksplit) {
   if (g.npix <= 0) return MUVO_OK;
+  if (ksplit > 1) return bf3_launch<64, 128, 1, 4, 4, 2>(g, ws, wp, nullptr, out, MUVO_ACT_NONE, 0.f, st, ksplit);
   // eight-wave tiles run the ping-pong schedule (three LDS stages); MUVO_BF3_VARIANT=2 selects the in-phase two-stage
   // schedule for comparison.  64-row tiles have four waves (one per SIMD) and keep the two-stage schedule.
   static const int variant = getenv("MUVO_BF3_VARIANT") ? atoi(getenv("MUVO_BF3_VARIANT")) : 0;   // tuning switch

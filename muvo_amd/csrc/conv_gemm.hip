@@ -431,7 +431,9 @@ static bool bf3_wants_phase(double gflop_phase, int C, double pix_phase) {
   if (!bf3_default_policy()) return gflop_phase >= bf3_min_gflop();
   static const double pg = getenv("MUVO_BF16X3_POLICY_GFLOP") ? atof(getenv("MUVO_BF16X3_POLICY_GFLOP")) : 0.1;
   static const double pp = getenv("MUVO_BF16X3_POLICY_PIXELS") ? atof(getenv("MUVO_BF16X3_POLICY_PIXELS")) : 256.0;
-  return gflop_phase * t_nphase >= pg && pix_phase * t_nphase >= pp && C >= 16;
+  // (few result pixels are fine when the reduction is long: the bf16x3 kernel then splits K, bf3_fwd_ksplit)
+  static const int long_c = getenv("MUVO_BF16X3_POLICY_LONG_C") ? atoi(getenv("MUVO_BF16X3_POLICY_LONG_C")) : 128;
+  return gflop_phase * t_nphase >= pg && (pix_phase * t_nphase >= pp || C >= long_c) && C >= 16;
 }
 
 static thread_local int t_force_family = 0;   // +1 / -1: make this phase bf16x3 / fp32 regardless of its own size (see below)
@@ -663,7 +665,8 @@ static void launch_fwd_run(const ConvPhase& g, const float* in, const float* wp,
 
 // split-K factor of a fp32 phase: only for small grids with a long reduction
 static int phase_ksplit(const ConvPhase& g) {
-  if (g.bf3 || g.npix <= 0) return 1;
+  if (g.npix <= 0) return 1;
+  if (g.bf3) return bf3_fwd_ksplit(g);
   const int bm = g.M > 64 ? 128 : (g.M > 32 ? 64 : 32);
   const long blocks = (long)cdiv(g.npix, 128) * cdiv(g.M, bm);
   const int nk = g.Kp / 16;
@@ -678,7 +681,7 @@ static int phase_ksplit(const ConvPhase& g) {
 static int launch_fwd_phase(const ConvPhase& g, const float* in, const float* wp, const float* bias, float* out,
                             int act, float slope, hipStream_t st, const void* ws, int ksplit) {
   if (g.npix <= 0) return MUVO_OK;
-  if (g.bf3) return bf3_launch_fwd_phase(g, ws, wp, bias, out, act, slope, st);
+  if (g.bf3) return bf3_launch_fwd_phase(g, ws, wp, bias, out, act, slope, st, ksplit);
   if (g.M > 64) launch_fwd_run<128, 128, 2, 2>(g, in, wp, bias, out, act, slope, st, ksplit);
   else if (g.M > 32) launch_fwd_run<64, 128, 2, 2>(g, in, wp, bias, out, act, slope, st, ksplit);
   else launch_fwd_run<32, 128, 1, 4>(g, in, wp, bias, out, act, slope, st, ksplit);

@@ -78,7 +78,7 @@ __device__ __forceinline__ void conv_tile_store(const ConvPhase& g, const V (&ac
       const size_t obase = (size_t)nn * g.out_sN +
                            ((size_t)(jz * g.os[0] + g.mop[grp][0]) * g.OH + (jy * g.os[1] + g.mop[grp][1])) * g.OW +
                            (jx * g.os[2] + g.mop[grp][2]);
-      if (VEC4 && g.out_sC == 1) {   // (uniform)
+      if (VEC4 && g.out_sC == 1 && ksplit <= 1) {   // (uniform)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int m = mo + 8 * q + 4 * (lane >> 5);

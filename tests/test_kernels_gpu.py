@@ -54,6 +54,9 @@ CONV_CASES = [
     # split-K path of the fp32 kernel (tiny pixel grid, long reduction) incl. the finishing bias+activation pass
     (2, False, 256, 64, 3, 1, 1, 0, (6, 7), True, 3),
     (2, True, 160, 96, 6, 2, 2, 0, (3, 4), True, 3),
+    # few result pixels, long reduction (ResNet stage 4 at 5 x 13): split-K on both kernel families (bf16x3: bf3_fwd_ksplit)
+    (2, False, 512, 512, 3, 1, 1, 0, (5, 13), True, 3),
+    (2, True, 384, 256, 5, 2, 2, 1, (4, 6), True, 0),
     # decoder heads (conv_pw.hip: float4 VALU kernels), Cout <= 4, spatial size % 4 == 0 and >= 1024
     (3, False, 8, 2, 1, 1, 0, 0, (16, 16, 8), True, 0),
     (3, False, 32, 2, 1, 1, 0, 0, (12, 12, 8), True, 0),
