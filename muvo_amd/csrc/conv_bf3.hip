@@ -919,23 +919,42 @@ nchw_split_nhwc_v4_kernel(const float* __restrict__ in, uint4* __restrict__ out_
   const float* yn = yact ? yact + (size_t)n * C * S : nullptr;
   const long s = s0 + 4 * lane;
   const bool sin = s < S;                // S % 4 == 0: the four pixels are inside or outside together
+  // 16 (32 with the activation output) UNCONDITIONAL 16-byte loads per lane, clamped to a valid address and masked
+  // afterwards: behind `if (sin && c < C)` every load sat in its own basic block with its own wait
+  const long sc = sin ? s : s0;
   f32x4 v[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int c = c0 + 2 * (w * 8 + (r >> 1)) + (r & 1);
-    v[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (sin && c < C) v[r] = *(const f32x4*)(inn + (size_t)c * S + s);
+    v[r] = *(const f32x4*)(inn + (size_t)(c < C ? c : C - 1) * S + sc);
   }
   if (yn) {
+    f32x4 y[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int c = c0 + 2 * (w * 8 + (r >> 1)) + (r & 1);
-      if (sin && c < C) {
-        const f32x4 y = *(const f32x4*)(yn + (size_t)c * S + s);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[r][j] *= act_grad_from_out(y[j], act, slope);
-      }
+      y[r] = *(const f32x4*)(yn + (size_t)(c < C ? c : C - 1) * S + sc);
     }
+    // derivative through the activation output, one instance of the loop per activation (no switch per element)
+    switch (act) {
+#define SPLIT_ACT_CASE(A)                                                                   \
+      case A:                                                                               \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r)                                      \
+          _Pragma("unroll") for (int j = 0; j < 4; ++j) v[r][j] *= act_grad_from_out(y[r][j], A, slope); \
+        break;
+      SPLIT_ACT_CASE(MUVO_ACT_RELU)
+      SPLIT_ACT_CASE(MUVO_ACT_LEAKY)
+      SPLIT_ACT_CASE(MUVO_ACT_ELU)
+      SPLIT_ACT_CASE(MUVO_ACT_TANH)
+      SPLIT_ACT_CASE(MUVO_ACT_SIGMOID)
+#undef SPLIT_ACT_CASE
+      default: break;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int c = c0 + 2 * (w * 8 + (r >> 1)) + (r & 1);
+    if (!(sin && c < C)) v[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
@@ -966,11 +985,22 @@ nchw_split_nhwc_v4_kernel(const float* __restrict__ in, uint4* __restrict__ out_
     }
   }
   if (dbias) {   // lanes of a wave = 256 pixels of the same 16 channels
+    // lane reduction through an LDS transpose (the staging tile is free now): 16 wave_sum chains of six dependent
+    // cross-lane shuffles each took ~3 us at the end of a ~10-us workgroup
+    __syncthreads();
+    float* red = (float*)sp_lds + w * (64 * 17);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int c = c0 + 2 * (w * 8 + (r >> 1)) + (r & 1);
-      const float sum = wave_sum(v[r][0] + v[r][1] + v[r][2] + v[r][3]);
-      if (lane == 0 && c < C) atomicAdd(dbias + (size_t)(blockIdx.x % BIAS_REPLICAS) * Cp + c, sum);
+    for (int r = 0; r < 16; ++r) red[lane * 17 + r] = (v[r][0] + v[r][1]) + (v[r][2] + v[r][3]);
+    __syncthreads();
+    if (lane < 16) {
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+      for (int l = 0; l < 64; l += 4) {
+        s0 += red[l * 17 + lane]; s1 += red[(l + 1) * 17 + lane];
+        s2 += red[(l + 2) * 17 + lane]; s3 += red[(l + 3) * 17 + lane];
+      }
+      const int c = c0 + 2 * (w * 8 + (lane >> 1)) + (lane & 1);
+      if (c < C) atomicAdd(dbias + (size_t)(blockIdx.x % BIAS_REPLICAS) * Cp + c, (s0 + s1) + (s2 + s3));
     }
   }
   if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0)
@@ -1078,15 +1108,18 @@ __global__ void __launch_bounds__(256) pack_table_kernel(const PackItem* __restr
         t = (k >> 5) - q * uT;
         c0 = q * 32 + (k & 31);
       }
+      // eight UNCONDITIONAL loads (clamped row / tap / channel, masked afterwards): behind `if (c0 + e < C)` each load had its
+      // own basic block and wait, eight dependent round trips per unit
       float v[8];
+      const bool okrow = t < uT && m < (unsigned)M;
+      const unsigned mm = okrow ? m : 0u, tt = okrow ? t : 0u;
+      const unsigned grp = nmerge > 1 ? mm / uMsub : 0u, co = mm - grp * uMsub;
+      const float* src = w + (size_t)co * wsm + s_tw[grp * MAX_TAPS + tt];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = 0.f;
-      if (t < uT && m < (unsigned)M) {
-        const unsigned grp = nmerge > 1 ? m / uMsub : 0u, co = m - grp * uMsub;
-        const float* src = w + (size_t)co * wsm + s_tw[grp * MAX_TAPS + t];
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (c0 + e < (unsigned)C) v[e] = src[(size_t)(c0 + e) * wsc];
+      for (int e = 0; e < 8; ++e) {
+        const bool ok = okrow && c0 + e < (unsigned)C;
+        const float x = src[(size_t)(ok ? c0 + e : 0u) * wsc];
+        v[e] = ok ? x : 0.f;
       }
       uint4 h, l;
       split2(v[0], v[1], h.x, l.x);
@@ -1102,12 +1135,11 @@ __global__ void __launch_bounds__(256) pack_table_kernel(const PackItem* __restr
     for (unsigned idx = first; idx < total; idx += stride) {
       const unsigned k = idx / uMp, m = idx - k * uMp;
       const unsigned t = k / uCp, c = k - t * uCp;
-      float v = 0.f;
-      if (t < uT && c < (unsigned)C && m < (unsigned)M) {
-        const unsigned grp = nmerge > 1 ? m / uMsub : 0u, co = m - grp * uMsub;
-        v = w[(size_t)co * wsm + (size_t)c * wsc + s_tw[grp * MAX_TAPS + t]];
-      }
-      dst[wp_off + idx] = v;
+      const bool ok = t < uT && c < (unsigned)C && m < (unsigned)M;
+      const unsigned mm = ok ? m : 0u;
+      const unsigned grp = nmerge > 1 ? mm / uMsub : 0u, co = mm - grp * uMsub;
+      const float x = w[(size_t)co * wsm + (size_t)(ok ? c : 0u) * wsc + s_tw[grp * MAX_TAPS + (ok ? t : 0u)]];
+      dst[wp_off + idx] = ok ? x : 0.f;
     }
   }
 }
@@ -1153,8 +1185,8 @@ int bf3_split_input(const float* x, void* ws, int N, int C, long S, hipStream_t 
       return MUVO_ERR_HIP;
     }
   }
-  static const int split_v4 = getenv("MUVO_SPLIT_V4") ? atoi(getenv("MUVO_SPLIT_V4")) : 1;
-  if (split_v4 && !yact && S % 4 == 0 && S >= 1024 && ((uintptr_t)x & 15) == 0) {   // 5.5 vs 4.5 TB/s (profiles/r02b_hbm.txt); the fused act'(y) form is faster on the 4-byte kernel
+  static const int split_v4 = getenv("MUVO_SPLIT_V4") ? atoi(getenv("MUVO_SPLIT_V4")) : 2;   // 2: also the fused dy * act'(y) form, 1: plain splits only, 0: 4-byte kernel everywhere
+  if (split_v4 && (!yact || split_v4 >= 2) && S % 4 == 0 && S >= 1024 && (((uintptr_t)x | (uintptr_t)yact) & 15) == 0) {   // 5.5 vs 4.5 TB/s (profiles/r02b_hbm.txt)
     static bool attr_set = false;
     constexpr int lds = 2 * 32 * SPLIT2_PS * 4;
     if (!attr_set) {

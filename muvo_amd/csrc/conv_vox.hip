@@ -569,6 +569,9 @@ vox_bf3_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* __re
 // ================================================================================================
 // CI = 16: MFMA columns = 16 input channels of one tap.  CI = 8: columns = 8 input channels x two (dx, dy) combinations
 // (column j: channel j & 7, combination 2 * pair + (j >> 3)), 5 pairs x 3 dz = 15 accumulator tiles.
+#ifndef VOX_WGRAD_BUFLOAD16
+#define VOX_WGRAD_BUFLOAD16 0      // A/B: unconditional buffer loads in the 16-input-channel variant too
+#endif
 template <int Z, int CI>
 __global__ void __launch_bounds__(512)
 vox_bf3_wgrad_kernel(const VoxArgs a, const float* __restrict__ x, const float* __restrict__ dz, float* __restrict__ dw,
@@ -636,7 +639,7 @@ vox_bf3_wgrad_kernel(const VoxArgs a, const float* __restrict__ x, const float* 
       const int gy = y0 - 1 + rr;
       const bool ok = t < XT && px >= 0 && px < a.X && gy >= 0 && gy < a.Y;
       const long eoff = (long)ci * a.XYZ + (long)px * YZ + (long)gy * Z + z8 * 8;
-      if constexpr (CI == 8) load8b(rs_x, ok ? (unsigned)(eoff * 4) : OOB, xst[k]);     // channels past Cin: range check
+      if constexpr (CI == 8 || VOX_WGRAD_BUFLOAD16) load8b(rs_x, ok ? (unsigned)(eoff * 4) : OOB, xst[k]);     // channels past Cin: range check
       else load8(xb + eoff, ok && ci0 + ci < a.Cin, xst[k]);
     }
   };
@@ -657,7 +660,7 @@ vox_bf3_wgrad_kernel(const VoxArgs a, const float* __restrict__ x, const float* 
       const int gy = y0 + r;
       const bool ok = t < DT && px < xe && gy < a.Y && co < a.Cout;
       const long eoff = (long)co * a.XYZ + (long)px * YZ + (long)gy * Z + z8 * 8;
-      if constexpr (CI == 8) load8b(rs_d, ok ? (unsigned)(eoff * 4) : OOB, dst[k]);
+      if constexpr (CI == 8 || VOX_WGRAD_BUFLOAD16) load8b(rs_d, ok ? (unsigned)(eoff * 4) : OOB, dst[k]);
       else load8(db + eoff, ok, dst[k]);
     }
   };

@@ -449,6 +449,42 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   }
 }
 
+// float4 form, two float4 per lane and array, every load before the first store, one pass per thread (see the memory-ordering
+// notes in DESIGN.md section 7: a grid-stride loop makes each iteration's loads wait for the previous iteration's stores)
+__global__ void __launch_bounds__(256) adamw_vec_kernel(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m,
+                                                        float4* __restrict__ v, long n4, float lr, float b1, float b2, float eps,
+                                                        float wd, float bc1, float bc2_sqrt, float grad_scale) {
+  const long i0 = blockIdx.x * 512L + threadIdx.x;
+  float4 pv[2], gv[2], mv[2], vv[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const long i = i0 + 256 * u, ic = i < n4 ? i : n4 - 1;
+    pv[u] = p[ic]; gv[u] = g[ic]; mv[u] = m[ic]; vv[u] = v[ic];
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const long i = i0 + 256 * u;
+    float pe[4] = {pv[u].x, pv[u].y, pv[u].z, pv[u].w}, me[4] = {mv[u].x, mv[u].y, mv[u].z, mv[u].w}, ve[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
+    const float ge[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {              // same operation order as adamw_kernel
+      const float gi = ge[e] * grad_scale;
+      float pi = pe[e] * (1.f - lr * wd);
+      const float mi = b1 * me[e] + (1.f - b1) * gi;
+      const float vi = b2 * ve[e] + (1.f - b2) * gi * gi;
+      me[e] = mi;
+      ve[e] = vi;
+      const float denom = sqrtf(vi) / bc2_sqrt + eps;
+      pi -= (lr / bc1) * (mi / denom);
+      pe[e] = pi;
+    }
+    if (i < n4) {
+      m[i] = make_float4(me[0], me[1], me[2], me[3]);
+      v[i] = make_float4(ve[0], ve[1], ve[2], ve[3]);
+      p[i] = make_float4(pe[0], pe[1], pe[2], pe[3]);
+    }
+  }
+}
 
 // ---- per-pixel weighted cross entropy of SegmentationLoss (muvo/losses.py:22-37: F.cross_entropy(reduction='none',
 // weight=w)); logits (N, C, HW), target (N, HW) bytes, loss (N, HW).  loss = -w[t] log_softmax(x)[t]
@@ -601,8 +637,12 @@ int muvo_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, flo
   if (n == 0) return MUVO_OK;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(n)), dim3(256), 0, ST, p, g, m, v, (long)n, lr, beta1, beta2, eps, weight_decay,
-                     (float)bc1, (float)sqrt(bc2), grad_scale);
+  if (n % 4 == 0 && n >= 4096 && n / 4 / 512 < (1l << 31) && (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0)
+    hipLaunchKernelGGL(adamw_vec_kernel, dim3((unsigned)cdiv(n / 4, 512)), dim3(256), 0, ST, (float4*)p, (const float4*)g, (float4*)m,
+                       (float4*)v, (long)(n / 4), lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+  else
+    hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(n)), dim3(256), 0, ST, p, g, m, v, (long)n, lr, beta1, beta2, eps, weight_decay,
+                       (float)bc1, (float)sqrt(bc2), grad_scale);
   MUVO_CHECK_LAUNCH("adamw_step");
   return MUVO_OK;
 }
