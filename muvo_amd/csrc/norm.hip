@@ -21,17 +21,27 @@ __global__ void __launch_bounds__(256) moments_kernel(const float* __restrict__ 
   double ds = 0.0, dq = 0.0;
   int k = 0;
   if (vec4) {
-    // S % 4 == 0, chunk bounds multiples of 4, 16-byte aligned base: one float4 per lane and step, (segment, offset) advanced
-    // incrementally - no 64-bit division per element
-    long i = i0 + 4L * threadIdx.x;
-    long o = i / S, r = i - o * S;
-    for (; i < i1; i += 1024) {
-      const float4 v = *reinterpret_cast<const float4*>(x + o * outer_stride + (long)g * S + r);
-      s += (v.x + v.y) + (v.z + v.w);
-      q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-      if (++k == 16) { ds += s; dq += q; s = 0.f; q = 0.f; k = 0; }
-      r += 1024;
-      while (r >= S) { r -= S; ++o; }
+    // S % 4 == 0, chunk bounds multiples of 4, 16-byte aligned base: one float4 per lane and step.  Four steps per pass with
+    // all four loads issued before the first is consumed (clamped address, masked value): the incremental one-load-per-
+    // iteration loop paid one memory round trip per 16 bytes and lane
+    for (long base = i0 + 4L * threadIdx.x; base < i1; base += 4096) {
+      float4 v[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long i = base + 1024 * u;
+        ok[u] = i < i1;
+        const long ic = ok[u] ? i : i0;
+        const long o = ic / S, r = ic - o * S;
+        v[u] = *reinterpret_cast<const float4*>(x + o * outer_stride + (long)g * S + r);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (!ok[u]) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+        q += (v[u].x * v[u].x + v[u].y * v[u].y) + (v[u].z * v[u].z + v[u].w * v[u].w);
+      }
+      if (++k == 4) { ds += s; dq += q; s = 0.f; q = 0.f; k = 0; }
     }
   } else {
     for (long i = i0 + threadIdx.x; i < i1; i += 256) {
@@ -74,28 +84,42 @@ __global__ void __launch_bounds__(256) bwd_moments_kernel(const float* __restric
   float s = 0.f, q = 0.f;
   double ds = 0.0, dq = 0.0;
   int k = 0;
-  if (vec4) {    // as in moments_kernel: float4 per lane, no per-element division
-    long i = i0 + 4L * threadIdx.x;
-    long o = i / S, r = i - o * S;
-    for (; i < i1; i += 1024) {
-      const long idx = o * outer_stride + (long)g * S + r;
-      const float4 xv = *reinterpret_cast<const float4*>(x + o * x_outer_stride + (long)g * S + r);
-      const float4 dv = *reinterpret_cast<const float4*>(dy + idx);
-      float4 yv = make_float4(1.f, 1.f, 1.f, 1.f);
-      if (mask_mode == 1) yv = *reinterpret_cast<const float4*>(y + idx);
-      const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w};
+  if (vec4) {    // as in moments_kernel: float4 per lane, four steps per pass with all loads in flight together
+    for (long base = i0 + 4L * threadIdx.x; base < i1; base += 4096) {
+      float4 xv[4], dv[4], yv[4];
+      long yoff[4];
+      bool ok[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float xh = (xs[e] - mu) * rs;
-        float d = dd[e];
-        if (mask_mode == 1) d = ys[e] > 0.f ? d : 0.f;
-        else if (mask_mode == 2) d = (xs[e] * (rs * ga) + (be - mu * (rs * ga))) > 0.f ? d : 0.f;   /* the forward's own expression: same sign bit */
-        s += d;
-        q += d * xh;
+      for (int u = 0; u < 4; ++u) {
+        const long i = base + 1024 * u;
+        ok[u] = i < i1;
+        const long ic = ok[u] ? i : i0;
+        const long o = ic / S, r = ic - o * S;
+        const long idx = o * outer_stride + (long)g * S + r;
+        xv[u] = *reinterpret_cast<const float4*>(x + o * x_outer_stride + (long)g * S + r);
+        dv[u] = *reinterpret_cast<const float4*>(dy + idx);
+        yv[u] = make_float4(1.f, 1.f, 1.f, 1.f);
+        yoff[u] = idx;
       }
-      if (++k == 16) { ds += s; dq += q; s = 0.f; q = 0.f; k = 0; }
-      r += 1024;
-      while (r >= S) { r -= S; ++o; }
+      if (mask_mode == 1) {      // (uniform) one block with all four loads
+#pragma unroll
+        for (int u = 0; u < 4; ++u) yv[u] = *reinterpret_cast<const float4*>(y + yoff[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w}, dd[4] = {dv[u].x, dv[u].y, dv[u].z, dv[u].w};
+        const float ys[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xh = (xs[e] - mu) * rs;
+          float d = ok[u] ? dd[e] : 0.f;
+          if (mask_mode == 1) d = ys[e] > 0.f ? d : 0.f;
+          else if (mask_mode == 2) d = (xs[e] * (rs * ga) + (be - mu * (rs * ga))) > 0.f ? d : 0.f;   /* the forward's own expression: same sign bit */
+          s += d;
+          q += d * xh;
+        }
+      }
+      if (++k == 4) { ds += s; dq += q; s = 0.f; q = 0.f; k = 0; }
     }
   } else {
     for (long i = i0 + threadIdx.x; i < i1; i += 256) {
