@@ -119,6 +119,15 @@ int muvo_conv_forward_moments(const muvo_conv_desc* d, const float* x, const flo
                               float slope, double* moments, void* stream);
 int muvo_adain_fwd_moments(const float* x, const float* style, float* y, float* save_mean, float* save_rstd, double* moments,
                            int N, int C, int64_t S, float eps, void* stream);
+/* Grouped Linear: L <= 16 layers y_l = x W_l^T + b_l on the same input x (M <= 24 rows, K features, K % 4 == 0) in one launch
+ * per pass — the style projections of all AdaptiveInstanceNorm layers of a decoder (muvo/models/common.py:205-246,227-246:
+ * `self.latent_affine(style)` per layer on the same latent).  W[l]: (N[l], K) row-major, b[l]: (N[l]) or NULL, Y[l]: (M, N[l]).
+ * bwd: dx (M, K) is OVERWRITTEN with sum_l dY_l W_l (NULL: skipped); dW[l] / db[l] are accumulated (NULL entries / NULL
+ * arrays: skipped).  The pointer arrays are host arrays. */
+int muvo_grouped_linear_fwd(const float* x, int M, int K, int L, const float* const* W, const float* const* b, float* const* Y,
+                            const int* N, void* stream);
+int muvo_grouped_linear_bwd(const float* x, int M, int K, int L, const float* const* W, float* const* dY, float* dx,
+                            float* const* dW, float* const* db, const int* N, void* stream);
 /* Clock probe of the dominant kernel class (eight-wave bf16x3 implicit-GEMM tiles): shader clock (MHz) and wall time per
  * K step (32 deep, 24 MFMA 32x32x16 per wave) that workgroup 0 of the most recent launch measured over its K loop.  The
  * kernels run power-limited well below the 2.4 GHz the dense MFMA peak is quoted at; bench.py reports both. */

@@ -372,6 +372,246 @@ __global__ void __launch_bounds__(256) gemm_skinny_ncontig_kernel(const GemmArgs
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Grouped Linear: up to GL_MAX layers y_l = x W_l^T + b_l that read the SAME few-row input x (M <= 24 rows, K features) —
+// the AdaIN style projections of a decoder (muvo/models/common.py:205-246: every AdaptiveInstanceNorm owns a
+// Linear(latent, 2 C) applied to the same latent).  Per layer these are tiny GEMMs (N_l = 16 .. 1024 columns): seven to nine
+// launches per decoder and pass, each bound by launch latency and a serial tail.  One launch per decoder and pass instead:
+//   forward   workgroup = four columns of one layer, the k-vector kernel's scheme (eight waves split K, LDS-transpose reduce);
+//   dgrad     dx = sum_l dy_l W_l: workgroup = 64 columns of dx x a 128-row slab of one W_l, atomics into the zeroed dx;
+//   wgrad     dW_l += dy_l^T x, db_l += column sums of dy_l: one float4 of a weight row per lane (M FMAs each).
+// The layer table travels by value in the kernel arguments.
+// ------------------------------------------------------------------------------------------------
+#define GL_MAX 16
+struct GroupedLinearArgs {
+  const float* W[GL_MAX];      // [N_l][K] row-major (nn.Linear.weight)
+  const float* b[GL_MAX];      // [N_l] or null
+  float* Y[GL_MAX];            // forward: [M][N_l] outputs; dgrad / wgrad: dy_l (read)
+  float* dW[GL_MAX];           // wgrad: gradient buffers (accumulated), or null
+  float* db[GL_MAX];
+  int N[GL_MAX];
+  int blk0[GL_MAX + 1];        // first workgroup of each layer (exclusive prefix of the per-layer workgroup counts)
+  int L, M, K;
+};
+
+template <int RM>
+__global__ void __launch_bounds__(512, 2) grouped_linear_fwd_kernel(const GroupedLinearArgs a, const float* __restrict__ x) {
+  __shared__ float red[8][RM][4];
+  __shared__ float tr[8][64 * 33];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int l = 0;
+  while (l + 1 < a.L && (int)blockIdx.x >= a.blk0[l + 1]) ++l;
+  const int n0 = ((int)blockIdx.x - a.blk0[l]) * 4, N = a.N[l], K = a.K, M = a.M;
+  const float* __restrict__ B = a.W[l];
+  float acc[RM][4];
+#pragma unroll
+  for (int r = 0; r < RM; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[r][c] = 0.f;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int mlast = M - 1;
+  for (int k = (wave * 64 + lane) * 4; k < K; k += 4096) {
+    const bool has2 = k + 2048 < K;
+    const int k2 = has2 ? k + 2048 : k;
+    float4 w[2][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float* bp = B + (long)(n0 + c < N ? n0 + c : n0) * K;
+      w[0][c] = *reinterpret_cast<const float4*>(bp + k);
+      const float4 t = *reinterpret_cast<const float4*>(bp + k2);
+      w[1][c] = has2 ? t : zero4;
+    }
+#pragma unroll
+    for (int rg = 0; rg < RM; rg += 4) {
+      float4 a0[4], a1[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float* ar = x + (long)(rg + q < mlast ? rg + q : mlast) * K;
+        a0[q] = *reinterpret_cast<const float4*>(ar + k);
+        a1[q] = *reinterpret_cast<const float4*>(ar + k2);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          acc[rg + q][c] += a0[q].x * w[0][c].x + a0[q].y * w[0][c].y + a0[q].z * w[0][c].z + a0[q].w * w[0][c].w +
+                            a1[q].x * w[1][c].x + a1[q].y * w[1][c].y + a1[q].z * w[1][c].z + a1[q].w * w[1][c].w;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  constexpr int NV = RM * 4, CH = NV < 32 ? NV : 32;
+  float* trw = tr[wave];
+#pragma unroll
+  for (int c0 = 0; c0 < NV; c0 += CH) {
+    if (c0) __syncthreads();
+#pragma unroll
+    for (int v = 0; v < CH; ++v) trw[lane * 33 + v] = acc[(c0 + v) >> 2][(c0 + v) & 3];
+    __syncthreads();
+    if (lane < CH) {
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+      for (int q = 0; q < 64; q += 4) {
+        s0 += trw[q * 33 + lane]; s1 += trw[(q + 1) * 33 + lane];
+        s2 += trw[(q + 2) * 33 + lane]; s3 += trw[(q + 3) * 33 + lane];
+      }
+      red[wave][(c0 + lane) >> 2][(c0 + lane) & 3] = (s0 + s1) + (s2 + s3);
+    }
+  }
+  __syncthreads();
+  float* __restrict__ Y = a.Y[l];
+  const float* __restrict__ bias = a.b[l];
+  for (int i = threadIdx.x; i < RM * 4; i += 512) {
+    const int r = i >> 2, c = i & 3;
+    if (r < M && n0 + c < N) {
+      float sum = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) sum += red[w8][r][c];
+      Y[(long)r * N + n0 + c] = sum + (bias ? bias[n0 + c] : 0.f);
+    }
+  }
+}
+
+// dx[m][k] += sum over a 128-row slab of W_l:  dy_l[m][n] * W_l[n][k];  grid.x = K / 64 column blocks, grid.y = slabs
+__global__ void __launch_bounds__(256) grouped_linear_dgrad_kernel(const GroupedLinearArgs a, float* __restrict__ dx) {
+  constexpr int RM = 24, NC = 128;
+  __shared__ float red[4][RM][64];
+  __shared__ __attribute__((aligned(16))) float sA[RM][NC];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int l = 0;
+  while (l + 1 < a.L && (int)blockIdx.y >= a.blk0[l + 1]) ++l;
+  const int nb = ((int)blockIdx.y - a.blk0[l]) * NC, N = a.N[l], K = a.K, M = a.M;
+  const float* __restrict__ W = a.W[l];
+  const float* __restrict__ dy = a.Y[l];
+  const int k = blockIdx.x * 64 + lane;
+  const int kc = k < K ? k : K - 1;
+  for (int i = threadIdx.x; i < RM * NC; i += 256) {          // dy slab -> LDS (zero past M / N)
+    const int r = i / NC, nn = i - r * NC;
+    const bool ok = r < M && nb + nn < N;
+    const float v = dy[(long)(ok ? r : 0) * N + (ok ? nb + nn : 0)];
+    sA[r][nn] = ok ? v : 0.f;
+  }
+  __syncthreads();
+  float acc[RM];
+#pragma unroll
+  for (int r = 0; r < RM; ++r) acc[r] = 0.f;
+#pragma unroll 2
+  for (int nn = wave * 32; nn < wave * 32 + 32; nn += 4) {
+    float w[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int n = nb + nn + u;
+      w[u] = W[(long)(n < N ? n : N - 1) * K + kc];             // rows past N meet the zeros in sA
+    }
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+      const float4 d = *reinterpret_cast<const float4*>(&sA[r][nn]);
+      acc[r] += (d.x * w[0] + d.y * w[1]) + (d.z * w[2] + d.w * w[3]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RM; ++r) red[wave][r][lane] = acc[r];
+  __syncthreads();
+  for (int r = wave; r < RM; r += 4)
+    if (r < M && k < K) atomicAdd(dx + (long)r * K + k, red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + red[3][r][lane]);
+}
+
+// dW_l[n][k .. k+3] += sum_m dy_l[m][n] * x[m][k .. k+3]  (one float4 per lane, 16 weight rows per workgroup pass);
+// db_l[n] += sum_m dy_l[m][n] by the lanes of the first column block.  grid.x = K / 256 blocks of 64 float4, grid.y = row groups
+__global__ void __launch_bounds__(256) grouped_linear_wgrad_kernel(const GroupedLinearArgs a, const float* __restrict__ x) {
+  constexpr int RM = 24;
+  int l = 0;
+  while (l + 1 < a.L && (int)blockIdx.y >= a.blk0[l + 1]) ++l;
+  const int N = a.N[l], K = a.K, M = a.M;
+  if (a.dW[l] == nullptr) return;                              // (uniform) frozen layer
+  const float* __restrict__ dy = a.Y[l];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k4 = blockIdx.x * 64 + lane;                       // float4 index inside a row
+  const bool kok = k4 * 4 < K;
+  float4 xv[RM];
+#pragma unroll
+  for (int m = 0; m < RM; ++m) xv[m] = reinterpret_cast<const float4*>(x + (long)(m < M ? m : M - 1) * K)[kok ? k4 : 0];
+  const int n_base = ((int)blockIdx.y - a.blk0[l]) * 16;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int n = n_base + wave * 4 + q;
+    if (n >= N) continue;                                      // (wave-uniform)
+    float d[RM];
+#pragma unroll
+    for (int m = 0; m < RM; ++m) d[m] = m < M ? dy[(long)m * N + n] : 0.f;     // wave-uniform addresses
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    float sb = 0.f;
+#pragma unroll
+    for (int m = 0; m < RM; ++m) {
+      g.x += d[m] * xv[m].x; g.y += d[m] * xv[m].y; g.z += d[m] * xv[m].z; g.w += d[m] * xv[m].w;
+      sb += d[m];
+    }
+    if (kok) {
+      float4* dst = reinterpret_cast<float4*>(a.dW[l] + (long)n * K) + k4;
+      float4 o = *dst;
+      o.x += g.x; o.y += g.y; o.z += g.z; o.w += g.w;
+      *dst = o;
+    }
+    if (blockIdx.x == 0 && lane == 0 && a.db[l] != nullptr) a.db[l][n] += sb;
+  }
+}
+
+static int grouped_fill(GroupedLinearArgs& a, int L, int M, int K, const float* const* W, const float* const* b, float* const* Y,
+                        float* const* dW, float* const* db, const int* N, int cols_per_block) {
+  MUVO_CHECK_ARG(L > 0 && L <= GL_MAX, "grouped_linear: %d layers (max %d)", L, GL_MAX);
+  MUVO_CHECK_ARG(M > 0 && M <= 24 && K >= 64 && K % 4 == 0, "grouped_linear: M=%d K=%d unsupported (M <= 24, K %% 4 == 0)", M, K);
+  a.L = L; a.M = M; a.K = K;
+  int blk = 0;
+  for (int l = 0; l < L; ++l) {
+    MUVO_CHECK_ARG(W[l] && Y[l] && N[l] > 0 && (((uintptr_t)W[l]) & 15) == 0, "grouped_linear: bad layer %d", l);
+    a.W[l] = W[l]; a.b[l] = b ? b[l] : nullptr; a.Y[l] = Y[l];
+    a.dW[l] = dW ? dW[l] : nullptr; a.db[l] = db ? db[l] : nullptr;
+    a.N[l] = N[l];
+    a.blk0[l] = blk;
+    blk += cdiv(N[l], cols_per_block);
+  }
+  a.blk0[L] = blk;
+  return MUVO_OK;
+}
+
+extern "C" int muvo_grouped_linear_fwd(const float* x, int M, int K, int L, const float* const* W, const float* const* b,
+                                       float* const* Y, const int* N, void* stream) {
+  MUVO_CHECK_ARG(x && W && Y && N && (((uintptr_t)x) & 15) == 0, "grouped_linear_fwd: bad args");
+  GroupedLinearArgs a;
+  int rc = grouped_fill(a, L, M, K, W, b, Y, nullptr, nullptr, N, 4);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (M <= 8) hipLaunchKernelGGL((grouped_linear_fwd_kernel<8>), dim3(a.blk0[L]), dim3(512), 0, st, a, x);
+  else hipLaunchKernelGGL((grouped_linear_fwd_kernel<24>), dim3(a.blk0[L]), dim3(512), 0, st, a, x);
+  MUVO_CHECK_LAUNCH("grouped_linear_fwd");
+  return MUVO_OK;
+}
+
+// dx (M x K) is OVERWRITTEN with sum_l dy_l W_l;  dW_l / db_l (may be null per layer) are accumulated
+extern "C" int muvo_grouped_linear_bwd(const float* x, int M, int K, int L, const float* const* W, float* const* dY, float* dx,
+                                       float* const* dW, float* const* db, const int* N, void* stream) {
+  MUVO_CHECK_ARG(x && W && dY && N && (((uintptr_t)x) & 15) == 0, "grouped_linear_bwd: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  GroupedLinearArgs a;
+  if (dx) {
+    int rc = grouped_fill(a, L, M, K, W, nullptr, dY, nullptr, nullptr, N, 128);
+    if (rc) return rc;
+    if (hipMemsetAsync(dx, 0, sizeof(float) * (size_t)M * K, st) != hipSuccess) {
+      muvo_set_error("grouped_linear_bwd: memset failed");
+      return MUVO_ERR_HIP;
+    }
+    hipLaunchKernelGGL(grouped_linear_dgrad_kernel, dim3(cdiv(K, 64), a.blk0[L]), dim3(256), 0, st, a, dx);
+  }
+  if (dW) {
+    int rc = grouped_fill(a, L, M, K, W, nullptr, dY, dW, db, N, 16);
+    if (rc) return rc;
+    for (int l = 0; l < L; ++l)
+      MUVO_CHECK_ARG(dW[l] == nullptr || (((uintptr_t)dW[l]) & 15) == 0, "grouped_linear_bwd: unaligned gradient buffer");
+    hipLaunchKernelGGL(grouped_linear_wgrad_kernel, dim3(cdiv(K, 256), a.blk0[L]), dim3(256), 0, st, a, x);
+  }
+  MUVO_CHECK_LAUNCH("grouped_linear_bwd");
+  return MUVO_OK;
+}
+
 template <int BM, int BN, int WM, int WN>
 static void launch_gemm_lay(const GemmArgs& g, const float* A, const float* B, float* C, dim3 grid, hipStream_t st) {
   const int al = (g.sam == 1 && g.sak != 1) ? 0 : (g.sak == 1 ? 1 : 0);

@@ -924,44 +924,68 @@ __global__ void __launch_bounds__(256) add_dropout_ln_bwd_kernel(const float* __
   float ag[MAXV], ab[MAXV];
 #pragma unroll
   for (int k = 0; k < MAXV; ++k) { ag[k] = 0.f; ab[k] = 0.f; }
-  for (int rr = w; rr < rows_per_block; rr += 4) {
-    const int row = r0 + rr;
-    if (row >= rows) break;
-    const float mu = mean[row], rs = rstd[row];
-    float d[MAXV], xh[MAXV];
-    float s1 = 0.f, s2 = 0.f;
-    // unconditional loads (index clamped, value masked): behind `if (e < E)` every k had its own basic block and its own
-    // wait, i.e. MAXV sequential memory round trips per row
-    float gv[MAXV], zv[MAXV], gm[MAXV];
+  float gm[MAXV];
 #pragma unroll
-    for (int k = 0; k < MAXV; ++k) {
-      const int e = lane + 64 * k, ec = e < E ? e : 0;
-      const long idx = (long)row * E + ec;
-      gv[k] = dy[idx];
-      zv[k] = z[idx];
-      gm[k] = gamma[ec];
+  for (int k = 0; k < MAXV; ++k) gm[k] = gamma[lane + 64 * k < E ? lane + 64 * k : 0];
+  // A wave takes its rows four at a time: all loads of the four rows first (unconditional: clamped index, masked value), the
+  // eight row sums reduced in ONE interleaved butterfly, the stores last.  Row by row, every row paid the previous row's
+  // store acknowledgement (loads behind stores wait for them), its own load round trip and two dependent shuffle chains.
+  constexpr int RPW = 4;
+  for (int rr0 = w * RPW; rr0 < rows_per_block; rr0 += 4 * RPW) {
+    float gv[RPW][MAXV], zv[RPW][MAXV], mu[RPW], rs[RPW];
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+      const int row = r0 + rr0 + j, rc = row < rows && rr0 + j < rows_per_block ? row : rows - 1;
+      mu[j] = mean[rc];
+      rs[j] = rstd[rc];
+#pragma unroll
+      for (int k = 0; k < MAXV; ++k) {
+        const int e = lane + 64 * k;
+        const long idx = (long)rc * E + (e < E ? e : 0);
+        gv[j][k] = dy[idx];
+        zv[j][k] = z[idx];
+      }
+    }
+    float s[2 * RPW];
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+      const bool rok = r0 + rr0 + j < rows && rr0 + j < rows_per_block;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < MAXV; ++k) {
+        const bool ok = rok && lane + 64 * k < E;
+        const float g = ok ? gv[j][k] : 0.f;
+        const float xh = ok ? (zv[j][k] - mu[j]) * rs[j] : 0.f;
+        ag[k] += g * xh;
+        ab[k] += g;
+        const float d = g * gm[k];
+        gv[j][k] = d;            // d and xhat replace the loaded values
+        zv[j][k] = xh;
+        s1 += d;
+        s2 += d * xh;
+      }
+      s[2 * j] = s1;
+      s[2 * j + 1] = s2;
     }
 #pragma unroll
-    for (int k = 0; k < MAXV; ++k) {
-      const bool ok = lane + 64 * k < E;
-      const float g = ok ? gv[k] : 0.f;
-      xh[k] = ok ? (zv[k] - mu) * rs : 0.f;
-      ag[k] += g * xh[k];
-      ab[k] += g;
-      d[k] = g * gm[k];
-      s1 += d[k];
-      s2 += d[k] * xh[k];
-    }
-    s1 = wave_sum(s1) / E;
-    s2 = wave_sum(s2) / E;
+    for (int o = 32; o > 0; o >>= 1)
 #pragma unroll
-    for (int k = 0; k < MAXV; ++k) {
-      const int e = lane + 64 * k;
-      if (e < E) {
-        const long idx = (long)row * E + e;
-        const float dz = rs * (d[k] - s1 - xh[k] * s2);
-        dx[idx] = dz;
-        if (da) da[idx] = dz * dropout_scale(seed, (uint64_t)idx, p);
+      for (int q = 0; q < 2 * RPW; ++q) s[q] += __shfl_xor(s[q], o, 64);
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+      const int row = r0 + rr0 + j;
+      if (row < rows && rr0 + j < rows_per_block) {      // (uniform)
+        const float s1 = s[2 * j] / E, s2 = s[2 * j + 1] / E;
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) {
+          const int e = lane + 64 * k;
+          if (e < E) {
+            const long idx = (long)row * E + e;
+            const float dz = rs[j] * (gv[j][k] - s1 - zv[j][k] * s2);
+            dx[idx] = dz;
+            if (da) da[idx] = dz * dropout_scale(seed, (uint64_t)idx, p);
+          }
+        }
       }
     }
   }

@@ -84,6 +84,39 @@ class Decoder(nn.Module):
         return x
 
 
+class StyleBank:
+    """The (scale, bias) styles of ALL AdaptiveInstanceNorm layers of one decoder, computed from the latent in one grouped
+    launch (ops.grouped_linear: every layer's `latent_affine` reads the same latent, common.py:205-246) instead of one tiny
+    GEMM per layer and pass.  Stands in for the latent `w` on its way through the decoder: the norm layers ask it for their
+    style; anything else still finds the latent in `.latent`."""
+
+    def __init__(self, latent, modules, styles):
+        self.latent = latent
+        self.shape = latent.shape
+        self._styles = {id(m): s for m, s in zip(modules, styles)}
+
+    def style_of(self, norm):
+        return self._styles[id(norm)]
+
+    @staticmethod
+    def build(decoder, w):
+        """w itself when the grouped kernels do not apply (then every layer runs its own Linear, as before)"""
+        if isinstance(w, StyleBank):
+            return w
+        norms = decoder.__dict__.get('_adain_layers')
+        if norms is None:
+            norms = [m for m in decoder.modules() if isinstance(m, (AdaptiveInstanceNorm3d, AdaptiveInstanceNorm))]
+            decoder.__dict__['_adain_layers'] = norms          # plain attribute: not a registered submodule list
+        linears = [m.latent_affine for m in norms]
+        if not norms or not ops.grouped_linear_supported(w, linears):
+            return w
+        return StyleBank(w, norms, ops.grouped_linear(w, linears))
+
+
+def _style(norm, style):
+    return style.style_of(norm) if isinstance(style, StyleBank) else norm.latent_affine(style)
+
+
 class AdaptiveInstanceNorm3d(nn.Module):
     def __init__(self, latent_n_channels, out_channels, epsilon=1e-8):
         super().__init__()
@@ -92,7 +125,7 @@ class AdaptiveInstanceNorm3d(nn.Module):
         self.latent_affine = hnn.Linear(latent_n_channels, 2 * out_channels)
 
     def forward(self, x, style, pre_act=ops.ACT_NONE, pre_slope=0.0, moments=None):
-        return ops.adain(x, self.latent_affine(style), self.epsilon, style.shape[0], pre_act, pre_slope, moments)
+        return ops.adain(x, _style(self, style), self.epsilon, style.shape[0], pre_act, pre_slope, moments)
 
 
 class ConvInstanceNorm3d(nn.Module):
@@ -115,7 +148,7 @@ class ConvInstanceNorm3d(nn.Module):
         x = self.conv_act[0](x, act=ops.ACT_LEAKY, slope=0.2, act_bwd_fused=True, moments=moments)
         if ops.adain_head_supported(x, head_conv.weight, moments):
             an = self.adaptive_norm
-            return ops.adain_head(x, an.latent_affine(w), head_conv.weight, head_conv.bias, an.epsilon, moments, ops.ACT_LEAKY, 0.2)
+            return ops.adain_head(x, _style(an, w), head_conv.weight, head_conv.bias, an.epsilon, moments, ops.ACT_LEAKY, 0.2)
         return head_conv(self.adaptive_norm(x, w, pre_act=ops.ACT_LEAKY, pre_slope=0.2, moments=moments))
 
 
@@ -130,7 +163,7 @@ class AdaptiveInstanceNorm(nn.Module):
 
     def forward(self, x, style, pre_act=ops.ACT_NONE, pre_slope=0.0):
         x5 = x.unsqueeze(-3)                       # (N, C, 1, H, W) or the broadcast parameter (C, 1, H, W)
-        y = ops.adain(x5, self.latent_affine(style), self.epsilon, style.shape[0], pre_act, pre_slope)
+        y = ops.adain(x5, _style(self, style), self.epsilon, style.shape[0], pre_act, pre_slope)
         return y.squeeze(2)
 
 
@@ -198,6 +231,7 @@ class BevDecoder(nn.Module):
         self.head_1 = SegmentationHead(64, semantic_n_channels, downsample_factor=1)
 
     def forward(self, w):
+        w = StyleBank.build(self, w)
         x = self.first_norm(self.constant_tensor, w)      # the parameter is broadcast over the batch inside the kernel
         x = self.first_conv(x, w)
         for module in self.middle_conv:
@@ -287,6 +321,7 @@ class VoxelDecoder1(nn.Module):
 
     def forward(self, w):
         # constant_tensor is broadcast over the batch inside the AdaIN kernel (no repeat() copy)
+        w = StyleBank.build(self, w)
         x = self.first_norm(self.constant_tensor, w)
         x = self.first_conv(x, w)
         for module in self.middle_conv:

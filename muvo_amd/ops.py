@@ -67,6 +67,7 @@ EXPORTS = [
     'muvo_split_planes_bytes', 'muvo_split_planes', 'muvo_attention_supported', 'muvo_attention_fwd', 'muvo_attention_bwd',
     'muvo_conv_dgrad_accumulate', 'muvo_conv_forward_moments_supported', 'muvo_conv_forward_moments', 'muvo_adain_fwd_moments',
     'muvo_adain_head_supported', 'muvo_adain_head_fwd', 'muvo_adain_head_bwd', 'muvo_bf3_loop_clock',
+    'muvo_grouped_linear_fwd', 'muvo_grouped_linear_bwd',
     'muvo_rssm_supported', 'muvo_rssm_transposed_floats', 'muvo_rssm_scratch_floats', 'muvo_rssm_forward', 'muvo_rssm_backward',
 ]
 
@@ -358,6 +359,67 @@ class LinearFn(torch.autograd.Function):
             if bias is not None:
                 _ck(lib().muvo_colsum_acc(_f(dz), _f(grad_of(bias)), _i64(rows), _i64(out_f), _i64(out_f), _st()))
         return dx, None, None, None, None
+
+
+GROUPED_LINEAR = os.environ.get('MUVO_GROUPED_LINEAR', '1') != '0'
+
+
+def _ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+class GroupedLinearFn(torch.autograd.Function):
+    """(y_1, ..., y_L) = (x W_1^T + b_1, ..., x W_L^T + b_L) for L Linear layers that read the same few-row input: the AdaIN
+    style projections of a decoder in one launch per pass (csrc/gemm.hip: grouped_linear_*).  args: x, then W_1, b_1, ..."""
+
+    @staticmethod
+    def forward(ctx, x, *wb):
+        x = x.contiguous()
+        ws, bs = list(wb[0::2]), list(wb[1::2])
+        m, k = x.shape
+        ns = [w.shape[0] for w in ws]
+        ys = [torch.empty(m, n, device=x.device, dtype=torch.float32) for n in ns]
+        narr = (C.c_int * len(ns))(*ns)
+        _ck(lib().muvo_grouped_linear_fwd(_f(x), m, k, len(ws), _ptr_array(ws), _ptr_array(bs), _ptr_array(ys), narr, _st()))
+        ctx.ws, ctx.bs, ctx.ns = ws, bs, ns
+        ctx.save_for_backward(x)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        x, = ctx.saved_tensors
+        ws, bs, ns = ctx.ws, ctx.bs, ctx.ns
+        m, k = x.shape
+        dys = [torch.zeros(m, n, device=x.device, dtype=torch.float32) if d is None else d.contiguous() for d, n in zip(dys, ns)]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dws = [grad_of(w) if w.requires_grad else None for w in ws]
+        dbs = [grad_of(b) if (b is not None and b.requires_grad) else None for b in bs]
+        narr = (C.c_int * len(ns))(*ns)
+        _ck(lib().muvo_grouped_linear_bwd(_f(x), m, k, len(ws), _ptr_array(ws), _ptr_array(dys), _f(dx) if dx is not None else None,
+                                          _ptr_array(dws), _ptr_array(dbs), narr, _st()))
+        return (dx,) + (None,) * (2 * len(ws))
+
+
+def grouped_linear_supported(x, linears):
+    if not GROUPED_LINEAR or x.dim() != 2 or not (1 <= len(linears) <= 16):
+        return False
+    m, k = x.shape
+    if m > 24 or k < 64 or k % 4:
+        return False
+    return all(l.weight.shape[1] == k and l.weight.is_contiguous() and l.weight.data_ptr() % 16 == 0 and
+               (l.weight.grad is None or l.weight.grad.data_ptr() % 16 == 0) and
+               getattr(l.weight, '_muvo_flat_grad', l.weight).data_ptr() % 16 == 0 for l in linears)
+
+
+def grouped_linear(x, linears):
+    """styles of `linears` (nn.Linear-like modules with .weight / .bias) applied to the same 2-D input, as a tuple"""
+    args = []
+    for l in linears:
+        args += [l.weight, l.bias]
+    return GroupedLinearFn.apply(x, *args)
 
 
 class _LinearPacked:

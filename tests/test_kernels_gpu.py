@@ -155,6 +155,41 @@ GEMM_SHAPES = [(7, 33, 5), (130, 257, 70), (324, 48, 324), (2, 1600, 1088), (300
                (20, 1536, 1536), (3, 100, 70), (9, 64, 16)]  # skinny (M <= 32) kernels incl. row chunking
 
 
+def test_grouped_linear(dev):
+    """All style projections of a decoder in one launch per pass (ops.grouped_linear; common.py:205-246: each
+    AdaptiveInstanceNorm applies its own Linear to the same latent): outputs, the summed data gradient and the per-layer
+    weight / bias gradients (accumulated into existing .grad) against separate torch Linears."""
+    from muvo_amd import nn as hnn
+    from muvo_amd import ops
+    torch.manual_seed(3)
+    m, k = 20, 1536
+    outs = [128, 16, 512, 64, 2, 1024, 32, 128]
+    with torch.device(dev):
+        lins = [hnn.Linear(k, n) for n in outs]
+    x = torch.randn(m, k)
+    xg = x.to(dev).requires_grad_(True)
+    assert ops.grouped_linear_supported(xg, lins)
+    for l in lins:
+        l.weight.grad, l.bias.grad = torch.full_like(l.weight, 0.25), torch.full_like(l.bias, -0.5)
+    ys = ops.grouped_linear(xg, lins)
+    xc = x.clone().requires_grad_(True)
+    ws = [l.weight.detach().cpu().requires_grad_(True) for l in lins]
+    bs = [l.bias.detach().cpu().requires_grad_(True) for l in lins]
+    yr = [F.linear(xc, w, b) for w, b in zip(ws, bs)]
+    for i, (y, r) in enumerate(zip(ys, yr)):
+        _close(y, r, name=f'grouped fwd {i}')
+    gs = [torch.randn_like(r) for r in yr]
+    torch.autograd.backward(yr, gs)
+    torch.autograd.backward(list(ys), [g.to(dev) for g in gs])
+    _close(xg.grad, xc.grad, rtol=5e-4, name='grouped dx')
+    for i, l in enumerate(lins):
+        _close(l.weight.grad - 0.25, ws[i].grad, rtol=5e-4, atol=1e-4, name=f'grouped dW {i}')
+        _close(l.bias.grad + 0.5, bs[i].grad, rtol=5e-4, atol=1e-4, name=f'grouped db {i}')
+    # a consumer that uses only some of the outputs: the missing gradients count as zero
+    ys = ops.grouped_linear(xg.detach().requires_grad_(True), lins[:3])
+    ys[1].sum().backward()
+
+
 @pytest.mark.parametrize('shape', GEMM_SHAPES)
 def test_linear(dev, shape):
     from muvo_amd import nn as hnn
