@@ -524,30 +524,46 @@ __global__ void __launch_bounds__(256) upsample3d_x2_bwd_row_kernel(const float*
   const float w1a = f > 0 ? 0.75f : 1.f, w2b = 2 * f + 1 < W - 1 ? 0.75f : 1.f, w2a = 2 * f < W - 1 ? 0.75f : 1.f;
   const float* gp = dy + nc * (2L * D) * OH * OW + 4 * f;
   const long ps = (long)OH * OW;
-  auto contrib = [&](int a) -> float2 {
-    float2 acc = make_float2(0.f, 0.f);
-    if (a < 0 || a >= 2 * D) return acc;       // (uniform)
-    const float* plane = gp + (long)a * ps;
+  // the four fine rows of plane a that this lane's coarse row receives (clamped row / plane: masked by the weights below)
+  auto load_rows = [&](int a, float4 (&g)[4]) {
+    const int ac = a < 0 ? 0 : (a >= 2 * D ? 2 * D - 1 : a);
+    const float* plane = gp + (long)ac * ps;
 #pragma unroll
     for (int ib = 0; ib < 4; ++ib) {
-      if (wb[ib] == 0.f) continue;             // the row does not exist (uniform within a row of lanes)
-      const float4 g = *(const float4*)(plane + (long)(2 * h - 1 + ib) * OW);
-      const float lft = __shfl_up(g.w, 1), rgt = __shfl_down(g.x, 1);
+      int r = 2 * h - 1 + ib;
+      r = r < 0 ? 0 : (r > OH - 1 ? OH - 1 : r);
+      g[ib] = *(const float4*)(plane + (long)r * OW);
+    }
+  };
+  auto reduce_rows = [&](int a, const float4 (&g)[4]) -> float2 {
+    float2 acc = make_float2(0.f, 0.f);
+    const float pw = (a < 0 || a >= 2 * D) ? 0.f : 1.f;      // (uniform) the plane does not exist
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib) {
+      const float lft = __shfl_up(g[ib].w, 1), rgt = __shfl_down(g[ib].x, 1);
       const float gl = f > 0 ? lft : 0.f, gr = f < OQ - 1 ? rgt : 0.f;
-      acc.x += wb[ib] * ((0.25f * gl + w1a * g.x) + (w2a * g.y + 0.25f * g.z));
-      acc.y += wb[ib] * ((0.25f * g.y + 0.75f * g.z) + (w2b * g.w + 0.25f * gr));
+      const float wgt = wb[ib] * pw;                          // 0 for the rows that do not exist
+      acc.x += wgt * ((0.25f * gl + w1a * g[ib].x) + (w2a * g[ib].y + 0.25f * g[ib].z));
+      acc.y += wgt * ((0.25f * g[ib].y + 0.75f * g[ib].z) + (w2b * g[ib].w + 0.25f * gr));
     }
     return acc;
   };
-  float2 pm1 = contrib(2 * d0 - 1), p0 = contrib(2 * d0);
+  // Walk along d with the loads of the NEXT coarse plane issued before the store of the current one (a load behind a store
+  // waits for the store's acknowledgement): eight unconditional float4 loads in flight per lane while a result leaves.
+  float4 ga[4], gb[4];
+  load_rows(2 * d0 - 1, ga); load_rows(2 * d0, gb);
+  float2 pm1 = reduce_rows(2 * d0 - 1, ga), p0 = reduce_rows(2 * d0, gb);
+  load_rows(2 * d0 + 1, ga); load_rows(2 * d0 + 2, gb);
   for (int d = d0; d < d1; ++d) {
-    const float2 p1 = contrib(2 * d + 1), p2 = contrib(2 * d + 2);
+    const float2 p1 = reduce_rows(2 * d + 1, ga), p2 = reduce_rows(2 * d + 2, gb);
+    if (d + 1 < d1) { load_rows(2 * d + 3, ga); load_rows(2 * d + 4, gb); }     // (uniform)
     float wa[4];
     up2_bwd_weights(d, D, wa);
     float2 o;
     o.x = (wa[0] * pm1.x + wa[1] * p0.x) + (wa[2] * p1.x + wa[3] * p2.x);
     o.y = (wa[0] * pm1.y + wa[1] * p0.y) + (wa[2] * p1.y + wa[3] * p2.y);
-    if (live) *((float2*)(dx + ((nc * D + d) * H + h) * (long)W) + f) = o;
+    // rows past H (partial last workgroup) recompute row H - 1 and store the identical value
+    *((float2*)(dx + ((nc * D + d) * H + h) * (long)W) + f) = o;
     pm1 = p1; p0 = p2;
   }
 }
