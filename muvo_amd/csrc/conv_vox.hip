@@ -380,16 +380,15 @@ __device__ __forceinline__ void vox_dummy_stores(__amdgpu_buffer_rsrc_t rs) {
 }
 
 __device__ __forceinline__ void vox_split2(float a, float b, unsigned& hi, unsigned& lo) {
-  // two fp32 -> packed bf16 pairs: hi = RNE(x), lo = RNE(x - hi)
-  auto rne = [](float x) -> unsigned {
-    unsigned u = __float_as_uint(x);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
-  };
-  const unsigned ha = rne(a), hb = rne(b);
-  const float ra = a - __uint_as_float(ha << 16), rb = b - __uint_as_float(hb << 16);
-  hi = ha | (hb << 16);
-  lo = rne(ra) | (rne(rb) << 16);
+  // two fp32 -> packed bf16 pairs: hi = RNE(x), lo = RNE(x - hi), with the hardware pair conversion (v_cvt_pk_bf16_f32) as in
+  // conv_bf3.hip; the integer round-to-nearest-even emulation used here before cost ~3x the VALU instructions per pair
+  typedef __bf16 vbf16x2 __attribute__((ext_vector_type(2)));
+  typedef float vf32x2 __attribute__((ext_vector_type(2)));
+  const vbf16x2 h = __builtin_convertvector((vf32x2){a, b}, vbf16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  const float h0 = __uint_as_float(hi << 16), h1 = __uint_as_float(hi & 0xffff0000u);
+  const vbf16x2 l = __builtin_convertvector((vf32x2){a - h0, b - h1}, vbf16x2);
+  lo = __builtin_bit_cast(unsigned, l);
 }
 
 // GENERIC: the variant with the accumulating second pass of a 32-channel reduction and / or an activation beyond
