@@ -89,6 +89,8 @@ MANY_TILE_CASES = [
     (2, False, 48, 96, 3, 1, 1, 0, (150, 181), True, 0),      # 319 tiles of 128x256, Cp = 48
     (2, True, 64, 64, 6, 2, 2, 0, (120, 97), True, 3),        # merged phases: M = 256, 273 tiles; dgrad: stride-2 conv
     (2, False, 160, 64, 3, 1, 1, 0, (100, 131), False, 0),    # dgrad runs the 256x128 tiles (M = 160)
+    (3, False, 64, 32, 3, 1, 1, 0, (24, 40, 12), True, 3),    # 32 produced channels (half of the 64-row tile), 27 taps
+    (2, False, 48, 24, 3, 1, 1, 0, (100, 120), True, 0),      # 24 produced channels, Cp = 48
 ]
 
 
