@@ -37,7 +37,7 @@ extern "C" int muvo_bf3_loop_clock(double* shader_mhz, double* us_per_k_step) {
 // ran and when it passed setup / prologue / K loop / epilogue (100 MHz wall clock), read back by tools/bf3_stamps.py
 __device__ unsigned long long g_bf3_stamps[8 * 16384];
 #define BF3_STAMP(slot)                                                                      \
-  if (threadIdx.x == 0 && blockIdx.x < 16384) g_bf3_stamps[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime()
+  if (MUVO_BF3_STAMPS != 3 && threadIdx.x == 0 && blockIdx.x < 16384) g_bf3_stamps[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime()
 extern "C" int muvo_debug_bf3_stamps_reset() {
   void* p = nullptr;
   return hipGetSymbolAddress(&p, HIP_SYMBOL(g_bf3_stamps)) == hipSuccess && hipMemset(p, 0, sizeof(unsigned long long) * 8 * 16384) == hipSuccess ? 0 : 1;
@@ -45,8 +45,12 @@ extern "C" int muvo_debug_bf3_stamps_reset() {
 extern "C" int muvo_debug_bf3_stamps(unsigned long long* host_out, int n_u64) {
   return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_bf3_stamps), sizeof(unsigned long long) * n_u64) == hipSuccess ? 0 : 1;
 }
+#define BF3_LINEAR_BLOCK ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x)
+#define BF3_STAMP3(slot)                                                                     \
+  if (threadIdx.x == 0 && BF3_LINEAR_BLOCK < 16384) g_bf3_stamps[BF3_LINEAR_BLOCK * 8 + (slot)] = __builtin_amdgcn_s_memrealtime()
 #else
 #define BF3_STAMP(slot)
+#define BF3_STAMP3(slot)
 #endif
 
 // two floats -> packed bf16 hi pair and bf16 lo pair (RNE both)
@@ -104,7 +108,7 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   BF3_STAMP(0);
-#ifdef MUVO_BF3_STAMPS
+#if defined(MUVO_BF3_STAMPS) && MUVO_BF3_STAMPS != 3
   if (threadIdx.x == 0 && blockIdx.x < 16384)
     g_bf3_stamps[blockIdx.x * 8 + 5] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492);
 #endif
@@ -412,7 +416,7 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
     g_bf3_clock[1] = __builtin_amdgcn_s_memrealtime() - rt0;
     g_bf3_clock[2] = (unsigned long long)nk;
   }
-#ifdef MUVO_BF3_STAMPS
+#if defined(MUVO_BF3_STAMPS) && MUVO_BF3_STAMPS != 3
   if (threadIdx.x == 0 && blockIdx.x < 16384) g_bf3_stamps[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime() - clk0;
 #endif
 #define BF3_STORE(ACT) conv_tile_store<ACT, true>(g, acc, bias, out, slope, ksplit, bx * BN, m_tile, wm, wn, lane, sbias)
@@ -636,6 +640,13 @@ conv_bf3_wgrad_pp_kernel(const ConvPhase g, const uint4* __restrict__ xs, long x
   if (s_end > nsteps) s_end = nsteps;
   const int ns = s_end - s_begin;
   if (ns <= 0) return;
+#if defined(MUVO_BF3_STAMPS) && MUVO_BF3_STAMPS == 3
+  BF3_STAMP3(0);
+  if (threadIdx.x == 0 && BF3_LINEAR_BLOCK < 16384) {
+    g_bf3_stamps[BF3_LINEAR_BLOCK * 8 + 5] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492);
+    g_bf3_stamps[BF3_LINEAR_BLOCK * 8 + 7] = (unsigned long long)ns;
+  }
+#endif
 
   const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)dzs, 0, (int)(2 * dzplane_u4 * 16), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)xs, 0, (int)(2 * xplane_u4 * 16), 0x00020000);
@@ -735,6 +746,9 @@ conv_bf3_wgrad_pp_kernel(const ConvPhase g, const uint4* __restrict__ xs, long x
   };
 
   // prologue: steps 0 and 1 into stages 0 and 1, step 2 into R
+#if defined(MUVO_BF3_STAMPS) && MUVO_BF3_STAMPS == 3
+  BF3_STAMP3(1);
+#endif
 #pragma unroll
   for (int pre = 0; pre < 2; ++pre) {
     pixstate();
@@ -748,6 +762,9 @@ conv_bf3_wgrad_pp_kernel(const ConvPhase g, const uint4* __restrict__ xs, long x
   for (int q = 0; q < DPS; ++q) gload_piece(q);
   pixstate();                                       // offsets of step 3
   __syncthreads();
+#if defined(MUVO_BF3_STAMPS) && MUVO_BF3_STAMPS == 3
+  BF3_STAMP3(2);
+#endif
   const int grp = wave / (NW / 2);
   if (grp == 1) __builtin_amdgcn_s_barrier();
   int stage = 0;
@@ -785,6 +802,9 @@ conv_bf3_wgrad_pp_kernel(const ConvPhase g, const uint4* __restrict__ xs, long x
     stage = stage == 2 ? 0 : stage + 1;
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
+#if defined(MUVO_BF3_STAMPS) && MUVO_BF3_STAMPS == 3
+  BF3_STAMP3(3);
+#endif
 
   float* wt = wg + g.wp_off + (size_t)t * g.M * g.C;   // [m][c] slab of this tap
 #pragma unroll
@@ -799,6 +819,9 @@ conv_bf3_wgrad_pp_kernel(const ConvPhase g, const uint4* __restrict__ xs, long x
         if (m < g.M) atomicAdd(wt + (size_t)m * g.C + c, acc[i][j][r]);
       }
   }
+#if defined(MUVO_BF3_STAMPS) && MUVO_BF3_STAMPS == 3
+  BF3_STAMP3(4);
+#endif
 }
 
 // dw[m*wsm + c*wsc + tap_w[t]] += Wg[t][m][c]   (thread order follows the PyTorch weight layout)
