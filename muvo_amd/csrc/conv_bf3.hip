@@ -126,24 +126,40 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
   constexpr int NPS = CPW / 2;
   static_assert(CPW % 2 == 0 && NPS * NW * 16 == BN, "B load roles must tile");
   const int cp8 = g.Cp >> 3;
+  // Tap tables in LDS first: [0, T) the input offset of a tap (uint4 units) for the K loop, [64, 64 + T) its packed
+  // (dz, dy, dx) for the validity masks below — with `g.tap_d[tt]` read from the kernel arguments the mask loop was a chain
+  // of dependent scalar loads (a third of the 3-us setup of a 24-us workgroup of the four-wave tile).
+  int* taptab = (int*)(smem + NST * STAGE);
+  for (int tt = tid; tt < g.T; tt += 64 * NW) {
+    const int d = g.tap_d[tt];
+    taptab[tt] = (((((d >> 16) & 255) - 128) * g.IH + ((d >> 8) & 255) - 128) * g.IW + (d & 255) - 128) * cp8;
+    taptab[64 + tt] = d;
+  }
+  __syncthreads();
   int pixoff[NPS];                       // may be "negative" at borders: only used when valid
   unsigned long long vmask[NPS];         // bit t: tap t of this pixel is inside the input
+  int z0[NPS], y0[NPS], x0[NPS];
+  bool pvalid[NPS];
 #pragma unroll
   for (int sidx = 0; sidx < NPS; ++sidx) {
     const int p = bx * BN + (wave * NPS + sidx) * 16 + (lane >> 2);
-    const bool pvalid = p < g.npix;
+    pvalid[sidx] = p < g.npix;
     int n, iz, iy, ix;
-    decode_pix(g, pvalid ? p : 0, n, iz, iy, ix);
-    const int z0 = iz * g.is[0] + g.ib[0], y0 = iy * g.is[1] + g.ib[1], x0 = ix * g.is[2] + g.ib[2];
-    pixoff[sidx] = (((n * g.ID + z0) * g.IH + y0) * g.IW + x0) * cp8;
-    unsigned long long vm = 0ull;
-    for (int tt = 0; tt < g.T; ++tt) {
-      const int d = g.tap_d[tt];
-      const int z = z0 + ((d >> 16) & 255) - 128, y = y0 + ((d >> 8) & 255) - 128, x = x0 + (d & 255) - 128;
-      const bool ok = pvalid && (unsigned)z < (unsigned)g.ID && (unsigned)y < (unsigned)g.IH && (unsigned)x < (unsigned)g.IW;
-      vm |= (unsigned long long)ok << tt;
+    decode_pix(g, pvalid[sidx] ? p : 0, n, iz, iy, ix);
+    z0[sidx] = iz * g.is[0] + g.ib[0]; y0[sidx] = iy * g.is[1] + g.ib[1]; x0[sidx] = ix * g.is[2] + g.ib[2];
+    pixoff[sidx] = (((n * g.ID + z0[sidx]) * g.IH + y0[sidx]) * g.IW + x0[sidx]) * cp8;
+    vmask[sidx] = 0ull;
+  }
+#pragma unroll 3
+  for (int tt = 0; tt < g.T; ++tt) {
+    const int d = taptab[64 + tt];
+    const int dz = ((d >> 16) & 255) - 128, dy = ((d >> 8) & 255) - 128, dx = (d & 255) - 128;
+#pragma unroll
+    for (int sidx = 0; sidx < NPS; ++sidx) {
+      const bool ok = pvalid[sidx] && (unsigned)(z0[sidx] + dz) < (unsigned)g.ID && (unsigned)(y0[sidx] + dy) < (unsigned)g.IH &&
+                      (unsigned)(x0[sidx] + dx) < (unsigned)g.IW;
+      vmask[sidx] |= (unsigned long long)ok << tt;
     }
-    vmask[sidx] = vm;
   }
   const int zero_off = (int)(2 * plane_u4);
   const int m_tile = by * BM;
@@ -160,12 +176,7 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
   // (global_load_lds_dwordx4): 1.6-1.76 PFLOP/s against 0.96-1.5 with the same bytes per MFMA.
   // The per-tap input offset comes from a small LDS table so that the loop holds no scalar memory loads (their
   // out-of-order return would force full lgkmcnt(0) waits in front of the fragment reads).
-  int* taptab = (int*)(smem + NST * STAGE);
-  float* sbias = (float*)(taptab + 64) + wave * (32 * TM);     // this wave's bias rows (epilogue, conv_plan.h)
-  for (int tt = tid; tt < g.T; tt += 64 * NW) {
-    const int d = g.tap_d[tt];
-    taptab[tt] = (((((d >> 16) & 255) - 128) * g.IH + ((d >> 8) & 255) - 128) * g.IW + (d & 255) - 128) * cp8;
-  }
+  float* sbias = (float*)(taptab + 128) + wave * (32 * TM);    // this wave's bias rows (epilogue, conv_plan.h)
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in registers (uint4 is a struct)
   // Buffer loads (descriptor in SGPRs + 32-bit byte offset): no 64-bit address temporaries — with flat loads the
   // compiler recycled the destination registers of in-flight loads for address math and put s_waitcnt vmcnt(0) in front
@@ -287,7 +298,6 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
   bf16x8 a0h[TM], a0l[TM], b0h[TN], b0l[TN], a1h[TM], a1l[TM], b1h[TN], b1l[TN];
   using par0 = std::integral_constant<int, 0>;
   using par1 = std::integral_constant<int, 1>;
-  __syncthreads();                       // tap table
   BF3_STAMP(1);
   bstate(kt0);
 #pragma unroll
@@ -1255,7 +1265,7 @@ int bf3_split_rows(const float* x, void* ws, long rows, int C, hipStream_t st) {
 template <int BM, int BN, int WM, int WN, int BKC, int NST>
 static int bf3_launch(const ConvPhase& g, const void* ws, const float* wp, const float* bias, float* out, int act,
                       float slope, hipStream_t st, int ksplit = 1) {
-  constexpr size_t lds = (size_t)NST * 2 * BKC * (BM + BN) * 16 + 256 + 4 * BM * WN;   // stages + tap table + bias rows per wave
+  constexpr size_t lds = (size_t)NST * 2 * BKC * (BM + BN) * 16 + 512 + 4 * BM * WN;   // stages + tap tables + bias rows per wave
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   static const uint4* zero16 = nullptr;
@@ -1407,7 +1417,10 @@ int bf3_wgrad_phase(const ConvPhase& g, const void* ws_x, int Cin_total, const v
                                    : bf3_wgrad_launch<64, 64, 1, 2, 2>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st);
   if (rc) return rc;
   const long total = (long)g.M * g.C * g.T;
-  hipLaunchKernelGGL(bf3_unpack_wgrad_kernel, dim3(ew_grid(total)), dim3(256), 0, st, g, wg, dw);
+  // one element per thread (no grid-stride loop: its second iteration's loads would wait for the first iteration's stores)
+  static const int unpack_cap = getenv("MUVO_UNPACK_GRID_CAP") ? atoi(getenv("MUVO_UNPACK_GRID_CAP")) : (1 << 22);
+  const long ublocks = cdiv(total, 256);
+  hipLaunchKernelGGL(bf3_unpack_wgrad_kernel, dim3((unsigned)(ublocks < unpack_cap ? ublocks : unpack_cap)), dim3(256), 0, st, g, wg, dw);
   MUVO_CHECK_LAUNCH("bf3_unpack_wgrad_kernel");
   return MUVO_OK;
 }
