@@ -568,6 +568,12 @@ vox_bf3_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* __re
 // ================================================================================================
 // CI = 16: MFMA columns = 16 input channels of one tap.  CI = 8: columns = 8 input channels x two (dx, dy) combinations
 // (column j: channel j & 7, combination 2 * pair + (j >> 3)), 5 pairs x 3 dz = 15 accumulator tiles.
+#ifndef VOX_WGRAD_PIPE16
+#define VOX_WGRAD_PIPE16 1     // A/B (tools/ab_local.sh): software-pipelined plane loop, 16- / 8-input-channel variants
+#endif
+#ifndef VOX_WGRAD_PIPE8
+#define VOX_WGRAD_PIPE8 1
+#endif
 #ifndef VOX_WGRAD_BUFLOAD16
 #define VOX_WGRAD_BUFLOAD16 0      // A/B: unconditional buffer loads in the 16-input-channel variant too
 #endif
@@ -584,8 +590,8 @@ vox_bf3_wgrad_kernel(const VoxArgs a, const float* __restrict__ x, const float* 
   constexpr int NT = CI == 16 ? 27 : 15;               // accumulator tiles   // staging tasks (8 voxels each)
   constexpr int XPT = (XT + 511) / 512, DPT = (DT + 511) / 512;
   extern __shared__ char wsm[];
-  char* xring = wsm;
-  char* dzb = wsm + 3 * XSLOT;
+  char* xring = wsm;                                   // FOUR x planes: three being read by the MFMA phase, the fourth being staged
+  char* dzb = wsm + 4 * XSLOT;
   float* dbsum = (float*)(dzb + 2 * DBUF);             // 16 floats
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nseg = (a.X + xseg - 1) / xseg;
@@ -597,7 +603,7 @@ vox_bf3_wgrad_kernel(const VoxArgs a, const float* __restrict__ x, const float* 
   const long YZ = (long)a.Y * Z;
   const float* xb = x + (long)n * a.sN_in + (long)ci0 * a.XYZ;
   const float* db = dz + (long)n * a.sN_out;
-  for (int i = tid; i < (3 * XSLOT + 2 * DBUF + 64) / 16; i += 512) ((uint4*)wsm)[i] = uint4{0u, 0u, 0u, 0u};
+  for (int i = tid; i < (4 * XSLOT + 2 * DBUF + 64) / 16; i += 512) ((uint4*)wsm)[i] = uint4{0u, 0u, 0u, 0u};
   __syncthreads();
 
   float xst[XPT][8], dst[DPT][8];
@@ -642,14 +648,15 @@ vox_bf3_wgrad_kernel(const VoxArgs a, const float* __restrict__ x, const float* 
       else load8(xb + eoff, ok && ci0 + ci < a.Cin, xst[k]);
     }
   };
+  auto xstore_task = [&](int k, int slot) {
+    const int t = tid + k * 512;
+    if (t >= XT) return;
+    const int z8 = t % (Z / 8), rr = (t / (Z / 8)) % ROWS, ci = t / ((Z / 8) * ROWS);
+    split_store(xst[k], xring + slot * XSLOT + ci * XCI + rr * XROW + 16 + z8 * 16, XHL);
+  };
   auto xstore = [&](int slot) {
 #pragma unroll
-    for (int k = 0; k < XPT; ++k) {
-      const int t = tid + k * 512;
-      if (t >= XT) continue;
-      const int z8 = t % (Z / 8), rr = (t / (Z / 8)) % ROWS, ci = t / ((Z / 8) * ROWS);
-      split_store(xst[k], xring + slot * XSLOT + ci * XCI + rr * XROW + 16 + z8 * 16, XHL);
-    }
+    for (int k = 0; k < XPT; ++k) xstore_task(k, slot);
   };
   auto dload = [&](int px) {
 #pragma unroll
@@ -663,20 +670,21 @@ vox_bf3_wgrad_kernel(const VoxArgs a, const float* __restrict__ x, const float* 
       else load8(db + eoff, ok, dst[k]);
     }
   };
+  auto dstore_task = [&](int k, int buf) {
+    const int t = tid + k * 512;
+    if (t >= DT) return;
+    const int z8 = t % (Z / 8), r = (t / (Z / 8)) % WROWS, co = t / ((Z / 8) * WROWS);
+    split_store(dst[k], dzb + buf * DBUF + co * DCO + r * DROW + z8 * 16, DHL);
+    if (blockIdx.y == 0 && dbias) {
+      float sdz = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sdz += dst[k][e];
+      if (sdz != 0.f) atomicAdd(dbsum + co, sdz);
+    }
+  };
   auto dstore = [&](int buf) {
 #pragma unroll
-    for (int k = 0; k < DPT; ++k) {
-      const int t = tid + k * 512;
-      if (t >= DT) continue;
-      const int z8 = t % (Z / 8), r = (t / (Z / 8)) % WROWS, co = t / ((Z / 8) * WROWS);
-      split_store(dst[k], dzb + buf * DBUF + co * DCO + r * DROW + z8 * 16, DHL);
-      if (blockIdx.y == 0 && dbias) {
-        float sdz = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sdz += dst[k][e];
-        if (sdz != 0.f) atomicAdd(dbsum + co, sdz);
-      }
-    }
+    for (int k = 0; k < DPT; ++k) dstore_task(k, buf);
   };
 
   vf32x4 acc[NT];
@@ -688,16 +696,34 @@ vox_bf3_wgrad_kernel(const VoxArgs a, const float* __restrict__ x, const float* 
   const int b_off = (j & (CI - 1)) * XCI + 16 + (z0 + kg * 8) * 2;      // B: columns -> channel j & (CI - 1) (+ row term below)
   const int sel = CI == 8 ? j >> 3 : 0;                                 // CI = 8: which combination of the pair this column reads
 
-  xload(xs - 1); xstore((xs - 1 + 3) % 3);
-  xload(xs); xstore(xs % 3);
-  xload(xs + 1);
-  dload(xs);
+  // Plane loop, software-pipelined over a ring of four x planes and two dz planes: while the MFMA phase of plane px reads the
+  // x planes px - 1 .. px + 1 and dz plane px, the same waves split and store x plane px + 2 and dz plane px + 1 (loaded one
+  // step earlier) piece by piece between their MFMA groups, then issue the loads of the planes after those.  ONE barrier per
+  // plane.  (With a three-plane ring the staging had to finish behind its own barrier before the MFMA phase could start:
+  // 2000 of 6900 clocks per plane with the matrix pipe idle, another 800 at the second barrier.)
+  // Same-box A/B against the two-barrier schedule (tools/ab_local.sh, VOX_WGRAD_PIPE16 / _PIPE8): 2.78 -> 2.64 ms (16 -> 8 at
+  // 192 x 192 x 64), 1.78 -> 1.73 (8 -> 8), 0.96 -> 0.93 (32 -> 16), 0.49 -> 0.47 (16 -> 16): the phases are bound by their
+  // vector and LDS instructions more than by the barriers, so the gain is 3-5 %, not the 1.5x the idle clocks suggested.
+  constexpr bool PIPE = CI == 16 ? VOX_WGRAD_PIPE16 : VOX_WGRAD_PIPE8;
+  xload(xs - 1); xstore((xs - 1 + 4) & 3);
+  xload(xs); xstore(xs & 3);
+  if (PIPE) {
+    xload(xs + 1); xstore((xs + 1) & 3);
+    dload(xs); dstore(xs & 1);
+    xload(xs + 2);
+    dload(xs + 1);
+  } else {
+    xload(xs + 1);
+    dload(xs);
+  }
   __syncthreads();
   for (int px = xs; px < xe; ++px) {
-    xstore((px + 1) % 3);
-    dstore(px & 1);
-    __syncthreads();
-    if (px + 1 < xe) { xload(px + 2); dload(px + 1); }
+    if (!PIPE) {
+      xstore((px + 1) & 3);
+      dstore(px & 1);
+      __syncthreads();
+      if (px + 1 < xe) { xload(px + 2); dload(px + 1); }
+    }
     const char* A = dzb + (px & 1) * DBUF + a_off;
     const vbf16x8 ah = __builtin_bit_cast(vbf16x8, *(const vu32x4*)A);
     const vbf16x8 al = __builtin_bit_cast(vbf16x8, *(const vu32x4*)(A + DHL));
@@ -707,7 +733,7 @@ vox_bf3_wgrad_kernel(const VoxArgs a, const float* __restrict__ x, const float* 
       int c = CI == 16 ? cb : 2 * cb + sel;             // this lane's combination
       if (c > 8) c = 8;                                 // the phantom second half of the last pair (its tile half is discarded)
       const int dx = c / 3, dy = c - 3 * dx;
-      const char* R = xring + ((px + dx - 1 + 3) % 3) * XSLOT + b_off + (row + dy) * XROW;   // source row = row + 1 + (dy - 1)
+      const char* R = xring + ((px + dx - 1 + 4) & 3) * XSLOT + b_off + (row + dy) * XROW;   // source row = row + 1 + (dy - 1)
       vu32x4 w[2];
       unsigned pw[2], nw[2];
 #pragma unroll
@@ -738,6 +764,14 @@ vox_bf3_wgrad_kernel(const VoxArgs a, const float* __restrict__ x, const float* 
       acc[t0 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bp[0], acc[t0 + 2], 0, 0, 0);
       acc[t0 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bp[1], acc[t0 + 2], 0, 0, 0);
       acc[t0 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bp[0], acc[t0 + 2], 0, 0, 0);
+      // staging of the next planes between the MFMA groups (compile-time schedule: one task per combination)
+      static_assert(XPT + DPT + 1 <= NCOMB, "one staging piece per combination");
+      if (PIPE) {
+        if (cb < XPT) xstore_task(cb, (px + 2) & 3);
+        else if (cb < XPT + DPT) dstore_task(cb - XPT, (px + 1) & 1);
+        else if (cb == XPT + DPT) { xload(px + 3); dload(px + 2); }     // planes past the tensor / segment read as zeros
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     __syncthreads();
   }
@@ -1196,7 +1230,8 @@ bool vox_bf3_wgrad_shape_ok(const muvo_conv_desc* d) {
 template <int Z, int CI>
 static int launch_vox_bf3_wgrad(const muvo_conv_desc* d, const float* x, const float* dz, float* dw, float* dbias, hipStream_t st) {
   constexpr int ZH = Z / 32, WROWS = 8 / ZH, ROWS = WROWS + 2;
-  constexpr size_t lds = (size_t)3 * 2 * CI * (ROWS * (Z + 16) * 2 + 16) + (size_t)2 * 2 * 16 * (WROWS * Z * 2 + 16) + 64;
+  constexpr size_t lds = (size_t)4 * 2 * CI * (ROWS * (Z + 16) * 2 + 16) + (size_t)2 * 2 * 16 * (WROWS * Z * 2 + 16) + 64;
+  static_assert(lds <= 160 * 1024, "LDS budget");
   static_assert(lds >= (CI == 16 ? 27 : 15) * 256 * 4, "the reduction reuses the rings");
   VoxArgs a{};
   a.N = d->N; a.Cin = d->Cin; a.Cout = d->Cout; a.X = d->in_sz[0]; a.Y = d->in_sz[1];
