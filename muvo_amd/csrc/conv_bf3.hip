@@ -941,7 +941,8 @@ nchw_split_nhwc_kernel(const float* __restrict__ in, uint4* __restrict__ out_hi,
 #define SPLIT2_PS 258
 __global__ void __launch_bounds__(256)
 nchw_split_nhwc_v4_kernel(const float* __restrict__ in, uint4* __restrict__ out_hi, uint4* __restrict__ out_lo, int C, int Cp,
-                          long S, const float* __restrict__ yact, int act, float slope, float* __restrict__ dbias) {
+                          long S, const float* __restrict__ yact, int act, float slope, float* __restrict__ dbias,
+                          const float* __restrict__ dhead, const float* __restrict__ head_w, int CO) {
   extern __shared__ unsigned sp_lds[];
   unsigned* th = sp_lds;
   unsigned* tl = sp_lds + 32 * SPLIT2_PS;
@@ -956,10 +957,33 @@ nchw_split_nhwc_v4_kernel(const float* __restrict__ in, uint4* __restrict__ out_
   // afterwards: behind `if (sin && c < C)` every load sat in its own basic block with its own wait
   const long sc = sin ? s : s0;
   f32x4 v[16];
+  if (in != nullptr) {      // (uniform)
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int c = c0 + 2 * (w * 8 + (r >> 1)) + (r & 1);
-    v[r] = *(const f32x4*)(inn + (size_t)(c < C ? c : C - 1) * S + sc);
+    for (int r = 0; r < 16; ++r) {
+      const int c = c0 + 2 * (w * 8 + (r >> 1)) + (r & 1);
+      v[r] = *(const f32x4*)(inn + (size_t)(c < C ? c : C - 1) * S + sc);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  if (dhead != nullptr) {
+    // + W_head^T dlogits: the data gradient of a 1x1 output head (<= 4 produced channels) that reads the same feature map is
+    // formed here from its CO gradient planes instead of being written (or accumulated) by a pass over all C channels and
+    // read back (muvo_conv_prepare_dy_head)
+    f32x4 dh[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dh[k] = *(const f32x4*)(dhead + ((size_t)n * CO + (k < CO ? k : 0)) * S + sc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = c0 + 2 * (w * 8 + (r >> 1)) + (r & 1);
+      const int cc = c < C ? c : C - 1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float wk = k < CO ? head_w[(size_t)k * C + cc] : 0.f;     // wave-uniform
+        v[r] += wk * dh[k];
+      }
+    }
   }
   if (yn) {
     f32x4 y[16];
@@ -1206,7 +1230,7 @@ long bf3_workspace_bytes(int N, int C, long S) {
 }
 
 int bf3_split_input(const float* x, void* ws, int N, int C, long S, hipStream_t st, const float* yact, int act, float slope,
-                    float* dbias) {
+                    float* dbias, const float* dhead, const float* head_w, int CO) {
   const int Cp = roundup(C, 8);
   uint4* hi = (uint4*)ws;
   uint4* lo = hi + (size_t)N * S * Cp / 8;
@@ -1219,6 +1243,11 @@ int bf3_split_input(const float* x, void* ws, int N, int C, long S, hipStream_t 
     }
   }
   static const int split_v4 = getenv("MUVO_SPLIT_V4") ? atoi(getenv("MUVO_SPLIT_V4")) : 2;   // 2: also the fused dy * act'(y) form, 1: plain splits only, 0: 4-byte kernel everywhere
+  if (dhead != nullptr && !(split_v4 >= 2 && S % 4 == 0 && S >= 1024 && CO >= 1 && CO <= 4 &&
+                            (((uintptr_t)x | (uintptr_t)yact | (uintptr_t)dhead) & 15) == 0)) {
+    muvo_set_error("bf3_split_input: the head-gradient form needs S %% 4 == 0, S >= 1024, <= 4 head channels and 16-byte aligned tensors");
+    return MUVO_ERR_INVALID_ARG;
+  }
   if (split_v4 && (!yact || split_v4 >= 2) && S % 4 == 0 && S >= 1024 && (((uintptr_t)x | (uintptr_t)yact) & 15) == 0) {   // 5.5 vs 4.5 TB/s (profiles/r02b_hbm.txt)
     static bool attr_set = false;
     constexpr int lds = 2 * 32 * SPLIT2_PS * 4;
@@ -1227,7 +1256,7 @@ int bf3_split_input(const float* x, void* ws, int N, int C, long S, hipStream_t 
       attr_set = true;
     }
     dim3 grid(cdiv(S, 256), cdiv(Cp, 64), N);
-    hipLaunchKernelGGL(nchw_split_nhwc_v4_kernel, grid, dim3(256), lds, st, x, hi, lo, C, Cp, S, yact, act, slope, rep);
+    hipLaunchKernelGGL(nchw_split_nhwc_v4_kernel, grid, dim3(256), lds, st, x, hi, lo, C, Cp, S, yact, act, slope, rep, dhead, head_w, CO);
   } else {
     dim3 grid(cdiv(cdiv(S, 64), SPLIT_TILES), cdiv(Cp, 64), N);
     hipLaunchKernelGGL(nchw_split_nhwc_kernel, grid, dim3(256), 0, st, x, hi, lo, C, Cp, S, yact, act, slope, rep);

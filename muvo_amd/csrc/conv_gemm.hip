@@ -948,6 +948,26 @@ int muvo_conv_prepare_dy(const muvo_conv_desc* d, const float* y, const float* d
                          dbias);
 }
 
+// muvo_conv_prepare_dy for a layer whose output y also feeds a 1x1 head with CO <= 4 produced channels (RGBHead / LidarReHead on
+// the transposed convolutions of ConvDecoder, common.py:608-632): the planes hold (dy + W_head^T dhead) * act'(y) — dy: the
+// gradient that came back through the trunk (NULL at the last stage, whose output feeds the head only), dhead (N, CO, S): the
+// gradient of the head's output, head_w (CO, Cout).  The head's data gradient is never materialised.
+int muvo_conv_prepare_dy_head(const muvo_conv_desc* d, const float* y, const float* dy, const float* dhead, const float* head_w,
+                              int CO, int act, float slope, void* ws_dy, float* dbias, void* stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  MUVO_CHECK_ARG(dhead && head_w && ws_dy && CO >= 1 && CO <= 4 && (y || act == MUVO_ACT_NONE), "conv_prepare_dy_head: bad args");
+  const long S_out = (long)d->out_sz[0] * d->out_sz[1] * d->out_sz[2];
+  return bf3_split_input(dy, ws_dy, d->N, d->Cout, S_out, (hipStream_t)stream, act == MUVO_ACT_NONE ? nullptr : y, act, slope,
+                         dbias, dhead, head_w, CO);
+}
+// 1 when muvo_conv_prepare_dy_head can serve this layer (spatial size % 4 == 0 and >= 1024)
+int muvo_conv_prepare_dy_head_supported(const muvo_conv_desc* d, int CO) {
+  if (check_desc(d)) return 0;
+  const long S_out = (long)d->out_sz[0] * d->out_sz[1] * d->out_sz[2];
+  return CO >= 1 && CO <= 4 && S_out % 4 == 0 && S_out >= 1024;
+}
+
 // Weight gradients are leaves of the backward graph (their rounding error does not propagate into other gradients), so
 // they can go to bf16x3 at a lower work threshold than forward / data-gradient.
 static double bf3_wgrad_min_gflop() {

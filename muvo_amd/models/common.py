@@ -400,13 +400,22 @@ class ConvDecoder(nn.Module):
         x = _Seed1x1ConvTFn.apply(x.view(x.shape[0], -1, 1, 1), seed.weight, seed.bias, ops.ACT_ELU)
         for i in (2, 4, 6):
             x = self.pre_transpose_conv[i](x, act=ops.ACT_ELU)
-        x = self.trans_conv1[0](x, act=ops.ACT_ELU)
-        x, output_4 = self.head_4.branch(x)
-        x = self.trans_conv2[0](x, act=ops.ACT_ELU)
-        x, output_2 = self.head_2.branch(x)
-        x = self.trans_conv3[0](x, act=ops.ACT_ELU)
-        output_1 = self.head_1(x)
+        x, output_4 = self._stage(self.trans_conv1[0], self.head_4, x)
+        x, output_2 = self._stage(self.trans_conv2[0], self.head_2, x)
+        _, output_1 = self._stage(self.trans_conv3[0], self.head_1, x)
         return {**output_4, **output_2, **output_1}
+
+    @staticmethod
+    def _stage(conv, head, x):
+        """ELU(ConvTranspose(x)) and the 1x1 head on it.  Fused form (ops.ConvHeadFn): the head's data gradient is formed inside
+        the stage's backward split pass instead of a pass over the whole feature map; otherwise the head hangs off the trunk
+        through HeadBranchFn as before."""
+        hc = getattr(head, head._attr)[0]
+        if ops.conv_head_supported(x, conv.geom, hc.geom):
+            y, logits = ops.conv_head(x, conv.weight, conv.bias, conv.geom, conv._packed, ops.ACT_ELU, 0.0,
+                                      hc.weight, hc.bias, hc.geom, hc._packed)
+            return y, {f'{head._key}_{head.downsample_factor}': logits}
+        return head.branch(conv(x, act=ops.ACT_ELU))
 
 
 def position_embedding_sine(h, w, num_pos_feats, temperature=10000, scale=2 * math.pi):

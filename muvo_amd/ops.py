@@ -67,7 +67,7 @@ EXPORTS = [
     'muvo_split_planes_bytes', 'muvo_split_planes', 'muvo_attention_supported', 'muvo_attention_fwd', 'muvo_attention_bwd',
     'muvo_conv_dgrad_accumulate', 'muvo_conv_forward_moments_supported', 'muvo_conv_forward_moments', 'muvo_adain_fwd_moments',
     'muvo_adain_head_supported', 'muvo_adain_head_fwd', 'muvo_adain_head_bwd', 'muvo_bf3_loop_clock',
-    'muvo_grouped_linear_fwd', 'muvo_grouped_linear_bwd',
+    'muvo_grouped_linear_fwd', 'muvo_grouped_linear_bwd', 'muvo_conv_prepare_dy_head', 'muvo_conv_prepare_dy_head_supported',
     'muvo_rssm_supported', 'muvo_rssm_transposed_floats', 'muvo_rssm_scratch_floats', 'muvo_rssm_forward', 'muvo_rssm_backward',
 ]
 
@@ -714,24 +714,48 @@ class ConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        return ConvFn._backward(ctx, dy, None)
+
+    @staticmethod
+    def _backward(ctx, dy, head):
+        """head: None, or (dlogits, head_weight (CO, Cout)) of a 1x1 output head that reads this layer's output: its data
+        gradient W_head^T dlogits is added to dy inside the split pass (muvo_conv_prepare_dy_head) — dy may then be None (the
+        head is the only consumer)."""
         x, y = ctx.saved_tensors
         geom, packed, weight, bias = ctx.geom, ctx.packed, ctx.weight, ctx.bias
         d, out_sz, ff, df = geom.plan(x.shape[0], ctx.in_sz)
         L = lib()
-        dy = dy.contiguous()
+        if dy is not None:
+            dy = dy.contiguous()
         key = (x.shape[0], ctx.in_sz, _plan_epoch[0])
         fam, wsb = geom.family[key], geom.ws_bytes[key]
         # both gradient kernels read dy through the channels-last split planes: one fused pass makes them from (y, dy)
         # together with the activation derivative and the bias gradient
         fused_dy = (fam[1] == 1 and fam[2] == 1 and ctx.needs_input_grad[0] and weight.requires_grad and wsb[1] > 0
                     and wsb[3] > 0)
+        if head is not None:
+            gl, head_w = head
+            co = head_w.shape[0]
+            if not (fused_dy and L.muvo_conv_prepare_dy_head_supported(C.byref(d), co)):
+                # no fused preamble for this shape: materialise the head's data gradient (dy + W_head^T dlogits)
+                hd = torch.einsum('nk...,kc->nc...', gl, head_w.view(co, -1))
+                dy = hd.contiguous() if dy is None else dy + hd
+                head = None
         ws_dy_fused = None
         if fused_dy:
             ws_dy_fused = scratch('conv_ws_dy', (max(wsb[1], wsb[3]) + 3) // 4, x.device)
             use_act = ctx.act != ACT_NONE and not ctx.act_bwd_fused
-            _ck(L.muvo_conv_prepare_dy(C.byref(d), _f(y) if use_act else None, _f(dy), ctx.act if use_act else ACT_NONE,
-                                       _fl(ctx.slope), _p(ws_dy_fused), _f(grad_of(bias)) if bias is not None else None,
-                                       _st()))
+            if head is not None:
+                _ck(L.muvo_conv_prepare_dy_head(C.byref(d), _f(y) if use_act else None, _f(dy) if dy is not None else None,
+                                                _f(gl.contiguous()), _f(head_w.contiguous().view(co, -1)), co,
+                                                ctx.act if use_act else ACT_NONE, _fl(ctx.slope), _p(ws_dy_fused),
+                                                _f(grad_of(bias)) if bias is not None else None, _st()))
+                if dy is None:
+                    dy = y if y is not None else x     # placeholder pointer: the bf16x3 kernels read the planes only
+            else:
+                _ck(L.muvo_conv_prepare_dy(C.byref(d), _f(y) if use_act else None, _f(dy), ctx.act if use_act else ACT_NONE,
+                                           _fl(ctx.slope), _p(ws_dy_fused), _f(grad_of(bias)) if bias is not None else None,
+                                           _st()))
             dz = dy   # not read by the bf16x3 kernels
         elif ctx.act != ACT_NONE and not ctx.act_bwd_fused:
             dz = torch.empty_like(dy)
@@ -859,6 +883,72 @@ class HeadBranchFn(torch.autograd.Function):
             _ck(L.muvo_conv_wgrad(C.byref(d), _f(x), _f(gy), _f(ws), _f(grad_of(weight)), _f(grad_of(bias)) if bias is not None else None,
                                   None, None, 0, _st()))
         return dx, None, None, None, None
+
+
+class ConvHeadFn(torch.autograd.Function):
+    """(y, logits) = (act(conv(x)), head(y)) for a decoder stage whose output feeds a 1x1 head with <= 4 produced channels
+    (ConvDecoder: trans_conv1/2/3 + head_4/2/1, common.py:608-632).  Forward: the two convolutions.  Backward: the head's weight /
+    bias gradient, then the stage's own backward with the head's data gradient added to dy INSIDE the split pass
+    (muvo_conv_prepare_dy_head) — neither the accumulate pass over the feature map (HeadBranchFn) nor, at the last stage, the
+    materialised head gradient exists."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, geom, packed, act, slope, head_w, head_b, head_geom, head_packed):
+        y = ConvFn.forward(ctx, x, weight, bias, geom, packed, act, slope)
+        ctx.save_for_backward(x, y)            # y is needed for the head's weight gradient even when act needs no derivative
+        n = y.shape[0]
+        hin = tuple(y.shape[2:]) if head_geom.nd == 3 else (1,) + tuple(y.shape[2:])
+        hd, hout, hff, _ = head_geom.plan(n, hin)
+        L = lib()
+        if head_packed.fwd is None or head_packed.fwd.numel() < hff:
+            head_packed.fwd = torch.empty(hff, device=x.device, dtype=torch.float32)
+            head_packed.fwd_key = None
+        k, pkey = _wkey(head_w), (hin, _plan_epoch[0])
+        if head_packed.fwd_key != k or head_packed.fwd_plan != pkey:
+            _ck(L.muvo_conv_pack_weights(C.byref(hd), _f(head_w), _f(head_packed.fwd), None, _st()))
+            head_packed.fwd_key, head_packed.fwd_plan = k, pkey
+            _PACKS.register((id(head_packed), pkey), ('conv', hd, head_w, weakref.ref(head_packed), pkey))
+        logits = torch.empty((n, head_geom.cout) + (hout if head_geom.nd == 3 else hout[1:]), device=x.device, dtype=torch.float32)
+        _ck(L.muvo_conv_forward(C.byref(hd), _f(y), _f(head_packed.fwd), _f(head_b), _f(logits), ACT_NONE, _fl(0.0), None, _st()))
+        ctx.head = (head_w, head_b, head_geom, hin)
+        return y, logits
+
+    @staticmethod
+    def backward(ctx, gy, gl):
+        if gl is None:
+            return ConvFn._backward(ctx, gy, None)[:7] + (None,) * 4
+        x, y = ctx.saved_tensors
+        head_w, head_b, head_geom, hin = ctx.head
+        hd, _, hff, _ = head_geom.plan(y.shape[0], hin)
+        gl = gl.contiguous()
+        if head_w.requires_grad:
+            ws = scratch_zeroed('wgrad', hff, x.device)
+            _ck(lib().muvo_conv_wgrad(C.byref(hd), _f(y), _f(gl), _f(ws), _f(grad_of(head_w)),
+                                      _f(grad_of(head_b)) if head_b is not None else None, None, None, 0, _st()))
+        return ConvFn._backward(ctx, gy, (gl, head_w))[:7] + (None,) * 4
+
+
+def conv_head_supported(x, geom, head_geom, act_bwd_fused=False):
+    """can (stage convolution, 1x1 head) run as ConvHeadFn?  The head must be on the 1x1 head kernels, the stage on the bf16x3
+    kernels in both gradient directions (its backward preamble is the split pass that absorbs the head's data gradient)."""
+    if not CONV_HEAD or not (x.requires_grad and torch.is_grad_enabled()) or act_bwd_fused:
+        return False
+    n = x.shape[0]
+    in_sz = tuple(x.shape[2:]) if geom.nd == 3 else (1,) + tuple(x.shape[2:])
+    d, out_sz, _, _ = geom.plan(n, in_sz)
+    fam = geom.family[(n, in_sz, _plan_epoch[0])]
+    if not (fam[1] == 1 and fam[2] == 1):
+        return False
+    head_geom.plan(n, out_sz)
+    hf = head_geom.family[(n, out_sz, _plan_epoch[0])]
+    return hf[0] == 3 and hf[2] == 3 and bool(lib().muvo_conv_prepare_dy_head_supported(C.byref(d), head_geom.cout))
+
+
+CONV_HEAD = os.environ.get('MUVO_CONV_HEAD', '1') != '0'
+
+
+def conv_head(x, weight, bias, geom, packed, act, slope, head_w, head_b, head_geom, head_packed):
+    return ConvHeadFn.apply(x, weight, bias, geom, packed, act, slope, head_w, head_b, head_geom, head_packed)
 
 
 def head_branch(x, weight, bias, geom, packed):

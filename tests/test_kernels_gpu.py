@@ -157,6 +157,51 @@ GEMM_SHAPES = [(7, 33, 5), (130, 257, 70), (324, 48, 324), (2, 1600, 1088), (300
                (20, 1536, 1536), (3, 100, 70), (9, 64, 16)]  # skinny (M <= 32) kernels incl. row chunking
 
 
+@pytest.mark.parametrize('trunk_used', [True, False])
+def test_conv_stage_with_head(dev, trunk_used):
+    """A ConvDecoder stage (common.py:608-632): ELU(ConvTranspose2d) whose output feeds a 1x1 head (and, except at the last
+    stage, the next stage).  ops.ConvHeadFn forms the head's data gradient inside the stage's backward split pass
+    (muvo_conv_prepare_dy_head); checked against the plain PyTorch composition."""
+    from muvo_amd import nn as hnn
+    from muvo_amd import ops
+    old = ops.get_conv_mode()
+    ops.set_conv_mode(ops.CONV_BF16X3, min_gflop=0.0)
+    try:
+        torch.manual_seed(17)
+        with torch.device(dev):
+            conv = hnn.ConvTranspose2d(64, 64, 6, 2, 2)
+            head = hnn.Conv2d(64, 3, 1, 1, 0)
+        x = torch.randn(3, 64, 20, 26)
+        xg = x.to(dev).requires_grad_(True)
+        assert ops.conv_head_supported(xg, conv.geom, head.geom)
+        for p in (conv.weight, conv.bias, head.weight, head.bias):
+            p.grad = torch.zeros_like(p)
+        y, logits = ops.conv_head(xg, conv.weight, conv.bias, conv.geom, conv._packed, ops.ACT_ELU, 0.0,
+                                  head.weight, head.bias, head.geom, head._packed)
+        xc = x.clone().requires_grad_(True)
+        w, b = conv.weight.detach().cpu().requires_grad_(True), conv.bias.detach().cpu().requires_grad_(True)
+        hw, hb = head.weight.detach().cpu().requires_grad_(True), head.bias.detach().cpu().requires_grad_(True)
+        yr = F.elu(F.conv_transpose2d(xc, w, b, 2, 2))
+        lr = F.conv2d(yr, hw, hb)
+        _close(y, yr, name='stage output')
+        _close(logits, lr, name='head output')
+        gl = torch.randn_like(lr)
+        gy = torch.randn_like(yr)
+        if trunk_used:
+            torch.autograd.backward([yr, lr], [gy, gl])
+            torch.autograd.backward([y, logits], [gy.to(dev), gl.to(dev)])
+        else:
+            lr.backward(gl)
+            logits.backward(gl.to(dev))
+        _close(xg.grad, xc.grad, rtol=5e-4, name='dx')
+        _close(conv.weight.grad, w.grad, rtol=5e-4, name='dW')
+        _close(conv.bias.grad, b.grad, rtol=5e-4, atol=1e-3, name='db')
+        _close(head.weight.grad, hw.grad, rtol=5e-4, atol=1e-3, name='head dW')
+        _close(head.bias.grad, hb.grad, rtol=5e-4, atol=1e-3, name='head db')
+    finally:
+        ops.set_conv_mode(old, min_gflop=-1.0)
+
+
 def test_grouped_linear(dev):
     """All style projections of a decoder in one launch per pass (ops.grouped_linear; common.py:205-246: each
     AdaptiveInstanceNorm applies its own Linear to the same latent): outputs, the summed data gradient and the per-layer
