@@ -154,10 +154,11 @@ int muvo_conv_prepare_dy(const muvo_conv_desc* d, const float* y, const float* d
 /* The same preamble for a layer whose output also feeds a 1x1 head with CO <= 4 produced channels (RGBHead / LidarReHead behind the
  * transposed convolutions of ConvDecoder, common.py:608-632): planes of (dy + W_head^T dhead) * act'(y).  dy: gradient from the
  * trunk, NULL at the last stage (its output feeds the head only); dhead (N, CO, S); head_w (CO, Cout).  The head's data gradient
- * (a pass over all Cout channels of the feature map) is never written. */
+ * (a pass over all Cout channels of the feature map) is never written.  dhead_w (CO, Cout) / dhead_b (CO), optional and only with
+ * an activation (y is then read by the pass anyway): the head's weight / bias gradient sum_pixels dhead * y, accumulated. */
 int muvo_conv_prepare_dy_head_supported(const muvo_conv_desc* d, int CO);
 int muvo_conv_prepare_dy_head(const muvo_conv_desc* d, const float* y, const float* dy, const float* dhead, const float* head_w,
-                              int CO, int act, float slope, void* ws_dy, float* dbias, void* stream);
+                              int CO, int act, float slope, void* ws_dy, float* dbias, float* dhead_w, float* dhead_b, void* stream);
 /* The operand layout of the bf16x3 kernels on its own: x (N,C,S) fp32 -> ws = [bf16 hi plane | bf16 lo plane] channels-last
  * (N,S,roundup(C,8)) (+ 16 zero bytes + scratch); optionally multiplied by act'(y) first and with per-channel sums added to
  * dbias (the backward preamble above without a descriptor).  ws: muvo_split_planes_bytes(N, C, S) bytes. */

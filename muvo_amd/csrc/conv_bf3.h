@@ -8,9 +8,11 @@ int bf3_pack_phase(const ConvPhase& g, const float* w, float* wp, hipStream_t st
 // workspace = channels-last bf16 hi/lo copy of the activation operand (N*S*roundup(C,8)*4 bytes)
 long bf3_workspace_bytes(int N, int C, long S);
 // yact/act/slope/dbias (optional): write the planes of x * act'(yact) and add its per-channel sums to dbias
-// dhead / head_w / CO: optional data gradient of a 1x1 head on the same tensor, added on the fly (x may then be NULL)
+// dhead / head_w / CO: optional data gradient of a 1x1 head on the same tensor, added on the fly (x may then be NULL);
+// dhead_w / dhead_b: the head's weight / bias gradient accumulated in the same pass (needs yact = the head's input)
 int bf3_split_input(const float* x, void* ws, int N, int C, long S, hipStream_t st, const float* yact = nullptr, int act = 0,
-                    float slope = 0.f, float* dbias = nullptr, const float* dhead = nullptr, const float* head_w = nullptr, int CO = 0);
+                    float slope = 0.f, float* dbias = nullptr, const float* dhead = nullptr, const float* head_w = nullptr, int CO = 0,
+                    float* dhead_w = nullptr, float* dhead_b = nullptr);
 int bf3_launch_fwd_phase(const ConvPhase& g, const void* ws, const float* wp, const float* bias, float* out, int act,
                          float slope, hipStream_t st, int ksplit = 1);
 // split-K factor the caller should use for this phase (1: none; > 1: zero the output first, finish bias / activation after)

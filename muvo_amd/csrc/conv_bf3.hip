@@ -942,7 +942,8 @@ nchw_split_nhwc_kernel(const float* __restrict__ in, uint4* __restrict__ out_hi,
 __global__ void __launch_bounds__(256)
 nchw_split_nhwc_v4_kernel(const float* __restrict__ in, uint4* __restrict__ out_hi, uint4* __restrict__ out_lo, int C, int Cp,
                           long S, const float* __restrict__ yact, int act, float slope, float* __restrict__ dbias,
-                          const float* __restrict__ dhead, const float* __restrict__ head_w, int CO) {
+                          const float* __restrict__ dhead, const float* __restrict__ head_w, int CO,
+                          float* __restrict__ hw_rep) {
   extern __shared__ unsigned sp_lds[];
   unsigned* th = sp_lds;
   unsigned* tl = sp_lds + 32 * SPLIT2_PS;
@@ -967,13 +968,17 @@ nchw_split_nhwc_v4_kernel(const float* __restrict__ in, uint4* __restrict__ out_
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
+  f32x4 dh[4];
+  float hacc[16][4];                     // head weight gradient partials [channel slot][head channel] (hw_rep != nullptr)
   if (dhead != nullptr) {
     // + W_head^T dlogits: the data gradient of a 1x1 output head (<= 4 produced channels) that reads the same feature map is
     // formed here from its CO gradient planes instead of being written (or accumulated) by a pass over all C channels and
     // read back (muvo_conv_prepare_dy_head)
-    f32x4 dh[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) dh[k] = *(const f32x4*)(dhead + ((size_t)n * CO + (k < CO ? k : 0)) * S + sc);
+    for (int k = 0; k < 4; ++k) {
+      dh[k] = *(const f32x4*)(dhead + ((size_t)n * CO + (k < CO ? k : 0)) * S + sc);
+      if (!sin || k >= CO) dh[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int c = c0 + 2 * (w * 8 + (r >> 1)) + (r & 1);
@@ -991,6 +996,15 @@ nchw_split_nhwc_v4_kernel(const float* __restrict__ in, uint4* __restrict__ out_
     for (int r = 0; r < 16; ++r) {
       const int c = c0 + 2 * (w * 8 + (r >> 1)) + (r & 1);
       y[r] = *(const f32x4*)(yn + (size_t)(c < C ? c : C - 1) * S + sc);
+    }
+    if (hw_rep != nullptr) {
+      // the head's weight gradient dW_head[k][c] += sum_pixels dlogits[k] * y[c] rides along: y is in registers for the
+      // activation derivative anyway (the separate pass read the whole feature map once more: 0.9 ms per step)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          hacc[r][k] = (dh[k][0] * y[r][0] + dh[k][1] * y[r][1]) + (dh[k][2] * y[r][2] + dh[k][3] * y[r][3]);
     }
     // derivative through the activation output, one instance of the loop per activation (no switch per element)
     switch (act) {
@@ -1060,8 +1074,61 @@ nchw_split_nhwc_v4_kernel(const float* __restrict__ in, uint4* __restrict__ out_
       if (c < C) atomicAdd(dbias + (size_t)(blockIdx.x % BIAS_REPLICAS) * Cp + c, (s0 + s1) + (s2 + s3));
     }
   }
+  if (hw_rep != nullptr) {
+    // lane reduction of the 16 x 4 head-gradient partials (+ the 4 head-bias partials) through the same LDS transpose, in two
+    // halves of 8 channel slots; replica r = blockIdx.x % BIAS_REPLICAS of [r][4][Cp] weight sums and [r][4] bias sums
+    float* red = (float*)sp_lds + w * (64 * 37);
+    float* hb_rep = hw_rep + (size_t)BIAS_REPLICAS * 4 * Cp;
+    const int rep = blockIdx.x % BIAS_REPLICAS;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      __syncthreads();
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[lane * 37 + rr * 4 + k] = hacc[half * 8 + rr][k];
+      if (half == 0)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[lane * 37 + 32 + k] = (dh[k][0] + dh[k][1]) + (dh[k][2] + dh[k][3]);
+      __syncthreads();
+      if (lane < (half == 0 ? 36 : 32)) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int l = 0; l < 64; l += 4) {
+          s0 += red[l * 37 + lane]; s1 += red[(l + 1) * 37 + lane];
+          s2 += red[(l + 2) * 37 + lane]; s3 += red[(l + 3) * 37 + lane];
+        }
+        const float sum = (s0 + s1) + (s2 + s3);
+        if (lane < 32) {
+          const int r = half * 8 + (lane >> 2), k = lane & 3;
+          const int c = c0 + 2 * (w * 8 + (r >> 1)) + (r & 1);
+          if (k < CO && c < C) atomicAdd(hw_rep + ((size_t)rep * 4 + k) * Cp + c, sum);
+        } else if (w == 0 && blockIdx.y == 0 && lane - 32 < CO) {
+          atomicAdd(hb_rep + rep * 4 + (lane - 32), sum);      // the four waves see the same pixels: one of them counts
+        }
+      }
+    }
+  }
   if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0)
     out_hi[2 * ((size_t)gridDim.z * S * Cp >> 3)] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+// dhead_w[k][c] += sum over replicas of the head weight sums, dhead_b[k] += ... of the bias sums (clears what it reads)
+__global__ void head_replica_reduce_kernel(float* __restrict__ hw_rep, float* __restrict__ dhead_w, float* __restrict__ dhead_b,
+                                           int C, int Cp, int CO) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float* hb_rep = hw_rep + (size_t)BIAS_REPLICAS * 4 * Cp;
+  if (i < 4 * Cp) {
+    const int k = i / Cp, c = i - k * Cp;
+    float s = 0.f;
+    for (int r = 0; r < BIAS_REPLICAS; ++r) { s += hw_rep[((size_t)r * 4 + k) * Cp + c]; hw_rep[((size_t)r * 4 + k) * Cp + c] = 0.f; }
+    if (k < CO && c < C) dhead_w[(size_t)k * C + c] += s;
+  } else if (i < 4 * Cp + 4) {
+    const int k = i - 4 * Cp;
+    float s = 0.f;
+    for (int r = 0; r < BIAS_REPLICAS; ++r) { s += hb_rep[r * 4 + k]; hb_rep[r * 4 + k] = 0.f; }
+    if (k < CO && dhead_b != nullptr) dhead_b[k] += s;
+  }
 }
 
 // dbias[c] += sum over replicas
@@ -1075,10 +1142,10 @@ __global__ void bias_replica_reduce_kernel(float* __restrict__ rep, float* __res
 }
 
 // BIAS_REPLICAS x Cp floats, zero on allocation and left zero by bias_replica_reduce_kernel (all users run on one stream)
-static float* bias_replica_buffer(int Cp) {
+static float* bias_replica_buffer(int Cp) {       // [R][Cp] bias sums, then [R][4][Cp] + [R][4] head-gradient sums
   static float* buf = nullptr;
   static size_t cap = 0;
-  const size_t need = (size_t)BIAS_REPLICAS * Cp;
+  const size_t need = (size_t)BIAS_REPLICAS * (5 * (size_t)Cp + 4);
   if (need > cap) {
     if (buf) { hipDeviceSynchronize(); hipFree(buf); buf = nullptr; }
     const size_t n = need < 65536 ? 65536 : need;
@@ -1230,13 +1297,19 @@ long bf3_workspace_bytes(int N, int C, long S) {
 }
 
 int bf3_split_input(const float* x, void* ws, int N, int C, long S, hipStream_t st, const float* yact, int act, float slope,
-                    float* dbias, const float* dhead, const float* head_w, int CO) {
+                    float* dbias, const float* dhead, const float* head_w, int CO, float* dhead_w, float* dhead_b) {
   const int Cp = roundup(C, 8);
   uint4* hi = (uint4*)ws;
   uint4* lo = hi + (size_t)N * S * Cp / 8;
   float* rep = nullptr;
-  if (dbias) {
+  float* hw_rep = nullptr;
+  if (dhead_w != nullptr && !(dhead != nullptr && yact != nullptr)) {
+    muvo_set_error("bf3_split_input: the fused head weight gradient needs the head gradient and the activation output");
+    return MUVO_ERR_INVALID_ARG;
+  }
+  if (dbias || dhead_w) {
     rep = bias_replica_buffer(Cp);
+    if (rep != nullptr && dhead_w != nullptr) hw_rep = rep + (size_t)BIAS_REPLICAS * Cp;
     if (rep == nullptr) {
       muvo_set_error("bf3_split_input: cannot allocate the bias partial-sum buffer");
       return MUVO_ERR_HIP;
@@ -1256,12 +1329,14 @@ int bf3_split_input(const float* x, void* ws, int N, int C, long S, hipStream_t 
       attr_set = true;
     }
     dim3 grid(cdiv(S, 256), cdiv(Cp, 64), N);
-    hipLaunchKernelGGL(nchw_split_nhwc_v4_kernel, grid, dim3(256), lds, st, x, hi, lo, C, Cp, S, yact, act, slope, rep, dhead, head_w, CO);
+    hipLaunchKernelGGL(nchw_split_nhwc_v4_kernel, grid, dim3(256), lds, st, x, hi, lo, C, Cp, S, yact, act, slope, dbias ? rep : nullptr,
+                       dhead, head_w, CO, hw_rep);
   } else {
     dim3 grid(cdiv(cdiv(S, 64), SPLIT_TILES), cdiv(Cp, 64), N);
     hipLaunchKernelGGL(nchw_split_nhwc_kernel, grid, dim3(256), 0, st, x, hi, lo, C, Cp, S, yact, act, slope, rep);
   }
   if (dbias) hipLaunchKernelGGL(bias_replica_reduce_kernel, dim3(cdiv(Cp, 64)), dim3(64), 0, st, rep, dbias, C, Cp);
+  if (hw_rep) hipLaunchKernelGGL(head_replica_reduce_kernel, dim3(cdiv(4 * Cp + 4, 64)), dim3(64), 0, st, hw_rep, dhead_w, dhead_b, C, Cp, CO);
   MUVO_CHECK_LAUNCH("nchw_split_nhwc_kernel");
   return MUVO_OK;
 }

@@ -953,13 +953,15 @@ int muvo_conv_prepare_dy(const muvo_conv_desc* d, const float* y, const float* d
 // gradient that came back through the trunk (NULL at the last stage, whose output feeds the head only), dhead (N, CO, S): the
 // gradient of the head's output, head_w (CO, Cout).  The head's data gradient is never materialised.
 int muvo_conv_prepare_dy_head(const muvo_conv_desc* d, const float* y, const float* dy, const float* dhead, const float* head_w,
-                              int CO, int act, float slope, void* ws_dy, float* dbias, void* stream) {
+                              int CO, int act, float slope, void* ws_dy, float* dbias, float* dhead_w, float* dhead_b, void* stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   MUVO_CHECK_ARG(dhead && head_w && ws_dy && CO >= 1 && CO <= 4 && (y || act == MUVO_ACT_NONE), "conv_prepare_dy_head: bad args");
   const long S_out = (long)d->out_sz[0] * d->out_sz[1] * d->out_sz[2];
+  MUVO_CHECK_ARG(dhead_w == nullptr || (y != nullptr && act != MUVO_ACT_NONE),
+                 "conv_prepare_dy_head: the fused head weight gradient needs the activation output y");
   return bf3_split_input(dy, ws_dy, d->N, d->Cout, S_out, (hipStream_t)stream, act == MUVO_ACT_NONE ? nullptr : y, act, slope,
-                         dbias, dhead, head_w, CO);
+                         dbias, dhead, head_w, CO, dhead_w, dhead_b);
 }
 // 1 when muvo_conv_prepare_dy_head can serve this layer (spatial size % 4 == 0 and >= 1024)
 int muvo_conv_prepare_dy_head_supported(const muvo_conv_desc* d, int CO) {

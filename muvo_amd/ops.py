@@ -734,22 +734,29 @@ class ConvFn(torch.autograd.Function):
         fused_dy = (fam[1] == 1 and fam[2] == 1 and ctx.needs_input_grad[0] and weight.requires_grad and wsb[1] > 0
                     and wsb[3] > 0)
         if head is not None:
-            gl, head_w = head
+            gl, head_w, head_b, head_wgrad = head
             co = head_w.shape[0]
             if not (fused_dy and L.muvo_conv_prepare_dy_head_supported(C.byref(d), co)):
                 # no fused preamble for this shape: materialise the head's data gradient (dy + W_head^T dlogits)
                 hd = torch.einsum('nk...,kc->nc...', gl, head_w.view(co, -1))
                 dy = hd.contiguous() if dy is None else dy + hd
+                head_wgrad()
                 head = None
         ws_dy_fused = None
         if fused_dy:
             ws_dy_fused = scratch('conv_ws_dy', (max(wsb[1], wsb[3]) + 3) // 4, x.device)
             use_act = ctx.act != ACT_NONE and not ctx.act_bwd_fused
             if head is not None:
+                # with an activation the pass reads y anyway: the head's weight / bias gradient rides along
+                ride = use_act and head_w.requires_grad
+                if not ride:
+                    head_wgrad()
                 _ck(L.muvo_conv_prepare_dy_head(C.byref(d), _f(y) if use_act else None, _f(dy) if dy is not None else None,
                                                 _f(gl.contiguous()), _f(head_w.contiguous().view(co, -1)), co,
                                                 ctx.act if use_act else ACT_NONE, _fl(ctx.slope), _p(ws_dy_fused),
-                                                _f(grad_of(bias)) if bias is not None else None, _st()))
+                                                _f(grad_of(bias)) if bias is not None else None,
+                                                _f(grad_of(head_w)) if ride else None,
+                                                _f(grad_of(head_b)) if (ride and head_b is not None) else None, _st()))
                 if dy is None:
                     dy = y if y is not None else x     # placeholder pointer: the bf16x3 kernels read the planes only
             else:
@@ -921,11 +928,13 @@ class ConvHeadFn(torch.autograd.Function):
         head_w, head_b, head_geom, hin = ctx.head
         hd, _, hff, _ = head_geom.plan(y.shape[0], hin)
         gl = gl.contiguous()
-        if head_w.requires_grad:
-            ws = scratch_zeroed('wgrad', hff, x.device)
-            _ck(lib().muvo_conv_wgrad(C.byref(hd), _f(y), _f(gl), _f(ws), _f(grad_of(head_w)),
-                                      _f(grad_of(head_b)) if head_b is not None else None, None, None, 0, _st()))
-        return ConvFn._backward(ctx, gy, (gl, head_w))[:7] + (None,) * 4
+
+        def head_wgrad():        # the head's own weight-gradient pass (when it cannot ride on the split pass)
+            if head_w.requires_grad:
+                ws = scratch_zeroed('wgrad', hff, x.device)
+                _ck(lib().muvo_conv_wgrad(C.byref(hd), _f(y), _f(gl), _f(ws), _f(grad_of(head_w)),
+                                          _f(grad_of(head_b)) if head_b is not None else None, None, None, 0, _st()))
+        return ConvFn._backward(ctx, gy, (gl, head_w, head_b, head_wgrad))[:7] + (None,) * 4
 
 
 def conv_head_supported(x, geom, head_geom, act_bwd_fused=False):
