@@ -458,11 +458,29 @@ __device__ __forceinline__ bf16x8 tr_read8(const char* lds_addr0, const char* ld
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// The weight-gradient grids are (tap x channel tile, row tile, pixel range): the workgroups that read the SAME pixel range
+// (all taps and tiles of one blockIdx.z) are consecutive in dispatch order, i.e. dealt over all eight XCDs, and every XCD's L2
+// fetches every operand tile.  With xcd_order the linear workgroup id is swizzled so that one XCD walks consecutive
+// (tap, tile) workgroups of one pixel range: the operand rows are fetched into one L2 and hit there by the other taps.
+struct WgradBlock { int x, y, z; };
+__device__ __forceinline__ WgradBlock wgrad_block(int xcd_order) {
+  WgradBlock b = {(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+  if (xcd_order) {
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int v = xcd_swizzle((b.z * gy + b.y) * gx + b.x, gx * gy * (int)gridDim.z);
+    b.x = v % gx;
+    const int r = v / gx;
+    b.y = r % gy;
+    b.z = r / gy;
+  }
+  return b;
+}
+
 template <int BM, int BN, int WM, int WN, int WK>
 __global__ void __launch_bounds__(64 * WM * WN * WK)
 conv_bf3_wgrad_kernel(const ConvPhase g, const uint4* __restrict__ xs, long xplane_u4, int xc8, const uint4* __restrict__ dzs,
                       long dzplane_u4, int dzc8, float* __restrict__ wg, int steps_per_split,
-                      const uint4* __restrict__ zero16) {
+                      const uint4* __restrict__ zero16, int xcd_order) {
   constexpr int BK = 32, NW = WM * WN * WK;         // WK = 2: two wave groups split the 32 pixels of a step
   constexpr int CA = BM / 8, CB = BN / 8;           // 8-channel chunks per pixel row
   constexpr int STAGE = 2 * 32 * (CA + CB);         // uint4 per stage: A [plane][CA][32] then B [plane][CB][32]
@@ -475,11 +493,12 @@ conv_bf3_wgrad_kernel(const ConvPhase g, const uint4* __restrict__ xs, long xpla
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wk = wave / (WM * WN), wm = (wave / WN) % WM, wn = wave % WN;
   const int ctiles = (g.C + BN - 1) / BN;
-  const int t = blockIdx.x / ctiles, c_tile = (blockIdx.x % ctiles) * BN, m_tile = blockIdx.y * BM;
+  const WgradBlock blk = wgrad_block(xcd_order);
+  const int t = blk.x / ctiles, c_tile = (blk.x % ctiles) * BN, m_tile = blk.y * BM;
   const int td = g.tap_d[t];
   const int dz_ = ((td >> 16) & 255) - 128, dy_ = ((td >> 8) & 255) - 128, dx_ = (td & 255) - 128;
   const int nsteps = (g.npix + BK - 1) / BK;
-  const int s_begin = blockIdx.z * steps_per_split;
+  const int s_begin = blk.z * steps_per_split;
   int s_end = s_begin + steps_per_split;
   if (s_end > nsteps) s_end = nsteps;
   const int ns = s_end - s_begin;
@@ -628,7 +647,7 @@ conv_bf3_wgrad_kernel(const ConvPhase g, const uint4* __restrict__ xs, long xpla
 template <int BM, int BN, int WM, int WN>
 __global__ void __launch_bounds__(64 * WM * WN)
 conv_bf3_wgrad_pp_kernel(const ConvPhase g, const uint4* __restrict__ xs, long xplane_u4, int xc8, const uint4* __restrict__ dzs,
-                         long dzplane_u4, int dzc8, float* __restrict__ wg, int steps_per_split) {
+                         long dzplane_u4, int dzc8, float* __restrict__ wg, int steps_per_split, int xcd_order) {
   constexpr int BK = 32, NW = WM * WN;
   static_assert(NW == 8 && BM == WM * 64 && BN == WN * 64, "two groups of four waves, 64x64 wave tiles");
   constexpr int CA = BM / 8, CB = BN / 8;           // 8-channel chunks per pixel row
@@ -641,11 +660,12 @@ conv_bf3_wgrad_pp_kernel(const ConvPhase g, const uint4* __restrict__ xs, long x
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int ctiles = (g.C + BN - 1) / BN;
-  const int t = blockIdx.x / ctiles, c_tile = (blockIdx.x % ctiles) * BN, m_tile = blockIdx.y * BM;
+  const WgradBlock blk = wgrad_block(xcd_order);
+  const int t = blk.x / ctiles, c_tile = (blk.x % ctiles) * BN, m_tile = blk.y * BM;
   const int td = g.tap_d[t];
   const int dz_ = ((td >> 16) & 255) - 128, dy_ = ((td >> 8) & 255) - 128, dx_ = (td & 255) - 128;
   const int nsteps = (g.npix + BK - 1) / BK;
-  const int s_begin = blockIdx.z * steps_per_split;
+  const int s_begin = blk.z * steps_per_split;
   int s_end = s_begin + steps_per_split;
   if (s_end > nsteps) s_end = nsteps;
   const int ns = s_end - s_begin;
@@ -1436,6 +1456,11 @@ int bf3_launch_fwd_phase(const ConvPhase& g, const void* ws, const float* wp, co
   return bf3_launch<64, 128, 1, 4, 4, 2>(g, ws, wp, bias, out, act, slope, st);
 }
 
+static int bf3_wgrad_xcd_order() {
+  static const int v = getenv("MUVO_BF3_WGRAD_XCD") ? atoi(getenv("MUVO_BF3_WGRAD_XCD")) : 1;   // A/B switch
+  return v;
+}
+
 template <int BM, int BN, int WM, int WN>
 static int bf3_wgrad_pp_launch(const ConvPhase& g, const void* ws_x, int Cin_total, const void* ws_dz, int Cout_total,
                                float* wg, hipStream_t st) {
@@ -1464,7 +1489,7 @@ static int bf3_wgrad_pp_launch(const ConvPhase& g, const void* ws_x, int Cin_tot
   ksplit = cdiv(nsteps, sps);
   dim3 grid(ctiles * g.T, mtiles, ksplit);
   hipLaunchKernelGGL((conv_bf3_wgrad_pp_kernel<BM, BN, WM, WN>), grid, dim3(64 * WM * WN), lds, st, p, (const uint4*)ws_x, xplane,
-                     xc8, (const uint4*)ws_dz, dzplane, dzc8, wg, sps);
+                     xc8, (const uint4*)ws_dz, dzplane, dzc8, wg, sps, bf3_wgrad_xcd_order());
   MUVO_CHECK_LAUNCH("conv_bf3_wgrad_pp_kernel");
   return MUVO_OK;
 }
@@ -1499,7 +1524,7 @@ static int bf3_wgrad_launch(const ConvPhase& g, const void* ws_x, int Cin_total,
   ksplit = cdiv(nsteps, sps);
   dim3 grid(ctiles * g.T, mtiles, ksplit);
   hipLaunchKernelGGL((conv_bf3_wgrad_kernel<BM, BN, WM, WN, WK>), grid, dim3(64 * WM * WN * WK), lds, st, p, (const uint4*)ws_x, xplane,
-                     xc8, (const uint4*)ws_dz, dzplane, dzc8, wg, sps, zero16);
+                     xc8, (const uint4*)ws_dz, dzplane, dzc8, wg, sps, zero16, bf3_wgrad_xcd_order());
   MUVO_CHECK_LAUNCH("conv_bf3_wgrad_kernel");
   return MUVO_OK;
 }

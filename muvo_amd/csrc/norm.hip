@@ -174,39 +174,69 @@ static double* norm_sums(size_t n_doubles) {
   return g_norm_sums;
 }
 
-// ------------------------------------------------------------------------------------------ BN
-// (the finalize kernels clear the sums they read: the workspace is all-zero between norm operations, so none of them
-// needs a memset in front of its statistics pass)
-__global__ void bn_finalize_kernel(double* __restrict__ sums, float* __restrict__ mean, float* __restrict__ rstd,
-                                   float* __restrict__ run_mean, float* __restrict__ run_var, int C, double cnt,
-                                   float eps, float momentum) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const double m = sums[2 * c] / cnt;
-  double var = sums[2 * c + 1] / cnt - m * m;
-  sums[2 * c] = 0.0;
-  sums[2 * c + 1] = 0.0;
-  if (var < 0) var = 0;
-  mean[c] = (float)m;
-  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-  if (run_mean) {
-    const double unb = cnt > 1 ? var * cnt / (cnt - 1.0) : var;
-    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)m;
-    run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
+// BatchNorm statistics slots: a ring of zeroed doubles.  Every BatchNorm pass takes a fresh slot for its (sum, sum of squares)
+// or (sum dz, sum dz*xhat), its statistics kernel adds into it and its apply kernel reads the totals straight from the slot
+// (mean / rstd / running statistics / dgamma / dbeta are written by the first thread of each channel) - no finalize launch
+// between the two (152 four-microsecond launches per step).  When the ring wraps it is cleared with one memset on the
+// stream, behind every kernel that read the old slots.
+static double* g_bn_ring = nullptr;
+static size_t g_bn_ring_pos = 0;
+static const size_t BN_RING = 1u << 20;
+static double* bn_slot(size_t n_doubles, hipStream_t st) {
+  if (n_doubles > BN_RING) return nullptr;
+  if (!g_bn_ring) {
+    if (hipMalloc((void**)&g_bn_ring, BN_RING * sizeof(double)) != hipSuccess) { g_bn_ring = nullptr; return nullptr; }
+    if (hipMemsetAsync(g_bn_ring, 0, BN_RING * sizeof(double), st) != hipSuccess) return nullptr;
+    g_bn_ring_pos = 0;
   }
+  if (g_bn_ring_pos + n_doubles > BN_RING) {
+    if (hipMemsetAsync(g_bn_ring, 0, BN_RING * sizeof(double), st) != hipSuccess) return nullptr;
+    g_bn_ring_pos = 0;
+  }
+  double* p = g_bn_ring + g_bn_ring_pos;
+  g_bn_ring_pos += (n_doubles + 15) & ~(size_t)15;
+  return p;
 }
 
+// ------------------------------------------------------------------------------------------ BN
+// per-channel statistics from the slot totals; `first` (one thread per channel) also stores them for the backward pass and
+// updates the running statistics (nn.BatchNorm2d train mode: unbiased variance, momentum)
+struct BnStat { float mean, rstd; };
+__device__ __forceinline__ BnStat bn_stat(const double* __restrict__ sums, int c, double cnt, float eps, bool first,
+                                          float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ run_mean,
+                                          float* __restrict__ run_var, float momentum) {
+  const double m = sums[2 * c] / cnt;
+  double var = sums[2 * c + 1] / cnt - m * m;
+  if (var < 0) var = 0;
+  BnStat r;
+  r.mean = (float)m;
+  r.rstd = (float)(1.0 / sqrt(var + (double)eps));
+  if (first) {
+    mean[c] = r.mean;
+    rstd[c] = r.rstd;
+    if (run_mean) {
+      const double unb = cnt > 1 ? var * cnt / (cnt - 1.0) : var;
+      run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)m;
+      run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
+    }
+  }
+  return r;
+}
+#define BN_STAT_PARAMS const double* __restrict__ sums, double cnt, float eps, float* __restrict__ run_mean, \
+                       float* __restrict__ run_var, float momentum
 // y = act((x-mean)*rstd*gamma+beta [+res before act]) [+res after act]
 __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
-                                                       float* __restrict__ y, const float* __restrict__ mean,
-                                                       const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                       float* __restrict__ y, float* __restrict__ mean,
+                                                       float* __restrict__ rstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, int C, long S, long total4,
-                                                       int res_mode, int relu) {
+                                                       int res_mode, int relu, BN_STAT_PARAMS) {
   // S % 4 == 0 path (vectorised); the host falls back to total4 = total, vec = 1 otherwise via template below
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
     const long e = i * 4;
-    const int c = (int)((e / S) % C);
-    const float sc = rstd[c] * gamma[c], sh = beta[c] - mean[c] * sc;
+    const long row = e / S;
+    const int c = (int)(row % C);
+    const BnStat bs = bn_stat(sums, c, cnt, eps, row < C && e == row * S, mean, rstd, run_mean, run_var, momentum);
+    const float sc = bs.rstd * gamma[c], sh = beta[c] - bs.mean * sc;
     float4 v = *(const float4*)(x + e);
     float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
     if (res_mode) r = *(const float4*)(res + e);
@@ -222,14 +252,16 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__
   }
 }
 __global__ void __launch_bounds__(256) bn_apply_scalar_kernel(const float* __restrict__ x, const float* __restrict__ res,
-                                                              float* __restrict__ y, const float* __restrict__ mean,
-                                                              const float* __restrict__ rstd,
+                                                              float* __restrict__ y, float* __restrict__ mean,
+                                                              float* __restrict__ rstd,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, int C, long S, long total,
-                                                              int res_mode, int relu) {
+                                                              int res_mode, int relu, BN_STAT_PARAMS) {
   for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const int c = (int)((e / S) % C);
-    const float sc = rstd[c] * gamma[c], sh = beta[c] - mean[c] * sc;
+    const long row = e / S;
+    const int c = (int)(row % C);
+    const BnStat bs = bn_stat(sums, c, cnt, eps, row < C && e == row * S, mean, rstd, run_mean, run_var, momentum);
+    const float sc = bs.rstd * gamma[c], sh = beta[c] - bs.mean * sc;
     float o = x[e] * sc + sh;
     if (res_mode == 1) o += res[e];
     if (relu) o = o > 0.f ? o : 0.f;
@@ -238,31 +270,24 @@ __global__ void __launch_bounds__(256) bn_apply_scalar_kernel(const float* __res
   }
 }
 
-// sums -> dgamma/dbeta and a copy for the apply pass (fin: the caller's workspace), then cleared
-__global__ void bn_bwd_finalize_kernel(double* __restrict__ sums, double* __restrict__ fin, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const double s1 = sums[2 * c], s2 = sums[2 * c + 1];
-  dbeta[c] += (float)s1;
-  dgamma[c] += (float)s2;
-  fin[2 * c] = s1;
-  fin[2 * c + 1] = s2;
-  sums[2 * c] = 0.0;
-  sums[2 * c + 1] = 0.0;
-}
-
 // dx = gamma*rstd*(dz - s1/cnt - xhat*s2/cnt); dres = dz (res_mode 1 only)
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                            const float* __restrict__ dy, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const double* __restrict__ sums,
                                                            float* __restrict__ dx, float* __restrict__ dres, int C, long S,
-                                                           long total, double cnt, int mask_mode) {
+                                                           long total, double cnt, int mask_mode, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta) {
   for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const int c = (int)((e / S) % C);
+    const long row = e / S;
+    const int c = (int)(row % C);
     const float mu = mean[c], rs = rstd[c], ga = gamma[c];
-    const float m1 = (float)(sums[2 * c] / cnt), m2 = (float)(sums[2 * c + 1] / cnt);
+    const double s1 = sums[2 * c], s2 = sums[2 * c + 1];
+    if (row < C && e == row * S) {      // first element of the channel: the parameter gradients (accumulated into .grad)
+      dbeta[c] += (float)s1;
+      dgamma[c] += (float)s2;
+    }
+    const float m1 = (float)(s1 / cnt), m2 = (float)(s2 / cnt);
     const float xh = (x[e] - mu) * rs;
     float d = dy[e];
     if (mask_mode == 1) d = y[e] > 0.f ? d : 0.f;
@@ -274,13 +299,15 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restri
 
 // float4 variants (S % 4 == 0, 16-byte aligned tensors, N*C <= 65535): grid = (chunks, N*C), one (n, c) row per workgroup row
 __global__ void __launch_bounds__(256) bn_apply_vec_kernel(const float* __restrict__ x, const float* __restrict__ res,
-                                                           float* __restrict__ y, const float* __restrict__ mean,
-                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                           float* __restrict__ y, float* __restrict__ mean,
+                                                           float* __restrict__ rstd, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, int C, long S, int res_mode,
-                                                           int relu) {
+                                                           int relu, BN_STAT_PARAMS) {
   const long g = blockIdx.y;
   const int c = (int)(g % C);
-  const float sc = rstd[c] * gamma[c], sh = beta[c] - mean[c] * sc;
+  const BnStat bs = bn_stat(sums, c, cnt, eps, g < C && blockIdx.x == 0 && threadIdx.x == 0, mean, rstd, run_mean, run_var,
+                            momentum);
+  const float sc = bs.rstd * gamma[c], sh = beta[c] - bs.mean * sc;
   const float4* xp = reinterpret_cast<const float4*>(x + g * S);
   const float4* rp = reinterpret_cast<const float4*>(res + g * S);
   float4* yp = reinterpret_cast<float4*>(y + g * S);
@@ -306,11 +333,17 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_vec_kernel(const float* __re
                                                                const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, const double* __restrict__ sums,
                                                                float* __restrict__ dx, float* __restrict__ dres, int C, long S,
-                                                               double cnt, int mask_mode) {
+                                                               double cnt, int mask_mode, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta) {
   const long g = blockIdx.y;
   const int c = (int)(g % C);
   const float mu = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
-  const float m1 = (float)(sums[2 * c] / cnt), m2 = (float)(sums[2 * c + 1] / cnt);
+  const double s1 = sums[2 * c], s2 = sums[2 * c + 1];
+  if (g < C && blockIdx.x == 0 && threadIdx.x == 0) {      // the parameter gradients (accumulated into .grad)
+    dbeta[c] += (float)s1;
+    dgamma[c] += (float)s2;
+  }
+  const float m1 = (float)(s1 / cnt), m2 = (float)(s2 / cnt);
   const float4* xp = reinterpret_cast<const float4*>(x + g * S);
   const float4* yp = reinterpret_cast<const float4*>(y + g * S);
   const float4* gp = reinterpret_cast<const float4*>(dy + g * S);
@@ -348,24 +381,24 @@ extern "C" int muvo_bn_train_fwd(const float* x, const float* gamma, const float
   const long cnt = (long)N * S;
   int chunks = cdiv(cnt, norm_chunk_elems());
   if (chunks > norm_max_chunks(256)) chunks = norm_max_chunks(256);
-  double* sums = norm_sums(2 * (size_t)C);
-  MUVO_CHECK_ARG(sums != nullptr, "bn_train_fwd: cannot allocate the statistics buffer");
+  double* sums = bn_slot(2 * (size_t)C, st);
+  MUVO_CHECK_ARG(sums != nullptr, "bn_train_fwd: cannot allocate the statistics ring");
   hipLaunchKernelGGL(moments_kernel, dim3(C, chunks), dim3(256), 0, st, x, sums, (long)S, (long)C * S, cnt,
                      (int)(S % 4 == 0 && ((uintptr_t)x & 15) == 0));
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, sums, save_mean, save_rstd, running_mean,
-                     running_var, C, (double)cnt, eps, momentum);
   const long total = cnt * C;
   if (S % 4 == 0 && S >= 1024 && (long)N * C <= 65535 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)(residual ? residual : x)) & 15) == 0) {
     int gx = cdiv(S / 4, 256 * 4);
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(bn_apply_vec_kernel, dim3(gx, N * C), dim3(256), 0, st, x, residual, y, save_mean, save_rstd, gamma, beta,
-                       C, (long)S, res_mode, relu);
+                       C, (long)S, res_mode, relu, (const double*)sums, (double)cnt, eps, running_mean, running_var, momentum);
   } else if (S % 4 == 0)
     hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(total / 4)), dim3(256), 0, st, x, residual, y, save_mean,
-                       save_rstd, gamma, beta, C, (long)S, total / 4, res_mode, relu);
+                       save_rstd, gamma, beta, C, (long)S, total / 4, res_mode, relu, (const double*)sums, (double)cnt, eps,
+                       running_mean, running_var, momentum);
   else
     hipLaunchKernelGGL(bn_apply_scalar_kernel, dim3(ew_grid(total)), dim3(256), 0, st, x, residual, y, save_mean,
-                       save_rstd, gamma, beta, C, (long)S, total, res_mode, relu);
+                       save_rstd, gamma, beta, C, (long)S, total, res_mode, relu, (const double*)sums, (double)cnt, eps,
+                       running_mean, running_var, momentum);
   MUVO_CHECK_LAUNCH("bn_train_fwd");
   return MUVO_OK;
 }
@@ -382,22 +415,21 @@ extern "C" int muvo_bn_train_bwd(const float* x, const float* y, const float* dy
   const long cnt = (long)N * S;
   int chunks = cdiv(cnt, norm_chunk_elems());
   if (chunks > norm_max_chunks(256)) chunks = norm_max_chunks(256);
-  double* sums = norm_sums(2 * (size_t)C);
-  MUVO_CHECK_ARG(sums != nullptr, "bn_train_bwd: cannot allocate the statistics buffer");
+  double* sums = bn_slot(2 * (size_t)C, st);
+  MUVO_CHECK_ARG(sums != nullptr, "bn_train_bwd: cannot allocate the statistics ring");
   hipLaunchKernelGGL(bwd_moments_kernel, dim3(C, chunks), dim3(256), 0, st, x, y, dy, save_mean, save_rstd, gamma, beta,
                      sums, (long)S, (long)C * S, (long)C * S, cnt, mask_mode, 0,
                      (int)(S % 4 == 0 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)(mask_mode == 1 ? y : x)) & 15) == 0));
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, sums, ws, dgamma, dbeta, C);
   const long total = cnt * C;
   if (S % 4 == 0 && S >= 1024 && (long)N * C <= 65535 &&
       (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)(mask_mode == 1 ? y : x) | (uintptr_t)(dres ? dres : dx)) & 15) == 0) {
     int gx = cdiv(S / 4, 256 * 4);
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3(gx, N * C), dim3(256), 0, st, x, y, dy, save_mean, save_rstd, gamma, beta,
-                       ws, dx, dres, C, (long)S, (double)cnt, mask_mode);
+                       (const double*)sums, dx, dres, C, (long)S, (double)cnt, mask_mode, dgamma, dbeta);
   } else
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, st, x, y, dy, save_mean, save_rstd, gamma,
-                       beta, ws, dx, dres, C, (long)S, total, (double)cnt, mask_mode);
+                       beta, (const double*)sums, dx, dres, C, (long)S, total, (double)cnt, mask_mode, dgamma, dbeta);
   MUVO_CHECK_LAUNCH("bn_train_bwd");
   return MUVO_OK;
 }

@@ -903,6 +903,9 @@ class ConvHeadFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, geom, packed, act, slope, head_w, head_b, head_geom, head_packed):
         y = ConvFn.forward(ctx, x, weight, bias, geom, packed, act, slope)
         ctx.save_for_backward(x, y)            # y is needed for the head's weight gradient even when act needs no derivative
+        # an output nobody differentiates through (the last stage's feature map has the head as its only consumer) arrives
+        # as None in backward instead of a zero tensor of its size (1.36 GB filled, then read by the split pass)
+        ctx.set_materialize_grads(False)
         n = y.shape[0]
         hin = tuple(y.shape[2:]) if head_geom.nd == 3 else (1,) + tuple(y.shape[2:])
         hd, hout, hff, _ = head_geom.plan(n, hin)
@@ -923,6 +926,8 @@ class ConvHeadFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, gl):
         if gl is None:
+            if gy is None:
+                return (None,) * 11
             return ConvFn._backward(ctx, gy, None)[:7] + (None,) * 4
         x, y = ctx.saved_tensors
         head_w, head_b, head_geom, hin = ctx.head
