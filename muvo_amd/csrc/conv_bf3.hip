@@ -1456,6 +1456,29 @@ int bf3_launch_fwd_phase(const ConvPhase& g, const void* ws, const float* wp, co
   return bf3_launch<64, 128, 1, 4, 4, 2>(g, ws, wp, bias, out, act, slope, st);
 }
 
+// Split-K factor of a weight-gradient launch.  Many tiles: the measured default (about `tgt` workgroups, >= `minst` steps each).
+// Few tiles (decoder stages with 5 x 13 ... 10 x 26 pixels, ResNet stage 4: tiles x default split < 4 rounds of the chip): the
+// split that minimises  rounds x (steps x 1.2 us + 12 us)  with rounds = ceil(workgroups / resident slots) - e.g. 72 tiles with
+// 163 steps ran as 360 workgroups = two rounds of 33 steps; 216 workgroups are one round of 55 (tools/bf3_wgrad_stamps.py:
+// 1.2 us per step, 4 us setup + prologue, 6-10 us until the epilogue's atomics have drained and the LDS is free again).
+static int bf3_wgrad_ksplit(long tiles, int nsteps, int tgt, int minst, int slots) {
+  int ksplit = cdiv(tgt, tiles);
+  if (ksplit > cdiv(nsteps, minst)) ksplit = cdiv(nsteps, minst);
+  if (ksplit < 1) ksplit = 1;
+  static const int quant = getenv("MUVO_BF3_WGRAD_QUANT") ? atoi(getenv("MUVO_BF3_WGRAD_QUANT")) : 1;   // A/B switch
+  if (quant && tiles * ksplit < 4L * slots) {
+    const int kmax = nsteps / 12 > 1 ? nsteps / 12 : 1;
+    double best = 1e30;
+    for (int ks = 1; ks <= kmax && tiles * ks <= 8L * slots; ++ks) {
+      const int sps = cdiv(nsteps, ks);
+      if (cdiv(nsteps, sps) != ks) continue;            // not a distinct partition
+      const double cost = (double)cdiv(tiles * ks, slots) * (sps * 1.2 + 12.0);
+      if (cost < best - 1e-9) { best = cost; ksplit = ks; }
+    }
+  }
+  return ksplit;
+}
+
 static int bf3_wgrad_xcd_order() {
   static const int v = getenv("MUVO_BF3_WGRAD_XCD") ? atoi(getenv("MUVO_BF3_WGRAD_XCD")) : 1;   // A/B switch
   return v;
@@ -1482,9 +1505,7 @@ static int bf3_wgrad_pp_launch(const ConvPhase& g, const void* ws_x, int Cin_tot
   const int nsteps = cdiv(g.npix, 32);
   static const int tgt = getenv("MUVO_BF3_WGRAD_PP_BLOCKS") ? atoi(getenv("MUVO_BF3_WGRAD_PP_BLOCKS")) : 2048;
   static const int minst = getenv("MUVO_BF3_WGRAD_PP_MINSTEPS") ? atoi(getenv("MUVO_BF3_WGRAD_PP_MINSTEPS")) : 32;   // measured: 16.2 -> 15.5 ms/step over all ping-pong weight gradients vs (1536, 16): fewer split-K atomics per tile
-  int ksplit = cdiv(tgt, (long)ctiles * g.T * mtiles);
-  if (ksplit > cdiv(nsteps, minst)) ksplit = cdiv(nsteps, minst);
-  if (ksplit < 1) ksplit = 1;
+  int ksplit = bf3_wgrad_ksplit((long)ctiles * g.T * mtiles, nsteps, tgt, minst, 256);   // one 147-KB workgroup per CU
   const int sps = cdiv(nsteps, ksplit);
   ksplit = cdiv(nsteps, sps);
   dim3 grid(ctiles * g.T, mtiles, ksplit);
@@ -1517,9 +1538,7 @@ static int bf3_wgrad_launch(const ConvPhase& g, const void* ws_x, int Cin_total,
   const int nsteps = cdiv(g.npix, 32);
   static const int tgt = getenv("MUVO_BF3_WGRAD_BLOCKS") ? atoi(getenv("MUVO_BF3_WGRAD_BLOCKS")) : 2048;
   static const int minst = getenv("MUVO_BF3_WGRAD_MINSTEPS") ? atoi(getenv("MUVO_BF3_WGRAD_MINSTEPS")) : 32;     // measured 3.6 -> 3.3 ms/step vs (1536, 16)
-  int ksplit = cdiv(tgt, (long)ctiles * g.T * mtiles);
-  if (ksplit > cdiv(nsteps, minst)) ksplit = cdiv(nsteps, minst);
-  if (ksplit < 1) ksplit = 1;
+  int ksplit = bf3_wgrad_ksplit((long)ctiles * g.T * mtiles, nsteps, tgt, minst, 256 * (int)(160 * 1024 / lds));
   const int sps = cdiv(nsteps, ksplit);
   ksplit = cdiv(nsteps, sps);
   dim3 grid(ctiles * g.T, mtiles, ksplit);

@@ -16,7 +16,12 @@ LAYERS = [('convT 128->64 in 160x416', lambda: hnn.ConvTranspose2d(128, 64, 6, 2
           ('convT 512->256 in 40x104', lambda: hnn.ConvTranspose2d(512, 256, 6, 2, 2), (20, 512, 40, 104)),
           ('conv 128->128 3x3 in 40x104', lambda: hnn.Conv2d(128, 128, 3, 1, 1), (20, 128, 40, 104)),
           ('conv 256->256 3x3 in 20x52', lambda: hnn.Conv2d(256, 256, 3, 1, 1), (20, 256, 20, 52)),
-          ('conv 512->512 3x3 in 10x26', lambda: hnn.Conv2d(512, 512, 3, 1, 1), (20, 512, 10, 26))]
+          ('conv 512->512 3x3 in 10x26', lambda: hnn.Conv2d(512, 512, 3, 1, 1), (20, 512, 10, 26)),
+          ('convT 512->512 k5 in 10x26', lambda: hnn.ConvTranspose2d(512, 512, 5, 2, 2, 1), (20, 512, 10, 26)),
+          ('convT 512->512 k5 in 5x13', lambda: hnn.ConvTranspose2d(512, 512, 5, 2, 2, 1), (20, 512, 5, 13)),
+          ('convT 512->512 k6 in 4x64', lambda: hnn.ConvTranspose2d(512, 512, 6, 2, 2), (20, 512, 4, 64))]
+if len(sys.argv) > 1:
+    LAYERS = [l for l in LAYERS if sys.argv[1] in l[0]]
 for name, make, shape in LAYERS:
     torch.manual_seed(0)
     with torch.device(dev):
