@@ -482,6 +482,8 @@ conv_bf3_wgrad_kernel(const ConvPhase g, const uint4* __restrict__ xs, long xpla
                       long dzplane_u4, int dzc8, float* __restrict__ wg, int steps_per_split,
                       const uint4* __restrict__ zero16, int xcd_order) {
   constexpr int BK = 32, NW = WM * WN * WK;         // WK = 2: two wave groups split the 32 pixels of a step
+  constexpr int TI = BM / (32 * WM), TJ = BN / (32 * WN);   // 32 x 32 MFMA blocks of a wave tile
+  static_assert(TI >= 1 && TJ >= 1 && TI * 32 * WM == BM && TJ * 32 * WN == BN, "wave tiles must tile the workgroup tile");
   constexpr int CA = BM / 8, CB = BN / 8;           // 8-channel chunks per pixel row
   constexpr int STAGE = 2 * 32 * (CA + CB);         // uint4 per stage: A [plane][CA][32] then B [plane][CB][32]
   constexpr int NA = CA, NB = CB;                   // DMA wave-instructions per stage (2 planes x chunks/2)
@@ -568,11 +570,11 @@ conv_bf3_wgrad_kernel(const ConvPhase g, const uint4* __restrict__ xs, long xpla
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[TI][TJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -594,26 +596,30 @@ conv_bf3_wgrad_kernel(const ConvPhase g, const uint4* __restrict__ xs, long xpla
     __builtin_amdgcn_s_barrier();
     if (st + 2 < ns) issue(stage == 0 ? 2 : stage - 1);
     const char* S = (const char*)(smem + stage * STAGE);
-    const char* Ah = S + (size_t)(wm * 8) * 512;                     // chunk base of this wave's 64 rows
+    const char* Ah = S + (size_t)(wm * TI * 4) * 512;                // chunk base of this wave's TI x 32 rows
     const char* Al = Ah + (size_t)CA * 512;
-    const char* Bh = S + (size_t)2 * CA * 512 + (size_t)(wn * 8) * 512;
+    const char* Bh = S + (size_t)2 * CA * 512 + (size_t)(wn * TJ * 4) * 512;
     const char* Bl = Bh + (size_t)CB * 512;
 #pragma unroll
     for (int ks0 = 0; ks0 < 2 / WK; ++ks0) {
       const int ks = WK == 2 ? wk : ks0;
-      bf16x8 ah[2], al[2], bh[2], bl[2];
+      bf16x8 ah[TI], al[TI], bh[TJ], bl[TJ];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < TI; ++i) {
         const int o = i * 4 * 512 + ks * 256;
         ah[i] = tr_read8(Ah + o + lane_off0, Ah + o + lane_off1);
         al[i] = tr_read8(Al + o + lane_off0, Al + o + lane_off1);
-        bh[i] = tr_read8(Bh + o + lane_off0, Bh + o + lane_off1);
-        bl[i] = tr_read8(Bl + o + lane_off0, Bl + o + lane_off1);
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < TJ; ++j) {
+        const int o = j * 4 * 512 + ks * 256;
+        bh[j] = tr_read8(Bh + o + lane_off0, Bh + o + lane_off1);
+        bl[j] = tr_read8(Bl + o + lane_off0, Bl + o + lane_off1);
+      }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
@@ -625,14 +631,14 @@ conv_bf3_wgrad_kernel(const ConvPhase g, const uint4* __restrict__ xs, long xpla
 
   float* wt = wg + g.wp_off + (size_t)t * g.M * g.C;   // [m][c] slab of this tap
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int c = c_tile + wn * 64 + j * 32 + (lane & 31);
+  for (int j = 0; j < TJ; ++j) {
+    const int c = c_tile + (wn * TJ + j) * 32 + (lane & 31);
     if (c >= g.C) continue;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m_tile + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int m = m_tile + (wm * TI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (m < g.M) atomicAdd(wt + (size_t)m * g.C + c, acc[i][j][r]);
       }
   }
@@ -1554,12 +1560,14 @@ int bf3_wgrad_phase(const ConvPhase& g, const void* ws_x, int Cin_total, const v
   if (g.npix <= 0 || g.T == 0) return MUVO_OK;
   int rc;
   static const int w64 = getenv("MUVO_BF3_WGRAD_64") ? atoi(getenv("MUVO_BF3_WGRAD_64")) : 1;
+  static const int w32 = getenv("MUVO_BF3_WGRAD_32") ? atoi(getenv("MUVO_BF3_WGRAD_32")) : 1;   // 32-row tile for <= 32 produced channels
   static const int wvariant = getenv("MUVO_BF3_WGRAD_VARIANT") ? atoi(getenv("MUVO_BF3_WGRAD_VARIANT")) : 0;   // 1: in-phase DMA kernels
   if (g.M > 128) rc = wvariant == 1 ? bf3_wgrad_launch<256, 128, 4, 2, 1>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st)
                                     : bf3_wgrad_pp_launch<256, 128, 4, 2>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st);
   else if (g.M > 64) rc = g.C > 64 ? (wvariant == 1 ? bf3_wgrad_launch<128, 256, 2, 4, 1>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st)
                                                      : bf3_wgrad_pp_launch<128, 256, 2, 4>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st))
                                     : bf3_wgrad_launch<128, 128, 2, 2, 2>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st);
+  else if (g.M <= 32 && g.C <= 64 && w32) rc = bf3_wgrad_launch<32, 64, 1, 2, 2>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st);
   else rc = g.C > 128 ? bf3_wgrad_launch<64, 256, 1, 4, 2>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st)
             : g.C > 64 || w64 == 0 ? bf3_wgrad_launch<64, 128, 1, 2, 2>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st)
                                    : bf3_wgrad_launch<64, 64, 1, 2, 2>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st);

@@ -993,7 +993,8 @@ static bool wgrad_uses_bf3(const ConvPlan& pf) {
     const ConvPhase& g = pf.fwd[i];
     const double gflop = 2.0 * g.Msub * g.T * g.C * (double)g.SD * g.SH * g.SW * 1e-9;   // per original phase
     if (g.Msub < g_bf3_wgrad_min_m || g.C < 32 || g.Msub % 16 != 0 && g.nmerge > 1) return false;
-    if (g.Msub <= 32 && g.C < 64) return false;     // 32 x 32 channels: the fp32 kernel is as fast (measured)
+    static const int allow32 = getenv("MUVO_BF3_WGRAD_32X32") ? atoi(getenv("MUVO_BF3_WGRAD_32X32")) : 1;
+    if (g.Msub <= 32 && g.C < 64 && !allow32) return false;     // (32 x 32 channels lost to the fp32 kernel on the 64-row tile; the 32-row tile wins)
     if (!dflt && gflop < bf3_wgrad_min_gflop()) return false;
     total += gflop * g.nmerge;
     taps += g.T * g.nmerge;
