@@ -44,6 +44,14 @@ static inline int ew_grid(long n, int block = 256) {
   return (int)g;
 }
 
+// XCD-aware workgroup order (guide T1, bijective form): workgroups are dealt round-robin over the 8 XCDs, so give each
+// XCD a contiguous chunk of the tile space — the 32 workgroups resident on one XCD then share weight / pixel tiles in
+// that XCD's L2 instead of every L2 streaming every operand.
+__device__ __forceinline__ int xcd_swizzle(int orig, int nwg) {
+  const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
 // ---- activations -----------------------------------------------------------------------------
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {
   switch (act) {

@@ -62,13 +62,6 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigne
   lo = __builtin_bit_cast(unsigned, l);
 }
 
-// XCD-aware workgroup order (guide T1, bijective form): workgroups are dealt round-robin over the 8 XCDs, so give each
-// XCD a contiguous chunk of the tile space — the 32 workgroups resident on one XCD then share weight / pixel tiles in
-// that XCD's L2 instead of every L2 streaming every operand.
-__device__ __forceinline__ int xcd_swizzle(int orig, int nwg) {
-  const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-}
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;

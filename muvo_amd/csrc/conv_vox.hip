@@ -26,7 +26,12 @@ struct VoxArgs {
   int XYZ;           // X*Y*Z
   long sN_in, sN_out;  // batch strides (floats)
   double* moments;     // optional (bf16x3 forward kernels): [N][Cout][2] += (sum, sum of squares) of the activated output
+  int xcd_order;       // bf16x3 kernels: walk (x segment, row tile, batch) in XCD order (row tiles that share halo rows share an L2)
 };
+static int vox_xcd_order() {
+  static const int v = getenv("MUVO_VOX_XCD") ? atoi(getenv("MUVO_VOX_XCD")) : 1;   // A/B switch
+  return v;
+}
 
 __device__ __forceinline__ float dpp_wave_shr1(float v) {  // lane l <- lane l-1, lane 0 <- 0
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
@@ -404,7 +409,7 @@ vox_bf3_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* __re
   extern __shared__ vu32x4 vsm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nseg = (a.X + xseg - 1) / xseg;
-  int bid = blockIdx.x;
+  int bid = a.xcd_order ? xcd_swizzle(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int seg = bid % nseg; bid /= nseg;
   const int ytile = bid % a.ytiles, n = bid / a.ytiles;
   const int y0 = ytile * TY, xs = seg * xseg, xe = xs + xseg < a.X ? xs + xseg : a.X;
@@ -595,7 +600,7 @@ vox_bf3_wgrad_kernel(const VoxArgs a, const float* __restrict__ x, const float* 
   float* dbsum = (float*)(dzb + 2 * DBUF);             // 16 floats
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nseg = (a.X + xseg - 1) / xseg;
-  int bid = blockIdx.x;
+  int bid = a.xcd_order ? xcd_swizzle(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int seg = bid % nseg; bid /= nseg;
   const int ytile = bid % a.ytiles, n = bid / a.ytiles;
   const int y0 = ytile * WROWS, xs = seg * xseg, xe = xs + xseg < a.X ? xs + xseg : a.X;
@@ -819,7 +824,7 @@ vox_bf3_2row_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4*
   extern __shared__ vu32x4 vsm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nseg = (a.X + xseg - 1) / xseg;
-  int bid = blockIdx.x;
+  int bid = a.xcd_order ? xcd_swizzle(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int seg = bid % nseg; bid /= nseg;
   const int ytile = bid % a.ytiles, n = bid / a.ytiles;
   const int y0 = ytile * TY, xs = seg * xseg, xe = xs + xseg < a.X ? xs + xseg : a.X;
@@ -1056,6 +1061,7 @@ template <int CQ, int TY, int Z>
 static int launch_vox_conv(const muvo_conv_desc* d, int Cin, int Cout, const float* in, const float* wp, const float* bias,
                            float* out, int act, float slope, hipStream_t st) {
   VoxArgs a{};
+  a.xcd_order = vox_xcd_order();
   a.N = d->N; a.Cin = Cin; a.Cout = Cout; a.X = d->in_sz[0]; a.Y = d->in_sz[1];
   a.ytiles = cdiv(a.Y, TY);
   a.xgroups = cdiv(a.X, 64 / Z);
@@ -1082,6 +1088,7 @@ template <int CK, int Z, int TY>
 static int launch_vox_bf3_ty(const muvo_conv_desc* d, int Cin, int Cout, const float* in, const float* wp, const float* bias,
                              float* out, int act, float slope, hipStream_t st, int cin_total, int accum, double* moments) {
   VoxArgs a{};
+  a.xcd_order = vox_xcd_order();
   a.moments = moments;
   a.N = d->N; a.Cin = Cin; a.Cout = Cout; a.X = d->in_sz[0]; a.Y = d->in_sz[1];
   a.ytiles = cdiv(a.Y, TY);
@@ -1124,6 +1131,7 @@ static int launch_vox_bf3_2row(const muvo_conv_desc* d, const float* in, const f
                                float slope, hipStream_t st, double* moments) {
   constexpr int TY = CK == 16 ? 8 : 16;
   VoxArgs a{};
+  a.xcd_order = vox_xcd_order();
   a.moments = moments;
   a.N = d->N; a.Cin = CK; a.Cout = 8; a.X = d->in_sz[0]; a.Y = d->in_sz[1];
   a.ytiles = cdiv(a.Y, TY);
@@ -1199,6 +1207,7 @@ static int launch_vox_wgrad(const muvo_conv_desc* d, const float* x, const float
                             hipStream_t st) {
   constexpr int CQB = 2;
   VoxArgs a{};
+  a.xcd_order = vox_xcd_order();
   a.N = d->N; a.Cin = d->Cin; a.Cout = d->Cout; a.X = d->in_sz[0]; a.Y = d->in_sz[1];
   a.ytiles = cdiv(a.Y, TYB);
   a.xgroups = 0;
@@ -1234,6 +1243,7 @@ static int launch_vox_bf3_wgrad(const muvo_conv_desc* d, const float* x, const f
   static_assert(lds <= 160 * 1024, "LDS budget");
   static_assert(lds >= (CI == 16 ? 27 : 15) * 256 * 4, "the reduction reuses the rings");
   VoxArgs a{};
+  a.xcd_order = vox_xcd_order();
   a.N = d->N; a.Cin = d->Cin; a.Cout = d->Cout; a.X = d->in_sz[0]; a.Y = d->in_sz[1];
   a.ytiles = cdiv(a.Y, WROWS);
   a.xgroups = 0;
