@@ -582,7 +582,11 @@ vox_bf3_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* __re
 #ifndef VOX_WGRAD_BUFLOAD16
 #define VOX_WGRAD_BUFLOAD16 0      // A/B: unconditional buffer loads in the 16-input-channel variant too
 #endif
-template <int Z, int CI>
+// CO8 (<= 8 produced channels): MFMA rows 8-15, which would be zero padding, hold the SAME channels shifted by one voxel along z
+// (A'[z] = dz[z + 1]).  Against the x fragment shifted by t they produce the tap t - 1 while rows 0-7 produce the tap t, so the
+// three z taps of a (dx, dy) combination cost two accumulator tiles / six MFMAs (t = 0: taps 0 and -1; t = +1: tap +1, the
+// upper half repeats tap 0 and is discarded) instead of three / nine, and the dz = -1 fragment is never built.
+template <int Z, int CI, bool CO8>
 __global__ void __launch_bounds__(512)
 vox_bf3_wgrad_kernel(const VoxArgs a, const float* __restrict__ x, const float* __restrict__ dz, float* __restrict__ dw,
                      float* __restrict__ dbias, int xseg) {
@@ -592,7 +596,8 @@ vox_bf3_wgrad_kernel(const VoxArgs a, const float* __restrict__ x, const float* 
   constexpr int XHL = CI * XCI, XSLOT = 2 * XHL;
   constexpr int DROW = Z * 2, DCO = WROWS * DROW + 16, DHL = 16 * DCO, DBUF = 2 * DHL;
   constexpr int XT = CI * ROWS * (Z / 8), DT = 16 * WROWS * (Z / 8);
-  constexpr int NT = CI == 16 ? 27 : 15;               // accumulator tiles   // staging tasks (8 voxels each)
+  constexpr int NCOMB_ = CI == 16 ? 9 : 5, TPC = CO8 ? 2 : 3;   // (dx, dy) combinations (or pairs of them); tiles per combination
+  constexpr int NT = NCOMB_ * TPC;                     // accumulator tiles   // staging tasks (8 voxels each)
   constexpr int XPT = (XT + 511) / 512, DPT = (DT + 511) / 512;
   extern __shared__ char wsm[];
   char* xring = wsm;                                   // FOUR x planes: three being read by the MFMA phase, the fourth being staged
@@ -697,7 +702,8 @@ vox_bf3_wgrad_kernel(const VoxArgs a, const float* __restrict__ x, const float* 
   for (int t = 0; t < NT; ++t) acc[t] = vf32x4{0.f, 0.f, 0.f, 0.f};
   const int row = wave / ZH, z0 = (wave % ZH) * 32;     // this wave's output row and z half
   const int j = lane & 15, kg = lane >> 4;
-  const int a_off = j * DCO + row * DROW + (z0 + kg * 8) * 2;           // A: rows = co = lane & 15
+  const int a_off = (CO8 ? (j & 7) : j) * DCO + row * DROW + (z0 + kg * 8) * 2;   // A: rows = co = lane & 15 (CO8: & 7)
+  const bool a_last = z0 + kg * 8 + 8 >= Z;                             // CO8: the voxel after this lane's eight lies past the row
   const int b_off = (j & (CI - 1)) * XCI + 16 + (z0 + kg * 8) * 2;      // B: columns -> channel j & (CI - 1) (+ row term below)
   const int sel = CI == 8 ? j >> 3 : 0;                                 // CI = 8: which combination of the pair this column reads
 
@@ -730,9 +736,21 @@ vox_bf3_wgrad_kernel(const VoxArgs a, const float* __restrict__ x, const float* 
       if (px + 1 < xe) { xload(px + 2); dload(px + 1); }
     }
     const char* A = dzb + (px & 1) * DBUF + a_off;
-    const vbf16x8 ah = __builtin_bit_cast(vbf16x8, *(const vu32x4*)A);
-    const vbf16x8 al = __builtin_bit_cast(vbf16x8, *(const vu32x4*)(A + DHL));
-    constexpr int NCOMB = CI == 16 ? 9 : 5;             // (dx, dy) combinations, or pairs of them
+    vu32x4 aq[2] = {*(const vu32x4*)A, *(const vu32x4*)(A + DHL)};
+    if constexpr (CO8) {
+#pragma unroll
+      for (int hl = 0; hl < 2; ++hl) {
+        unsigned nx = *(const unsigned*)(A + hl * DHL + 16);
+        nx = a_last ? 0u : nx;
+        const vu32x4 q = aq[hl];
+        const vu32x4 sh = {__builtin_amdgcn_alignbyte(q.y, q.x, 2), __builtin_amdgcn_alignbyte(q.z, q.y, 2),
+                           __builtin_amdgcn_alignbyte(q.w, q.z, 2), __builtin_amdgcn_alignbyte(nx, q.w, 2)};
+        aq[hl] = j >= 8 ? sh : q;
+      }
+    }
+    const vbf16x8 ah = __builtin_bit_cast(vbf16x8, aq[0]);
+    const vbf16x8 al = __builtin_bit_cast(vbf16x8, aq[1]);
+    constexpr int NCOMB = NCOMB_;
 #pragma unroll
     for (int cb = 0; cb < NCOMB; ++cb) {
       int c = CI == 16 ? cb : 2 * cb + sel;             // this lane's combination
@@ -744,7 +762,7 @@ vox_bf3_wgrad_kernel(const VoxArgs a, const float* __restrict__ x, const float* 
 #pragma unroll
       for (int hl = 0; hl < 2; ++hl) {
         w[hl] = *(const vu32x4*)(R + hl * XHL);
-        pw[hl] = *(const unsigned*)(R + hl * XHL - 4);
+        if constexpr (!CO8) pw[hl] = *(const unsigned*)(R + hl * XHL - 4);
         nw[hl] = *(const unsigned*)(R + hl * XHL + 16);
       }
       vbf16x8 bm[2], bz[2], bp[2];                      // dz = -1, 0, +1
@@ -752,23 +770,34 @@ vox_bf3_wgrad_kernel(const VoxArgs a, const float* __restrict__ x, const float* 
       for (int hl = 0; hl < 2; ++hl) {
         const vu32x4 q = w[hl];
         bz[hl] = __builtin_bit_cast(vbf16x8, q);
-        const vu32x4 m = {__builtin_amdgcn_alignbyte(q.x, pw[hl], 2), __builtin_amdgcn_alignbyte(q.y, q.x, 2),
-                          __builtin_amdgcn_alignbyte(q.z, q.y, 2), __builtin_amdgcn_alignbyte(q.w, q.z, 2)};
+        if constexpr (!CO8) {
+          const vu32x4 m = {__builtin_amdgcn_alignbyte(q.x, pw[hl], 2), __builtin_amdgcn_alignbyte(q.y, q.x, 2),
+                            __builtin_amdgcn_alignbyte(q.z, q.y, 2), __builtin_amdgcn_alignbyte(q.w, q.z, 2)};
+          bm[hl] = __builtin_bit_cast(vbf16x8, m);
+        }
         const vu32x4 pl = {__builtin_amdgcn_alignbyte(q.y, q.x, 2), __builtin_amdgcn_alignbyte(q.z, q.y, 2),
                            __builtin_amdgcn_alignbyte(q.w, q.z, 2), __builtin_amdgcn_alignbyte(nw[hl], q.w, 2)};
-        bm[hl] = __builtin_bit_cast(vbf16x8, m);
         bp[hl] = __builtin_bit_cast(vbf16x8, pl);
       }
-      const int t0 = cb * 3;
-      acc[t0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bm[0], acc[t0], 0, 0, 0);
-      acc[t0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[1], acc[t0], 0, 0, 0);
-      acc[t0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[0], acc[t0], 0, 0, 0);
-      acc[t0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bz[0], acc[t0 + 1], 0, 0, 0);
-      acc[t0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bz[1], acc[t0 + 1], 0, 0, 0);
-      acc[t0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bz[0], acc[t0 + 1], 0, 0, 0);
-      acc[t0 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bp[0], acc[t0 + 2], 0, 0, 0);
-      acc[t0 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bp[1], acc[t0 + 2], 0, 0, 0);
-      acc[t0 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bp[0], acc[t0 + 2], 0, 0, 0);
+      const int t0 = cb * TPC;
+      if constexpr (CO8) {
+        acc[t0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bz[0], acc[t0], 0, 0, 0);
+        acc[t0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bz[1], acc[t0], 0, 0, 0);
+        acc[t0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bz[0], acc[t0], 0, 0, 0);
+        acc[t0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bp[0], acc[t0 + 1], 0, 0, 0);
+        acc[t0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bp[1], acc[t0 + 1], 0, 0, 0);
+        acc[t0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bp[0], acc[t0 + 1], 0, 0, 0);
+      } else {
+        acc[t0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bm[0], acc[t0], 0, 0, 0);
+        acc[t0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[1], acc[t0], 0, 0, 0);
+        acc[t0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[0], acc[t0], 0, 0, 0);
+        acc[t0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bz[0], acc[t0 + 1], 0, 0, 0);
+        acc[t0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bz[1], acc[t0 + 1], 0, 0, 0);
+        acc[t0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bz[0], acc[t0 + 1], 0, 0, 0);
+        acc[t0 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bp[0], acc[t0 + 2], 0, 0, 0);
+        acc[t0 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bp[1], acc[t0 + 2], 0, 0, 0);
+        acc[t0 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bp[0], acc[t0 + 2], 0, 0, 0);
+      }
       // staging of the next planes between the MFMA groups (compile-time schedule: one task per combination)
       static_assert(XPT + DPT + 1 <= NCOMB, "one staging piece per combination");
       if (PIPE) {
@@ -790,13 +819,19 @@ vox_bf3_wgrad_kernel(const VoxArgs a, const float* __restrict__ x, const float* 
     for (int r = 0; r < 4; ++r) atomicAdd(red + (t * 16 + 4 * kg + r) * 16 + j, acc[t][r]);
   __syncthreads();
   for (int i = tid; i < NT * 256; i += 512) {
-    const int col = i & 15, co = (i >> 4) & 15, t = i >> 8;
+    const int col = i & 15, t = i >> 8;
+    int co = (i >> 4) & 15;
     int ci, tap;
-    if (CI == 16) { ci = col; tap = t; }
+    int tz = t % TPC;                                                   // z tap index 0..2 (dz + 1) of this tile
+    if (CO8) {                                                          // tile 0: rows 0-7 tap 0, rows 8-15 tap -1; tile 1: rows 0-7 tap +1
+      tz = tz == 0 ? (co < 8 ? 1 : 0) : (co < 8 ? 2 : -1);
+      co &= 7;
+    }
+    if (CI == 16) { ci = col; tap = tz >= 0 ? (t / TPC) * 3 + tz : -1; }
     else {
-      const int comb = 2 * (t / 3) + (col >> 3);                        // (dx, dy) combination of this column
+      const int comb = 2 * (t / TPC) + (col >> 3);                      // (dx, dy) combination of this column
       ci = col & 7;
-      tap = comb <= 8 ? comb * 3 + t % 3 : -1;
+      tap = comb <= 8 && tz >= 0 ? comb * 3 + tz : -1;
     }
     const float vsum = red[i];
     if (tap >= 0 && co < a.Cout && ci0 + ci < a.Cin && vsum != 0.f) atomicAdd(dw + ((long)co * a.Cin + ci0 + ci) * 27 + tap, vsum);
@@ -1236,7 +1271,7 @@ bool vox_bf3_wgrad_shape_ok(const muvo_conv_desc* d) {
   return vox_wgrad_applicable(d) && (d->Cin == 8 || d->Cin % 16 == 0) && d->Cin <= 64 && (d->Cout == 8 || d->Cout == 16);
 }
 
-template <int Z, int CI>
+template <int Z, int CI, bool CO8>
 static int launch_vox_bf3_wgrad(const muvo_conv_desc* d, const float* x, const float* dz, float* dw, float* dbias, hipStream_t st) {
   constexpr int ZH = Z / 32, WROWS = 8 / ZH, ROWS = WROWS + 2;
   constexpr size_t lds = (size_t)4 * 2 * CI * (ROWS * (Z + 16) * 2 + 16) + (size_t)2 * 2 * 16 * (WROWS * Z * 2 + 16) + 64;
@@ -1253,14 +1288,14 @@ static int launch_vox_bf3_wgrad(const muvo_conv_desc* d, const float* x, const f
   while ((long)a.N * a.ytiles * cdiv(a.X, xseg) * (a.Cin / CI) < vox_blocks_target(1) && xseg > 12) xseg = cdiv(xseg, 2);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)vox_bf3_wgrad_kernel<Z, CI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)vox_bf3_wgrad_kernel<Z, CI, CO8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       muvo_set_error("vox_bf3_wgrad: cannot raise the dynamic LDS limit to %zu bytes", lds);
       return MUVO_ERR_HIP;
     }
     attr_set = true;
   }
   dim3 grid((unsigned)((long)a.N * a.ytiles * cdiv(a.X, xseg)), a.Cin / CI);
-  hipLaunchKernelGGL((vox_bf3_wgrad_kernel<Z, CI>), grid, dim3(512), lds, st, a, x, dz, dw, dbias, xseg);
+  hipLaunchKernelGGL((vox_bf3_wgrad_kernel<Z, CI, CO8>), grid, dim3(512), lds, st, a, x, dz, dw, dbias, xseg);
   MUVO_CHECK_LAUNCH("vox_bf3_wgrad_kernel");
   return MUVO_OK;
 }
@@ -1268,8 +1303,15 @@ static int launch_vox_bf3_wgrad(const muvo_conv_desc* d, const float* x, const f
 int vox_wgrad(const muvo_conv_desc* d, const float* x, const float* dz, float* dw, float* dbias, hipStream_t st, bool bf3) {
   const int Z = d->in_sz[2];
   if (bf3) {
-    if (d->Cin == 8) return Z == 64 ? launch_vox_bf3_wgrad<64, 8>(d, x, dz, dw, dbias, st) : launch_vox_bf3_wgrad<32, 8>(d, x, dz, dw, dbias, st);
-    return Z == 64 ? launch_vox_bf3_wgrad<64, 16>(d, x, dz, dw, dbias, st) : launch_vox_bf3_wgrad<32, 16>(d, x, dz, dw, dbias, st);
+    // <= 8 produced channels: the idle half of the MFMA rows carries a second z tap (MUVO_VOX_WGRAD_CO8=0: padded rows, for A/B)
+    static const bool co8_on = !(getenv("MUVO_VOX_WGRAD_CO8") && atoi(getenv("MUVO_VOX_WGRAD_CO8")) == 0);
+    const bool co8 = d->Cout <= 8 && co8_on;
+    if (d->Cin == 8) {
+      if (Z == 64) return co8 ? launch_vox_bf3_wgrad<64, 8, true>(d, x, dz, dw, dbias, st) : launch_vox_bf3_wgrad<64, 8, false>(d, x, dz, dw, dbias, st);
+      return co8 ? launch_vox_bf3_wgrad<32, 8, true>(d, x, dz, dw, dbias, st) : launch_vox_bf3_wgrad<32, 8, false>(d, x, dz, dw, dbias, st);
+    }
+    if (Z == 64) return co8 ? launch_vox_bf3_wgrad<64, 16, true>(d, x, dz, dw, dbias, st) : launch_vox_bf3_wgrad<64, 16, false>(d, x, dz, dw, dbias, st);
+    return co8 ? launch_vox_bf3_wgrad<32, 16, true>(d, x, dz, dw, dbias, st) : launch_vox_bf3_wgrad<32, 16, false>(d, x, dz, dw, dbias, st);
   }
   const bool r4 = d->Cin % 16 == 0;
   // 16 input channels per workgroup with 2 output quads per role, or 8 input channels with 1 output quad per role
