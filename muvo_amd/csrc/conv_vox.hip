@@ -594,8 +594,9 @@ vox_bf3_wgrad_kernel(const VoxArgs a, const float* __restrict__ x, const float* 
   constexpr int XROW = (Z + 16) * 2;                    // bytes of an x row: 16-byte zero pad on both sides
   constexpr int XCI = ROWS * XROW + 16;                 // channel stride (bytes), +16 spreads 16 channels over all banks
   constexpr int XHL = CI * XCI, XSLOT = 2 * XHL;
-  constexpr int DROW = Z * 2, DCO = WROWS * DROW + 16, DHL = 16 * DCO, DBUF = 2 * DHL;
-  constexpr int XT = CI * ROWS * (Z / 8), DT = 16 * WROWS * (Z / 8);
+  constexpr int DCH = CO8 ? 8 : 16;                    // dz channels held in LDS
+  constexpr int DROW = Z * 2, DCO = WROWS * DROW + 16, DHL = DCH * DCO, DBUF = 2 * DHL;
+  constexpr int XT = CI * ROWS * (Z / 8), DT = DCH * WROWS * (Z / 8);
   constexpr int NCOMB_ = CI == 16 ? 9 : 5, TPC = CO8 ? 2 : 3;   // (dx, dy) combinations (or pairs of them); tiles per combination
   constexpr int NT = NCOMB_ * TPC;                     // accumulator tiles   // staging tasks (8 voxels each)
   constexpr int XPT = (XT + 511) / 512, DPT = (DT + 511) / 512;
@@ -1274,9 +1275,9 @@ bool vox_bf3_wgrad_shape_ok(const muvo_conv_desc* d) {
 template <int Z, int CI, bool CO8>
 static int launch_vox_bf3_wgrad(const muvo_conv_desc* d, const float* x, const float* dz, float* dw, float* dbias, hipStream_t st) {
   constexpr int ZH = Z / 32, WROWS = 8 / ZH, ROWS = WROWS + 2;
-  constexpr size_t lds = (size_t)4 * 2 * CI * (ROWS * (Z + 16) * 2 + 16) + (size_t)2 * 2 * 16 * (WROWS * Z * 2 + 16) + 64;
+  constexpr size_t lds = (size_t)4 * 2 * CI * (ROWS * (Z + 16) * 2 + 16) + (size_t)2 * 2 * (CO8 ? 8 : 16) * (WROWS * Z * 2 + 16) + 64;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  static_assert(lds >= (CI == 16 ? 27 : 15) * 256 * 4, "the reduction reuses the rings");
+  static_assert(lds >= (CI == 16 ? 27 : 15) * 256 * 4 + 64, "the reduction reuses the rings");
   VoxArgs a{};
   a.xcd_order = vox_xcd_order();
   a.N = d->N; a.Cin = d->Cin; a.Cout = d->Cout; a.X = d->in_sz[0]; a.Y = d->in_sz[1];
