@@ -119,6 +119,19 @@ int muvo_conv_forward_moments(const muvo_conv_desc* d, const float* x, const flo
                               float slope, double* moments, void* stream);
 int muvo_adain_fwd_moments(const float* x, const float* style, float* y, float* save_mean, float* save_rstd, double* moments,
                            int N, int C, int64_t S, float eps, void* stream);
+/* AdaIN folded into the consumer (muvo/models/common.py:190-202: conv -> AdaptiveInstanceNorm3d -> next conv inside a
+ * DecoderBlock3d).  muvo_adain_affine: statistics from `moments` (as muvo_adain_fwd_moments; cleared) -> save_mean / save_rstd
+ * (N*C, for muvo_adain_bwd) and aff[N][C][2] = (style_scale * rstd, style_shift - style_scale * rstd * mean); no pass over x.
+ * muvo_conv_forward_affine / muvo_conv_wgrad_affine: the convolution / its weight gradient on scale * x + shift per (n, input
+ * channel) with zero padding applied after the map (bf16x3 voxel kernels with 8 / 16 input channels:
+ * muvo_conv_affine_supported); moments (may be NULL) as in muvo_conv_forward_moments; dw / dbias are accumulated. */
+int muvo_adain_affine(const float* style, double* moments, float* save_mean, float* save_rstd, float* aff, int N, int C, int64_t S,
+                      float eps, void* stream);
+int muvo_conv_affine_supported(const muvo_conv_desc* d);
+int muvo_conv_forward_affine(const muvo_conv_desc* d, const float* x, const float* aff, const float* wp_fwd, const float* bias,
+                             float* y, int act, float slope, double* moments, void* stream);
+int muvo_conv_wgrad_affine(const muvo_conv_desc* d, const float* x, const float* aff, const float* dy, float* dw, float* dbias,
+                           void* stream);
 /* Grouped Linear: L <= 16 layers y_l = x W_l^T + b_l on the same input x (M <= 24 rows, K features, K % 4 == 0) in one launch
  * per pass — the style projections of all AdaptiveInstanceNorm layers of a decoder (muvo/models/common.py:205-246,227-246:
  * `self.latent_affine(style)` per layer on the same latent).  W[l]: (N[l], K) row-major, b[l]: (N[l]) or NULL, Y[l]: (M, N[l]).

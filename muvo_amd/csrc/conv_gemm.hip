@@ -916,6 +916,33 @@ int muvo_conv_forward_moments(const muvo_conv_desc* d, const float* x, const flo
   return vox_forward(d, x, wp_fwd, bias, y, act, slope, (hipStream_t)stream, true, moments);
 }
 
+// Convolution of (scale * x + shift) per (n, input channel), zero padding applied AFTER the affine map: the AdaIN between two
+// convolutions of a voxel-decoder block (common.py:190-202, 227-246) applied while the consumer stages its input, so the
+// normalised tensor is never written.  aff: [N][Cin][2] floats (muvo_adain_affine).  moments may be NULL.
+int muvo_conv_affine_supported(const muvo_conv_desc* d) {
+  if (check_desc(d)) return 0;
+  return (conv_mode() == 1 && !pw_applicable(d) && vox_fwd_ok(d) && vox_uses_bf3(d, 0) && vox_wgrad_applicable(d) &&
+          vox_wgrad_uses_bf3(d) && vox_affine_ok(d)) ? 1 : 0;
+}
+int muvo_conv_forward_affine(const muvo_conv_desc* d, const float* x, const float* aff, const float* wp_fwd, const float* bias,
+                             float* y, int act, float slope, double* moments, void* stream) {
+  ConvPlan pl;
+  int rc = build_plan(d, &pl);
+  if (rc) return rc;
+  MUVO_CHECK_ARG(x && aff && wp_fwd && y, "conv_forward_affine: null pointer");
+  MUVO_CHECK_ARG(muvo_conv_affine_supported(d), "conv_forward_affine: shape not served by the bf16x3 voxel kernels");
+  return vox_forward(d, x, wp_fwd, bias, y, act, slope, (hipStream_t)stream, true, moments, aff);
+}
+int muvo_conv_wgrad_affine(const muvo_conv_desc* d, const float* x, const float* aff, const float* dy, float* dw, float* dbias,
+                           void* stream) {
+  ConvPlan pl;
+  int rc = build_plan(d, &pl, 0, false);
+  if (rc) return rc;
+  MUVO_CHECK_ARG(x && aff && dy && dw, "conv_wgrad_affine: null pointer");
+  MUVO_CHECK_ARG(muvo_conv_affine_supported(d), "conv_wgrad_affine: shape not served by the bf16x3 voxel kernels");
+  return vox_wgrad(d, x, dy, dw, dbias, (hipStream_t)stream, true, aff);
+}
+
 int muvo_conv_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp_dgrad, float* dx, void* ws, int ws_valid,
                     void* stream) {
   ConvPlan pl;

@@ -10,7 +10,9 @@ long vox_pack_floats(const muvo_conv_desc* d);
 bool vox_bf3_shape_ok(const muvo_conv_desc* d, int dgrad);   // bf16x3 variant (16x16x32 MFMA) available for this direction
 int vox_pack(const muvo_conv_desc* d, const float* w, float* wp, int dgrad, hipStream_t st, bool bf3);
 int vox_forward(const muvo_conv_desc* d, const float* x, const float* wp, const float* bias, float* y, int act, float slope,
-                hipStream_t st, bool bf3, double* moments = nullptr);
+                hipStream_t st, bool bf3, double* moments = nullptr, const float* aff = nullptr);
+bool vox_affine_ok(const muvo_conv_desc* d);   // forward / weight gradient can apply a per-(n, channel) scale / shift while staging
 int vox_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp, float* dx, hipStream_t st, bool bf3);
 bool vox_bf3_wgrad_shape_ok(const muvo_conv_desc* d);
-int vox_wgrad(const muvo_conv_desc* d, const float* x, const float* dz, float* dw, float* dbias, hipStream_t st, bool bf3);
+int vox_wgrad(const muvo_conv_desc* d, const float* x, const float* dz, float* dw, float* dbias, hipStream_t st, bool bf3,
+              const float* aff = nullptr);

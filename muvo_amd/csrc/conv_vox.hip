@@ -27,7 +27,10 @@ struct VoxArgs {
   long sN_in, sN_out;  // batch strides (floats)
   double* moments;     // optional (bf16x3 forward kernels): [N][Cout][2] += (sum, sum of squares) of the activated output
   int xcd_order;       // bf16x3 kernels: walk (x segment, row tile, batch) in XCD order (row tiles that share halo rows share an L2)
+  const float* aff;    // optional (bf16x3 forward / weight-gradient kernels): [N][Cin][2] = (scale, shift); the kernel convolves
+                       // scale * x + shift (zero padding stays zero): the AdaIN of the producing layer applied while staging
 };
+static thread_local const float* t_vox_aff = nullptr;   // set by vox_forward / vox_wgrad around their launches (VoxArgs::aff)
 static int vox_xcd_order() {
   static const int v = getenv("MUVO_VOX_XCD") ? atoi(getenv("MUVO_VOX_XCD")) : 1;   // A/B switch
   return v;
@@ -431,6 +434,23 @@ vox_bf3_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* __re
 
   // staging: task t -> (cg, row r, z); loads 8 channels of one voxel, splits, writes two 16-byte entries
   float stg[TPT][8];
+  unsigned stg_ok = 0u;                         // bit k: task k of the staged plane lies inside the tensor
+  // AdaIN scale / shift of the staged channels (a.aff): one channel group -> registers; two -> a table in LDS (a lane's tasks
+  // belong to different groups, 48 more registers spilled)
+  float afs[8], afb[8];
+  __shared__ float s_aff[2 * CK];
+  if (a.aff) {
+    if (CG == 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        afs[e] = a.aff[((long)n * a.Cin + e) * 2];
+        afb[e] = a.aff[((long)n * a.Cin + e) * 2 + 1];
+      }
+    } else {
+      if (tid < 2 * CK) s_aff[tid] = a.aff[(long)n * a.Cin * 2 + tid];   // [c][2] as stored
+      __syncthreads();
+    }
+  }
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)inb, 0, (int)((long)CK * a.XYZ * 4), 0x00020000);
   const unsigned xyz4 = (unsigned)a.XYZ * 4u;
   auto stage_load = [&](int x) {
@@ -440,6 +460,7 @@ vox_bf3_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* __re
       const int z = t % Z, r = (t / Z) % ROWS, cg = t / (Z * ROWS);
       const int gy = y0 - 1 + r;
       const bool ok = t < NTASK && x >= 0 && x < a.X && gy >= 0 && gy < a.Y;
+      stg_ok = k == 0 ? (unsigned)ok : stg_ok | ((unsigned)ok << k);
       // buffer loads, out-of-range -> zeros: unconditional, so the loads stay in flight across the MFMA work of the previous
       // plane (behind `ok ? p[..] : 0` the compiler branched around them and waited right there)
       const unsigned off = ok ? (unsigned)(((long)(cg * 8) * a.XYZ + (long)x * YZ + (long)gy * Z + z) * 4) : 0x7fffff00u;
@@ -455,6 +476,14 @@ vox_bf3_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* __re
       const int t = tid + k * 64 * TY;
       if (t >= NTASK) continue;
       const int z = t % Z, r = (t / Z) % ROWS, cg = t / (Z * ROWS);
+      if (a.aff) {      // (uniform) the producing layer's AdaIN: scale * x + shift per channel; padding stays zero
+        const bool ok = (stg_ok >> k) & 1u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float sc = CG == 1 ? afs[e] : s_aff[(cg * 8 + e) * 2], sh = CG == 1 ? afb[e] : s_aff[(cg * 8 + e) * 2 + 1];
+          stg[k][e] = ok ? stg[k][e] * sc + sh : 0.f;
+        }
+      }
       unsigned h[4], l[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) vox_split2(stg[k][2 * q], stg[k][2 * q + 1], h[q], l[q]);
@@ -618,6 +647,16 @@ vox_bf3_wgrad_kernel(const VoxArgs a, const float* __restrict__ x, const float* 
   __syncthreads();
 
   float xst[XPT][8], dst[DPT][8];
+  unsigned xok = 0u;                            // bit k: x task k of the plane in xst lies inside the tensor
+  float xas[XPT], xab[XPT];                     // AdaIN scale / shift of the channel of x task k (a.aff)
+#pragma unroll
+  for (int k = 0; k < XPT; ++k) {
+    const int t = tid + k * 512;
+    const int ci = t < XT ? t / ((Z / 8) * ROWS) : 0;
+    const bool have = a.aff != nullptr && ci0 + ci < a.Cin;
+    xas[k] = have ? a.aff[((long)n * a.Cin + ci0 + ci) * 2] : 1.f;
+    xab[k] = have ? a.aff[((long)n * a.Cin + ci0 + ci) * 2 + 1] : 0.f;
+  }
   auto split_store = [&](const float (&v)[8], char* hi_addr, int hl_stride) {
     unsigned h[4], l[4];
 #pragma unroll
@@ -654,6 +693,7 @@ vox_bf3_wgrad_kernel(const VoxArgs a, const float* __restrict__ x, const float* 
       const int z8 = t % (Z / 8), rr = (t / (Z / 8)) % ROWS, ci = t / ((Z / 8) * ROWS);
       const int gy = y0 - 1 + rr;
       const bool ok = t < XT && px >= 0 && px < a.X && gy >= 0 && gy < a.Y;
+      xok = k == 0 ? (unsigned)ok : xok | ((unsigned)ok << k);
       const long eoff = (long)ci * a.XYZ + (long)px * YZ + (long)gy * Z + z8 * 8;
       if constexpr (CI == 8 || VOX_WGRAD_BUFLOAD16) load8b(rs_x, ok ? (unsigned)(eoff * 4) : OOB, xst[k]);     // channels past Cin: range check
       else load8(xb + eoff, ok && ci0 + ci < a.Cin, xst[k]);
@@ -663,6 +703,11 @@ vox_bf3_wgrad_kernel(const VoxArgs a, const float* __restrict__ x, const float* 
     const int t = tid + k * 512;
     if (t >= XT) return;
     const int z8 = t % (Z / 8), rr = (t / (Z / 8)) % ROWS, ci = t / ((Z / 8) * ROWS);
+    if (a.aff) {        // (uniform) the operand is scale * x + shift of the producing layer's AdaIN; padding stays zero
+      const bool ok = (xok >> k) & 1u;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xst[k][e] = ok ? xst[k][e] * xas[k] + xab[k] : 0.f;
+    }
     split_store(xst[k], xring + slot * XSLOT + ci * XCI + rr * XROW + 16 + z8 * 16, XHL);
   };
   auto xstore = [&](int slot) {
@@ -875,6 +920,23 @@ vox_bf3_2row_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4*
   for (int i = tid; i < 3 * PLANE; i += NT) vsm[i] = vu32x4{0u, 0u, 0u, 0u};
   __syncthreads();
   float stg[TPT][8];
+  unsigned stg_ok = 0u;                         // bit k: task k of the staged plane lies inside the tensor
+  // AdaIN scale / shift of the staged channels (a.aff): one channel group -> registers; two -> a table in LDS (a lane's tasks
+  // belong to different groups, 48 more registers spilled)
+  float afs[8], afb[8];
+  __shared__ float s_aff[2 * CK];
+  if (a.aff) {
+    if (CG == 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        afs[e] = a.aff[((long)n * a.Cin + e) * 2];
+        afb[e] = a.aff[((long)n * a.Cin + e) * 2 + 1];
+      }
+    } else {
+      if (tid < 2 * CK) s_aff[tid] = a.aff[(long)n * a.Cin * 2 + tid];   // [c][2] as stored
+      __syncthreads();
+    }
+  }
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)inb, 0, (int)((long)CK * a.XYZ * 4), 0x00020000);
   const unsigned xyz4 = (unsigned)a.XYZ * 4u;
   auto stage_load = [&](int x) {
@@ -884,6 +946,7 @@ vox_bf3_2row_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4*
       const int z = t % Z, r = (t / Z) % ROWS, cg = t / (Z * ROWS);
       const int gy = y0 - 1 + r;
       const bool ok = t < NTASK && x >= 0 && x < a.X && gy >= 0 && gy < a.Y;
+      stg_ok = k == 0 ? (unsigned)ok : stg_ok | ((unsigned)ok << k);
       // buffer loads, out-of-range -> zeros: unconditional, so the loads stay in flight across the MFMA work of the previous
       // plane (behind `ok ? p[..] : 0` the compiler branched around them and waited right there)
       const unsigned off = ok ? (unsigned)(((long)(cg * 8) * a.XYZ + (long)x * YZ + (long)gy * Z + z) * 4) : 0x7fffff00u;
@@ -899,6 +962,14 @@ vox_bf3_2row_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4*
       const int t = tid + k * NT;
       if (t >= NTASK) continue;
       const int z = t % Z, r = (t / Z) % ROWS, cg = t / (Z * ROWS);
+      if (a.aff) {      // (uniform) the producing layer's AdaIN: scale * x + shift per channel; padding stays zero
+        const bool ok = (stg_ok >> k) & 1u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float sc = CG == 1 ? afs[e] : s_aff[(cg * 8 + e) * 2], sh = CG == 1 ? afb[e] : s_aff[(cg * 8 + e) * 2 + 1];
+          stg[k][e] = ok ? stg[k][e] * sc + sh : 0.f;
+        }
+      }
       unsigned h[4], l[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) vox_split2(stg[k][2 * q], stg[k][2 * q + 1], h[q], l[q]);
@@ -1098,6 +1169,7 @@ static int launch_vox_conv(const muvo_conv_desc* d, int Cin, int Cout, const flo
                            float* out, int act, float slope, hipStream_t st) {
   VoxArgs a{};
   a.xcd_order = vox_xcd_order();
+  a.aff = t_vox_aff;
   a.N = d->N; a.Cin = Cin; a.Cout = Cout; a.X = d->in_sz[0]; a.Y = d->in_sz[1];
   a.ytiles = cdiv(a.Y, TY);
   a.xgroups = cdiv(a.X, 64 / Z);
@@ -1125,6 +1197,7 @@ static int launch_vox_bf3_ty(const muvo_conv_desc* d, int Cin, int Cout, const f
                              float* out, int act, float slope, hipStream_t st, int cin_total, int accum, double* moments) {
   VoxArgs a{};
   a.xcd_order = vox_xcd_order();
+  a.aff = t_vox_aff;
   a.moments = moments;
   a.N = d->N; a.Cin = Cin; a.Cout = Cout; a.X = d->in_sz[0]; a.Y = d->in_sz[1];
   a.ytiles = cdiv(a.Y, TY);
@@ -1168,6 +1241,7 @@ static int launch_vox_bf3_2row(const muvo_conv_desc* d, const float* in, const f
   constexpr int TY = CK == 16 ? 8 : 16;
   VoxArgs a{};
   a.xcd_order = vox_xcd_order();
+  a.aff = t_vox_aff;
   a.moments = moments;
   a.N = d->N; a.Cin = CK; a.Cout = 8; a.X = d->in_sz[0]; a.Y = d->in_sz[1];
   a.ytiles = cdiv(a.Y, TY);
@@ -1231,8 +1305,17 @@ static int vox_conv_dispatch(const muvo_conv_desc* d, int Cin, int Cout, const f
 }
 
 int vox_forward(const muvo_conv_desc* d, const float* x, const float* wp, const float* bias, float* y, int act, float slope,
-                hipStream_t st, bool bf3, double* moments) {
-  return vox_conv_dispatch(d, d->Cin, d->Cout, x, wp, bias, y, act, slope, st, bf3, moments);
+                hipStream_t st, bool bf3, double* moments, const float* aff) {
+  if (aff && !vox_affine_ok(d)) { muvo_set_error("vox_forward: no affine staging for this shape"); return MUVO_ERR_INVALID_ARG; }
+  t_vox_aff = aff;
+  const int rc = vox_conv_dispatch(d, d->Cin, d->Cout, x, wp, bias, y, act, slope, st, bf3 || aff != nullptr, moments);
+  t_vox_aff = nullptr;
+  return rc;
+}
+// can the forward and weight-gradient kernels of this convolution apply a per-(n, channel) scale / shift while staging?
+// (bf16x3 voxel kernels with 8 or 16 reduction channels; 32 run as two passes of 16 and are not covered)
+bool vox_affine_ok(const muvo_conv_desc* d) {
+  return vox_fwd_applicable(d) && vox_bf3_shape_ok(d, 0) && vox_bf3_wgrad_shape_ok(d) && (d->Cin == 8 || d->Cin == 16);
 }
 int vox_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp, float* dx, hipStream_t st, bool bf3) {
   return vox_conv_dispatch(d, d->Cout, d->Cin, dy, wp, nullptr, dx, MUVO_ACT_NONE, 0.f, st, bf3);
@@ -1244,6 +1327,7 @@ static int launch_vox_wgrad(const muvo_conv_desc* d, const float* x, const float
   constexpr int CQB = 2;
   VoxArgs a{};
   a.xcd_order = vox_xcd_order();
+  a.aff = t_vox_aff;
   a.N = d->N; a.Cin = d->Cin; a.Cout = d->Cout; a.X = d->in_sz[0]; a.Y = d->in_sz[1];
   a.ytiles = cdiv(a.Y, TYB);
   a.xgroups = 0;
@@ -1280,6 +1364,7 @@ static int launch_vox_bf3_wgrad(const muvo_conv_desc* d, const float* x, const f
   static_assert(lds >= (CI == 16 ? 27 : 15) * 256 * 4 + 64, "the reduction reuses the rings");
   VoxArgs a{};
   a.xcd_order = vox_xcd_order();
+  a.aff = t_vox_aff;
   a.N = d->N; a.Cin = d->Cin; a.Cout = d->Cout; a.X = d->in_sz[0]; a.Y = d->in_sz[1];
   a.ytiles = cdiv(a.Y, WROWS);
   a.xgroups = 0;
@@ -1301,7 +1386,11 @@ static int launch_vox_bf3_wgrad(const muvo_conv_desc* d, const float* x, const f
   return MUVO_OK;
 }
 
-int vox_wgrad(const muvo_conv_desc* d, const float* x, const float* dz, float* dw, float* dbias, hipStream_t st, bool bf3) {
+int vox_wgrad(const muvo_conv_desc* d, const float* x, const float* dz, float* dw, float* dbias, hipStream_t st, bool bf3,
+              const float* aff) {
+  if (aff && !vox_affine_ok(d)) { muvo_set_error("vox_wgrad: no affine staging for this shape"); return MUVO_ERR_INVALID_ARG; }
+  struct AffScope { AffScope(const float* p) { t_vox_aff = p; } ~AffScope() { t_vox_aff = nullptr; } } scope(aff);
+  if (aff) bf3 = true;
   const int Z = d->in_sz[2];
   if (bf3) {
     // <= 8 produced channels: the idle half of the MFMA rows carries a second z tap (MUVO_VOX_WGRAD_CO8=0: padded rows, for A/B)

@@ -626,6 +626,34 @@ extern "C" int muvo_adain_fwd_moments(const float* x, const float* style, float*
   return MUVO_OK;
 }
 
+// statistics -> (mean, rstd) and the affine map of the AdaIN, y = st * ((x - mean) * rstd) + sh = a * x + b, for a consumer
+// that applies it while staging (muvo_conv_forward_affine); the moments are cleared for the next use
+__global__ void adain_affine_kernel(double* __restrict__ sums, const float* __restrict__ style, float* __restrict__ mean,
+                                    float* __restrict__ rstd, float* __restrict__ aff, int N, int C, double cnt, float eps) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= N * C) return;
+  const int n = g / C, c = g - n * C;
+  const double m = sums[2 * g] / cnt;
+  double var = sums[2 * g + 1] / cnt - m * m;
+  sums[2 * g] = 0.0;
+  sums[2 * g + 1] = 0.0;
+  if (var < 0) var = 0;
+  const float mu = (float)m, rs = (float)(1.0 / sqrt(var + (double)eps));
+  mean[g] = mu;
+  rstd[g] = rs;
+  const float a = style[(long)n * 2 * C + c] * rs;
+  aff[2 * g] = a;
+  aff[2 * g + 1] = style[(long)n * 2 * C + C + c] - a * mu;
+}
+extern "C" int muvo_adain_affine(const float* style, double* moments, float* save_mean, float* save_rstd, float* aff, int N, int C,
+                                 int64_t S, float eps, void* stream) {
+  MUVO_CHECK_ARG(style && moments && save_mean && save_rstd && aff && N > 0 && C > 0 && S > 0, "adain_affine: bad args");
+  hipLaunchKernelGGL(adain_affine_kernel, dim3(cdiv((long)N * C, 64)), dim3(64), 0, (hipStream_t)stream, moments, style, save_mean,
+                     save_rstd, aff, N, C, (double)S, eps);
+  MUVO_CHECK_LAUNCH("adain_affine");
+  return MUVO_OK;
+}
+
 // ================================================================================================
 // Last stage of VoxelDecoder1 (common.py:541-545): AdaIN of the last 3x3x3 convolution, then the 1x1x1 class head
 // (VoxelSemHead :354-367).  The normalised tensor (8 channels x 2.36 M voxels x 20 frames = 1.5 GB) has ONE consumer, the head,

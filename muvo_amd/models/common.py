@@ -134,18 +134,26 @@ class ConvInstanceNorm3d(nn.Module):
         self.conv_act = nn.Sequential(hnn.Conv3d(in_channels, out_channels, 3, 1, 1), hnn.Placeholder())
         self.adaptive_norm = AdaptiveInstanceNorm3d(latent_n_channels, out_channels)
 
-    def forward(self, x, w):
+    def forward(self, x, w, lazy=None, next_conv=None):
+        """lazy: (raw, aff) when x is the placeholder of the previous layer's lazy AdaIN (this convolution applies it).
+        next_conv: the convolution that is the ONLY consumer of this layer's output; when it can apply an AdaIN while staging
+        (ops.conv_affine_supported) the result is (placeholder, (raw, aff)) and the normalised tensor is never written."""
         # LeakyReLU is fused into the conv epilogue; its derivative is chained inside the AdaIN backward kernel
         # (top two levels, bf16x3 voxel kernels: the conv epilogue also delivers the instance-norm statistics of its output)
         moments = ops.conv_moments_buffer(x, self.conv_act[0].geom)
-        x = self.conv_act[0](x, act=ops.ACT_LEAKY, slope=0.2, act_bwd_fused=True, moments=moments)
-        return self.adaptive_norm(x, w, pre_act=ops.ACT_LEAKY, pre_slope=0.2, moments=moments)
+        x = self.conv_act[0](x, act=ops.ACT_LEAKY, slope=0.2, act_bwd_fused=True, moments=moments, lazy=lazy)
+        if next_conv is not None and ops.conv_affine_supported(x, next_conv.geom, moments):
+            an = self.adaptive_norm
+            y, raw, aff = ops.adain_lazy(x, _style(an, w), an.epsilon, ops.ACT_LEAKY, 0.2, moments)
+            return y, (raw, aff)
+        y = self.adaptive_norm(x, w, pre_act=ops.ACT_LEAKY, pre_slope=0.2, moments=moments)
+        return y if next_conv is None else (y, None)
 
-    def forward_with_head(self, x, w, head_conv):
+    def forward_with_head(self, x, w, head_conv, lazy=None):
         """This layer followed by a 1x1x1 head that is the ONLY consumer of its output (VoxelDecoder1's last stage): returns
         the head's logits; the normalised tensor is never materialised when the fused kernels apply (ops.AdaINHeadFn)."""
         moments = ops.conv_moments_buffer(x, self.conv_act[0].geom)
-        x = self.conv_act[0](x, act=ops.ACT_LEAKY, slope=0.2, act_bwd_fused=True, moments=moments)
+        x = self.conv_act[0](x, act=ops.ACT_LEAKY, slope=0.2, act_bwd_fused=True, moments=moments, lazy=lazy)
         if ops.adain_head_supported(x, head_conv.weight, moments):
             an = self.adaptive_norm
             return ops.adain_head(x, _style(an, w), head_conv.weight, head_conv.bias, an.epsilon, moments, ops.ACT_LEAKY, 0.2)
@@ -255,9 +263,11 @@ class DecoderBlock3d(nn.Module):
     def forward(self, x, w, head_conv=None):
         if self.upsample:
             x = ops.upsample3d_x2(x)
+        # conv1 -> AdaIN -> conv2: conv2 is the only consumer of the first AdaIN and applies it while staging when it can
+        y, lazy = self.conv1(x, w, next_conv=self.conv2.conv_act[0])
         if head_conv is not None:
-            return self.conv2.forward_with_head(self.conv1(x, w), w, head_conv)
-        return self.conv2(self.conv1(x, w), w)
+            return self.conv2.forward_with_head(y, w, head_conv, lazy=lazy)
+        return self.conv2(y, w, lazy=lazy)
 
 
 class _Head(nn.Module):

@@ -28,8 +28,8 @@ class _ConvNd(nn.Module):
         if bias:
             _uniform_(self.bias, 1.0 / math.sqrt(fan_in))
 
-    def forward(self, x, act=ops.ACT_NONE, slope=0.0, act_bwd_fused=False, moments=None):
-        return ops.conv(x, self.weight, self.bias, self.geom, self._packed, act, slope, act_bwd_fused, moments)
+    def forward(self, x, act=ops.ACT_NONE, slope=0.0, act_bwd_fused=False, moments=None, lazy=None):
+        return ops.conv(x, self.weight, self.bias, self.geom, self._packed, act, slope, act_bwd_fused, moments, lazy)
 
 
 class Conv2d(_ConvNd):

@@ -68,6 +68,7 @@ EXPORTS = [
     'muvo_conv_dgrad_accumulate', 'muvo_conv_forward_moments_supported', 'muvo_conv_forward_moments', 'muvo_adain_fwd_moments',
     'muvo_adain_head_supported', 'muvo_adain_head_fwd', 'muvo_adain_head_bwd', 'muvo_bf3_loop_clock',
     'muvo_grouped_linear_fwd', 'muvo_grouped_linear_bwd', 'muvo_conv_prepare_dy_head', 'muvo_conv_prepare_dy_head_supported',
+    'muvo_adain_affine', 'muvo_conv_affine_supported', 'muvo_conv_forward_affine', 'muvo_conv_wgrad_affine',
     'muvo_rssm_supported', 'muvo_rssm_transposed_floats', 'muvo_rssm_scratch_floats', 'muvo_rssm_forward', 'muvo_rssm_backward',
 ]
 
@@ -668,7 +669,12 @@ _KEEP_WS = os.environ.get('MUVO_KEEP_WS', '1') != '0'
 
 class ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, geom, packed, act, slope, act_bwd_fused=False, moments=None):
+    def forward(ctx, x, weight, bias, geom, packed, act, slope, act_bwd_fused=False, moments=None, aff_src=None, aff=None):
+        # aff given: x is the placeholder output of a lazy AdaIN (AdaINFn, lazy=True), the real operand is aff * aff_src + shift,
+        # applied by the kernels while they stage aff_src (muvo_conv_forward_affine / muvo_conv_wgrad_affine)
+        ctx.aff = aff
+        if aff is not None:
+            x = aff_src
         x = x.contiguous()
         ctx.act_bwd_fused = act_bwd_fused
         n = x.shape[0]
@@ -701,7 +707,9 @@ class ConvFn(torch.autograd.Function):
         else:
             ws = scratch('conv_ws', (wsb[0] + 3) // 4, x.device) if wsb[0] else None
         ctx.ws_x = ws if keep_ws else None
-        if moments is not None:     # instance-norm statistics of y from the epilogue registers (voxel bf16x3 kernels)
+        if aff is not None:
+            _ck(L.muvo_conv_forward_affine(C.byref(d), _f(x), _f(aff), _f(packed.fwd), _f(bias), _f(y), act, _fl(slope), _p(moments), _st()))
+        elif moments is not None:     # instance-norm statistics of y from the epilogue registers (voxel bf16x3 kernels)
             _ck(L.muvo_conv_forward_moments(C.byref(d), _f(x), _f(packed.fwd), _f(bias), _f(y), act, _fl(slope), _p(moments), _st()))
         else:
             _ck(L.muvo_conv_forward(C.byref(d), _f(x), _f(packed.fwd), _f(bias), _f(y), act, _fl(slope), _p(ws), _st()))
@@ -811,15 +819,39 @@ class ConvFn(torch.autograd.Function):
                 ws_x = scratch('conv_ws', (wsb[2] + 3) // 4, x.device)
             if wsb[3] and ws_dy is None:
                 ws_dy = scratch('conv_ws_dy', (wsb[3] + 3) // 4, x.device)
-            _ck(L.muvo_conv_wgrad(C.byref(d), _f(x), _f(dz), _f(ws), _f(grad_of(weight)), _f(db), _p(ws_x), _p(ws_dy),
-                                  flags, _st()))
+            if ctx.aff is not None:
+                _ck(L.muvo_conv_wgrad_affine(C.byref(d), _f(x), _f(ctx.aff), _f(dz), _f(grad_of(weight)), _f(db), _st()))
+            else:
+                _ck(L.muvo_conv_wgrad(C.byref(d), _f(x), _f(dz), _f(ws), _f(grad_of(weight)), _f(db), _p(ws_x), _p(ws_dy),
+                                      flags, _st()))
             if kt is not None:
                 e1.record()
-        return dx, None, None, None, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None, None, None, None
 
 
-def conv(x, weight, bias, geom, packed, act=ACT_NONE, slope=0.0, act_bwd_fused=False, moments=None):
+def conv(x, weight, bias, geom, packed, act=ACT_NONE, slope=0.0, act_bwd_fused=False, moments=None, lazy=None):
+    """lazy: (raw, aff) of a lazy AdaIN whose placeholder output is x (adain_lazy); the convolution applies the AdaIN itself."""
+    if lazy is not None:
+        return ConvFn.apply(x, weight, bias, geom, packed, act, slope, act_bwd_fused, moments, lazy[0], lazy[1])
     return ConvFn.apply(x, weight, bias, geom, packed, act, slope, act_bwd_fused, moments)
+
+
+CONV_AFFINE = os.environ.get('MUVO_CONV_AFFINE', '1') != '0'
+
+
+def conv_affine_supported(x, geom, moments):
+    """can the convolution `geom` consume x = the (not yet normalised) output of the previous layer together with that layer's
+    AdaIN as a per-(n, channel) scale / shift (muvo_conv_forward_affine)?  Needs the statistics from the producer's epilogue."""
+    if not CONV_AFFINE or moments is None or x.dim() != 5 or not (x.requires_grad and torch.is_grad_enabled()):
+        return False
+    n = x.shape[0]
+    in_sz = tuple(x.shape[2:])
+    d = geom.plan(n, in_sz)[0]
+    key = ('affine', n, in_sz, _plan_epoch[0])
+    ok = geom.family.get(key)
+    if ok is None:
+        ok = geom.family[key] = bool(lib().muvo_conv_affine_supported(C.byref(d)))
+    return ok
 
 
 CONV_MOMENTS = os.environ.get('MUVO_CONV_MOMENTS', '1') != '0'
@@ -1052,7 +1084,7 @@ class AdaINFn(torch.autograd.Function):
     """AdaptiveInstanceNorm3d. x: (N,C,D,H,W) or a broadcast (C,D,H,W) parameter; style: (N, 2C)."""
 
     @staticmethod
-    def forward(ctx, x, style, eps, n_batch, pre_act=ACT_NONE, pre_slope=0.0, moments=None):
+    def forward(ctx, x, style, eps, n_batch, pre_act=ACT_NONE, pre_slope=0.0, moments=None, aff_out=None):
         x = x.contiguous()
         style = style.contiguous()
         bcast = x.dim() == 4
@@ -1060,9 +1092,16 @@ class AdaINFn(torch.autograd.Function):
         c = x.shape[0] if bcast else x.shape[1]
         s = x.numel() // c if bcast else x.numel() // (x.shape[0] * c)
         n = n_batch
-        y = torch.empty((n, c) + tuple(x.shape[-3:]), device=x.device, dtype=torch.float32)
         mean = torch.empty(n * c, device=x.device, dtype=torch.float32)
         rstd = torch.empty(n * c, device=x.device, dtype=torch.float32)
+        if aff_out is not None:
+            # lazy form: statistics -> (mean, rstd, scale / shift table); the consumer applies the map while staging x, the
+            # normalised tensor is never written.  The returned tensor is a shape-only placeholder (no storage of its size).
+            _ck(lib().muvo_adain_affine(_f(style), _p(moments), _f(mean), _f(rstd), _f(aff_out), n, c, _i64(s), _fl(eps), _st()))
+            ctx.dims = (n, c, s, bcast)
+            ctx.save_for_backward(x, style, mean, rstd)
+            return torch.empty(1, device=x.device, dtype=torch.float32).expand((n, c) + tuple(x.shape[-3:]))
+        y = torch.empty((n, c) + tuple(x.shape[-3:]), device=x.device, dtype=torch.float32)
         if moments is not None and not bcast:   # statistics already accumulated by the producing convolution's epilogue
             _ck(lib().muvo_adain_fwd_moments(_f(x), _f(style), _f(y), _f(mean), _f(rstd), _p(moments), n, c, _i64(s), _fl(eps), _st()))
         else:
@@ -1088,7 +1127,16 @@ class AdaINFn(torch.autograd.Function):
             _ck(lib().muvo_batchsum(_f(dxf), _f(dx), n, _i64(c * s), 0, _st()))
         else:
             dx = dxf
-        return dx, dstyle, None, None, None, None, None
+        return dx, dstyle, None, None, None, None, None, None
+
+
+def adain_lazy(x, style, eps, pre_act, pre_slope, moments):
+    """AdaIN of x (N, C, D, H, W) whose consumer applies it while staging: returns (placeholder, x, aff) for
+    conv(..., lazy=(x, aff)).  The placeholder carries the autograd edge and the shape, nothing else may read it."""
+    n, c = x.shape[:2]
+    aff = torch.empty(n, c, 2, device=x.device, dtype=torch.float32)
+    y = AdaINFn.apply(x, style, eps, n, pre_act, pre_slope, moments, aff)
+    return y, x, aff
 
 
 def adain(x, style, eps, n_batch, pre_act=ACT_NONE, pre_slope=0.0, moments=None):

@@ -518,6 +518,62 @@ def test_adain_head_fused(dev, pre):
     _close(hbg.grad + 0.25, hbc.grad, rtol=5e-4, atol=1e-3, name='dhead_b')
 
 
+@pytest.mark.parametrize('cin,cout,shape', [(16, 8, (5, 13, 64)), (32, 16, (3, 9, 32)), (8, 8, (4, 7, 32))])
+def test_decoder_block3d_lazy_adain(dev, cin, cout, shape):
+    """DecoderBlock3d (common.py:161-202, 498-546): conv1 -> LeakyReLU -> AdaIN -> conv2 -> LeakyReLU -> AdaIN.  With the bf16x3
+    voxel kernels conv2 applies the first AdaIN while staging its input (ops.adain_lazy, muvo_conv_forward_affine /
+    muvo_conv_wgrad_affine): the normalised tensor is never written.  Output and every gradient against the plain PyTorch
+    composition, and the fused path must really have been taken where it is supported."""
+    from muvo_amd import ops
+    from muvo_amd.models.common import DecoderBlock3d
+    old = ops.get_conv_mode()
+    ops.set_conv_mode(ops.CONV_BF16X3, min_gflop=0.0)
+    try:
+        torch.manual_seed(9)
+        lat = 24
+        with torch.device(dev):
+            blk = DecoderBlock3d(cin, cout, lat, upsample=False)
+        n = 3
+        x = torch.randn(n, cin, *shape)
+        w = torch.randn(n, lat)
+        xg, wg = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+        for p in blk.parameters():
+            p.grad = torch.zeros_like(p)
+        calls = []
+        real = ops.adain_lazy
+        ops.adain_lazy = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+        try:
+            y = blk(xg, wg)
+        finally:
+            ops.adain_lazy = real
+        mid = torch.empty(n, cout, *shape, device=dev).requires_grad_(True)
+        expect = ops.conv_affine_supported(mid, blk.conv2.conv_act[0].geom, ops.conv_moments_buffer(xg, blk.conv1.conv_act[0].geom))
+        assert bool(calls) == bool(expect)
+        if cin <= 16:
+            assert expect, 'the 8 / 16-channel voxel layers must take the fused path'
+        P = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in blk.named_parameters()}
+        xc, wc = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+
+        def cin3d(h, pre):
+            h = F.leaky_relu(F.conv3d(h, P[pre + '.conv_act.0.weight'], P[pre + '.conv_act.0.bias'], padding=1), 0.2)
+            st = F.linear(wc, P[pre + '.adaptive_norm.latent_affine.weight'], P[pre + '.adaptive_norm.latent_affine.bias'])
+            c = h.shape[1]
+            hm = h - h.mean(dim=(-1, -2, -3), keepdim=True)
+            hn = hm / torch.sqrt((hm ** 2).mean(dim=(-1, -2, -3), keepdim=True) + 1e-8)
+            return st[:, :c, None, None, None] * hn + st[:, c:, None, None, None]
+        yr = cin3d(cin3d(xc, 'conv1'), 'conv2')
+        _close(y, yr, rtol=5e-4, name='block output')
+        g = torch.randn_like(yr)
+        yr.backward(g)
+        y.backward(g.to(dev))
+        _close(xg.grad, xc.grad, rtol=1e-3, name='dx')
+        _close(wg.grad, wc.grad, rtol=1e-3, atol=1e-3, name='dlatent')
+        for k, v in blk.named_parameters():
+            _close(v.grad, P[k].grad, rtol=1e-3, atol=2e-3, name='d' + k)
+    finally:
+        ops.set_conv_mode(old, min_gflop=-1.0)
+
+
 @pytest.mark.parametrize('l,n,e', [(70, 3, 96), (324, 2, 384)])    # head dim 12: unfused attention; 48: the fused kernel
 def test_transformer_layer(dev, l, n, e):
     from muvo_amd import nn as hnn
