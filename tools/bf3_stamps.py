@@ -20,6 +20,8 @@ LAYERS = [('convT 128->64 in 160x416', lambda: hnn.ConvTranspose2d(128, 64, 6, 2
 LAYERS.append(('conv 64->64 3x3 in 80x208 (four-wave 64x128 tile)', lambda: hnn.Conv2d(64, 64, 3, 1, 1), (20, 64, 80, 208)))
 LAYERS.append(('conv 128->128 3x3 in 40x104', lambda: hnn.Conv2d(128, 128, 3, 1, 1), (20, 128, 40, 104)))
 NK = {LAYERS[0][0]: 36, LAYERS[1][0]: 72, LAYERS[2][0]: 144, LAYERS[3][0]: 18, LAYERS[4][0]: 36}
+if len(sys.argv) > 1:
+    LAYERS = [l for l in LAYERS if sys.argv[1] in l[0]]
 for name, make, shape in LAYERS:
     torch.manual_seed(0)
     with torch.device(dev):
@@ -64,5 +66,19 @@ for name, make, shape in LAYERS:
     gaps = np.array(gaps)
     print(f'   workgroups per CU {min(per_cu)}..{max(per_cu)};  gap end -> next start on the same CU: mean {gaps.mean():.2f} median '
           f'{np.median(gaps):.2f} p90 {np.percentile(gaps, 90):.2f} us')
+    # residency: time-average of the number of workgroups between their first and last stamp on one CU, and the hand-over
+    # delay of a slot: start of the (k + R)-th workgroup of a CU minus the end stamp of its k-th, R = residents the LDS allows
+    R = 1 if 'four-wave' not in name else 3
+    res, hand = [], []
+    for c in np.unique(cu):
+        sel = us[cu == c]
+        sel = sel[np.argsort(sel[:, 0])]
+        res.append((sel[:, 4] - sel[:, 0]).sum() / (sel[:, 4].max() - sel[:, 0].min()))
+        ends = np.sort(sel[:, 4])
+        if len(sel) > R:
+            hand += list(sel[R:, 0] - ends[:-R])
+    hand = np.array(hand)
+    print(f'   resident workgroups per CU (time average between a CU\'s first start and last end): mean {np.mean(res):.2f};  slot hand-over '
+          f'(start of workgroup k+{R} - k-th end on the CU): median {np.median(hand):.2f} p10 {np.percentile(hand, 10):.2f} p90 {np.percentile(hand, 90):.2f} us')
     first = np.sort(us[:, 0])[:256]
     print(f'   start of the first 256 workgroups: {first.min():.1f} .. {first.max():.1f} us;  last end {us[:, 4].max():.1f} us')
