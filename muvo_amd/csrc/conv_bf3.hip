@@ -422,8 +422,9 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
 #if defined(MUVO_BF3_STAMPS) && MUVO_BF3_STAMPS != 3
   if (threadIdx.x == 0 && blockIdx.x < 16384) g_bf3_stamps[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime() - clk0;
 #endif
-#define BF3_STORE(ACT) conv_tile_store<ACT, true>(g, acc, bias, out, slope, ksplit, bx * BN, m_tile, wm, wn, lane, sbias)
-  MUVO_ACT_SWITCH(ksplit > 1 ? MUVO_ACT_NONE : act, BF3_STORE)
+#define BF3_STORE(ACT) conv_tile_store<ACT, true, true>(g, acc, bias, out, slope, bx * BN, m_tile, wm, wn, lane, sbias)
+  if (ksplit > 1) conv_tile_atomic<true>(g, acc, out, bx * BN, m_tile, wm, wn, lane);
+  else { MUVO_ACT_SWITCH(act, BF3_STORE) }
   BF3_STAMP(4);
 #if defined(MUVO_BF3_STAMPS) && MUVO_BF3_STAMPS == 2
   __builtin_amdgcn_s_waitcnt(0);         // all stores of this wave acknowledged

@@ -40,7 +40,7 @@ conv_fwd_kernel(const ConvPhase g, const float* __restrict__ in, const float* __
 
   __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LDA + LDB)];
   __shared__ int s_tap[MAX_TAPS];
-  __shared__ float s_bias[4][32 * TM];          // per wave: bias of its rows, staged by the epilogue (conv_plan.h)
+  __shared__ __attribute__((aligned(16))) float s_bias[4][32 * TM];          // per wave: bias of its rows, staged by the epilogue (conv_plan.h)
   float* As0 = smem;
   float* Bs0 = smem + 2 * BK * LDA;
 
@@ -151,8 +151,9 @@ conv_fwd_kernel(const ConvPhase g, const float* __restrict__ in, const float* __
   if (ksplit > 1 && kt0 >= nk) return;
 
   // ---- epilogue, instantiated per activation (see act_dispatch in common.h)
-#define CONV_FWD_STORE(ACT) conv_tile_store<ACT, false>(g, acc, bias, out, slope, ksplit, blockIdx.x * BN, m_tile, wm, wn, lane, s_bias[wave])
-  MUVO_ACT_SWITCH(ksplit > 1 ? MUVO_ACT_NONE : act, CONV_FWD_STORE)
+#define CONV_FWD_STORE(ACT) conv_tile_store<ACT, false, true>(g, acc, bias, out, slope, blockIdx.x * BN, m_tile, wm, wn, lane, s_bias[wave])
+  if (ksplit > 1) conv_tile_atomic<true>(g, acc, out, blockIdx.x * BN, m_tile, wm, wn, lane);
+  else { MUVO_ACT_SWITCH(act, CONV_FWD_STORE) }
 #undef CONV_FWD_STORE
 }
 

@@ -50,19 +50,121 @@ __device__ __forceinline__ void decode_pix(const ConvPhase& g, int p, int& n, in
 // on lgkmcnt and cost no registers across the tile.
 // A function template on purpose: a lambda that captures the kernel's by-value ConvPhase by reference can make the compiler
 // copy the struct to scratch memory (2.8 KB per lane, 20-us workgroup launches) — muvo_amd/build.py rejects scratch use.
-template <int ACT, bool VEC4, int TM, int TN, class V>
+// (The output residue of a row group is looked up with static indices + selects, written out at each use: with g.mop[grp][..]
+// or with a helper taking the ConvPhase by reference the compiler copied the whole by-value kernel argument to scratch in
+// some instances, 2848 B per lane.)
+// Split-K partial sums: atomic adds into the zeroed output (bias / activation run in a finishing pass).  Separate from the
+// store epilogue so that its code exists once per kernel, not once per activation.
+template <bool MERGED, int TM, int TN, class V>
+__device__ __forceinline__ void conv_tile_atomic(const ConvPhase& g, const V (&acc)[TM][TN], float* __restrict__ out, int pix0,
+                                                 int m_tile, int wm, int wn, int lane) {
+  // output residues of the row groups as VALUES (static indices, made opaque): selecting among g.mop entries by a dynamic group
+  // index - directly or as a chain of conditional loads, which the optimiser turns into one load through a selected pointer -
+  // made the compiler copy the whole by-value ConvPhase to scratch (2848 B per lane)
+  constexpr int NG = MERGED ? 8 : 1;
+  int mopv[NG][3];
+#pragma unroll
+  for (int q = 0; q < NG; ++q)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) mopv[q][k] = __builtin_amdgcn_readfirstlane(g.mop[q][k]);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int pj = pix0 + wn * (TN * 32) + j * 32 + (lane & 31);
+    if (pj >= g.npix) continue;
+    int nn, jz, jy, jx;
+    decode_pix(g, pj, nn, jz, jy, jx);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int mb = m_tile + wm * (TM * 32) + i * 32;
+      const int grp = (MERGED && g.nmerge > 1) ? mb / g.Msub : 0;
+      const int mo = mb - grp * g.Msub;
+      int mz = mopv[0][0], my = mopv[0][1], mx = mopv[0][2];
+#pragma unroll
+      for (int q = 1; q < NG; ++q) { mz = grp == q ? mopv[q][0] : mz; my = grp == q ? mopv[q][1] : my; mx = grp == q ? mopv[q][2] : mx; }
+      const size_t obase = (size_t)nn * g.out_sN + ((size_t)(jz * g.os[0] + mz) * g.OH + (jy * g.os[1] + my)) * g.OW + (jx * g.os[2] + mx);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (mb + rr < g.M && mo + rr < g.Msub) atomicAdd(out + obase + (size_t)(mo + rr) * g.out_sC, acc[i][j][r]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+// MERGED = false: for callers that never run merged sub-pixel phases (none at present; both kernel families do): one row group
+// (see the note on the residue table below)
+template <int ACT, bool VEC4, bool MERGED, int TM, int TN, class V>
 __device__ __forceinline__ void conv_tile_store(const ConvPhase& g, const V (&acc)[TM][TN], const float* __restrict__ bias,
-                                                float* __restrict__ out, float slope, int ksplit, int pix0, int m_tile, int wm,
+                                                float* __restrict__ out, float slope, int pix0, int m_tile, int wm,
                                                 int wn, int lane, float* sb) {
-  const bool use_bias = bias != nullptr && ksplit <= 1;       // (uniform)
+  // output residues of the row groups as VALUES (static indices, made opaque): selecting among g.mop entries by a dynamic group
+  // index - directly or as a chain of conditional loads, which the optimiser turns into one load through a selected pointer -
+  // made the compiler copy the whole by-value ConvPhase to scratch (2848 B per lane)
+  constexpr int NG = MERGED ? 8 : 1;
+  int mopv[NG][3];
+#pragma unroll
+  for (int q = 0; q < NG; ++q)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) mopv[q][k] = __builtin_amdgcn_readfirstlane(g.mop[q][k]);
+  const bool use_bias = bias != nullptr;       // (uniform)
   if (use_bias) {
     if (lane < 32 * TM) {
       const int mb = m_tile + wm * (TM * 32) + (lane & ~31);
-      const int mo = mb - (g.nmerge > 1 ? mb / g.Msub : 0) * g.Msub;
+      const int mo = mb - ((MERGED && g.nmerge > 1) ? mb / g.Msub : 0) * g.Msub;
       const int rr = lane & 31;
       sb[lane] = (mb + rr < g.M && mo + rr < g.Msub) ? bias[mo + rr] : 0.f;
     }
     __builtin_amdgcn_sched_barrier(0);       // the (single) bias load is issued and consumed before the first store
+  }
+  // Channel-major outputs below 2 GB (every activation tensor of the model): range-checked buffer stores.  The address of a
+  // store is one per-lane byte offset per 32 x 32 tile (pixel + first row of the lane) plus a SCALAR row offset, rows or pixels
+  // that do not exist get an out-of-range offset and are dropped by the hardware - per store that leaves the bias add, the
+  // activation and the store itself.  (The pointer form below cost ~90 instructions and a branch per store: 64-bit address
+  // arithmetic, two row checks, and ~190 branches per instance; the epilogue of a 64 x 128 tile took 5 us.)
+  const long total_bytes = (long)g.N * g.out_sN * 4;
+  if (!(VEC4 && g.out_sC == 1) && total_bytes < 0x7fffff00L) {      // (uniform)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, (int)total_bytes, 0x00020000);
+    const unsigned sC4 = (unsigned)g.out_sC * 4u;
+    constexpr unsigned OOB = 0x80000000u;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int pj = pix0 + wn * (TN * 32) + j * 32 + (lane & 31);
+      const bool pix_ok = pj < g.npix;
+      int nn, jz, jy, jx;
+      decode_pix(g, pix_ok ? pj : 0, nn, jz, jy, jx);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int mb = m_tile + wm * (TM * 32) + i * 32;   // 32-row tile: inside one merged group (Msub % 32 == 0)
+        const int grp = (MERGED && g.nmerge > 1) ? mb / g.Msub : 0;
+        const int mo = mb - grp * g.Msub;
+        int mz = mopv[0][0], my = mopv[0][1], mx = mopv[0][2];
+#pragma unroll
+        for (int q = 1; q < NG; ++q) { mz = grp == q ? mopv[q][0] : mz; my = grp == q ? mopv[q][1] : my; mx = grp == q ? mopv[q][2] : mx; }
+        const size_t obase = (size_t)nn * g.out_sN + ((size_t)(jz * g.os[0] + mz) * g.OH + (jy * g.os[1] + my)) * g.OW + (jx * g.os[2] + mx);
+        const bool full = mb + 32 <= g.M && mo + 32 <= g.Msub;        // (uniform) all 32 rows of the tile exist
+        const int r0 = 4 * (lane >> 5);
+        const unsigned v0 = pix_ok ? (unsigned)(obase * 4) + (unsigned)(mo + r0) * sC4 : OOB;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float b4[4] = {0.f, 0.f, 0.f, 0.f};
+          if (use_bias) {
+            const float4 t = *reinterpret_cast<const float4*>(sb + i * 32 + 8 * q + r0);
+            b4[0] = t.x; b4[1] = t.y; b4[2] = t.z; b4[3] = t.w;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int rr = e + 8 * q + r0;
+            unsigned vo = v0;
+            if (!full) vo = (mb + rr < g.M && mo + rr < g.Msub) ? v0 : OOB;
+            const float val = act_apply_c<ACT>(acc[i][j][4 * q + e] + b4[e], slope);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), rs, vo, (unsigned)(8 * q + e) * sC4, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    return;
   }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -73,12 +175,13 @@ __device__ __forceinline__ void conv_tile_store(const ConvPhase& g, const V (&ac
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int mb = m_tile + wm * (TM * 32) + i * 32;   // 32-row tile: inside one merged group (Msub % 32 == 0)
-      const int grp = g.nmerge > 1 ? mb / g.Msub : 0;
+      const int grp = (MERGED && g.nmerge > 1) ? mb / g.Msub : 0;
       const int mo = mb - grp * g.Msub;
-      const size_t obase = (size_t)nn * g.out_sN +
-                           ((size_t)(jz * g.os[0] + g.mop[grp][0]) * g.OH + (jy * g.os[1] + g.mop[grp][1])) * g.OW +
-                           (jx * g.os[2] + g.mop[grp][2]);
-      if (VEC4 && g.out_sC == 1 && ksplit <= 1) {   // (uniform)
+      int mz = mopv[0][0], my = mopv[0][1], mx = mopv[0][2];
+#pragma unroll
+      for (int q = 1; q < NG; ++q) { mz = grp == q ? mopv[q][0] : mz; my = grp == q ? mopv[q][1] : my; mx = grp == q ? mopv[q][2] : mx; }
+      const size_t obase = (size_t)nn * g.out_sN + ((size_t)(jz * g.os[0] + mz) * g.OH + (jy * g.os[1] + my)) * g.OW + (jx * g.os[2] + mx);
+      if (VEC4 && g.out_sC == 1) {   // (uniform)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int m = mo + 8 * q + 4 * (lane >> 5);
@@ -99,10 +202,8 @@ __device__ __forceinline__ void conv_tile_store(const ConvPhase& g, const V (&ac
       for (int r = 0; r < 16; ++r) {
         const int rr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const int m = mo + rr;
-        if (mb + rr < g.M && m < g.Msub) {
-          if (ksplit > 1) atomicAdd(out + obase + (size_t)m * g.out_sC, acc[i][j][r]);
-          else out[obase + (size_t)m * g.out_sC] = act_apply_c<ACT>(acc[i][j][r] + (use_bias ? sb[i * 32 + rr] : 0.f), slope);
-        }
+        if (mb + rr < g.M && m < g.Msub)
+          out[obase + (size_t)m * g.out_sC] = act_apply_c<ACT>(acc[i][j][r] + (use_bias ? sb[i * 32 + rr] : 0.f), slope);
       }
       // the scheduler would otherwise form the addresses of all TM x TN x 16 stores up front (+100 VGPRs, or spills)
       __builtin_amdgcn_sched_barrier(0);
