@@ -114,6 +114,13 @@ int muvo_conv_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp_dg
  * (ConvInstanceNorm3d, common.py:190-202), taken from the epilogue registers instead of a pass over the output tensor.  Only
  * the bf16x3 voxel kernels (muvo_conv_kernel_family(d, 0) == 4) do this: ask muvo_conv_forward_moments_supported first.
  * muvo_adain_fwd_moments consumes such a buffer (and leaves it all-zero). */
+/* muvo_conv_forward + the 1x1 head on its output (ConvDecoder stage + RGBHead / LidarReHead, muvo/models/common.py:608-632,
+ * 287-303): logits (N, CO, out spatial) = head_b + head_w (CO, Cout) . y per pixel, formed in the convolution's epilogue from
+ * the activated values while they are stored - the head's forward makes no pass over y.  Ask _supported first (eight-wave
+ * bf16x3 tiles, no split-K, Cout % 64 == 0, CO <= 4, CO * Cout <= 1024, y below 2 GB). */
+int muvo_conv_forward_head_supported(const muvo_conv_desc* d, int CO);
+int muvo_conv_forward_head(const muvo_conv_desc* d, const float* x, const float* wp_fwd, const float* bias, float* y, int act,
+                           float slope, void* ws, const float* head_w, const float* head_b, int CO, float* logits, void* stream);
 int muvo_conv_forward_moments_supported(const muvo_conv_desc* d);
 int muvo_conv_forward_moments(const muvo_conv_desc* d, const float* x, const float* wp_fwd, const float* bias, float* y, int act,
                               float slope, double* moments, void* stream);

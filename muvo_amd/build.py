@@ -9,7 +9,11 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libmuvo_hip.so')
 SOURCES = ['abi.hip', 'conv_gemm.hip', 'conv_vox.hip', 'conv_pw.hip', 'conv_bf3.hip', 'gemm.hip', 'norm.hip', 'elementwise.hip', 'losses.hip', 'metrics.hip', 'bev.hip', 'input.hip', 'augment.hip', 'attention.hip', 'rssm.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-munsafe-fp-atomics', '-Wno-unused-result', '-Wno-unused-value',
-         '-ffp-contract=off', '-Rpass-analysis=kernel-resource-usage']
+         '-ffp-contract=off', '-Rpass-analysis=kernel-resource-usage',
+         # A by-value kernel argument struct (ConvPhase, 2.8 KB) is first copied to a private alloca by the front end; InstCombine
+         # forwards its loads to the kernel-argument segment only while the alloca has <= this many users (default 300).  The
+         # unrolled epilogues (x 6 activations) read `g` more often than that: beyond the limit the whole struct lands in scratch.
+         '-mllvm', '-instcombine-max-copied-from-constant-users=8000']
 # Kernels allowed to use scratch memory (bytes per lane).  Everything else must stay in registers: a kernel that silently
 # picks up scratch (an argument struct captured by reference and copied to the stack, register spills after a small edit)
 # loses tens of microseconds per workgroup launch — the build fails instead.

@@ -87,7 +87,8 @@ template <int BM, int BN, int WM, int WN, int BKC, int NST>
 __global__ void __launch_bounds__(64 * WM * WN)
 conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, const uint4* __restrict__ wp,
                 const float* __restrict__ bias, float* __restrict__ out, int act, float slope,
-                const uint4* __restrict__ zero16, int ksplit) {
+                const uint4* __restrict__ zero16, int ksplit, const float* __restrict__ head_w, const float* __restrict__ head_b,
+                float* __restrict__ head_out, int head_co) {
   constexpr int BK = 8 * BKC, NW = WM * WN;       // BKC = 8-channel chunks per K step (4: BK = 32, 2: BK = 16)
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   constexpr int STAGE = 2 * BKC * (BM + BN);      // uint4 per stage: A [plane][chunk][BM] then B [plane][BN pixels][4 chunks]
@@ -128,6 +129,10 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
     taptab[tt] = (((((d >> 16) & 255) - 128) * g.IH + ((d >> 8) & 255) - 128) * g.IW + (d & 255) - 128) * cp8;
     taptab[64 + tt] = d;
   }
+  // fused 1x1 head (conv_plan.h: conv_tile_store): its weights [head_co][Msub] behind the bias rows (the launcher adds the LDS)
+  float* head_lds = (float*)(taptab + 128) + NW * (32 * TM);
+  if (head_co > 0)
+    for (int i = tid; i < head_co * g.Msub; i += 64 * NW) head_lds[i] = head_w[i];
   __syncthreads();
   int pixoff[NPS];                       // may be "negative" at borders: only used when valid
   unsigned long long vmask[NPS];         // bit t: tap t of this pixel is inside the input
@@ -422,7 +427,7 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
 #if defined(MUVO_BF3_STAMPS) && MUVO_BF3_STAMPS != 3
   if (threadIdx.x == 0 && blockIdx.x < 16384) g_bf3_stamps[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime() - clk0;
 #endif
-#define BF3_STORE(ACT) conv_tile_store<ACT, true, true>(g, acc, bias, out, slope, bx * BN, m_tile, wm, wn, lane, sbias)
+#define BF3_STORE(ACT) conv_tile_store<ACT, true, true>(g, acc, bias, out, slope, bx * BN, m_tile, wm, wn, lane, sbias, head_lds, head_co, head_b, head_out)
   if (ksplit > 1) conv_tile_atomic<true>(g, acc, out, bx * BN, m_tile, wm, wn, lane);
   else { MUVO_ACT_SWITCH(act, BF3_STORE) }
   BF3_STAMP(4);
@@ -1386,16 +1391,23 @@ int bf3_split_rows(const float* x, void* ws, long rows, int C, hipStream_t st) {
   return MUVO_OK;
 }
 
+struct Bf3Head { const float* w; const float* b; float* out; int co; };     // fused 1x1 head of a forward launch (co = 0: none)
+static thread_local Bf3Head t_bf3_head = {nullptr, nullptr, nullptr, 0};
+
 template <int BM, int BN, int WM, int WN, int BKC, int NST>
 static int bf3_launch(const ConvPhase& g, const void* ws, const float* wp, const float* bias, float* out, int act,
                       float slope, hipStream_t st, int ksplit = 1) {
-  constexpr size_t lds = (size_t)NST * 2 * BKC * (BM + BN) * 16 + 512 + 4 * BM * WN;   // stages + tap tables + bias rows per wave
-  static_assert(lds <= 160 * 1024, "LDS budget");
+  constexpr size_t lds0 = (size_t)NST * 2 * BKC * (BM + BN) * 16 + 512 + 4 * BM * WN;   // stages + tap tables + bias rows per wave
+  static_assert(lds0 <= 160 * 1024, "LDS budget");
+  constexpr size_t HEAD_LDS = NST == 3 ? 4096 : 0;        // eight-wave tiles: room for the weights of a fused head (<= 1024 floats)
+  const Bf3Head hd = (NST == 3 && ksplit <= 1) ? t_bf3_head : Bf3Head{nullptr, nullptr, nullptr, 0};
+  const size_t lds = lds0 + (hd.co > 0 ? HEAD_LDS : 0);
+  static_assert(lds0 + HEAD_LDS <= 160 * 1024, "LDS budget with a fused head");
   static bool attr_set = false;
   static const uint4* zero16 = nullptr;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)conv_bf3_kernel<BM, BN, WM, WN, BKC, NST>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess ||
+                            (int)(lds0 + HEAD_LDS)) != hipSuccess ||
         hipGetSymbolAddress((void**)&zero16, HIP_SYMBOL(g_zero16)) != hipSuccess) {
       muvo_set_error("conv_bf3: kernel attribute / symbol setup failed");
       return MUVO_ERR_HIP;
@@ -1405,7 +1417,7 @@ static int bf3_launch(const ConvPhase& g, const void* ws, const float* wp, const
   const long plane_u4 = (long)g.N * g.ID * g.IH * g.IW * (g.Cp / 8);
   dim3 grid(cdiv(g.npix, BN) * cdiv(g.M, BM), ksplit, 1);
   hipLaunchKernelGGL((conv_bf3_kernel<BM, BN, WM, WN, BKC, NST>), grid, dim3(64 * WM * WN), lds, st, g, (const uint4*)ws, plane_u4,
-                     (const uint4*)wp, bias, out, act, slope, zero16, ksplit);
+                     (const uint4*)wp, bias, out, act, slope, zero16, ksplit, hd.w, hd.b, hd.out, hd.co);
   MUVO_CHECK_LAUNCH("conv_bf3_kernel");
   return MUVO_OK;
 }
@@ -1433,6 +1445,8 @@ int bf3_fwd_ksplit(const ConvPhase& g) {
   if (ks > nk / min_steps) ks = nk / min_steps;
   return ks < 1 ? 1 : ks;
 }
+
+void bf3_set_fused_head(const float* w, const float* b, float* out, int co) { t_bf3_head = Bf3Head{w, b, out, co}; }
 
 int bf3_launch_fwd_phase(const ConvPhase& g, const void* ws, const float* wp, const float* bias, float* out, int act,
                          float slope, hipStream_t st, int ksplit) {

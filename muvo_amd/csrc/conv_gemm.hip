@@ -903,6 +903,46 @@ int muvo_conv_forward(const muvo_conv_desc* d, const float* x, const float* wp_f
   return run_phases(pl.fwd, pl.nfwd, x, wp_fwd, bias, y, act, slope, ws, (hipStream_t)stream);
 }
 
+// A decoder stage and the 1x1 head on its output in one launch per phase (ConvDecoder: trans_conv1/2/3 + head_4/2/1,
+// common.py:608-632): y = act(conv(x)) as muvo_conv_forward, logits[n][k][pixel] = head_b[k] + sum_c head_w[k][c] y[n][c][pixel]
+// formed in the epilogue of the eight-wave bf16x3 tiles from the values being stored - no pass over y for the head's forward.
+// head_w: (CO, Cout) row-major, head_b: (CO) or NULL, logits: (N, CO, out spatial).  Supported when every forward phase runs
+// on those tiles without split-K, Cout % 64 == 0, CO * Cout <= 1024, CO <= 4 and y is below 2 GB.
+int muvo_conv_forward_head_supported(const muvo_conv_desc* d, int CO) {
+  if (check_desc(d) || CO < 1 || CO > 4) return 0;
+  static const int on = getenv("MUVO_CONV_HEAD_FWD") ? atoi(getenv("MUVO_CONV_HEAD_FWD")) : 1;
+  if (!on || conv_mode() != 1 || pw_applicable(d) || vox_fwd_ok(d)) return 0;
+  ConvPlan pl;
+  if (build_plan(d, &pl) != MUVO_OK || pl.nfwd < 1) return 0;
+  for (int i = 0; i < pl.nfwd; ++i) {
+    const ConvPhase& g = pl.fwd[i];
+    if (!g.bf3 || !bf3_fwd_uses_pp(g) || phase_ksplit(g) > 1) return 0;
+    if (g.Msub != d->Cout || g.Msub % 64 != 0 || g.M % 64 != 0 || (long)CO * g.Msub > 1024) return 0;
+    if ((long)g.N * g.out_sN * 4 >= 0x7fffff00L) return 0;
+  }
+  return 1;
+}
+int muvo_conv_forward_head(const muvo_conv_desc* d, const float* x, const float* wp_fwd, const float* bias, float* y, int act,
+                           float slope, void* ws, const float* head_w, const float* head_b, int CO, float* logits, void* stream) {
+  ConvPlan pl;
+  int rc = build_plan(d, &pl);
+  if (rc) return rc;
+  MUVO_CHECK_ARG(x && wp_fwd && y && head_w && logits, "conv_forward_head: null pointer");
+  MUVO_CHECK_ARG(muvo_conv_forward_head_supported(d, CO), "conv_forward_head: shape not served by the eight-wave bf16x3 tiles");
+  hipStream_t st = (hipStream_t)stream;
+  if (d->Cout > 64) {     // the channels of a pixel are spread over several waves: partial sums are added atomically
+    const long S_out = (long)d->out_sz[0] * d->out_sz[1] * d->out_sz[2];
+    if (hipMemsetAsync(logits, 0, sizeof(float) * (size_t)d->N * CO * S_out, st) != hipSuccess) {
+      muvo_set_error("conv_forward_head: memset of the logits failed");
+      return MUVO_ERR_HIP;
+    }
+  }
+  bf3_set_fused_head(head_w, head_b, logits, CO);
+  rc = run_phases(pl.fwd, pl.nfwd, x, wp_fwd, bias, y, act, slope, ws, st);
+  bf3_set_fused_head(nullptr, nullptr, nullptr, 0);
+  return rc;
+}
+
 int muvo_conv_forward_moments_supported(const muvo_conv_desc* d) {
   if (check_desc(d)) return 0;
   return (!pw_applicable(d) && vox_fwd_ok(d) && vox_uses_bf3(d, 0)) ? 1 : 0;

@@ -50,17 +50,16 @@ __device__ __forceinline__ void decode_pix(const ConvPhase& g, int p, int& n, in
 // on lgkmcnt and cost no registers across the tile.
 // A function template on purpose: a lambda that captures the kernel's by-value ConvPhase by reference can make the compiler
 // copy the struct to scratch memory (2.8 KB per lane, 20-us workgroup launches) — muvo_amd/build.py rejects scratch use.
-// (The output residue of a row group is looked up with static indices + selects, written out at each use: with g.mop[grp][..]
-// or with a helper taking the ConvPhase by reference the compiler copied the whole by-value kernel argument to scratch in
-// some instances, 2848 B per lane.)
+// (Scratch copies of the by-value ConvPhase: the front end copies a by-value kernel argument struct to a private alloca and
+// InstCombine forwards the loads to the kernel-argument segment only while that alloca has <= 300 users by default; the
+// unrolled epilogues x 6 activations exceed it, and then the whole struct (2848 B per lane) lands in scratch.  muvo_amd/build.py
+// raises the limit (-mllvm -instcombine-max-copied-from-constant-users) and fails the build on any scratch use.)
 // Split-K partial sums: atomic adds into the zeroed output (bias / activation run in a finishing pass).  Separate from the
 // store epilogue so that its code exists once per kernel, not once per activation.
 template <bool MERGED, int TM, int TN, class V>
 __device__ __forceinline__ void conv_tile_atomic(const ConvPhase& g, const V (&acc)[TM][TN], float* __restrict__ out, int pix0,
                                                  int m_tile, int wm, int wn, int lane) {
-  // output residues of the row groups as VALUES (static indices, made opaque): selecting among g.mop entries by a dynamic group
-  // index - directly or as a chain of conditional loads, which the optimiser turns into one load through a selected pointer -
-  // made the compiler copy the whole by-value ConvPhase to scratch (2848 B per lane)
+  // output residues of the row groups as scalar values, selected by the (wave-uniform) group index
   constexpr int NG = MERGED ? 8 : 1;
   int mopv[NG][3];
 #pragma unroll
@@ -94,13 +93,17 @@ __device__ __forceinline__ void conv_tile_atomic(const ConvPhase& g, const V (&a
 
 // MERGED = false: for callers that never run merged sub-pixel phases (none at present; both kernel families do): one row group
 // (see the note on the residue table below)
+// Fused 1x1 head (hco > 0; ConvDecoder stage + RGBHead / LidarReHead, common.py:608-632): logits[n][k][pixel] = hb[k] +
+// sum_c hw[k][c] * y[n][c][pixel] for the hco <= 4 head channels, formed from the activated values while they are stored (hw: the
+// head weights [hco][Msub] in LDS).  A wave holds 64 channels of its 64 pixels: 4 * hco FMAs per stored value, one cross-half
+// shuffle per pixel column; layers with more than 64 channels per group add their partial sums atomically into the zeroed
+// logits (the wave with the group's first channels adds the bias).  Needs full tiles (M, Msub multiples of 64).
 template <int ACT, bool VEC4, bool MERGED, int TM, int TN, class V>
 __device__ __forceinline__ void conv_tile_store(const ConvPhase& g, const V (&acc)[TM][TN], const float* __restrict__ bias,
                                                 float* __restrict__ out, float slope, int pix0, int m_tile, int wm,
-                                                int wn, int lane, float* sb) {
-  // output residues of the row groups as VALUES (static indices, made opaque): selecting among g.mop entries by a dynamic group
-  // index - directly or as a chain of conditional loads, which the optimiser turns into one load through a selected pointer -
-  // made the compiler copy the whole by-value ConvPhase to scratch (2848 B per lane)
+                                                int wn, int lane, float* sb, const float* hw = nullptr, int hco = 0,
+                                                const float* __restrict__ hb = nullptr, float* __restrict__ hlogits = nullptr) {
+  // output residues of the row groups as scalar values, selected by the (wave-uniform) group index
   constexpr int NG = MERGED ? 8 : 1;
   int mopv[NG][3];
 #pragma unroll
@@ -133,6 +136,8 @@ __device__ __forceinline__ void conv_tile_store(const ConvPhase& g, const V (&ac
       const bool pix_ok = pj < g.npix;
       int nn, jz, jy, jx;
       decode_pix(g, pix_ok ? pj : 0, nn, jz, jy, jx);
+      float hacc[4] = {0.f, 0.f, 0.f, 0.f};
+      size_t hsp = 0;                                       // spatial offset of this lane's pixel (same for all rows of the wave)
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int mb = m_tile + wm * (TM * 32) + i * 32;   // 32-row tile: inside one merged group (Msub % 32 == 0)
@@ -145,6 +150,7 @@ __device__ __forceinline__ void conv_tile_store(const ConvPhase& g, const V (&ac
         const bool full = mb + 32 <= g.M && mo + 32 <= g.Msub;        // (uniform) all 32 rows of the tile exist
         const int r0 = 4 * (lane >> 5);
         const unsigned v0 = pix_ok ? (unsigned)(obase * 4) + (unsigned)(mo + r0) * sC4 : OOB;
+        if (i == 0) hsp = obase - (size_t)nn * g.out_sN;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float b4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -152,16 +158,41 @@ __device__ __forceinline__ void conv_tile_store(const ConvPhase& g, const V (&ac
             const float4 t = *reinterpret_cast<const float4*>(sb + i * 32 + 8 * q + r0);
             b4[0] = t.x; b4[1] = t.y; b4[2] = t.z; b4[3] = t.w;
           }
+          float vq[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int rr = e + 8 * q + r0;
             unsigned vo = v0;
             if (!full) vo = (mb + rr < g.M && mo + rr < g.Msub) ? v0 : OOB;
-            const float val = act_apply_c<ACT>(acc[i][j][4 * q + e] + b4[e], slope);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), rs, vo, (unsigned)(8 * q + e) * sC4, 0);
+            vq[e] = act_apply_c<ACT>(acc[i][j][4 * q + e] + b4[e], slope);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vq[e]), rs, vo, (unsigned)(8 * q + e) * sC4, 0);
+          }
+          if (hco > 0) {      // (uniform)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (k < hco) {
+                const float4 w4 = *reinterpret_cast<const float4*>(hw + k * g.Msub + mo + 8 * q + r0);
+                hacc[k] += (w4.x * vq[0] + w4.y * vq[1]) + (w4.z * vq[2] + w4.w * vq[3]);
+              }
           }
         }
         __builtin_amdgcn_sched_barrier(0);
+      }
+      if (hco > 0) {        // (uniform) rows 4 * (lane >> 5) + {0..3} + 8 q: the two lane halves hold the two halves of a pixel's channels
+        const int mb0 = m_tile + wm * (TM * 32);
+        const int mo0 = mb0 - ((MERGED && g.nmerge > 1) ? mb0 / g.Msub : 0) * g.Msub;
+        const bool split = g.Msub > TM * 32;               // the group's channels are spread over several waves / workgroups
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k < hco) {
+            float h = hacc[k] + __shfl_xor(hacc[k], 32, 64);
+            if (lane < 32 && pix_ok) {
+              float* dst = hlogits + ((size_t)nn * hco + k) * g.out_sC + hsp;
+              const float bk = hb != nullptr ? hb[k] : 0.f;
+              if (split) atomicAdd(dst, h + (mo0 == 0 ? bk : 0.f));
+              else *dst = h + bk;
+            }
+          }
       }
     }
     return;

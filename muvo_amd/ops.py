@@ -68,6 +68,7 @@ EXPORTS = [
     'muvo_conv_dgrad_accumulate', 'muvo_conv_forward_moments_supported', 'muvo_conv_forward_moments', 'muvo_adain_fwd_moments',
     'muvo_adain_head_supported', 'muvo_adain_head_fwd', 'muvo_adain_head_bwd', 'muvo_bf3_loop_clock',
     'muvo_grouped_linear_fwd', 'muvo_grouped_linear_bwd', 'muvo_conv_prepare_dy_head', 'muvo_conv_prepare_dy_head_supported',
+    'muvo_conv_forward_head_supported', 'muvo_conv_forward_head',
     'muvo_adain_affine', 'muvo_conv_affine_supported', 'muvo_conv_forward_affine', 'muvo_conv_wgrad_affine',
     'muvo_rssm_supported', 'muvo_rssm_transposed_floats', 'muvo_rssm_scratch_floats', 'muvo_rssm_forward', 'muvo_rssm_backward',
 ]
@@ -707,7 +708,11 @@ class ConvFn(torch.autograd.Function):
         else:
             ws = scratch('conv_ws', (wsb[0] + 3) // 4, x.device) if wsb[0] else None
         ctx.ws_x = ws if keep_ws else None
-        if aff is not None:
+        hf = getattr(ctx, '_head_fwd', None)
+        if hf is not None:
+            _ck(L.muvo_conv_forward_head(C.byref(d), _f(x), _f(packed.fwd), _f(bias), _f(y), act, _fl(slope), _p(ws),
+                                         _f(hf[0]), _f(hf[1]), hf[0].shape[0], _f(hf[2]), _st()))
+        elif aff is not None:
             _ck(L.muvo_conv_forward_affine(C.byref(d), _f(x), _f(aff), _f(packed.fwd), _f(bias), _f(y), act, _fl(slope), _p(moments), _st()))
         elif moments is not None:     # instance-norm statistics of y from the epilogue registers (voxel bf16x3 kernels)
             _ck(L.muvo_conv_forward_moments(C.byref(d), _f(x), _f(packed.fwd), _f(bias), _f(y), act, _fl(slope), _p(moments), _st()))
@@ -933,8 +938,26 @@ class ConvHeadFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, geom, packed, act, slope, head_w, head_b, head_geom, head_packed):
+        n0 = x.shape[0]
+        in_sz0 = tuple(x.shape[2:]) if geom.nd == 3 else (1,) + tuple(x.shape[2:])
+        d0, out_sz0 = geom.plan(n0, in_sz0)[:2]
+        co = head_geom.cout
+        fkey = ('head_fwd', n0, in_sz0, co, _plan_epoch[0])
+        fused = geom.family.get(fkey)
+        if fused is None:
+            fused = geom.family[fkey] = bool(lib().muvo_conv_forward_head_supported(C.byref(d0), co))
+        logits = None
+        if fused:
+            # the head's forward rides on the stage's epilogue (muvo_conv_forward_head): no pass over y
+            logits = torch.empty((n0, co) + (out_sz0 if geom.nd == 3 else out_sz0[1:]), device=x.device, dtype=torch.float32)
+            ctx._head_fwd = (head_w.contiguous().view(co, -1), head_b, logits)
         y = ConvFn.forward(ctx, x, weight, bias, geom, packed, act, slope)
+        ctx._head_fwd = None
         ctx.save_for_backward(x, y)            # y is needed for the head's weight gradient even when act needs no derivative
+        if fused:
+            ctx.head = (head_w, head_b, head_geom, tuple(y.shape[2:]) if head_geom.nd == 3 else (1,) + tuple(y.shape[2:]))
+            ctx.set_materialize_grads(False)
+            return y, logits
         # an output nobody differentiates through (the last stage's feature map has the head as its only consumer) arrives
         # as None in backward instead of a zero tensor of its size (1.36 GB filled, then read by the split pass)
         ctx.set_materialize_grads(False)

@@ -157,8 +157,9 @@ GEMM_SHAPES = [(7, 33, 5), (130, 257, 70), (324, 48, 324), (2, 1600, 1088), (300
                (20, 1536, 1536), (3, 100, 70), (9, 64, 16)]  # skinny (M <= 32) kernels incl. row chunking
 
 
+@pytest.mark.parametrize('shape', [(3, 64, 64, 20, 26), (2, 64, 64, 64, 160), (2, 32, 128, 48, 176)])
 @pytest.mark.parametrize('trunk_used', [True, False])
-def test_conv_stage_with_head(dev, trunk_used):
+def test_conv_stage_with_head(dev, trunk_used, shape):
     """A ConvDecoder stage (common.py:608-632): ELU(ConvTranspose2d) whose output feeds a 1x1 head (and, except at the last
     stage, the next stage).  ops.ConvHeadFn forms the head's data gradient inside the stage's backward split pass
     (muvo_conv_prepare_dy_head); checked against the plain PyTorch composition."""
@@ -168,12 +169,17 @@ def test_conv_stage_with_head(dev, trunk_used):
     ops.set_conv_mode(ops.CONV_BF16X3, min_gflop=0.0)
     try:
         torch.manual_seed(17)
+        nb, cin, cout, hh, ww = shape
         with torch.device(dev):
-            conv = hnn.ConvTranspose2d(64, 64, 6, 2, 2)
-            head = hnn.Conv2d(64, 3, 1, 1, 0)
-        x = torch.randn(3, 64, 20, 26)
+            conv = hnn.ConvTranspose2d(cin, cout, 6, 2, 2)
+            head = hnn.Conv2d(cout, 3, 1, 1, 0)
+        x = torch.randn(nb, cin, hh, ww)
         xg = x.to(dev).requires_grad_(True)
         assert ops.conv_head_supported(xg, conv.geom, head.geom)
+        if hh >= 48:     # the larger shapes run on the eight-wave tiles: the head's forward rides on the stage's epilogue
+            d = conv.geom.plan(nb, (1, hh, ww))[0]
+            import ctypes
+            assert ops.lib().muvo_conv_forward_head_supported(ctypes.byref(d), 3) == 1
         for p in (conv.weight, conv.bias, head.weight, head.bias):
             p.grad = torch.zeros_like(p)
         y, logits = ops.conv_head(xg, conv.weight, conv.bias, conv.geom, conv._packed, ops.ACT_ELU, 0.0,

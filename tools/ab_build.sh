@@ -8,7 +8,7 @@ mkdir -p /tmp/ab_$tag
 for f in muvo_amd/csrc/*.hip; do
   b=$(basename $f .hip)
   if [ "$b" = conv_bf3 ]; then
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -munsafe-fp-atomics -Wno-unused-result -Wno-unused-value -ffp-contract=off $flags -c $f -o /tmp/ab_$tag/$b.o
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -munsafe-fp-atomics -Wno-unused-result -Wno-unused-value -ffp-contract=off -mllvm -instcombine-max-copied-from-constant-users=8000 $flags -c $f -o /tmp/ab_$tag/$b.o
   else
     cp muvo_amd/build/$b.o /tmp/ab_$tag/$b.o
   fi

@@ -10,7 +10,7 @@ mkdir -p $out
 cp muvo_amd/build/*.o $out/
 for f in "$@"; do
   b=$(basename $f .hip)
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -munsafe-fp-atomics -Wno-unused-result -Wno-unused-value -ffp-contract=off $flags -c muvo_amd/csrc/$b.hip -o $out/$b.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -munsafe-fp-atomics -Wno-unused-result -Wno-unused-value -ffp-contract=off -mllvm -instcombine-max-copied-from-constant-users=8000 $flags -c muvo_amd/csrc/$b.hip -o $out/$b.o
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/libmuvo_hip.so $out/*.o
 rm -f $out/*.o
