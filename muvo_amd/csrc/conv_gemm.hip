@@ -591,7 +591,8 @@ static int build_transposed_form(const muvo_conv_desc* d, const int* in_dims, co
     }
   }
   // merge the phases into one GEMM when they all read the same input offsets (see conv_plan.h)
-  if (t_allow_merge && count > 1 && count <= 8 && M % 32 == 0 && (long)count * M <= 1024) {
+  static const long merge_max_rows = getenv("MUVO_MERGE_MAX_ROWS") ? atol(getenv("MUVO_MERGE_MAX_ROWS")) : 2048;   // (1024: the 512-channel stages as four launches, +0.8 ms/step)
+  if (t_allow_merge && count > 1 && count <= 8 && M % 32 == 0 && (long)count * M <= merge_max_rows) {
     bool same = true;
     for (int i = 1; i < count && same; ++i) {
       same = phs[i].T == phs[0].T && phs[i].SD == phs[0].SD && phs[i].SH == phs[0].SH && phs[i].SW == phs[0].SW;
