@@ -876,7 +876,8 @@ __global__ void __launch_bounds__(256) bf3_unpack_wgrad_kernel(const ConvPhase g
     else { c = r / uM; m = r - c * uM; }
     const unsigned grp = g.nmerge > 1 ? m / uMsub : 0u, co = m - grp * uMsub;
     float* src = base + ((size_t)t * uM + m) * uC + c;
-    dw[(size_t)co * g.wsm + (size_t)c * g.wsc + (g.nmerge > 1 ? g.tap_wm[grp][t] : s_tw[t])] += *src;
+    const int tw = g.nmerge > 1 ? g.tap_wm[grp][t] : s_tw[t];      // < 0: no such tap in this row group (union of tap sets)
+    if (tw >= 0) dw[(size_t)co * g.wsm + (size_t)c * g.wsc + tw] += *src;
     *src = 0.f;
   }
 }
@@ -1203,7 +1204,8 @@ __global__ void __launch_bounds__(256) bf3_pack_kernel(const ConvPhase g, const 
     float v = 0.f;
     if (t < g.T && c < g.C && m < g.M) {
       const int grp = m / g.Msub, co = m - grp * g.Msub;
-      v = w[(size_t)co * g.wsm + (size_t)c * g.wsc + (g.nmerge > 1 ? g.tap_wm[grp][t] : s_tw[t])];
+      const int tw = g.nmerge > 1 ? g.tap_wm[grp][t] : s_tw[t];
+      if (tw >= 0) v = w[(size_t)co * g.wsm + (size_t)c * g.wsc + tw];
     }
     unsigned hi, lo;
     split2(v, 0.f, hi, lo);
@@ -1263,10 +1265,11 @@ __global__ void __launch_bounds__(256) pack_table_kernel(const PackItem* __restr
       const bool okrow = t < uT && m < (unsigned)M;
       const unsigned mm = okrow ? m : 0u, tt = okrow ? t : 0u;
       const unsigned grp = nmerge > 1 ? mm / uMsub : 0u, co = mm - grp * uMsub;
-      const float* src = w + (size_t)co * wsm + s_tw[grp * MAX_TAPS + tt];
+      const int tw = s_tw[grp * MAX_TAPS + tt];            // < 0: this row group has no such tap (zero weights)
+      const float* src = w + (size_t)co * wsm + (tw >= 0 ? tw : 0);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const bool ok = okrow && c0 + e < (unsigned)C;
+        const bool ok = okrow && tw >= 0 && c0 + e < (unsigned)C;
         const float x = src[(size_t)(ok ? c0 + e : 0u) * wsc];
         v[e] = ok ? x : 0.f;
       }
@@ -1287,8 +1290,9 @@ __global__ void __launch_bounds__(256) pack_table_kernel(const PackItem* __restr
       const bool ok = t < uT && c < (unsigned)C && m < (unsigned)M;
       const unsigned mm = ok ? m : 0u;
       const unsigned grp = nmerge > 1 ? mm / uMsub : 0u, co = mm - grp * uMsub;
-      const float x = w[(size_t)co * wsm + (size_t)(ok ? c : 0u) * wsc + s_tw[grp * MAX_TAPS + (ok ? t : 0u)]];
-      dst[wp_off + idx] = ok ? x : 0.f;
+      const int tw = s_tw[grp * MAX_TAPS + (ok ? t : 0u)];
+      const float x = w[(size_t)co * wsm + (size_t)(ok ? c : 0u) * wsc + (tw >= 0 ? tw : 0)];
+      dst[wp_off + idx] = ok && tw >= 0 ? x : 0.f;
     }
   }
 }

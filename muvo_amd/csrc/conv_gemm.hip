@@ -317,7 +317,8 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const ConvPhase g, co
     float v = 0.f;
     if (t < g.T && c < g.C && m < g.M) {
       const int grp = m / g.Msub, co = m - grp * g.Msub;
-      v = w[(size_t)co * g.wsm + (size_t)c * g.wsc + (g.nmerge > 1 ? g.tap_wm[grp][t] : s_tw[t])];
+      const int tw = g.nmerge > 1 ? g.tap_wm[grp][t] : s_tw[t];      // < 0: this row group has no such tap (union of tap sets)
+      if (tw >= 0) v = w[(size_t)co * g.wsm + (size_t)c * g.wsc + tw];
     }
     wp[g.wp_off + idx] = v;
   }
@@ -593,20 +594,45 @@ static int build_transposed_form(const muvo_conv_desc* d, const int* in_dims, co
   // merge the phases into one GEMM when they all read the same input offsets (see conv_plan.h)
   static const long merge_max_rows = getenv("MUVO_MERGE_MAX_ROWS") ? atol(getenv("MUVO_MERGE_MAX_ROWS")) : 2048;   // (1024: the 512-channel stages as four launches, +0.8 ms/step)
   if (t_allow_merge && count > 1 && count <= 8 && M % 32 == 0 && (long)count * M <= merge_max_rows) {
-    bool same = true;
-    for (int i = 1; i < count && same; ++i) {
-      same = phs[i].T == phs[0].T && phs[i].SD == phs[0].SD && phs[i].SH == phs[0].SH && phs[i].SW == phs[0].SW;
-      for (int t = 0; t < phs[0].T && same; ++t) same = phs[i].tap_d[t] == phs[0].tap_d[t];
+    // The phases must cover sub-grids of one size.  Their tap sets may differ (5x5 stride 2: 9 / 6 / 6 / 4 taps; the data
+    // gradient of a 3x3 stride-2 convolution: 1 / 2 / 2 / 4): the merged GEMM runs over the UNION of the input offsets and a
+    // row group without a tap packs zero weights there (tap_wm = -1).  That is up to 1.8x the exact work, but one launch with
+    // count x M rows on the big tiles instead of `count` launches of a few taps each - taken when at least 60 % of the
+    // (group, tap) pairs are real (MUVO_MERGE_UNION=0: only identical tap sets, as before).
+    static const int allow_union = getenv("MUVO_MERGE_UNION") ? atoi(getenv("MUVO_MERGE_UNION")) : 1;
+    bool same_grid = true, same_taps = true;
+    int real = 0;
+    for (int i = 0; i < count; ++i) {
+      same_grid = same_grid && phs[i].SD == phs[0].SD && phs[i].SH == phs[0].SH && phs[i].SW == phs[0].SW && phs[i].T > 0;
+      same_taps = same_taps && phs[i].T == phs[0].T;
+      for (int t = 0; t < phs[0].T && same_taps && i > 0; ++t) same_taps = phs[i].tap_d[t] == phs[0].tap_d[t];
+      real += phs[i].T;
     }
-    if (same) {
+    int uni[MAX_TAPS], nu = 0;
+    bool fits = true;
+    for (int i = 0; i < count && fits; ++i)
+      for (int t = 0; t < phs[i].T && fits; ++t) {
+        int k = 0;
+        while (k < nu && uni[k] != phs[i].tap_d[t]) ++k;
+        if (k == nu) { if (nu < MAX_TAPS) uni[nu++] = phs[i].tap_d[t]; else fits = false; }
+      }
+    const bool merge = same_grid && (same_taps || (allow_union && fits && nu > 1 && 10 * real >= 6 * count * nu));
+    if (merge) {
       ConvPhase g = phs[0];
       g.nmerge = count;
       g.Msub = M;
       g.M = count * M;
+      g.T = nu;
+      for (int t = 0; t < nu; ++t) g.tap_d[t] = uni[t];
       for (int i = 0; i < count; ++i) {
         for (int a = 0; a < 3; ++a) g.mop[i][a] = phs[i].op[a];
-        for (int t = 0; t < g.T; ++t) g.tap_wm[i][t] = phs[i].tap_w[t];
+        for (int t = 0; t < nu; ++t) {
+          int k = 0;
+          while (k < phs[i].T && phs[i].tap_d[k] != uni[t]) ++k;
+          g.tap_wm[i][t] = k < phs[i].T ? phs[i].tap_w[k] : -1;
+        }
       }
+      for (int t = 0; t < nu; ++t) g.tap_w[t] = g.tap_wm[0][t] >= 0 ? g.tap_wm[0][t] : 0;
       finish_phase(g);
       phs[0] = g;
       count = 1;
