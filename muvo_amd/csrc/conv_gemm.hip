@@ -597,7 +597,7 @@ static int build_transposed_form(const muvo_conv_desc* d, const int* in_dims, co
     // The phases must cover sub-grids of one size.  Their tap sets may differ (5x5 stride 2: 9 / 6 / 6 / 4 taps; the data
     // gradient of a 3x3 stride-2 convolution: 1 / 2 / 2 / 4): the merged GEMM runs over the UNION of the input offsets and a
     // row group without a tap packs zero weights there (tap_wm = -1).  That is up to 1.8x the exact work, but one launch with
-    // count x M rows on the big tiles instead of `count` launches of a few taps each - taken when at least 60 % of the
+    // count x M rows on the big tiles instead of `count` launches of a few taps each - taken when at least half of the
     // (group, tap) pairs are real (MUVO_MERGE_UNION=0: only identical tap sets, as before).
     static const int allow_union = getenv("MUVO_MERGE_UNION") ? atoi(getenv("MUVO_MERGE_UNION")) : 1;
     bool same_grid = true, same_taps = true;
@@ -616,7 +616,8 @@ static int build_transposed_form(const muvo_conv_desc* d, const int* in_dims, co
         while (k < nu && uni[k] != phs[i].tap_d[t]) ++k;
         if (k == nu) { if (nu < MAX_TAPS) uni[nu++] = phs[i].tap_d[t]; else fits = false; }
       }
-    const bool merge = same_grid && (same_taps || (allow_union && fits && nu > 1 && 10 * real >= 6 * count * nu));
+    static const int min_pct = getenv("MUVO_MERGE_UNION_MIN_PCT") ? atoi(getenv("MUVO_MERGE_UNION_MIN_PCT")) : 50;
+    const bool merge = same_grid && (same_taps || (allow_union && fits && nu > 1 && 100 * real >= min_pct * count * nu));
     if (merge) {
       ConvPhase g = phs[0];
       g.nmerge = count;
