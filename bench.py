@@ -239,7 +239,7 @@ def main():
                     r['frac_at_that_clock'] = r['achieved'] / r['peak_at_that_clock']
                     # one K step of a workgroup = 24 MFMA 32x32x16 (8 passes = 32 clocks each) per wave, two waves per SIMD
                     r['k_loop_mfma_busy'] = 24 * 32 * 2 / (usk.value * mhz.value)
-                    r['clock_note'] = 'shader clock and time per K step measured by workgroup 0 of the last eight-wave launch (s_memtime / s_memrealtime)'
+                    r['clock_note'] = 'shader clock and time per K step measured by workgroup 0 of the last eight-wave launch with >= 2048 workgroups (s_memtime / s_memrealtime)'
             # HBM-side bytes per launch of the dominant class: PMC counters cannot be read from inside this process, so the
             # figure comes from the committed rocprofv3 --pmc passes over this same command (tools/pmc_step.sh)
             import glob
