@@ -134,8 +134,24 @@ __global__ void __launch_bounds__(256) maxpool2d_fwd_t_kernel(const float* __res
     constexpr int SPAN = 3 * S + K;                 // columns touched by 4 consecutive windows
     float v[SPAN];
     const int w0 = ow0 * S - P;
+    if (S == 2 && (W & 7) == 0 && OW * 2 == W && (((uintptr_t)x) & 15) == 0) {
+      // (uniform) the eight columns 2 * ow0 .. + 7 as two aligned 16-byte loads, plus the left neighbour for the 3-wide
+      // window: unconditional (clamped address, masked value) instead of nine predicated 4-byte loads per row
+      const float4 q0 = *reinterpret_cast<const float4*>(row + 2 * ow0), q1 = *reinterpret_cast<const float4*>(row + 2 * ow0 + 4);
+      const float qs[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+      if (P == 1) {
+        const float l = row[ow0 > 0 ? 2 * ow0 - 1 : 0];
+        v[0] = ow0 > 0 ? l : -INFINITY;
 #pragma unroll
-    for (int j = 0; j < SPAN; ++j) v[j] = ((unsigned)(w0 + j) < (unsigned)W) ? row[w0 + j] : -INFINITY;
+        for (int j = 0; j < 8; ++j) v[1 + j] = qs[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < SPAN && j < 8; ++j) v[j] = qs[j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < SPAN; ++j) v[j] = ((unsigned)(w0 + j) < (unsigned)W) ? row[w0 + j] : -INFINITY;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -160,16 +176,35 @@ __global__ void __launch_bounds__(256) maxpool2d_bwd_t_kernel(const float* __res
   // windows that contain row h: oh with oh*S - P <= h <= oh*S - P + K - 1
   const int oh_lo = (h + P - K + 1 <= 0) ? 0 : (h + P - K + S) / S, oh_hi = min((h + P) / S, OH - 1);
   const int ow_lo = (w0 + P - K + 1 <= 0) ? 0 : (w0 + P - K + S) / S, ow_hi = min((w0 + 3 + P) / S, OW - 1);
-  for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+  // at most NOH x NOW windows touch the four columns of this lane: all their (winner byte, gradient) loads are issued up front
+  // with clamped indices and masked afterwards (the two nested runtime loops made every load wait for the previous one)
+  constexpr int NOH = (K + S - 1) / S, NOW = (3 + K - 1) / S + 1;
+  int wv[NOH][NOW];
+  float dv[NOH][NOW];
+#pragma unroll
+  for (int i = 0; i < NOH; ++i) {
+    const int oh = oh_lo + i, ohc = min(oh <= oh_hi ? oh : oh_lo, OH - 1);     // (rows below the last window: nothing live, any valid address)
+    const long ro = (nc * OH + ohc) * (long)OW;
+#pragma unroll
+    for (int j = 0; j < NOW; ++j) {
+      const int ow = ow_lo + j, owc = min(ow <= ow_hi ? ow : ow_lo, OW - 1);
+      wv[i][j] = idx[ro + owc];
+      dv[i][j] = dy[ro + owc];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NOH; ++i) {
+    const int oh = oh_lo + i;
     const int a = h - (oh * S - P);
-    const long ro = (nc * OH + oh) * (long)OW;
-    for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+#pragma unroll
+    for (int j = 0; j < NOW; ++j) {
+      const int ow = ow_lo + j;
+      const bool live = oh <= oh_hi && ow <= ow_hi;
       const int b0 = w0 - (ow * S - P);            // position of column w0 inside window ow
-      const int win = idx[ro + ow] - a * K;        // winning column offset if the winner lies in row a
-      const float d = dy[ro + ow];
+      const int win = wv[i][j] - a * K;            // winning column offset if the winner lies in row a
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (win == b0 + e && (unsigned)(b0 + e) < (unsigned)K) g[e] += d;
+        if (live && win == b0 + e && (unsigned)(b0 + e) < (unsigned)K) g[e] += dv[i][j];
     }
   }
   float* o = dx + (nc * H + h) * (long)W + w0;
