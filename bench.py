@@ -32,8 +32,11 @@ def usable_cores():
 
 
 def cpu_baseline(cores):
-    """The oracle restatement (validated against the reference, tests/golden) timed on the host cores on a bounded
-    sample: three full training steps (fwd + 21 losses + bwd + AdamW) at batch 1 x seq_len 2, 2 frames each (10-20 s)."""
+    """The oracle restatement (validated against the reference, tests/golden) timed on the host cores on a bounded sample of
+    BASELINE.json configs[0] (batch 1 x seq_len 4, the reference's own CPU-runnable case): one warm-up step at batch 1 x
+    seq_len 2 (allocator, thread pool), then ONE full training step (fwd + 21 losses + bwd + AdamW) at batch 1 x seq_len 4;
+    ~20-30 s of CPU work on 16 cores.  value = frames/s / 10 (one sample = 10 frames)."""
+    import resource
     from muvo_amd.data.synthetic import make_batch, make_noise
     from muvo_amd.utils import detinit
     from oracle import muvo_ref as R
@@ -42,21 +45,24 @@ def cpu_baseline(cores):
     detinit.fill_state_dict_(model)
     model.train()
     opt, sched = R.make_optimizer(model, model.cfg)
-    batch = make_batch(1, 2, seed=1234)
-    eps, use_prior = make_noise(1, 2, seed=1234)
     times = []
-    for _ in range(3):            # first step warms allocator / thread pool; the mean of the other two is reported (~15 s in all)
+    for b, s in ((1, 2), (1, 4)):
+        batch = make_batch(b, s, seed=1234)
+        eps, use_prior = make_noise(b, s, seed=1234)
         t0 = time.time()
         total, _, _, _ = R.training_step(model, batch, eps, use_prior)
         opt.zero_grad(set_to_none=True)
         total.backward()
         opt.step()
         times.append(time.time() - t0)
-    dt = sum(times[1:]) / 2.0
-    frames_per_s = 2.0 / dt
+        del total
+    dt = times[1]
+    frames_per_s = 4.0 / dt
     return dict(value=frames_per_s / 10.0, unit='samples/s', cores=cores, kind='port',
-                sample=f'3 training steps of the oracle port at batch 1 x seq_len 2 (2 frames each; {sum(times):.1f} s of CPU work); '
-                       f'mean of steps 2-3: {dt:.1f} s = {frames_per_s:.3f} frames/s; value = frames/s / 10 (one sample = 10 frames)')
+                peak_rss_gb=round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2 ** 20, 1),
+                sample=f'one training step of the oracle port at batch 1 x seq_len 4 (BASELINE configs[0]; 4 frames) after one '
+                       f'warm-up step at batch 1 x seq_len 2; {sum(times):.1f} s of CPU work in all; the timed step: {dt:.1f} s = '
+                       f'{frames_per_s:.3f} frames/s; value = frames/s / 10 (one sample = 10 frames)')
 
 
 def main():
@@ -214,8 +220,15 @@ def main():
             'n_ranks_seen': dist.get_world_size() if dist.is_initialized() else 1,
             'rccl_version': '.'.join(str(v) for v in torch.cuda.nccl.version()) if (world > 1 or force_dist) else None,
         }
+        # whole-step fractions: all 15.89 TFLOP of the step against (a) the ceiling of ANY three-product bf16 scheme
+        # (2500 / 3 TFLOP/s) and (b), for the exact-fp32 run, the fp32 matrix peak
+        out['step_frac_of_bf16x3_ceiling'] = out['step_tflops_per_gpu'] / (2500.0 / 3.0) if args.conv_mfma == 'bf16x3' else None
+        if args.conv_mfma == 'f32':
+            out['step_frac_fp32_exact'] = out['step_tflops_per_gpu'] / 157.3
         if exact_f32 is not None:
+            exact_f32['step_tflops_per_gpu'] = GFLOP_PER_FRAME * frames_per_gpu_step / (exact_f32['ms_per_step'] * 1e-3) / 1e3
             out['exact_f32'] = exact_f32
+            out['step_frac_fp32_exact'] = exact_f32['step_tflops_per_gpu'] / 157.3
         if full_timing is not None and args.layer_table:
             with open(args.layer_table, 'w') as f:
                 f.write(full_timing.layer_table() + '\n')
@@ -247,12 +260,19 @@ def main():
             if out['roofline'] is not None and files:
                 tf = files[-1]                       # the latest round's measurement
                 pm = json.load(open(tf))
+                psteps = pm.get('steps_profiled', 3)         # tools/pmc_step.sh: bench.py --steps 2 --warmup 1
                 for cname, c in pm['classes'].items():
                     if ops.KERNEL_NAMES.get(cname) == out['roofline']['kernel']:
-                        out['roofline']['traffic'] = c['hbm_bytes_per_launch']
-                        out['roofline']['traffic_unit'] = 'bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, includes Infinity-Cache hits)'
-                        out['roofline']['traffic_source'] = f'profiles/{os.path.basename(tf)} (tools/pmc_step.sh)'
-                        out['roofline']['traffic_over_algorithmic'] = c['hbm_bytes_per_launch'] / max(out['roofline']['algorithmic_bytes'], 1.0)
+                        r = out['roofline']
+                        r['traffic'] = c['hbm_bytes_per_launch']
+                        r['traffic_unit'] = ('bytes per kernel DISPATCH (FETCH_SIZE x2 + WRITE_SIZE, includes Infinity-Cache hits); '
+                                             '`launches` / `algorithmic_bytes` count sub-pixel phases, of which a merged dispatch '
+                                             'carries several: compare the per-step totals below')
+                        r['traffic_source'] = (f'profiles/{os.path.basename(tf)} (tools/pmc_step.sh) - a STORED rocprofv3 --pmc profile of '
+                                               f'this command, not measured in this run: PMC counters cannot be read in-process')
+                        r['traffic_bytes_per_step'] = c['hbm_bytes_per_launch'] * c['dispatches'] / psteps
+                        r['algorithmic_bytes_per_step'] = r['algorithmic_bytes'] * r['launches'] / args.steps
+                        r['traffic_over_algorithmic'] = r['traffic_bytes_per_step'] / max(r['algorithmic_bytes_per_step'], 1.0)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(usable_cores())
         print(json.dumps(out), flush=True)

@@ -285,7 +285,9 @@ int muvo_attention_fwd(const float* qkv, float* out, float* lse, int L, int N, i
 int muvo_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int L, int N, int H,
                        int DH, float p, uint64_t seed, void* stream);
 /* The whole recurrent state-space model (muvo/models/transition.py:76-173) as two persistent kernels (csrc/rssm.hip): one
- * workgroup per CU walks the T time steps, 4 grid barriers per step; B <= 4 sequences, T <= 64, H/S/E/A multiples of 4.
+ * workgroup per CU walks the T time steps, 4 grid barriers per step; T <= 64, H/S/E/A multiples of 4; B <= 64 sequences, run as
+ * consecutive launches over slabs of 4 (sequences are independent).  The grid is clamped to what the occupancy calculator says
+ * is co-resident; a barrier spin that still times out (2 s) raises the sticky word barrier_word[1] and ends the kernel.
  * weights[18] (PyTorch [out][in] layouts): pre_gru_net.0.{weight,bias}, recurrent_model.{weight_ih,weight_hh,bias_ih,bias_hh},
  *   prior_action_module.0.{weight,bias}, posterior_action_module.0.{weight,bias}, prior.module.0.{weight,bias},
  *   prior.module.2.{weight,bias}, posterior.module.0.{weight,bias}, posterior.module.2.{weight,bias}.
@@ -300,7 +302,8 @@ int muvo_attention_bwd(const float* qkv, const float* out, const float* dout, co
  *   W_post2: dmls_post x y1_post; W_post0: dy1_post x x_post; W_prior2: dmls_prior x y1_prior; W_prior0: dy1_prior x x_prior;
  *   W_ih: dgi x u; W_hh: dgh x h_prev; W_pre: du x z_prev; action modules: dla x a_prev; biases: column sums of the dY.
  *   wt_scratch: muvo_rssm_transposed_floats() floats (the transposed weights are rebuilt by every call); scratch:
- *   muvo_rssm_scratch_floats() floats; barrier_word: 4 bytes of device memory. */
+ *   muvo_rssm_scratch_floats() floats; barrier_word: 8 bytes of device memory, zero before the first call: [0] the
+ *   barrier counter (reset by every launch), [1] the sticky time-out flag (the caller polls it: ops.rssm_check). */
 int muvo_rssm_supported(int B, int T, int H, int S, int E, int A, int AD);
 int64_t muvo_rssm_transposed_floats(int H, int S, int E, int A);
 int64_t muvo_rssm_scratch_floats(int B, int H, int S, int E, int A);

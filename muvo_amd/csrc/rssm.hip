@@ -58,17 +58,40 @@ __device__ __forceinline__ void coh_store(float* p, float v) { __hip_atomic_stor
 __device__ __forceinline__ float coh_load(const float* p) {
   return __hip_atomic_load(const_cast<float*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// all workgroups are resident (grid = number of CUs, one workgroup each): counter barrier.  Every wave first waits until its
-// own (write-through) stores are acknowledged, the workgroup barrier collects the waves, one thread signs in and spins.
-__device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned target) {
+// all workgroups are resident (grid <= occupancy x CUs, checked on the host before the launch): counter barrier.  Every wave
+// first waits until its own (write-through) stores are acknowledged, the workgroup barrier collects the waves, one thread signs
+// in and spins.  The spin is BOUNDED: if the grid is not co-resident after all (another persistent kernel holding CUs, a CU
+// mask) the spinning thread gives up after RSSM_BARRIER_TIMEOUT_TICKS of the 100-MHz constant clock, raises the sticky error
+// word bar[1] and every workgroup leaves the kernel (late workgroups see the word at their first barrier): the step ends with
+// an error the host reads (ops.rssm_check) instead of a hung GPU.  Returns false when the kernel has to exit.
+#define RSSM_BARRIER_TIMEOUT_TICKS 200000000ull /* 2 s */
+__device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned target) {
+  __shared__ unsigned s_ok;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
+    unsigned ok = 1u, spins = 0u;
     __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 255u) == 0u &&
+          (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+           __builtin_amdgcn_s_memrealtime() - t0 > RSSM_BARRIER_TIMEOUT_TICKS)) {
+        __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0u;
+        break;
+      }
+    }
+    s_ok = ok;
   }
   __syncthreads();
+  return s_ok != 0u;
 }
+#define GRID_BARRIER(bar, target) \
+  do {                            \
+    if (!grid_barrier(bar, target)) return; \
+  } while (0)
 
 // NR weight rows (each K floats, 16-byte aligned, K % 4 == 0) dotted with the B input vectors xs[r*ldx + k] in LDS
 template <int NR>
@@ -173,7 +196,7 @@ __global__ void __launch_bounds__(RSSM_THREADS) rssm_fwd_kernel(const RssmFwdArg
       coh_store(&a.xq[((long)b * T + t) * HQ + H + e], a.emb[((long)b * T + t) * E + e]);
     }
     target += gridDim.x;
-    grid_barrier(a.bar, target);
+    GRID_BARRIER(a.bar, target);
     // ------------------------------------------------------------------ stage 1: gi = W_ih u, GRU cell -> h_t
     lds_load(xa, a.u + (long)t * H, B, H, (long)T * H);
     __syncthreads();
@@ -195,7 +218,7 @@ __global__ void __launch_bounds__(RSSM_THREADS) rssm_fwd_kernel(const RssmFwdArg
       }
     }
     target += gridDim.x;
-    grid_barrier(a.bar, target);
+    GRID_BARRIER(a.bar, target);
     // ------------------------------------------------------------------ stage 2: first MLP layers (no activation: slope 1)
     lds_load(xa, a.xq + (long)t * HQ, B, HQ, (long)T * HQ);
     lds_load(xb, a.xp + (long)t * HP, B, HP, (long)T * HP);
@@ -214,7 +237,7 @@ __global__ void __launch_bounds__(RSSM_THREADS) rssm_fwd_kernel(const RssmFwdArg
       }
     }
     target += gridDim.x;
-    grid_barrier(a.bar, target);
+    GRID_BARRIER(a.bar, target);
     // ------------------------------------------------------------------ stage 3: (mu | log sigma), sample
     lds_load(xa, a.y1q + (long)t * HQ, B, HQ, (long)T * HQ);
     lds_load(xb, a.y1p + (long)t * HP, B, HP, (long)T * HP);
@@ -241,7 +264,7 @@ __global__ void __launch_bounds__(RSSM_THREADS) rssm_fwd_kernel(const RssmFwdArg
       }
     }
     target += gridDim.x;
-    grid_barrier(a.bar, target);
+    GRID_BARRIER(a.bar, target);
   }
 }
 
@@ -297,7 +320,7 @@ __global__ void __launch_bounds__(RSSM_THREADS) rssm_bwd_kernel(const RssmBwdArg
       }
     }
     target += gridDim.x;
-    grid_barrier(a.bar, target);
+    GRID_BARRIER(a.bar, target);
     // ------------------------------------------------------------------ B1: dx = W0^T dy1
     lds_load(xa, a.dy1q + (long)t * HQ, B, HQ, (long)T * HQ);
     lds_load(xb, a.dy1p + (long)t * HP, B, HP, (long)T * HP);
@@ -323,7 +346,7 @@ __global__ void __launch_bounds__(RSSM_THREADS) rssm_bwd_kernel(const RssmBwdArg
       }
     }
     target += gridDim.x;
-    grid_barrier(a.bar, target);
+    GRID_BARRIER(a.bar, target);
     // ------------------------------------------------------------------ B2: GRU cell backward, du = W_ih^T dgi, dh_{t-1}
     const float* carry_in = a.dh_carry + (long)(t & 1) * B * H;
     float* carry_out = a.dh_carry + (long)((t + 1) & 1) * B * H;
@@ -364,7 +387,7 @@ __global__ void __launch_bounds__(RSSM_THREADS) rssm_bwd_kernel(const RssmBwdArg
       }
     }
     target += gridDim.x;
-    grid_barrier(a.bar, target);
+    GRID_BARRIER(a.bar, target);
     // ------------------------------------------------------------------ B3: dz_{t-1} = W_pre^T du
     lds_load(xa, a.du + (long)t * H, B, H, (long)T * H);
     __syncthreads();
@@ -375,7 +398,7 @@ __global__ void __launch_bounds__(RSSM_THREADS) rssm_bwd_kernel(const RssmBwdArg
       if (lane < B) coh_store(&a.dz_carry[lane * S + o], pick(acc[0], lane));
     }
     target += gridDim.x;
-    grid_barrier(a.bar, target);
+    GRID_BARRIER(a.bar, target);
   }
 }
 
@@ -398,27 +421,54 @@ __global__ void __launch_bounds__(256) rssm_transpose_kernel(const TransTable tb
   }
 }
 
-static int rssm_grid() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0;
+// Per-device launch state: CU count, and per kernel the number of co-resident workgroups the occupancy calculator grants
+// for the dynamic-LDS size in use (the grid barrier needs the WHOLE grid resident; the grid is clamped to that number).
+#define RSSM_MAX_DEV 16
+struct RssmDev { int cus, attr_fwd, attr_bwd; };
+static RssmDev g_rssm_dev[RSSM_MAX_DEV];
+static RssmDev* rssm_dev() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= RSSM_MAX_DEV) return nullptr;
+  RssmDev* d = &g_rssm_dev[dev];
+  if (!d->cus) {
     hipDeviceProp_t p;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
-    n = p.multiProcessorCount;
-    if (getenv("MUVO_RSSM_GRID")) n = atoi(getenv("MUVO_RSSM_GRID"));
+    if (hipGetDeviceProperties(&p, dev) != hipSuccess) return nullptr;
+    d->cus = p.multiProcessorCount;
   }
-  return n;
+  return d;
+}
+// workgroups to launch: MUVO_RSSM_GRID or one per CU, never more than fit the chip at once
+static int rssm_grid(const void* kernel, size_t ldsb) {
+  RssmDev* d = rssm_dev();
+  if (!d) return 0;
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, RSSM_THREADS, ldsb) != hipSuccess || per_cu < 1) return 0;
+  static const int want = getenv("MUVO_RSSM_GRID") ? atoi(getenv("MUVO_RSSM_GRID")) : 0;
+  int g = want > 0 ? want : d->cus;
+  if (g > per_cu * d->cus) g = per_cu * d->cus;
+  return g;
 }
 static bool rssm_dims_ok(const RssmDims& d) {
-  return d.B >= 1 && d.B <= RSSM_BM && d.T >= 1 && d.T <= 64 && d.H % 4 == 0 && d.S % 4 == 0 && d.E % 4 == 0 && d.A % 4 == 0 &&
+  return d.B >= 1 && d.B <= 64 && d.T >= 1 && d.T <= 64 && d.H % 4 == 0 && d.S % 4 == 0 && d.E % 4 == 0 && d.A % 4 == 0 &&
          d.AD >= 1 && d.H > 0 && d.S > 0 && d.E > 0 && d.A > 0;
+}
+static size_t rssm_fwd_lds(int B, int H, int E, int A, int AD) {
+  return sizeof(float) * ((size_t)B * ((H + E + A) + (H + A) + H + AD) + 16);
+}
+static size_t rssm_bwd_lds(int B, int H, int E, int A) {
+  const int HP = H + A, HQ = H + E + A, m1 = HQ > 3 * H ? HQ : 3 * H, m2 = HP > 3 * H ? HP : 3 * H;
+  return sizeof(float) * ((size_t)B * (m1 + m2 + H) + 16);
 }
 
 extern "C" {
-/* pointer tables (see include/muvo_hip.h): weights[18], fwd_io[22], bwd_io[27] */
+/* pointer tables (see include/muvo_hip.h): weights[18], fwd_io[22], bwd_io[27].  Sequences are independent (transition.py:
+   76-127 loops over t, never over b): more than RSSM_BM of them run as consecutive launches over slabs of <= RSSM_BM
+   sequences of the same (B, T, .) tensors. */
 int muvo_rssm_supported(int B, int T, int H, int S, int E, int A, int AD) {
   const RssmDims d = {B, T, H, S, E, A, AD};
-  return rssm_dims_ok(d) && rssm_grid() > 0 ? 1 : 0;
+  if (!rssm_dims_ok(d) || !rssm_dev()) return 0;
+  const int Bc = B < RSSM_BM ? B : RSSM_BM;
+  return rssm_fwd_lds(Bc, H, E, A, AD) <= 160 * 1024 && rssm_bwd_lds(Bc, H, E, A) <= 160 * 1024 ? 1 : 0;
 }
 int64_t muvo_rssm_transposed_floats(int H, int S, int E, int A) {
   const int64_t HP = H + A, HQ = H + E + A;
@@ -429,27 +479,36 @@ int muvo_rssm_forward(int B, int T, int H, int S, int E, int A, int AD, const fl
                       uint32_t* barrier_word, float min_std, void* stream) {
   RssmFwdArgs a;
   a.d = {B, T, H, S, E, A, AD};
-  MUVO_CHECK_ARG(rssm_dims_ok(a.d), "rssm_forward: dims (B=%d <= %d, T=%d <= 64, sizes %% 4) outside the fused kernel's range", B,
-                 RSSM_BM, T);
+  MUVO_CHECK_ARG(rssm_dims_ok(a.d), "rssm_forward: dims (B=%d <= 64, T=%d <= 64, sizes %% 4) outside the fused kernel's range", B, T);
   MUVO_CHECK_ARG(weights && emb && act && noise && out7 && keep12 && barrier_word, "rssm_forward: null pointer");
   const float** wp = (const float**)&a.w;
   for (int i = 0; i < 18; ++i) { MUVO_CHECK_ARG(weights[i], "rssm_forward: weight %d is NULL", i); wp[i] = weights[i]; }
-  a.emb = emb; a.act = act; a.noise = noise; a.use_prior = use_prior_mask;
-  float** op = &a.h;
-  for (int i = 0; i < 7; ++i) { MUVO_CHECK_ARG(out7[i], "rssm_forward: output %d is NULL", i); op[i] = out7[i]; }
-  float** kp = &a.hprev;
-  for (int i = 0; i < 12; ++i) { MUVO_CHECK_ARG(keep12[i], "rssm_forward: workspace %d is NULL", i); kp[i] = keep12[i]; }
-  a.bar = barrier_word; a.min_std = min_std;
-  const int G = rssm_grid();
-  MUVO_CHECK_ARG(G > 0, "rssm_forward: cannot query the device");
+  for (int i = 0; i < 7; ++i) MUVO_CHECK_ARG(out7[i], "rssm_forward: output %d is NULL", i);
+  for (int i = 0; i < 12; ++i) MUVO_CHECK_ARG(keep12[i], "rssm_forward: workspace %d is NULL", i);
+  a.use_prior = use_prior_mask; a.bar = barrier_word; a.min_std = min_std;
   const int HP = H + A, HQ = H + E + A;
-  const size_t ldsb = sizeof(float) * ((size_t)B * (HQ + HP + H + AD) + 16);
+  const int Bmax = B < RSSM_BM ? B : RSSM_BM;
+  const size_t ldsb = rssm_fwd_lds(Bmax, H, E, A, AD);
   MUVO_CHECK_ARG(ldsb <= 160 * 1024, "rssm_forward: LDS");
-  static bool attr = false;
-  if (!attr) { hipFuncSetAttribute((const void*)rssm_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-  if (hipMemsetAsync(barrier_word, 0, 4, ST) != hipSuccess) { muvo_set_error("rssm_forward: memset failed"); return MUVO_ERR_HIP; }
-  hipLaunchKernelGGL(rssm_fwd_kernel, dim3(G), dim3(RSSM_THREADS), ldsb, ST, a);
-  MUVO_CHECK_LAUNCH("rssm_forward");
+  RssmDev* dv = rssm_dev();
+  MUVO_CHECK_ARG(dv, "rssm_forward: cannot query the device");
+  if (!dv->attr_fwd) { hipFuncSetAttribute((const void*)rssm_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); dv->attr_fwd = 1; }
+  const int G = rssm_grid((const void*)rssm_fwd_kernel, ldsb);
+  MUVO_CHECK_ARG(G > 0, "rssm_forward: the occupancy calculator grants no resident workgroup (LDS %zu B)", ldsb);
+  const long odim[7] = {H, S, S, S, S, S, S};
+  const long kdim[12] = {H, S, AD, H, 3L * H, 3L * H, HP, HQ, HP, HQ, 2L * S, 2L * S};
+  for (int b0 = 0; b0 < B; b0 += RSSM_BM) {
+    a.d.B = B - b0 < RSSM_BM ? B - b0 : RSSM_BM;
+    const long r0 = (long)b0 * T;
+    a.emb = emb + r0 * E; a.act = act + r0 * AD; a.noise = noise + r0 * 2 * S;
+    float** op = &a.h;
+    for (int i = 0; i < 7; ++i) op[i] = out7[i] + r0 * odim[i];
+    float** kp = &a.hprev;
+    for (int i = 0; i < 12; ++i) kp[i] = keep12[i] + r0 * kdim[i];
+    if (hipMemsetAsync(barrier_word, 0, 4, ST) != hipSuccess) { muvo_set_error("rssm_forward: memset failed"); return MUVO_ERR_HIP; }
+    hipLaunchKernelGGL(rssm_fwd_kernel, dim3(G), dim3(RSSM_THREADS), ldsb, ST, a);
+    MUVO_CHECK_LAUNCH("rssm_forward");
+  }
   return MUVO_OK;
 }
 int muvo_rssm_backward(int B, int T, int H, int S, int E, int A, int AD, const float* const* weights, float* wt_scratch,
@@ -473,26 +532,37 @@ int muvo_rssm_backward(int B, int T, int H, int S, int E, int A, int AD, const f
     wtp[mats[i].idx] = o;
     o += (size_t)mats[i].rows * mats[i].cols;
   }
-  hipLaunchKernelGGL(rssm_transpose_kernel, dim3(512, 1, 7), dim3(256), 0, ST, tb);
-  a.noise = noise; a.use_prior = use_prior_mask;
-  a.hprev = kept5[0]; a.gi = kept5[1]; a.gh = kept5[2]; a.mls_p = kept5[3]; a.mls_q = kept5[4];
   for (int i = 0; i < 5; ++i) MUVO_CHECK_ARG(kept5[i], "rssm_backward: kept tensor %d is NULL", i);
-  const float** up = &a.g_h;
-  for (int i = 0; i < 7; ++i) up[i] = upstream7[i];
-  float** gp = &a.d_emb;
-  for (int i = 0; i < 10; ++i) { MUVO_CHECK_ARG(grads10[i], "rssm_backward: gradient buffer %d is NULL", i); gp[i] = grads10[i]; }
-  a.dxp = scratch; a.dxq = a.dxp + (size_t)B * HP; a.dh_carry = a.dxq + (size_t)B * HQ; a.dz_carry = a.dh_carry + (size_t)2 * B * H;
-  a.bar = barrier_word;
-  const int G = rssm_grid();
-  MUVO_CHECK_ARG(G > 0, "rssm_backward: cannot query the device");
-  const int m1 = HQ > 3 * H ? HQ : 3 * H, m2 = HP > 3 * H ? HP : 3 * H;
-  const size_t ldsb = sizeof(float) * ((size_t)B * (m1 + m2 + H) + 16);
+  for (int i = 0; i < 10; ++i) MUVO_CHECK_ARG(grads10[i], "rssm_backward: gradient buffer %d is NULL", i);
+  const int Bmax = B < RSSM_BM ? B : RSSM_BM;
+  const size_t ldsb = rssm_bwd_lds(Bmax, H, E, A);
   MUVO_CHECK_ARG(ldsb <= 160 * 1024, "rssm_backward: LDS");
-  static bool attr = false;
-  if (!attr) { hipFuncSetAttribute((const void*)rssm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-  if (hipMemsetAsync(barrier_word, 0, 4, ST) != hipSuccess) { muvo_set_error("rssm_backward: memset failed"); return MUVO_ERR_HIP; }
-  hipLaunchKernelGGL(rssm_bwd_kernel, dim3(G), dim3(RSSM_THREADS), ldsb, ST, a);
-  MUVO_CHECK_LAUNCH("rssm_backward");
+  RssmDev* dv = rssm_dev();
+  MUVO_CHECK_ARG(dv, "rssm_backward: cannot query the device");
+  if (!dv->attr_bwd) { hipFuncSetAttribute((const void*)rssm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); dv->attr_bwd = 1; }
+  const int G = rssm_grid((const void*)rssm_bwd_kernel, ldsb);
+  MUVO_CHECK_ARG(G > 0, "rssm_backward: the occupancy calculator grants no resident workgroup (LDS %zu B)", ldsb);
+  hipLaunchKernelGGL(rssm_transpose_kernel, dim3(512, 1, 7), dim3(256), 0, ST, tb);
+  a.use_prior = use_prior_mask; a.bar = barrier_word;
+  const long kdim[5] = {H, 3L * H, 3L * H, 2L * S, 2L * S};
+  const long udim[7] = {H, S, S, S, S, S, S};
+  const long gdim[10] = {E, 2L * S, 2L * S, HP, HQ, 3L * H, 3L * H, H, A, A};
+  for (int b0 = 0; b0 < B; b0 += RSSM_BM) {
+    const int Bc = B - b0 < RSSM_BM ? B - b0 : RSSM_BM;
+    a.d.B = Bc;
+    const long r0 = (long)b0 * T;
+    a.noise = noise + r0 * 2 * S;
+    const float** kp = &a.hprev;
+    for (int i = 0; i < 5; ++i) kp[i] = kept5[i] + r0 * kdim[i];
+    const float** up = &a.g_h;
+    for (int i = 0; i < 7; ++i) up[i] = upstream7[i] ? upstream7[i] + r0 * udim[i] : nullptr;
+    float** gp = &a.d_emb;
+    for (int i = 0; i < 10; ++i) gp[i] = grads10[i] + r0 * gdim[i];
+    a.dxp = scratch; a.dxq = a.dxp + (size_t)Bc * HP; a.dh_carry = a.dxq + (size_t)Bc * HQ; a.dz_carry = a.dh_carry + (size_t)2 * Bc * H;
+    if (hipMemsetAsync(barrier_word, 0, 4, ST) != hipSuccess) { muvo_set_error("rssm_backward: memset failed"); return MUVO_ERR_HIP; }
+    hipLaunchKernelGGL(rssm_bwd_kernel, dim3(G), dim3(RSSM_THREADS), ldsb, ST, a);
+    MUVO_CHECK_LAUNCH("rssm_backward");
+  }
   return MUVO_OK;
 }
 int64_t muvo_rssm_scratch_floats(int B, int H, int S, int E, int A) {

@@ -24,21 +24,31 @@ class PreProcess(nn.Module):
         if cfg.EVAL.RESOLUTION.ENABLED:
             raise NotImplementedError('EVAL.RESOLUTION.ENABLED (preprocess.py:209-210: antialiased down-scaling of the input '
                                       'for evaluation) is outside the training hot path (SURVEY.md §8)')
-        self._pins, self._pin_i = {}, 0
+        self._pins = {}
         # state_dict parity with the reference module (preprocess.py:42-43); the kernels take the values as scalars
         self.register_buffer('image_mean', torch.tensor(self.mean).unsqueeze(1).unsqueeze(1))
         self.register_buffer('image_std', torch.tensor(self.std).unsqueeze(1).unsqueeze(1))
         self.augment = True     # False: no augmentation even in training mode (parity runs against augmentation-free fixtures)
 
     def _to_device(self, table, device):
-        """Small host table -> device through one of four rotating pinned buffers (no host/stream synchronisation)."""
+        """Small host table -> device through a ring of four pinned buffers PER TABLE SHAPE.  Each slot remembers the event
+        recorded behind its last host-to-device copy and waits for it before the slot is rewritten: the training loop never
+        synchronises, so the host runs several steps ahead of the stream and would otherwise overwrite a table whose copy
+        has not executed yet (a torn or future table)."""
         key = tuple(table.shape)
         ring = self._pins.get(key)
         if ring is None:
-            ring = self._pins[key] = [torch.empty(table.shape, dtype=torch.float32).pin_memory() for _ in range(4)]
-        self._pin_i = (self._pin_i + 1) % 4
-        ring[self._pin_i].copy_(table)
-        return ring[self._pin_i].to(device, non_blocking=True)
+            ring = self._pins[key] = dict(i=0, buf=[torch.empty(table.shape, dtype=torch.float32).pin_memory() for _ in range(4)],
+                                          ev=[None] * 4)
+        i = ring['i'] = (ring['i'] + 1) % 4
+        if ring['ev'][i] is not None:
+            ring['ev'][i].synchronize()
+        ring['buf'][i].copy_(table)
+        out = ring['buf'][i].to(device, non_blocking=True)
+        if out.is_cuda:
+            ring['ev'][i] = torch.cuda.Event()
+            ring['ev'][i].record(torch.cuda.current_stream(out.device))
+        return out
 
     def forward(self, batch):
         cfg = self.cfg

@@ -1713,7 +1713,8 @@ class RSSMFusedFn(torch.autograd.Function):
         new = lambda n: torch.empty(B, T, n, device=dev, dtype=torch.float32)
         out = [new(H)] + [new(S) for _ in range(6)]
         keep = [new(n) for n in (H, S, AD, H, 3 * H, 3 * H, H + A, H + E + A, H + A, H + E + A, 2 * S, 2 * S)]
-        bar = scratch('rssm_bar', 4, dev, torch.int32)
+        bar = rssm_barrier_words(dev)
+        rssm_check(dev, post=False)
         w = rssm_weights(rssm)
         _ck(lib().muvo_rssm_forward(B, T, H, S, E, A, AD, _ptr_table(w), _f(emb), _f(act), _f(noise), C.c_uint64(mask),
                                     _ptr_table(out), _ptr_table(keep), _p(bar), _fl(rssm.prior.min_std), _st()))
@@ -1734,11 +1735,12 @@ class RSSMFusedFn(torch.autograd.Function):
         dmls_p, dmls_q, dy1p, dy1q, dgi, dgh, du, dla_p, dla_q = (new(n) for n in (2 * S, 2 * S, H + A, H + E + A, 3 * H, 3 * H, H, A, A))
         wt = scratch('rssm_wt', L.muvo_rssm_transposed_floats(H, S, E, A), dev)
         sc = scratch('rssm_scratch', L.muvo_rssm_scratch_floats(B, H, S, E, A), dev)
-        bar = scratch('rssm_bar', 4, dev, torch.int32)
+        bar = rssm_barrier_words(dev)
         w = rssm_weights(rssm)
         _ck(L.muvo_rssm_backward(B, T, H, S, E, A, AD, _ptr_table(w), _f(wt), _f(noise), C.c_uint64(ctx.mask),
                                  _ptr_table([hprev, gi, gh, mls_p, mls_q]), _ptr_table(gout),
                                  _ptr_table([d_emb, dmls_p, dmls_q, dy1p, dy1q, dgi, dgh, du, dla_p, dla_q]), _f(sc), _p(bar), _st()))
+        rssm_check(dev)
         rows = B * T
         for dz, x, wi in ((du, zprev, 0), (dgi, u, 2), (dgh, hprev, 3), (dla_p, aprev, 6), (dla_q, aprev, 8), (dy1p, xp, 10),
                           (dmls_p, y1p, 12), (dy1q, xq, 14), (dmls_q, y1q, 16)):
@@ -1754,6 +1756,35 @@ class RSSMFusedFn(torch.autograd.Function):
 
 
 FUSED_RSSM = os.environ.get('MUVO_FUSED_RSSM', '1') != '0'
+_rssm_watch = {}
+
+
+def rssm_barrier_words(dev):
+    """The four 32-bit words the persistent RSSM kernels synchronise through: [0] the grid-barrier counter (reset by every
+    launch), [1] the STICKY error word a workgroup raises when its barrier spin times out (the grid was not co-resident)."""
+    t = _scratch.get(('rssm_bar', dev, torch.int32))
+    if t is None:
+        t = _scratch[('rssm_bar', dev, torch.int32)] = torch.zeros(4, device=dev, dtype=torch.int32)
+    return t
+
+
+def rssm_check(dev, post=True):
+    """Raise if an earlier fused RSSM launch on `dev` gave up in its grid barrier.  No synchronisation: after a launch
+    (`post`) the error word is copied to pinned host memory behind the kernel, an event marks the copy, and a later call looks
+    at the host copy once that event has completed - the error surfaces at the latest one step after the failed launch."""
+    w = _rssm_watch.get(dev)
+    if w is None:
+        w = _rssm_watch[dev] = dict(host=torch.zeros(1, dtype=torch.int32).pin_memory(), ev=None)
+    if w['ev'] is not None and w['ev'].query():
+        if int(w['host'][0]) != 0:
+            raise RuntimeError('muvo_rssm: a persistent RSSM kernel timed out in its grid barrier (its workgroups were not '
+                               'co-resident: another persistent kernel or a CU mask is holding compute units); set '
+                               'MUVO_FUSED_RSSM=0 or lower MUVO_RSSM_GRID')
+        w['ev'] = None
+    if post and w['ev'] is None:
+        w['host'].copy_(rssm_barrier_words(dev)[1:2], non_blocking=True)
+        w['ev'] = torch.cuda.Event()
+        w['ev'].record(torch.cuda.current_stream(dev))
 
 
 def rssm_fused_supported(B, T, H, S, E, A, AD):

@@ -929,7 +929,8 @@ def test_flash_attention(dev, l, n, heads, dh):
         assert not torch.allclose(of, o)                                          # the mask does something
 
 
-@pytest.mark.parametrize('b,t,dims', [(2, 5, (64, 32, 32, 8)), (1, 3, (64, 32, 32, 8)), (4, 4, (128, 64, 32, 16)), (2, 10, (1024, 512, 512, 64))])
+@pytest.mark.parametrize('b,t,dims', [(2, 5, (64, 32, 32, 8)), (1, 3, (64, 32, 32, 8)), (4, 4, (128, 64, 32, 16)), (2, 10, (1024, 512, 512, 64)),
+                                      (6, 4, (64, 32, 32, 8)), (8, 12, (1024, 512, 512, 64))])   # > 4 sequences: slabs of 4 (BASELINE cfg 5: batch 8 x seq 12)
 def test_fused_rssm(dev, b, t, dims):
     """The persistent RSSM kernels (csrc/rssm.hip) against the oracle's RSSM (plain torch on CPU; transition.py:76-173) and
     against the unfused per-op path of the same module: all eight outputs, the gradient w.r.t. the embedding and all 18

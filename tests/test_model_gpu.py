@@ -291,6 +291,86 @@ def test_full_size_step_properties(dev):
 
 
 @pytest.mark.parametrize('mode', ['f32', 'policy'])
+def test_headline_workload_matches_reference(dev, mode):
+    """The BASELINE workload itself - base_1d, batch 2 x seq_len 10, full sizes - against the REAL reference run on the same
+    batch (tests/golden/base1d_b2s10_fwd*: oracle/refimport/make_golden_fwd.py, forward + compute_loss of the imported
+    reference, muvo/trainer.py:213-231,251-390, train-mode BatchNorm over the 20 frames): the 21 losses and the total within
+    1e-3, L2 norm (1e-3) and 4096 strided samples (2e-3 of the tensor scale) of every output tensor and label pyramid, the
+    voxel argmax voxel by voxel (47.2 M voxels): exact fp32 - bit-exact wherever the reference's top-2 margin is >= 2e-3;
+    default arithmetic - no flip at a margin >= 1e-2."""
+    from muvo_amd import ops
+    from muvo_amd.config import base_1d_cfg
+    from muvo_amd.data.synthetic import make_batch, make_noise
+    from muvo_amd.trainer import WorldModelTrainer
+    from muvo_amd.utils import detinit
+    fx = json.load(open(os.path.join(GOLD, 'base1d_b2s10_fwd.json')))
+    smp = np.load(os.path.join(GOLD, 'base1d_b2s10_fwd_samples.npz'))
+    ref = np.load(os.path.join(GOLD, 'base1d_b2s10_fwd_argmax.npz'))
+    b, s, seed = fx['b'], fx['s'], fx['seed']
+    assert (b, s) == (2, 10)
+    g = fx['steps'][0]
+    old = ops.get_conv_mode()
+    ops.set_conv_mode(ops.CONV_F32 if mode == 'f32' else ops.CONV_BF16X3, min_gflop=-1.0)
+    try:
+        tr = WorldModelTrainer(base_1d_cfg(RECEPTIVE_FIELD=s, FUTURE_HORIZON=0, STEPS=100000).convert_to_dict(), device=dev)
+        tr.train()
+        tr.preprocess.augment = False
+        detinit.fill_state_dict_(tr.model)
+        for layer in tr.model.transformer_encoder.layers:
+            layer.p = 0.0
+        eps, use_prior = make_noise(b, s, seed=seed)
+        assert use_prior == fx['use_prior']
+        batch = make_batch(b, s, seed=seed, device=dev)
+        with torch.no_grad():
+            losses, output, _, _ = tr.shared_step(batch, mode='train', noise=eps.to(dev), use_prior=use_prior)
+            total = tr.loss_reducing(losses)
+    finally:
+        ops.set_conv_mode(old, min_gflop=-1.0)
+    assert set(losses) == set(g['losses']) and len(losses) == 21
+    lines = [f'{mode}: total {total.item():.7f} vs {g["total"]:.7f} (rel {_rel(total.item(), g["total"]):.2e})']
+    for k, v in g['losses'].items():
+        assert _rel(losses[k].item(), v) < 1e-3, f'loss {k}: {losses[k].item()} vs {v}'
+    assert _rel(total.item(), g['total']) < 1e-3
+    worst = max(g['losses'], key=lambda k: _rel(losses[k].item(), g['losses'][k]))
+    lines.append(f'{mode}: worst loss term {worst} rel {_rel(losses[worst].item(), g["losses"][worst]):.2e}')
+    flat = {k: v for k, v in output.items() if torch.is_tensor(v)}
+    for grp in ('prior', 'posterior'):
+        for k, v in output[grp].items():
+            flat[f'{grp}.{k}'] = v
+    for k, st in g['outputs'].items():
+        t = batch[k[6:]] if k.startswith('batch.') else flat[k]
+        assert list(t.shape) == st['shape'], k
+        f = t.float().contiguous().view(-1)
+        l2 = f.double().pow(2).sum().sqrt().item()
+        assert _rel(l2, st['l2']) < 1e-3, f'{k}: l2 {l2} vs {st["l2"]}'
+        want = torch.from_numpy(smp[('' if k.startswith('batch.') else 'out.') + k])
+        got = f[::st['stride']][:want.numel()].cpu()
+        err = (got - want).abs().max().item()
+        assert err < 2e-3 * max(st['absmean'], 1e-6, want.abs().max().item()), f'{k}: sample max err {err}'
+    am = flat['voxel_1'].argmax(dim=2).reshape(-1).to(torch.uint8).cpu().numpy().astype(bool)
+    n = am.size
+    ref_am = np.unpackbits(ref['argmax_bits'])[:n].astype(bool)
+    assert hashlib.sha256(np.packbits(ref_am).tobytes()).hexdigest() == g['voxel_1_argmax_sha256']
+    flip = am != ref_am
+    cls = {k: np.unpackbits(ref[f'margin_lt_{k}_bits'])[:n].astype(bool) for k in ('2e-3', '1e-2', '5e-2')}
+    inside = {k: int((flip & m).sum()) for k, m in cls.items()}
+    tot = int(flip.sum())
+    lines.append(f'b2s10 {mode}: {tot} of {n} voxels decide differently from the reference ({tot / n:.2e}); by reference margin: '
+                 f'{inside["2e-3"]} of {int(cls["2e-3"].sum())} below 2e-3, {inside["1e-2"] - inside["2e-3"]} in [2e-3, 1e-2), '
+                 f'{inside["5e-2"] - inside["1e-2"]} in [1e-2, 5e-2), {tot - inside["5e-2"]} above')
+    print('\n'.join(lines))
+    os.makedirs(os.path.join(os.path.dirname(GOLD), '..', 'gpurun_out'), exist_ok=True)
+    with open(os.path.join(os.path.dirname(GOLD), '..', 'gpurun_out', 'headline_parity.txt'), 'a') as f:
+        f.write('\n'.join(lines) + '\n')
+    if mode == 'f32':
+        assert tot == inside['2e-3'], lines[-1]
+        assert inside['2e-3'] <= 0.02 * cls['2e-3'].sum(), lines[-1]
+    else:
+        assert tot == inside['1e-2'], lines[-1]              # no flip at a reference margin >= 1e-2
+        assert tot <= 2e-4 * n, lines[-1]
+
+
+@pytest.mark.parametrize('mode', ['f32', 'policy'])
 def test_loss_curve_matches_reference(dev, mode):
     """Eight optimizer steps of the REAL reference (tests/golden/base1d_b1s2_curve.json: make_golden.py --steps 8, a new batch
     every step, OneCycleLR running) against the HIP step: every one of the 21 loss terms at every step, and the parameters after

@@ -33,7 +33,7 @@ def main():
     out = {'source': 'tools/pmc_step.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py '
                      '--steps 2 --warmup 1; per-dispatch KiB summed per kernel class; FETCH_SIZE x2 for the 16-byte loads of the '
                      'bf16x3 kernels (gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md; Infinity-Cache hits included), '
-                     'WRITE_SIZE as reported', 'classes': {}}
+                     'WRITE_SIZE as reported', 'steps_profiled': 3, 'classes': {}}
     for cls, (pats, corr) in CLASSES.items():
         n = sum(r[2] for r in fetch if r[1] == 'FETCH_SIZE' and any(p in r[0] for p in pats))
         if not n:
