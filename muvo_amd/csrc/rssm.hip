@@ -424,6 +424,7 @@ __global__ void __launch_bounds__(256) rssm_transpose_kernel(const TransTable tb
 // Per-device launch state: CU count, and per kernel the number of co-resident workgroups the occupancy calculator grants
 // for the dynamic-LDS size in use (the grid barrier needs the WHOLE grid resident; the grid is clamped to that number).
 #define RSSM_MAX_DEV 16
+#define RSSM_MAX_DYN_LDS (160 * 1024 - 256)   /* the kernels also hold a few bytes of static LDS */
 struct RssmDev { int cus, attr_fwd, attr_bwd; };
 static RssmDev g_rssm_dev[RSSM_MAX_DEV];
 static RssmDev* rssm_dev() {
@@ -468,7 +469,7 @@ int muvo_rssm_supported(int B, int T, int H, int S, int E, int A, int AD) {
   const RssmDims d = {B, T, H, S, E, A, AD};
   if (!rssm_dims_ok(d) || !rssm_dev()) return 0;
   const int Bc = B < RSSM_BM ? B : RSSM_BM;
-  return rssm_fwd_lds(Bc, H, E, A, AD) <= 160 * 1024 && rssm_bwd_lds(Bc, H, E, A) <= 160 * 1024 ? 1 : 0;
+  return rssm_fwd_lds(Bc, H, E, A, AD) <= RSSM_MAX_DYN_LDS && rssm_bwd_lds(Bc, H, E, A) <= RSSM_MAX_DYN_LDS ? 1 : 0;
 }
 int64_t muvo_rssm_transposed_floats(int H, int S, int E, int A) {
   const int64_t HP = H + A, HQ = H + E + A;
@@ -489,10 +490,17 @@ int muvo_rssm_forward(int B, int T, int H, int S, int E, int A, int AD, const fl
   const int HP = H + A, HQ = H + E + A;
   const int Bmax = B < RSSM_BM ? B : RSSM_BM;
   const size_t ldsb = rssm_fwd_lds(Bmax, H, E, A, AD);
-  MUVO_CHECK_ARG(ldsb <= 160 * 1024, "rssm_forward: LDS");
+  MUVO_CHECK_ARG(ldsb <= RSSM_MAX_DYN_LDS, "rssm_forward: LDS");
   RssmDev* dv = rssm_dev();
   MUVO_CHECK_ARG(dv, "rssm_forward: cannot query the device");
-  if (!dv->attr_fwd) { hipFuncSetAttribute((const void*)rssm_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); dv->attr_fwd = 1; }
+  if (!dv->attr_fwd) {       // (static LDS of the kernel: the barrier's 4-byte flag; static + dynamic <= 160 KB)
+    if (hipFuncSetAttribute((const void*)rssm_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RSSM_MAX_DYN_LDS) != hipSuccess) {
+      (void)hipGetLastError();
+      muvo_set_error("rssm_forward: cannot raise the dynamic LDS limit");
+      return MUVO_ERR_HIP;
+    }
+    dv->attr_fwd = 1;
+  }
   const int G = rssm_grid((const void*)rssm_fwd_kernel, ldsb);
   MUVO_CHECK_ARG(G > 0, "rssm_forward: the occupancy calculator grants no resident workgroup (LDS %zu B)", ldsb);
   const long odim[7] = {H, S, S, S, S, S, S};
@@ -536,10 +544,17 @@ int muvo_rssm_backward(int B, int T, int H, int S, int E, int A, int AD, const f
   for (int i = 0; i < 10; ++i) MUVO_CHECK_ARG(grads10[i], "rssm_backward: gradient buffer %d is NULL", i);
   const int Bmax = B < RSSM_BM ? B : RSSM_BM;
   const size_t ldsb = rssm_bwd_lds(Bmax, H, E, A);
-  MUVO_CHECK_ARG(ldsb <= 160 * 1024, "rssm_backward: LDS");
+  MUVO_CHECK_ARG(ldsb <= RSSM_MAX_DYN_LDS, "rssm_backward: LDS");
   RssmDev* dv = rssm_dev();
   MUVO_CHECK_ARG(dv, "rssm_backward: cannot query the device");
-  if (!dv->attr_bwd) { hipFuncSetAttribute((const void*)rssm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); dv->attr_bwd = 1; }
+  if (!dv->attr_bwd) {
+    if (hipFuncSetAttribute((const void*)rssm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RSSM_MAX_DYN_LDS) != hipSuccess) {
+      (void)hipGetLastError();
+      muvo_set_error("rssm_backward: cannot raise the dynamic LDS limit");
+      return MUVO_ERR_HIP;
+    }
+    dv->attr_bwd = 1;
+  }
   const int G = rssm_grid((const void*)rssm_bwd_kernel, ldsb);
   MUVO_CHECK_ARG(G > 0, "rssm_backward: the occupancy calculator grants no resident workgroup (LDS %zu B)", ldsb);
   hipLaunchKernelGGL(rssm_transpose_kernel, dim3(512, 1, 7), dim3(256), 0, ST, tb);
