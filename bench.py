@@ -126,6 +126,8 @@ def main():
         tr._reducer = SegmentedGradReducer(tr.store, force_collectives=True)
         tr.model.segment_done = tr._reducer.segment_done
     assert (tr._reducer is not None) == (world > 1 or force_dist)
+    if tr._reducer is not None:
+        tr._reducer.timing = True             # per-segment all-reduce time and exposed (not overlapped) time in the JSON line
     torch.manual_seed(1234 + 7919 * rank)    # RSSM noise / use-prior coins differ per rank from here on
 
     # two distinct synthetic batches per rank, staged in HBM before the timed region
@@ -152,11 +154,16 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    if tr._reducer is not None:
+        tr._reducer._steps_timed = []          # exchange timing: the timed steps only
+    c0 = time.process_time()
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
         loss = step(args.warmup + i)
         marks[i + 1].record()                  # stream-side step boundaries (no host sync): median step time
+    host_issue_ms = (time.perf_counter() - t0) / args.steps * 1e3      # until everything is queued (no sync inside the loop)
+    host_cpu_ms = (time.process_time() - c0) / args.steps * 1e3        # CPU time of this process (all threads) per step
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -165,6 +172,9 @@ def main():
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     timing = ops.KERNEL_TIMING
     ops.KERNEL_TIMING = None
+    dp_report = tr._reducer.timing_report() if tr._reducer is not None else None
+    if tr._reducer is not None:
+        tr._reducer.timing = False
     full_timing, extra_steps = None, 2
     if timing is not None:
         full_timing = ops.KERNEL_TIMING = ops.KernelTiming()
@@ -217,6 +227,10 @@ def main():
             'frames_per_s': samples * s / dt,
             'step_tflops_per_gpu': GFLOP_PER_FRAME * frames_per_gpu_step / (ms * 1e-3) / 1e3,
             'final_loss': loss_val,
+            # host side of a step: wall time until the step is queued / CPU time of the process.  Both include the time the
+            # launching threads spin on a full HIP queue: with the GPU work shrunk (batch 1 x 2 frames, same launch count) the
+            # same loop issues a step in 23 ms (tools/host_issue_time.py 1 2, profiles/r03a_host_issue.txt)
+            'host_issue_ms': host_issue_ms, 'host_cpu_ms': host_cpu_ms,
             'n_ranks_seen': dist.get_world_size() if dist.is_initialized() else 1,
             'rccl_version': '.'.join(str(v) for v in torch.cuda.nccl.version()) if (world > 1 or force_dist) else None,
         }
@@ -225,6 +239,8 @@ def main():
         out['step_frac_of_bf16x3_ceiling'] = out['step_tflops_per_gpu'] / (2500.0 / 3.0) if args.conv_mfma == 'bf16x3' else None
         if args.conv_mfma == 'f32':
             out['step_frac_fp32_exact'] = out['step_tflops_per_gpu'] / 157.3
+        if dp_report is not None:
+            out['gradient_exchange'] = dp_report     # rank 0's view: per-segment RCCL time, bus bandwidth, exposed time
         if exact_f32 is not None:
             exact_f32['step_tflops_per_gpu'] = GFLOP_PER_FRAME * frames_per_gpu_step / (exact_f32['ms_per_step'] * 1e-3) / 1e3
             out['exact_f32'] = exact_f32

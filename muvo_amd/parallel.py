@@ -40,6 +40,13 @@ class SegmentedGradReducer:
         self._rank = {name: i for i, (name, _) in enumerate(SEGMENTS)}     # completion order, also of absent segments
         self.launch_log = []          # (segment, was launched from a backward hook) of the last step
         self.late_writes = {}         # verify: segment -> max |difference|
+        # timing (bench.py, MUVO_DP_TIMING=1): HIP events around every segment's collective on the side stream and at the
+        # join, so that a multi-GPU run says by itself how long each all-reduce took and how much of the exchange was NOT
+        # hidden behind backward (the time the optimizer stream waits in finish())
+        import os
+        self.timing = os.environ.get('MUVO_DP_TIMING') == '1'
+        self._ev = []                 # (segment, start event, end event) of the current step
+        self._steps_timed = []        # per finished step: (events of the segments, join event on the main stream, last side event)
 
     @property
     def grad_scale(self):
@@ -68,7 +75,13 @@ class SegmentedGradReducer:
         if self.side is not None:
             self.side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.side):
+                if self.timing:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(self.side)
                 dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+                if self.timing:
+                    e1.record(self.side)
+                    self._ev.append((name, from_hook, e0, e1, (b - a) * 4))
         else:
             self._handles.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
@@ -101,6 +114,13 @@ class SegmentedGradReducer:
         for h in self._handles:
             h.wait()
         if self.side is not None:
+            if self.timing and self._ev:
+                join = torch.cuda.Event(enable_timing=True)
+                join.record(torch.cuda.current_stream())        # where backward ended on the compute stream
+                self._steps_timed.append((self._ev, join))
+                self._ev = []
+                if len(self._steps_timed) > 64:
+                    self._steps_timed.pop(0)
             torch.cuda.current_stream().wait_stream(self.side)
         assert self._done == self.order, (self._done, self.order)   # every segment exactly once, in layout order
         if self.verify and self.world == 1:
@@ -110,3 +130,33 @@ class SegmentedGradReducer:
                 self.late_writes[name] = float((self.store.flat_grad[a:b] - snap).abs().max())
         self._done, self._handles, self._snap = [], [], {}
         self._begun = False
+
+    def timing_report(self):
+        """Per segment (mean over the timed steps): duration of its all-reduce on the side stream, achieved bus bandwidth
+        (algorithm bytes 2 (G-1)/G x size), whether a backward hook launched it, and `exposed_ms`: how long after the end of
+        backward on the compute stream the segment's collective finished (<= 0: fully hidden).  The step's exposed exchange
+        time is the maximum over its segments.  Synchronises; call it after the timed region."""
+        if not self._steps_timed:
+            return None
+        torch.cuda.synchronize()
+        acc, exposed = {}, []
+        for evs, join in self._steps_timed:
+            worst = 0.0
+            for name, from_hook, e0, e1, nbytes in evs:
+                a = acc.setdefault(name, dict(ms=0.0, exposed_ms=0.0, n=0, bytes=nbytes, from_hook=from_hook))
+                ms = e0.elapsed_time(e1)
+                ex = join.elapsed_time(e1)                      # negative: done before backward ended
+                a['ms'] += ms
+                a['exposed_ms'] += ex
+                a['n'] += 1
+                worst = max(worst, ex)
+            exposed.append(worst)
+        g = self.world
+        segs = {}
+        for name, a in acc.items():
+            ms = a['ms'] / a['n']
+            segs[name] = dict(mbytes=round(a['bytes'] / 2 ** 20, 1), allreduce_ms=round(ms, 3),
+                              busbw_gbs=round(2.0 * (g - 1) / max(g, 1) * a['bytes'] / max(ms, 1e-6) / 1e6, 1),
+                              from_hook=a['from_hook'], exposed_ms=round(a['exposed_ms'] / a['n'], 3))
+        self._steps_timed = []
+        return dict(steps=len(exposed), exposed_ms_per_step=round(sum(exposed) / len(exposed), 3), segments=segs)

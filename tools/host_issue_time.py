@@ -19,5 +19,8 @@ def step(i):
 for i in range(2): step(i)
 torch.cuda.synchronize()
 for i in range(4):
-    t0 = time.perf_counter(); step(2 + i); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
-    print(f'host issue {1e3*(t1-t0):.1f} ms, gpu tail {1e3*(t2-t1):.1f} ms, total {1e3*(t2-t0):.1f} ms')
+    c0 = time.process_time(); t0 = time.perf_counter(); step(2 + i); t1 = time.perf_counter(); c1 = time.process_time()
+    torch.cuda.synchronize(); t2 = time.perf_counter()
+    # process CPU time (all threads: main + autograd engine) = what a rank costs its host; wall issue time also counts the
+    # time the launching thread spends blocked on a full HIP queue
+    print(f'host issue {1e3*(t1-t0):.1f} ms wall, {1e3*(c1-c0):.1f} ms CPU (all threads), gpu tail {1e3*(t2-t1):.1f} ms, total {1e3*(t2-t0):.1f} ms')
