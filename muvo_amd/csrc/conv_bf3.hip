@@ -1169,21 +1169,28 @@ __global__ void bias_replica_reduce_kernel(float* __restrict__ rep, float* __res
   if (c < C) dbias[c] += s;
 }
 
-// BIAS_REPLICAS x Cp floats, zero on allocation and left zero by bias_replica_reduce_kernel (all users run on one stream)
-static float* bias_replica_buffer(int Cp) {       // [R][Cp] bias sums, then [R][4][Cp] + [R][4] head-gradient sums
-  static float* buf = nullptr;
-  static size_t cap = 0;
+// BIAS_REPLICAS x Cp floats, zero on allocation and left zero by bias_replica_reduce_kernel.  One buffer PER HIP STREAM
+// (branches of the model run on side streams, muvo_amd/ops.py: branch)
+static float* bias_replica_buffer(int Cp, hipStream_t st) {       // [R][Cp] bias sums, then [R][4][Cp] + [R][4] head-gradient sums
+  struct Slot { hipStream_t st; bool used; float* buf; size_t cap; };
+  static Slot slots[16];
+  Slot* sl = nullptr;
+  for (int i = 0; i < 16 && !sl; ++i)
+    if (slots[i].used && slots[i].st == st) sl = &slots[i];
+  for (int i = 0; i < 16 && !sl; ++i)
+    if (!slots[i].used) { slots[i] = {st, true, nullptr, 0}; sl = &slots[i]; }
+  if (!sl) return nullptr;
   const size_t need = (size_t)BIAS_REPLICAS * (5 * (size_t)Cp + 4);
-  if (need > cap) {
-    if (buf) { hipDeviceSynchronize(); hipFree(buf); buf = nullptr; }
+  if (need > sl->cap) {
+    if (sl->buf) { hipDeviceSynchronize(); hipFree(sl->buf); sl->buf = nullptr; }
     const size_t n = need < 65536 ? 65536 : need;
-    if (hipMalloc((void**)&buf, n * sizeof(float)) != hipSuccess || hipMemset(buf, 0, n * sizeof(float)) != hipSuccess) {
-      buf = nullptr; cap = 0;
+    if (hipMalloc((void**)&sl->buf, n * sizeof(float)) != hipSuccess || hipMemset(sl->buf, 0, n * sizeof(float)) != hipSuccess) {
+      sl->buf = nullptr; sl->cap = 0;
       return nullptr;
     }
-    cap = n;
+    sl->cap = n;
   }
-  return buf;
+  return sl->buf;
 }
 
 __device__ uint4 g_zero16 = {0u, 0u, 0u, 0u};
@@ -1339,7 +1346,7 @@ int bf3_split_input(const float* x, void* ws, int N, int C, long S, hipStream_t 
     return MUVO_ERR_INVALID_ARG;
   }
   if (dbias || dhead_w) {
-    rep = bias_replica_buffer(Cp);
+    rep = bias_replica_buffer(Cp, st);
     if (rep != nullptr && dhead_w != nullptr) hw_rep = rep + (size_t)BIAS_REPLICAS * Cp;
     if (rep == nullptr) {
       muvo_set_error("bf3_split_input: cannot allocate the bias partial-sum buffer");

@@ -156,45 +156,66 @@ static long norm_chunk_elems() {
   return v;
 }
 
-// Statistics accumulator shared by all norm operations of the process (one compute stream per process): a device buffer
-// that is all-zero between operations - the moments passes add into it with double atomics and the finalize kernels clear
-// what they read - so no operation needs a memset in front of its statistics pass (that was ~180 memsets per step).
-static double* g_norm_sums = nullptr;
-static size_t g_norm_sums_cap = 0;
-static double* norm_sums(size_t n_doubles) {
-  if (n_doubles > g_norm_sums_cap) {
-    if (g_norm_sums) hipFree(g_norm_sums);           // synchronises the device: nobody is using the old buffer any more
-    g_norm_sums_cap = n_doubles < 65536 ? 65536 : 2 * n_doubles;
-    if (hipMalloc((void**)&g_norm_sums, g_norm_sums_cap * sizeof(double)) != hipSuccess ||
-        hipMemset(g_norm_sums, 0, g_norm_sums_cap * sizeof(double)) != hipSuccess) {
-      g_norm_sums = nullptr;
-      g_norm_sums_cap = 0;
+// Library-owned accumulators are PER HIP STREAM: independent branches of the model run on side streams (muvo_amd/ops.py:
+// branch) and two streams must never add into / clear the same words.  A handful of streams per process: linear search.
+#define NORM_MAX_STREAMS 16
+struct NormStreamBufs {
+  hipStream_t st;
+  bool used;
+  double* sums; size_t sums_cap;      // statistics accumulator of the instance / layer norm passes
+  double* ring; size_t ring_pos;      // BatchNorm statistics slots
+};
+static NormStreamBufs g_norm_bufs[NORM_MAX_STREAMS];
+static NormStreamBufs* norm_bufs(hipStream_t st) {
+  for (int i = 0; i < NORM_MAX_STREAMS; ++i)
+    if (g_norm_bufs[i].used && g_norm_bufs[i].st == st) return &g_norm_bufs[i];
+  for (int i = 0; i < NORM_MAX_STREAMS; ++i)
+    if (!g_norm_bufs[i].used) {
+      g_norm_bufs[i] = {st, true, nullptr, 0, nullptr, 0};
+      return &g_norm_bufs[i];
     }
-  }
-  return g_norm_sums;
+  return nullptr;
 }
 
-// BatchNorm statistics slots: a ring of zeroed doubles.  Every BatchNorm pass takes a fresh slot for its (sum, sum of squares)
-// or (sum dz, sum dz*xhat), its statistics kernel adds into it and its apply kernel reads the totals straight from the slot
-// (mean / rstd / running statistics / dgamma / dbeta are written by the first thread of each channel) - no finalize launch
-// between the two (152 four-microsecond launches per step).  When the ring wraps it is cleared with one memset on the
+// Statistics accumulator of all norm operations on one stream: a device buffer that is all-zero between operations - the
+// moments passes add into it with double atomics and the finalize kernels clear what they read - so no operation needs a
+// memset in front of its statistics pass (that was ~180 memsets per step).
+static double* norm_sums(size_t n_doubles, hipStream_t st) {
+  NormStreamBufs* b = norm_bufs(st);
+  if (!b) return nullptr;
+  if (n_doubles > b->sums_cap) {
+    if (b->sums) hipFree(b->sums);                   // synchronises the device: nobody is using the old buffer any more
+    b->sums_cap = n_doubles < 65536 ? 65536 : 2 * n_doubles;
+    if (hipMalloc((void**)&b->sums, b->sums_cap * sizeof(double)) != hipSuccess ||
+        hipMemset(b->sums, 0, b->sums_cap * sizeof(double)) != hipSuccess) {
+      b->sums = nullptr;
+      b->sums_cap = 0;
+    }
+  }
+  return b->sums;
+}
+
+// BatchNorm statistics slots: a ring of zeroed doubles per stream.  Every BatchNorm pass takes a fresh slot for its (sum, sum
+// of squares) or (sum dz, sum dz*xhat), its statistics kernel adds into it and its apply kernel reads the totals straight from
+// the slot (mean / rstd / running statistics / dgamma / dbeta are written by the first thread of each channel) - no finalize
+// launch between the two (152 four-microsecond launches per step).  When the ring wraps it is cleared with one memset on the
 // stream, behind every kernel that read the old slots.
-static double* g_bn_ring = nullptr;
-static size_t g_bn_ring_pos = 0;
 static const size_t BN_RING = 1u << 20;
 static double* bn_slot(size_t n_doubles, hipStream_t st) {
   if (n_doubles > BN_RING) return nullptr;
-  if (!g_bn_ring) {
-    if (hipMalloc((void**)&g_bn_ring, BN_RING * sizeof(double)) != hipSuccess) { g_bn_ring = nullptr; return nullptr; }
-    if (hipMemsetAsync(g_bn_ring, 0, BN_RING * sizeof(double), st) != hipSuccess) return nullptr;
-    g_bn_ring_pos = 0;
+  NormStreamBufs* b = norm_bufs(st);
+  if (!b) return nullptr;
+  if (!b->ring) {
+    if (hipMalloc((void**)&b->ring, BN_RING * sizeof(double)) != hipSuccess) { b->ring = nullptr; return nullptr; }
+    if (hipMemsetAsync(b->ring, 0, BN_RING * sizeof(double), st) != hipSuccess) return nullptr;
+    b->ring_pos = 0;
   }
-  if (g_bn_ring_pos + n_doubles > BN_RING) {
-    if (hipMemsetAsync(g_bn_ring, 0, BN_RING * sizeof(double), st) != hipSuccess) return nullptr;
-    g_bn_ring_pos = 0;
+  if (b->ring_pos + n_doubles > BN_RING) {
+    if (hipMemsetAsync(b->ring, 0, BN_RING * sizeof(double), st) != hipSuccess) return nullptr;
+    b->ring_pos = 0;
   }
-  double* p = g_bn_ring + g_bn_ring_pos;
-  g_bn_ring_pos += (n_doubles + 15) & ~(size_t)15;
+  double* p = b->ring + b->ring_pos;
+  b->ring_pos += (n_doubles + 15) & ~(size_t)15;
   return p;
 }
 
@@ -582,7 +603,7 @@ extern "C" int muvo_adain_fwd(const float* x, const float* style, float* y, floa
   const int G = N * C;
   int chunks = cdiv(S, norm_chunk_elems());
   if (chunks > norm_max_chunks(128)) chunks = norm_max_chunks(128);
-  double* sums = norm_sums(2 * (size_t)G);
+  double* sums = norm_sums(2 * (size_t)G, st);
   MUVO_CHECK_ARG(sums != nullptr, "adain_fwd: cannot allocate the statistics buffer");
   if (x_batch_stride == 0) {
     // broadcast input: stats of instance (n,c) equal those of (0,c); compute C groups then replicate via kernel launch per n
@@ -841,7 +862,7 @@ static int adain_head_run(int which, const float* x, const float* style, float* 
     hipLaunchKernelGGL((adain_head_fwd_kernel<C, CO>), dim3(gx, N), dim3(256), 0, st, x, (const float*)mean, (const float*)rstd, style,
                        wh, bh, logits, S);
   } else {
-    double* sums = norm_sums(2 * (size_t)G + (size_t)N * (CO * C + CO));
+    double* sums = norm_sums(2 * (size_t)G + (size_t)N * (CO * C + CO), st);
     if (!sums) { muvo_set_error("adain_head_bwd: cannot allocate the statistics buffer"); return MUVO_ERR_HIP; }
     double* hsum = sums + 2 * (size_t)G;
     int gx = cdiv(S4, 1024);                 // 4096 voxels per workgroup
@@ -895,7 +916,7 @@ extern "C" int muvo_adain_bwd(const float* x, const float* style, const float* d
   const int G = N * C;
   int chunks = cdiv(S, norm_chunk_elems());
   if (chunks > norm_max_chunks(128)) chunks = norm_max_chunks(128);
-  double* sums = norm_sums(2 * (size_t)G);
+  double* sums = norm_sums(2 * (size_t)G, st);
   MUVO_CHECK_ARG(sums != nullptr, "adain_bwd: cannot allocate the statistics buffer");
   // groups are (n,c) instances: x index = n*x_bs + c*S + s.  With outer_stride==0 trick the group index
   // addresses dy densely (g*S) and x through x_outer/g mapping: handle broadcast by per-n launches.

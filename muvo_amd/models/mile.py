@@ -139,6 +139,7 @@ class Mile(nn.Module):
     def forward(self, batch, deployment=False, noise=None, use_prior=None):
         if deployment:
             raise NotImplementedError('deployment_forward is outside the training hot path')
+        dev = batch['image'].device
         embedding = self.encode(batch)
         b, s = batch['image'].shape[:2]
         action = ops.cat_last([pack_sequence_dim(batch['throttle_brake']), pack_sequence_dim(batch['steering'])])
@@ -149,16 +150,28 @@ class Mile(nn.Module):
         post = state_dict['posterior']
         state = ops.cat_last([pack_sequence_dim(post['hidden_state']), pack_sequence_dim(post['sample'])])
         self._hook(state, 'policy')        # d(state) complete: every decoder and the policy are done
+        # The decoders only share their input: the range-view and voxel decoders run on side streams next to the RGB decoder
+        # (ops.branch; host order - and with it the order in which backward finishes the parameter segments - is unchanged)
+        state_ready = ops.stream_event(dev)
         pol = self.policy(state)
         output['throttle_brake'] = unpack_sequence_dim(ops.slice_last(pol, 0, 1), b, s)
         output['steering'] = unpack_sequence_dim(ops.slice_last(pol, 1, 2), b, s)
         if self.cfg.EVAL.RGB_SUPERVISION:
             output.update(unpack_sequence_dim(self.rgb_decoder(self._mark(state, 'rgb_decoder')), b, s))
+        joins = []
         if self.cfg.LIDAR_RE.ENABLED:
-            output.update(unpack_sequence_dim(self.lidar_re(self._mark(state, 'lidar_re')), b, s))
+            br = ops.branch('decoders', 'lidar_decoder', dev, inputs=(state,), after=state_ready)
+            with br:
+                output.update(br.out(unpack_sequence_dim(self.lidar_re(self._mark(state, 'lidar_re')), b, s)))
+            joins.append(br)
         output.update(self._aux_heads(state, b, s))
         if self.cfg.VOXEL_SEG.ENABLED:
-            output.update(unpack_sequence_dim(self.voxel_decoder(self._mark(state, 'voxel_decoder')), b, s))
+            br = ops.branch('decoders', 'voxel_decoder', dev, inputs=(state,), after=state_ready)
+            with br:
+                output.update(br.out(unpack_sequence_dim(self.voxel_decoder(self._mark(state, 'voxel_decoder')), b, s)))
+            joins.append(br)
+        for br in joins:
+            br.join()
         return output, state_dict
 
     def imagine(self, batch, predict_action=False, future_horizon=None, noise=None):
@@ -209,6 +222,7 @@ class Mile(nn.Module):
         return out
 
     def encode(self, batch):
+        ops.mark_inputs_ready(batch['image'].device)   # packed weights + preprocessed batch are queued: side-stream branches start here
         b, s = batch['image'].shape[:2]
         image = pack_sequence_dim(batch['image'])
         speed = pack_sequence_dim(batch['speed'])
@@ -226,7 +240,11 @@ class Mile(nn.Module):
             x = self.bev_down_sample_4[2](self.bev_down_sample_4[0](x, act=ops.ACT_RELU))
         # recorded before the range-view branch: its backward fires when that branch (and the token gradient) is done
         x = self._mark(x, 'lidar_branch')
-        lidar_features = self.range_view_decoder(self.range_view_encoder(pack_sequence_dim(batch['range_view_pcd_xyzd'])))
+        rv = pack_sequence_dim(batch['range_view_pcd_xyzd'])
+        br_lidar = ops.branch('lidar', 'lidar_encoder', x.device, inputs=(rv,))
+        with br_lidar:                 # next to the image encoder's kernels still queued on the main stream
+            lidar_features = br_lidar.out(self.range_view_decoder(self.range_view_encoder(rv)))
+        br_lidar.join()
         hi, wi = x.shape[-2:]
         hl, wl = lidar_features.shape[-2:]
         # x + pos -> flatten/permute -> + type embedding -> concat (mile.py:542-557), one transpose kernel per sensor
@@ -236,10 +254,16 @@ class Mile(nn.Module):
         tokens_out = self.transformer_encoder(tokens, self.step_seed())
         image_tokens_out = ops.untoken(tokens_out, 0, hi, wi)
         lidar_tokens_out = ops.untoken(tokens_out, hi * wi, hl, wl)
-        features = [self.image_feature_conv(image_tokens_out), self.lidar_feature_conv(lidar_tokens_out),
-                    self.backbone_route(pack_sequence_dim(batch['route_map']))]
-        sp = ops.divide_scalar(speed.float(), self.speed_normalisation)
-        sp = self.speed_enc[2](self.speed_enc[0](sp, act=ops.ACT_RELU), act=ops.ACT_RELU)
-        features.append(sp)
+        # route-map encoder (ResNet-18 on 64 x 64 pixels) and speed encoder: ~300 launches of 5-50 us that occupy a few compute
+        # units - on a side stream, next to whatever the main stream has queued (they depend on the preprocessed batch only)
+        route_map = pack_sequence_dim(batch['route_map'])
+        br_route = ops.branch('route', 'route_encoder', x.device, inputs=(route_map, speed))
+        with br_route:
+            route_features = br_route.out(self.backbone_route(route_map))
+            sp = ops.divide_scalar(speed.float(), self.speed_normalisation)
+            sp = br_route.out(self.speed_enc[2](self.speed_enc[0](sp, act=ops.ACT_RELU), act=ops.ACT_RELU))
+        features = [self.image_feature_conv(image_tokens_out), self.lidar_feature_conv(lidar_tokens_out)]
+        br_route.join()
+        features += [route_features, sp]
         embedding = self.features_combine(ops.cat_last(features))
         return unpack_sequence_dim(embedding, b, s)

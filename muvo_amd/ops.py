@@ -177,21 +177,139 @@ def grad_of(p):
 _scratch = {}
 
 
+def _stream_key(device):
+    """Scratch buffers are per (device, HIP stream): independent branches of the model run on side streams (see `branch`) and
+    must not share workspaces."""
+    device = torch.device(device)
+    if device.type != 'cuda':
+        return 0
+    return torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch.cuda.current_device())
+
+
 def scratch_zeroed(name, nfloats, device):
     """Scratch that is all-zero at allocation; its users (weight-gradient kernels + unpack) leave it all-zero."""
-    t = _scratch.get((name, device, torch.float32))
+    key = (name, device, torch.float32, _stream_key(device))
+    t = _scratch.get(key)
     if t is None or t.numel() < nfloats:
         t = torch.zeros(int(nfloats), device=device, dtype=torch.float32)
-        _scratch[(name, device, torch.float32)] = t
+        _scratch[key] = t
     return t
 
 
 def scratch(name, nfloats, device, dtype=torch.float32):
-    t = _scratch.get((name, device, dtype))
+    key = (name, device, dtype, _stream_key(device))
+    t = _scratch.get(key)
     if t is None or t.numel() < nfloats:
         t = torch.empty(int(nfloats), device=device, dtype=dtype)
-        _scratch[(name, device, dtype)] = t
+        _scratch[key] = t
     return t
+
+
+# ------------------------------------------------------------------------------------------------
+# Independent sub-networks on side HIP streams.  The route-map encoder (a ResNet-18 on 64 x 64 pixels: ~300 launches of 5-50 us
+# that keep a handful of compute units busy), the range-view encoder and two of the three decoders do not depend on what the
+# main stream is doing at that time: issued on their own stream they fill the compute units the main stream's kernels leave
+# idle.  autograd runs the backward of every node on the stream its forward ran on and synchronises across streams itself;
+# parameter gradients are written by the kernels (not by AccumulateGrad nodes), so whoever reads them (optimizer, gradient
+# exchange) first calls join_side_streams().  MUVO_STREAMS=0: everything on the current stream.
+STREAMS = os.environ.get('MUVO_STREAMS', '1') != '0'
+_side_streams = {}
+_inputs_ready = {}
+
+
+def side_stream(name, device):
+    device = torch.device(device)
+    key = (name, device.index)
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=device)
+    return st
+
+
+def mark_inputs_ready(device):
+    """Everything queued so far on the current stream (packed weights, preprocessed batch) is what a branch's first kernels
+    depend on: a side stream waits for THIS point, not for the main stream's later work."""
+    if STREAMS and torch.device(device).type == 'cuda':
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        _inputs_ready[torch.device(device).index] = ev
+
+
+def join_side_streams(device=None, into=None):
+    """Make `into` (default: the current stream) wait for everything queued on the side streams."""
+    if not _side_streams:
+        return
+    for (name, idx), st in _side_streams.items():
+        if device is not None and torch.device(device).index not in (None, idx):
+            continue
+        (into if into is not None else torch.cuda.current_stream(st.device)).wait_stream(st)
+
+
+BRANCHES = set(os.environ.get('MUVO_STREAM_BRANCHES', 'route,lidar,decoders').split(','))
+
+
+def stream_event(device):
+    """An event at the current point of the current stream (None when side streams are off): `branch(after=...)`."""
+    if not (STREAMS and torch.device(device).type == 'cuda'):
+        return None
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    return ev
+
+
+class branch:
+    """br = ops.branch('route', 'route', dev, inputs=(x,)); with br: y = br.out(f(x)); ...; br.join() - runs f's kernels on
+    the side stream `name` (if the branch group `group` is enabled).  The side stream starts after the event `after`
+    (default: the last mark_inputs_ready(); neither: after everything queued on the current stream so far); the current
+    stream waits for the branch in join() - call it right before the first consumer of the outputs.  Disabled
+    (MUVO_STREAMS=0, group not in MUVO_STREAM_BRANCHES, CPU tensors): a no-op."""
+
+    def __init__(self, group, name, device, inputs=(), after=None):
+        device = torch.device(device)
+        self.on = STREAMS and group in BRANCHES and device.type == 'cuda'
+        self.device, self.name, self.inputs, self.after = device, name, inputs, after
+        self.outs, self.joined = [], False
+
+    def __enter__(self):
+        if not self.on:
+            return self
+        self.main = torch.cuda.current_stream(self.device)
+        self.side = side_stream(self.name, self.device)
+        if self.side == self.main:
+            self.on = False
+            return self
+        ev = self.after if self.after is not None else _inputs_ready.get(self.device.index)
+        if ev is None:
+            self.side.wait_stream(self.main)
+        else:
+            self.side.wait_event(ev)
+        for t in self.inputs:
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(self.side)
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        return self
+
+    def out(self, t):
+        """declare a tensor (list / dict of tensors) that leaves the branch: used by the main stream after join()"""
+        if self.on:
+            for x in (t.values() if isinstance(t, dict) else t if isinstance(t, (list, tuple)) else (t,)):
+                if torch.is_tensor(x) and x.is_cuda:
+                    self.outs.append(x)
+        return t
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.ctx.__exit__(*exc)
+        return False
+
+    def join(self):
+        if self.on and not self.joined:
+            self.joined = True
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_stream(self.side)
+            for x in self.outs:
+                x.record_stream(cur)
 
 
 # ------------------------------------------------------------------------------------------------

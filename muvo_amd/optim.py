@@ -34,6 +34,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 loss = closure()
         self._step += 1
         st = self.store
+        ops.join_side_streams()      # branches on side streams (ops.branch) wrote their parameter gradients there
         st.settle_grads()
         for _, decay, start, end in st.ranges:
             g = self.param_groups[1 if decay else 0]

@@ -71,9 +71,13 @@ class SegmentedGradReducer:
         a, b = self.ranges[name]
         buf = self.store.flat_grad[a:b]
         if self.verify:
+            from muvo_amd import ops
+            ops.join_side_streams()
             self._snap[name] = buf.clone()
         if self.side is not None:
             self.side.wait_stream(torch.cuda.current_stream())
+            from muvo_amd import ops
+            ops.join_side_streams(into=self.side)      # the segment's kernels may have run on a branch stream (ops.branch)
             with torch.cuda.stream(self.side):
                 if self.timing:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
