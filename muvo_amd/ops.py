@@ -156,6 +156,24 @@ def get_conv_mode():
 _plan_epoch = [0]
 
 
+_join_queued = [False]
+
+
+def _queue_final_join():
+    """Parameter gradients are written by kernels on whatever stream their backward node runs on (branch streams, the
+    weight-gradient stream), not by AccumulateGrad nodes, so the autograd engine does not know about them: the first gradient
+    write of a backward pass installs an engine callback that makes the stream `backward()` was called on wait for every
+    side stream when the pass ends - `p.grad` is then safe to read right after `loss.backward()` like any other gradient."""
+    def cb():
+        _join_queued[0] = False
+        join_side_streams()
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(cb)
+        _join_queued[0] = True
+    except RuntimeError:      # not inside a backward pass
+        pass
+
+
 def grad_of(p):
     """The gradient buffer the kernels accumulate into.  With a ParamStore that is the parameter's slot of the flat gradient
     buffer: if something set p.grad to None (nn.Module.zero_grad(), optimizer.zero_grad(set_to_none=True) of a foreign
@@ -164,6 +182,8 @@ def grad_of(p):
     that always write a parameter gradient (BatchNorm / LayerNorm backward) add into one shared dump nobody reads."""
     if not p.requires_grad:
         return scratch('frozen_grad_dump', p.numel(), p.device).view(-1)[:p.numel()].view(p.shape)
+    if _side_streams and not _join_queued[0]:
+        _queue_final_join()
     if p.grad is None:
         view = getattr(p, '_muvo_flat_grad', None)
         if view is not None:
@@ -237,6 +257,7 @@ def mark_inputs_ready(device):
 
 def join_side_streams(device=None, into=None):
     """Make `into` (default: the current stream) wait for everything queued on the side streams."""
+    _join_queued[0] = False        # (a backward pass that raised never ran its callback)
     if not _side_streams:
         return
     for (name, idx), st in _side_streams.items():
@@ -310,6 +331,47 @@ class branch:
             cur.wait_stream(self.side)
             for x in self.outs:
                 x.record_stream(cur)
+
+
+# Weight gradients on their own stream.  In the backward pass of a convolution only the data gradient is on the critical path
+# (the next layer's backward needs it); the weight gradient is needed by the optimizer.  Issued on the stream 'wgrad' it runs
+# next to the following layers' data-gradient kernels and fills the compute units their tails and small launches leave idle.
+# What the two streams share: the split planes of dy - written by the main stream (prepare_dy / dgrad), read by the weight
+# gradient - come from a ring of WGRAD_RING buffers, a buffer is rewritten only after the weight gradient that read it has
+# finished (event); tensors owned by autograd (x, y, dy, kept planes of x) are marked with record_stream.
+WGRAD_STREAM = STREAMS and 'wgrad' in set(os.environ.get('MUVO_STREAM_BRANCHES', 'route,lidar,decoders,wgrad').split(','))
+WGRAD_RING = 3
+_dy_rings = {}
+
+
+class _DySlot:
+    __slots__ = ('t', 'done')
+
+    def __init__(self):
+        self.t, self.done = None, None
+
+
+def _dy_ws_acquire(nfloats, device):
+    """next buffer of the current stream's ring of dy-plane workspaces (waits for the weight gradient that last read it)"""
+    key = (torch.device(device).index, _stream_key(device))
+    ring = _dy_rings.get(key)
+    if ring is None:
+        ring = _dy_rings[key] = dict(i=0, slots=[_DySlot() for _ in range(WGRAD_RING)])
+    ring['i'] = (ring['i'] + 1) % WGRAD_RING
+    sl = ring['slots'][ring['i']]
+    if sl.done is not None:
+        torch.cuda.current_stream(device).wait_event(sl.done)
+        sl.done = None
+    if sl.t is None or sl.t.numel() < nfloats:
+        sl.t = torch.empty(int(nfloats), device=device, dtype=torch.float32)
+    return sl
+
+
+def wgrad_stream(device):
+    """the side stream weight gradients are issued on, or None (switched off / CPU / already on it)"""
+    if not WGRAD_STREAM or torch.device(device).type != 'cuda':
+        return None
+    return side_stream('wgrad', device)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -874,8 +936,21 @@ class ConvFn(torch.autograd.Function):
                 head_wgrad()
                 head = None
         ws_dy_fused = None
+        wst = wgrad_stream(x.device) if weight.requires_grad else None
+        dy_slot = None
+
+        def dy_workspace(nfloats):
+            # the dy planes both gradient kernels read: with the weight gradient on its own stream a ring buffer (one per
+            # backward call), otherwise the stream's scratch
+            nonlocal dy_slot
+            if wst is None:
+                return scratch('conv_ws_dy', nfloats, x.device)
+            if dy_slot is None:
+                dy_slot = _dy_ws_acquire(nfloats, x.device)
+            assert dy_slot.t.numel() >= nfloats
+            return dy_slot.t
         if fused_dy:
-            ws_dy_fused = scratch('conv_ws_dy', (max(wsb[1], wsb[3]) + 3) // 4, x.device)
+            ws_dy_fused = dy_workspace((max(wsb[1], wsb[3]) + 3) // 4)
             use_act = ctx.act != ACT_NONE and not ctx.act_bwd_fused
             if head is not None:
                 # with an activation the pass reads y anyway: the head's weight / bias gradient rides along
@@ -920,35 +995,53 @@ class ConvFn(torch.autograd.Function):
                                     _conv_bytes(geom, x.shape[0], ctx.in_sz, out_sz))
                 e0.record()
             nb = max(wsb[1], wsb[3])
-            ws_dy = scratch('conv_ws_dy', (nb + 3) // 4, x.device) if nb else None
+            ws_dy = dy_workspace((nb + 3) // 4) if nb else None
             dy_split = wsb[1] > 0
             _ck(L.muvo_conv_dgrad(C.byref(d), _f(dz), _f(packed.dgr), _f(dx), _p(ws_dy), 1 if fused_dy else 0, _st()))
             if kt is not None:
                 e1.record()
         if weight.requires_grad:
-            ws = scratch_zeroed('wgrad', ff, x.device)
+            gw = grad_of(weight)
             db = grad_of(bias) if (bias is not None and not fused_dy) else None   # fused_dy: already accumulated
-            kt = KERNEL_TIMING
-            if kt is not None:
-                import math
-                e0, e1 = kt.bracket(FAMILY[geom.tclass[(x.shape[0], ctx.in_sz, _plan_epoch[0])][2]] + ':wgrad',
-                                    _conv_flops(geom, x.shape[0], ctx.in_sz, out_sz),
-                                    math.prod(geom.stride) if geom.transposed else 1, _conv_tag(geom, x.shape[0], ctx.in_sz),
-                                    _conv_bytes(geom, x.shape[0], ctx.in_sz, out_sz))
-                e0.record()
             ws_x = ctx.ws_x
             flags = (1 if ws_x is not None else 0) | (2 if (dy_split and wsb[3] > 0) else 0)
-            if ws_x is None and wsb[2]:
-                ws_x = scratch('conv_ws', (wsb[2] + 3) // 4, x.device)
-            if wsb[3] and ws_dy is None:
-                ws_dy = scratch('conv_ws_dy', (wsb[3] + 3) // 4, x.device)
-            if ctx.aff is not None:
-                _ck(L.muvo_conv_wgrad_affine(C.byref(d), _f(x), _f(ctx.aff), _f(dz), _f(grad_of(weight)), _f(db), _st()))
+            cur = torch.cuda.current_stream(x.device)
+            if wst is not None and wst != cur:
+                # everything the weight gradient reads is queued on the current stream by now; it starts behind that point
+                wst.wait_stream(cur)
+                for t in (x, y, dz, ctx.ws_x, ctx.aff):
+                    if t is not None:
+                        t.record_stream(wst)
+                wctx = torch.cuda.stream(wst)
+                wctx.__enter__()
             else:
-                _ck(L.muvo_conv_wgrad(C.byref(d), _f(x), _f(dz), _f(ws), _f(grad_of(weight)), _f(db), _p(ws_x), _p(ws_dy),
-                                      flags, _st()))
-            if kt is not None:
-                e1.record()
+                wctx = None
+            try:
+                ws = scratch_zeroed('wgrad', ff, x.device)         # (per stream)
+                kt = KERNEL_TIMING
+                if kt is not None:
+                    import math
+                    e0, e1 = kt.bracket(FAMILY[geom.tclass[(x.shape[0], ctx.in_sz, _plan_epoch[0])][2]] + ':wgrad',
+                                        _conv_flops(geom, x.shape[0], ctx.in_sz, out_sz),
+                                        math.prod(geom.stride) if geom.transposed else 1, _conv_tag(geom, x.shape[0], ctx.in_sz),
+                                        _conv_bytes(geom, x.shape[0], ctx.in_sz, out_sz))
+                    e0.record()
+                if ws_x is None and wsb[2]:
+                    ws_x = scratch('conv_ws', (wsb[2] + 3) // 4, x.device)
+                if wsb[3] and ws_dy is None:
+                    ws_dy = scratch('conv_ws_dy', (wsb[3] + 3) // 4, x.device)
+                if ctx.aff is not None:
+                    _ck(L.muvo_conv_wgrad_affine(C.byref(d), _f(x), _f(ctx.aff), _f(dz), _f(gw), _f(db), _st()))
+                else:
+                    _ck(L.muvo_conv_wgrad(C.byref(d), _f(x), _f(dz), _f(ws), _f(gw), _f(db), _p(ws_x), _p(ws_dy), flags, _st()))
+                if kt is not None:
+                    e1.record()
+                if wctx is not None and dy_slot is not None:
+                    dy_slot.done = torch.cuda.Event()
+                    dy_slot.done.record(wst)
+            finally:
+                if wctx is not None:
+                    wctx.__exit__(None, None, None)
         return dx, None, None, None, None, None, None, None, None, None, None
 
 
