@@ -78,6 +78,10 @@ def main():
     ap.add_argument('--conv-mfma', default=os.environ.get('MUVO_CONV_MFMA', 'bf16x3'), choices=['f32', 'bf16x3'],
                     help='matrix-pipe arithmetic of the large convolutions (DESIGN.md section 5)')
     ap.add_argument('--layer-table', default='', help='write the per-layer conv timing table to this file')
+    ap.add_argument('--workload', default='base_1d', choices=['base_1d', 'rv2048', 'vox256'],
+                    help='base_1d: BASELINE.json configs[1] (the judged line).  Extensions through MODEL.CONSTANT_SIZE (no reference '
+                         'implementation, parity unpinned): rv2048 = the 64 x 2048 range view north_star names; vox256 = the '
+                         '256 x 256 x 64 voxel grid of configs[4] (use with --batch 8 --seq-len 12 for that configuration)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -116,7 +120,12 @@ def main():
     from muvo_amd.trainer import WorldModelTrainer
 
     s = args.seq_len
-    cfg = base_1d_cfg(RECEPTIVE_FIELD=min(6, s), FUTURE_HORIZON=s - min(6, s), BATCHSIZE=args.batch, STEPS=100000)
+    ext, sizes = {}, {}
+    if args.workload == 'rv2048':
+        ext, sizes = {'MODEL.CONSTANT_SIZE.LIDAR': [1, 32]}, dict(range_hw=(64, 2048))
+    elif args.workload == 'vox256':
+        ext, sizes = {'MODEL.CONSTANT_SIZE.VOXEL': [4, 4, 1]}, dict(voxel=(256, 256, 64))
+    cfg = base_1d_cfg(RECEPTIVE_FIELD=min(6, s), FUTURE_HORIZON=s - min(6, s), BATCHSIZE=args.batch, STEPS=100000, **ext)
     torch.manual_seed(1234)  # same initial weights on every rank (replicated data parallel)
     tr = WorldModelTrainer(cfg.convert_to_dict(), device=dev)
     tr.train()
@@ -131,7 +140,7 @@ def main():
     torch.manual_seed(1234 + 7919 * rank)    # RSSM noise / use-prior coins differ per rank from here on
 
     # two distinct synthetic batches per rank, staged in HBM before the timed region
-    batches = [make_batch(args.batch, s, seed=1234 + 2 * rank + k, device=dev) for k in range(2)]
+    batches = [make_batch(args.batch, s, seed=1234 + 2 * rank + k, device=dev, **sizes) for k in range(2)]
 
     def step(i):
         batch = dict(batches[i % 2])
@@ -219,13 +228,15 @@ def main():
             'data': 'synthetic',
             'peak_hbm_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
             'config': {'workload': f'base_1d (resnet18 + range-view + transformer fusion + 1D latent), batch={args.batch} '
-                                   f'per GPU, seq_len={s}, 600x960 RGB (crop 320x832) + 64x1024 range-view + '
-                                   f'192x192x64 voxels, full step incl. 21 losses, backward, AdamW',
+                                   f'per GPU, seq_len={s}, 600x960 RGB (crop 320x832) + 64x{sizes.get("range_hw", (64, 1024))[1]} range-view + '
+                                   f'{"x".join(str(v) for v in sizes.get("voxel", (192, 192, 64)))} voxels, full step incl. 21 losses, backward, AdamW'
+                                   + ('' if args.workload == 'base_1d' else f' [EXTENSION {args.workload}: MODEL.CONSTANT_SIZE, no reference code]'),
                        'global_batch': args.batch * world, 'seq_len': s, 'parallelism': f'dp{world}',
                        'conv_mfma': args.conv_mfma},
+            'parity': 'pinned by reference fixtures (tests/golden)' if args.workload == 'base_1d' else 'unpinned (extension, own oracle only)',
             'median_ms_per_step': median_ms, 'value_at_median': args.batch * world / (median_ms * 1e-3),
             'frames_per_s': samples * s / dt,
-            'step_tflops_per_gpu': GFLOP_PER_FRAME * frames_per_gpu_step / (ms * 1e-3) / 1e3,
+            'step_tflops_per_gpu': (GFLOP_PER_FRAME * frames_per_gpu_step / (ms * 1e-3) / 1e3) if args.workload == 'base_1d' else None,
             'final_loss': loss_val,
             # host side of a step: wall time until the step is queued / CPU time of the process.  Both include the time the
             # launching threads spin on a full HIP queue: with the GPU work shrunk (batch 1 x 2 frames, same launch count) the
@@ -236,15 +247,16 @@ def main():
         }
         # whole-step fractions: all 15.89 TFLOP of the step against (a) the ceiling of ANY three-product bf16 scheme
         # (2500 / 3 TFLOP/s) and (b), for the exact-fp32 run, the fp32 matrix peak
-        out['step_frac_of_bf16x3_ceiling'] = out['step_tflops_per_gpu'] / (2500.0 / 3.0) if args.conv_mfma == 'bf16x3' else None
-        if args.conv_mfma == 'f32':
+        out['step_frac_of_bf16x3_ceiling'] = (out['step_tflops_per_gpu'] / (2500.0 / 3.0)
+                                              if (args.conv_mfma == 'bf16x3' and args.workload == 'base_1d') else None)
+        if args.conv_mfma == 'f32' and args.workload == 'base_1d':
             out['step_frac_fp32_exact'] = out['step_tflops_per_gpu'] / 157.3
         if dp_report is not None:
             out['gradient_exchange'] = dp_report     # rank 0's view: per-segment RCCL time, bus bandwidth, exposed time
         if exact_f32 is not None:
             exact_f32['step_tflops_per_gpu'] = GFLOP_PER_FRAME * frames_per_gpu_step / (exact_f32['ms_per_step'] * 1e-3) / 1e3
             out['exact_f32'] = exact_f32
-            out['step_frac_fp32_exact'] = exact_f32['step_tflops_per_gpu'] / 157.3
+            out['step_frac_fp32_exact'] = exact_f32['step_tflops_per_gpu'] / 157.3 if args.workload == 'base_1d' else None
         if full_timing is not None and args.layer_table:
             with open(args.layer_table, 'w') as f:
                 f.write(full_timing.layer_table() + '\n')

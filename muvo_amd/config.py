@@ -10,6 +10,25 @@ import yaml
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 TOLERATED_EXTRA_KEYS = ('CML_DATASET_VERSION', 'MODEL.TRANSFORMER_TRANSITION', 'LOSSES.PERCEPTUAL')
+# Extension keys (NOT in the reference, absent from the defaults so that the default config stays equal to the reference's;
+# accepted from YAML files, cfg dicts and command-line overrides, and kept):
+#   MODEL.CONSTANT_SIZE.{RGB,LIDAR,VOXEL} - the seed sizes the reference hard-codes as (5, 13), (1, 16) and (3, 3, 1)
+#   (muvo/models/mile.py:322-336,391-396): every decoder output is 64x its seed, so (1, 32) gives the 64 x 2048 range view and
+#   (4, 4, 1) the 256 x 256 x 64 voxel grid BASELINE.json names.  Parity for non-default values: own oracle only ("unpinned").
+EXTENSION_KEYS = ('MODEL.CONSTANT_SIZE', 'MODEL.CONSTANT_SIZE.RGB', 'MODEL.CONSTANT_SIZE.LIDAR', 'MODEL.CONSTANT_SIZE.VOXEL')
+DEFAULT_CONSTANT_SIZE = {'RGB': (5, 13), 'LIDAR': (1, 16), 'VOXEL': (3, 3, 1)}
+
+
+def constant_sizes(cfg):
+    """(rgb, lidar, voxel) seed sizes of the three decoders: MODEL.CONSTANT_SIZE.* if given, else the reference's constants."""
+    cs = cfg.MODEL.get('CONSTANT_SIZE', None) or {}
+    out = []
+    for k in ('RGB', 'LIDAR', 'VOXEL'):
+        v = tuple(int(x) for x in cs.get(k, DEFAULT_CONSTANT_SIZE[k]))
+        if len(v) != len(DEFAULT_CONSTANT_SIZE[k]) or min(v) < 1:
+            raise ValueError(f'MODEL.CONSTANT_SIZE.{k} must be {len(DEFAULT_CONSTANT_SIZE[k])} positive integers, got {v}')
+        out.append(v)
+    return tuple(out)
 
 
 class CfgNode(dict):
@@ -64,7 +83,7 @@ class CfgNode(dict):
             if k not in self:
                 if full in TOLERATED_EXTRA_KEYS:
                     continue
-                if self._new_allowed:
+                if self._new_allowed or full in EXTENSION_KEYS:
                     dict.__setitem__(self, k, CfgNode(v) if isinstance(v, dict) else copy.deepcopy(v))
                     continue
                 raise KeyError(f'Non-existent config key: {full}')
@@ -102,9 +121,11 @@ class CfgNode(dict):
         for key, raw in zip(opts[0::2], opts[1::2]):
             node = self
             parts = key.split('.')
-            for p in parts[:-1]:
+            for i, p in enumerate(parts[:-1]):
+                if p not in node and '.'.join(parts[:i + 1]) in EXTENSION_KEYS:
+                    dict.__setitem__(node, p, CfgNode())
                 node = node[p]
-            if parts[-1] not in node:
+            if parts[-1] not in node and key not in EXTENSION_KEYS:
                 raise KeyError(f'Non-existent config key: {key}')
             val = raw
             if isinstance(raw, str):
@@ -147,7 +168,8 @@ def _extra_keys(known, other, path=''):
     for k, v in other.items():
         full = f'{path}.{k}' if path else k
         if k not in known:
-            out.append(full)
+            if full not in EXTENSION_KEYS:
+                out.append(full)
         elif isinstance(known[k], dict) and isinstance(v, dict):
             out.extend(_extra_keys(known[k], v, full))
     return sorted(out)

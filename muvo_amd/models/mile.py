@@ -47,6 +47,8 @@ class Mile(nn.Module):
             raise NotImplementedError('muvo_amd implements the base_1d hot path (SURVEY.md §8); not in scope: '
                                       + ', '.join(unsupported))
         emb, tc = m.EMBEDDING_DIM, m.TRANSFORMER.CHANNELS
+        from muvo_amd.config import constant_sizes
+        cs_rgb, cs_lidar, cs_voxel = constant_sizes(cfg)     # the reference's (5, 13), (1, 16), (3, 3, 1) unless MODEL.CONSTANT_SIZE says otherwise
         self.encoder = ResNet18Features(3, (2, 3, 4))
         feature_info = self.encoder.feature_info.get_dicts(keys=['num_chs', 'reduction'])
         self.feat_decoder = DecoderDS(feature_info, tc)
@@ -89,18 +91,18 @@ class Mile(nn.Module):
         if cfg.SEMANTIC_SEG.ENABLED:      # bird's-eye-view semantic + instance segmentation (mile.py:307-313)
             self.bev_decoder = BevDecoder(state_dim, cfg.SEMANTIC_SEG.N_CHANNELS, head='bev')
         if cfg.EVAL.RGB_SUPERVISION:
-            self.rgb_decoder = ConvDecoder(state_dim, 3, constant_size=(5, 13), head='rgb')
+            self.rgb_decoder = ConvDecoder(state_dim, 3, constant_size=cs_rgb, head='rgb')
         if cfg.LIDAR_RE.ENABLED:
-            self.lidar_re = ConvDecoder(state_dim, cfg.LIDAR_RE.N_CHANNELS, constant_size=(1, 16), head='lidar_re')
+            self.lidar_re = ConvDecoder(state_dim, cfg.LIDAR_RE.N_CHANNELS, constant_size=cs_lidar, head='lidar_re')
         # config-off heads of base_1d that share the ConvDecoder kernels (mile.py:337-363)
         if cfg.LIDAR_SEG.ENABLED:
-            self.lidar_segmentation = ConvDecoder(state_dim, cfg.LIDAR_SEG.N_CLASSES, constant_size=(1, 16), head='lidar_seg')
+            self.lidar_segmentation = ConvDecoder(state_dim, cfg.LIDAR_SEG.N_CLASSES, constant_size=cs_lidar, head='lidar_seg')
         if cfg.SEMANTIC_IMAGE.ENABLED:
-            self.sem_image_decoder = ConvDecoder(state_dim, cfg.SEMANTIC_IMAGE.N_CLASSES, constant_size=(5, 13), head='sem_image')
+            self.sem_image_decoder = ConvDecoder(state_dim, cfg.SEMANTIC_IMAGE.N_CLASSES, constant_size=cs_rgb, head='sem_image')
         if cfg.DEPTH.ENABLED:
-            self.depth_image_decoder = ConvDecoder(state_dim, 1, constant_size=(5, 13), head='depth')
+            self.depth_image_decoder = ConvDecoder(state_dim, 1, constant_size=cs_rgb, head='depth')
         if cfg.VOXEL_SEG.ENABLED:
-            self.voxel_decoder = VoxelDecoder1(state_dim, cfg.VOXEL_SEG.N_CLASSES, cfg.VOXEL_SEG.DIMENSION, (3, 3, 1))
+            self.voxel_decoder = VoxelDecoder1(state_dim, cfg.VOXEL_SEG.N_CLASSES, cfg.VOXEL_SEG.DIMENSION, cs_voxel)
         self._pos_cache = {}
         # data-parallel gradient overlap: called with a segment name (muvo_amd/param_store.SEGMENTS) from autograd
         # hooks the moment backward has finished that segment's parameters
