@@ -31,6 +31,13 @@ const char* muvo_last_error(void);
 int muvo_abi_version(void);
 /* one-launch self test of the MFMA operand/accumulator lane maps; returns 0 when C = A*B is exact */
 int muvo_selftest_mfma(void* stream);
+/* Deterministic mode (also MUVO_DETERMINISTIC=1 in the environment): reductions that otherwise depend on the arrival order of
+ * float / double atomics (split-K partial sums, weight-gradient pixel ranges, bias / statistics / loss partial sums) run with one
+ * contributor per address or are added in index order: two runs of the same step give bit-identical results.  A debugging
+ * aid for parity work - slower (the affected kernels lose their split parallelism).  The reference has no counterpart
+ * (torch.use_deterministic_algorithms plays this role for its cuDNN / ATen kernels). */
+int muvo_set_deterministic(int on);
+int muvo_get_deterministic(void);
 
 /* ---- convolution family (conv_gemm.hip) -------------------------------------------------------
  * Replaces nn.Conv2d / nn.Conv3d / nn.ConvTranspose2d forward, data-gradient and weight-gradient:

@@ -4,6 +4,14 @@
 #include "common.h"
 
 static thread_local char g_err[512] = "";
+// Deterministic mode (muvo_set_deterministic, MUVO_DETERMINISTIC=1): every reduction whose order would depend on the arrival
+// order of float / double atomics runs in a fixed order instead (one contributor per address, per-workgroup partials added in
+// index order, no split-K): two runs of the same step are bit-identical.  Slower; for debugging parity.
+int g_muvo_deterministic = -1;
+bool muvo_det() {
+  if (g_muvo_deterministic < 0) g_muvo_deterministic = getenv("MUVO_DETERMINISTIC") && atoi(getenv("MUVO_DETERMINISTIC")) ? 1 : 0;
+  return g_muvo_deterministic != 0;
+}
 
 void muvo_set_error(const char* fmt, ...) {
   va_list ap;
@@ -32,9 +40,26 @@ __global__ void mfma_selftest_kernel(int* bad) {
   if (nbad) atomicAdd(bad, nbad);
 }
 
+unsigned* muvo_det_ticket(hipStream_t st) {
+  if (!muvo_det()) return nullptr;
+  struct Slot { hipStream_t st; bool used; unsigned* word; };
+  static Slot slots[16];
+  Slot* sl = nullptr;
+  for (int i = 0; i < 16 && !sl; ++i)
+    if (slots[i].used && slots[i].st == st) sl = &slots[i];
+  for (int i = 0; i < 16 && !sl; ++i)
+    if (!slots[i].used) { slots[i] = {st, true, nullptr}; sl = &slots[i]; }
+  if (!sl) return nullptr;
+  if (!sl->word && hipMalloc((void**)&sl->word, 64) != hipSuccess) { sl->word = nullptr; return nullptr; }
+  if (hipMemsetAsync(sl->word, 0, 4, st) != hipSuccess) return nullptr;   // stream order: behind the previous user, ahead of the next
+  return sl->word;
+}
+
 extern "C" {
 const char* muvo_last_error(void) { return g_err; }
 int muvo_abi_version(void) { return 1; }
+int muvo_set_deterministic(int on) { g_muvo_deterministic = on ? 1 : 0; return MUVO_OK; }
+int muvo_get_deterministic(void) { return muvo_det() ? 1 : 0; }
 int muvo_selftest_mfma(void* stream) {
   int* d = nullptr;
   if (hipMalloc(&d, sizeof(int)) != hipSuccess) { muvo_set_error("selftest: hipMalloc failed"); return MUVO_ERR_HIP; }

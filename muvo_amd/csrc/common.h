@@ -14,6 +14,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---- error plumbing --------------------------------------------------------------------------
 void muvo_set_error(const char* fmt, ...);
+bool muvo_det();      // deterministic mode (abi.hip): launch shapes without order-dependent atomics
+// Deterministic mode, kernels whose workgroups add partial sums into shared words: a zeroed ticket word for the launch about to
+// be queued on `st` (nullptr when the mode is off).  The kernel brackets its atomics with det_turn_wait / det_turn_done: the
+// workgroups then add in linear block order.  Workgroups are dispatched in index order, so everything a waiting workgroup
+// depends on is already resident or finished.
+unsigned* muvo_det_ticket(hipStream_t st);
 
 #define MUVO_CHECK_ARG(cond, ...)            \
   do {                                       \
@@ -50,6 +56,24 @@ static inline int ew_grid(long n, int block = 256) {
 __device__ __forceinline__ int xcd_swizzle(int orig, int nwg) {
   const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
+__device__ __forceinline__ unsigned det_block_id() { return (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; }
+// every thread of the workgroup calls both (they contain workgroup barriers); ticket == nullptr: no-ops
+__device__ __forceinline__ void det_turn_wait(unsigned* ticket) {
+  if (ticket == nullptr) return;
+  if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) {
+    const unsigned me = det_block_id();
+    while (__hip_atomic_load(ticket, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != me) __builtin_amdgcn_s_sleep(2);
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void det_turn_done(unsigned* ticket) {
+  if (ticket == nullptr) return;
+  __threadfence();          // this workgroup's atomics are performed before the next workgroup starts its own
+  __syncthreads();
+  if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0)
+    __hip_atomic_store(ticket, det_block_id() + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- activations -----------------------------------------------------------------------------

@@ -894,9 +894,15 @@ __global__ void __launch_bounds__(256) bf3_unpack_wgrad_kernel(const ConvPhase g
 // (compile-time: as a runtime argument the loop stopped being unrolled away and the kernel ran 1.5x slower)
 #define SPLIT_TILES 1
 #define BIAS_REPLICAS 64   // the per-tile bias partial sums are spread over this many replicas to avoid atomic contention
+// Replica a workgroup adds its partial sums to.  nrep = BIAS_REPLICAS: many workgroups share a replica (float atomics, order of
+// arrival).  Deterministic mode (muvo_set_deterministic): nrep = gridDim.x * gridDim.z, every workgroup of a channel group owns
+// its replica and the reduce kernels add the replicas in index order.
+__device__ __forceinline__ int replica_of_block(int nrep) {
+  return (int)((blockIdx.z * gridDim.x + blockIdx.x) % (unsigned)nrep);
+}
 __global__ void __launch_bounds__(256)
 nchw_split_nhwc_kernel(const float* __restrict__ in, uint4* __restrict__ out_hi, uint4* __restrict__ out_lo, int C, int Cp,
-                       long S, const float* __restrict__ yact, int act, float slope, float* __restrict__ dbias) {
+                       long S, const float* __restrict__ yact, int act, float slope, float* __restrict__ dbias, int nrep) {
   constexpr int RS = 33;
   __shared__ unsigned th[64 * RS], tl[64 * RS];
   const int tid = threadIdx.x, pl = tid & 63, w = tid >> 6;
@@ -954,7 +960,7 @@ nchw_split_nhwc_kernel(const float* __restrict__ in, uint4* __restrict__ out_hi,
       for (int e = 0; e < 2; ++e) {
         const int c = c0 + 2 * (w + 4 * r) + e;
         const float sum = wave_sum(bsum[2 * r + e]);
-        if (pl == 0 && c < C) atomicAdd(dbias + (size_t)(blockIdx.x % BIAS_REPLICAS) * Cp + c, sum);
+        if (pl == 0 && c < C) atomicAdd(dbias + (size_t)replica_of_block(nrep) * Cp + c, sum);
       }
   }
   // zero page right after the two planes (source of out-of-bounds DMA reads)
@@ -971,7 +977,7 @@ __global__ void __launch_bounds__(256)
 nchw_split_nhwc_v4_kernel(const float* __restrict__ in, uint4* __restrict__ out_hi, uint4* __restrict__ out_lo, int C, int Cp,
                           long S, const float* __restrict__ yact, int act, float slope, float* __restrict__ dbias,
                           const float* __restrict__ dhead, const float* __restrict__ head_w, int CO,
-                          float* __restrict__ hw_rep) {
+                          float* __restrict__ hw_rep, int nrep) {
   extern __shared__ unsigned sp_lds[];
   unsigned* th = sp_lds;
   unsigned* tl = sp_lds + 32 * SPLIT2_PS;
@@ -1099,15 +1105,15 @@ nchw_split_nhwc_v4_kernel(const float* __restrict__ in, uint4* __restrict__ out_
         s2 += red[(l + 2) * 17 + lane]; s3 += red[(l + 3) * 17 + lane];
       }
       const int c = c0 + 2 * (w * 8 + (lane >> 1)) + (lane & 1);
-      if (c < C) atomicAdd(dbias + (size_t)(blockIdx.x % BIAS_REPLICAS) * Cp + c, (s0 + s1) + (s2 + s3));
+      if (c < C) atomicAdd(dbias + (size_t)replica_of_block(nrep) * Cp + c, (s0 + s1) + (s2 + s3));
     }
   }
   if (hw_rep != nullptr) {
     // lane reduction of the 16 x 4 head-gradient partials (+ the 4 head-bias partials) through the same LDS transpose, in two
     // halves of 8 channel slots; replica r = blockIdx.x % BIAS_REPLICAS of [r][4][Cp] weight sums and [r][4] bias sums
     float* red = (float*)sp_lds + w * (64 * 37);
-    float* hb_rep = hw_rep + (size_t)BIAS_REPLICAS * 4 * Cp;
-    const int rep = blockIdx.x % BIAS_REPLICAS;
+    float* hb_rep = hw_rep + (size_t)nrep * 4 * Cp;
+    const int rep = replica_of_block(nrep);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       __syncthreads();
@@ -1143,35 +1149,35 @@ nchw_split_nhwc_v4_kernel(const float* __restrict__ in, uint4* __restrict__ out_
 
 // dhead_w[k][c] += sum over replicas of the head weight sums, dhead_b[k] += ... of the bias sums (clears what it reads)
 __global__ void head_replica_reduce_kernel(float* __restrict__ hw_rep, float* __restrict__ dhead_w, float* __restrict__ dhead_b,
-                                           int C, int Cp, int CO) {
+                                           int C, int Cp, int CO, int nrep) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  float* hb_rep = hw_rep + (size_t)BIAS_REPLICAS * 4 * Cp;
+  float* hb_rep = hw_rep + (size_t)nrep * 4 * Cp;
   if (i < 4 * Cp) {
     const int k = i / Cp, c = i - k * Cp;
     float s = 0.f;
-    for (int r = 0; r < BIAS_REPLICAS; ++r) { s += hw_rep[((size_t)r * 4 + k) * Cp + c]; hw_rep[((size_t)r * 4 + k) * Cp + c] = 0.f; }
+    for (int r = 0; r < nrep; ++r) { s += hw_rep[((size_t)r * 4 + k) * Cp + c]; hw_rep[((size_t)r * 4 + k) * Cp + c] = 0.f; }
     if (k < CO && c < C) dhead_w[(size_t)k * C + c] += s;
   } else if (i < 4 * Cp + 4) {
     const int k = i - 4 * Cp;
     float s = 0.f;
-    for (int r = 0; r < BIAS_REPLICAS; ++r) { s += hb_rep[r * 4 + k]; hb_rep[r * 4 + k] = 0.f; }
+    for (int r = 0; r < nrep; ++r) { s += hb_rep[r * 4 + k]; hb_rep[r * 4 + k] = 0.f; }
     if (k < CO && dhead_b != nullptr) dhead_b[k] += s;
   }
 }
 
 // dbias[c] += sum over replicas
 // (clears what it reads: the library-owned replica buffer stays all-zero between uses, no memset launch per backward pass)
-__global__ void bias_replica_reduce_kernel(float* __restrict__ rep, float* __restrict__ dbias, int C, int Cp) {
+__global__ void bias_replica_reduce_kernel(float* __restrict__ rep, float* __restrict__ dbias, int C, int Cp, int nrep) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= Cp) return;
   float s = 0.f;
-  for (int r = 0; r < BIAS_REPLICAS; ++r) { s += rep[(size_t)r * Cp + c]; rep[(size_t)r * Cp + c] = 0.f; }
+  for (int r = 0; r < nrep; ++r) { s += rep[(size_t)r * Cp + c]; rep[(size_t)r * Cp + c] = 0.f; }
   if (c < C) dbias[c] += s;
 }
 
 // BIAS_REPLICAS x Cp floats, zero on allocation and left zero by bias_replica_reduce_kernel.  One buffer PER HIP STREAM
 // (branches of the model run on side streams, muvo_amd/ops.py: branch)
-static float* bias_replica_buffer(int Cp, hipStream_t st) {       // [R][Cp] bias sums, then [R][4][Cp] + [R][4] head-gradient sums
+static float* bias_replica_buffer(int Cp, hipStream_t st, int nrep) {       // [R][Cp] bias sums, then [R][4][Cp] + [R][4] head-gradient sums
   struct Slot { hipStream_t st; bool used; float* buf; size_t cap; };
   static Slot slots[16];
   Slot* sl = nullptr;
@@ -1180,11 +1186,12 @@ static float* bias_replica_buffer(int Cp, hipStream_t st) {       // [R][Cp] bia
   for (int i = 0; i < 16 && !sl; ++i)
     if (!slots[i].used) { slots[i] = {st, true, nullptr, 0}; sl = &slots[i]; }
   if (!sl) return nullptr;
-  const size_t need = (size_t)BIAS_REPLICAS * (5 * (size_t)Cp + 4);
+  const size_t need = (size_t)nrep * (5 * (size_t)Cp + 4);
   if (need > sl->cap) {
     if (sl->buf) { hipDeviceSynchronize(); hipFree(sl->buf); sl->buf = nullptr; }
     const size_t n = need < 65536 ? 65536 : need;
-    if (hipMalloc((void**)&sl->buf, n * sizeof(float)) != hipSuccess || hipMemset(sl->buf, 0, n * sizeof(float)) != hipSuccess) {
+    // (cleared on the stream that uses it: a null-stream hipMemset is not ordered with PyTorch's non-blocking side streams)
+    if (hipMalloc((void**)&sl->buf, n * sizeof(float)) != hipSuccess || hipMemsetAsync(sl->buf, 0, n * sizeof(float), st) != hipSuccess) {
       sl->buf = nullptr; sl->cap = 0;
       return nullptr;
     }
@@ -1345,36 +1352,38 @@ int bf3_split_input(const float* x, void* ws, int N, int C, long S, hipStream_t 
     muvo_set_error("bf3_split_input: the fused head weight gradient needs the head gradient and the activation output");
     return MUVO_ERR_INVALID_ARG;
   }
+  static const int split_v4 = getenv("MUVO_SPLIT_V4") ? atoi(getenv("MUVO_SPLIT_V4")) : 2;   // 2: also the fused dy * act'(y) form, 1: plain splits only, 0: 4-byte kernel everywhere
+  const bool v4 = split_v4 && (!yact || split_v4 >= 2) && S % 4 == 0 && S >= 1024 && (((uintptr_t)x | (uintptr_t)yact) & 15) == 0;   // 5.5 vs 4.5 TB/s (profiles/r02b_hbm.txt)
+  const dim3 grid = v4 ? dim3(cdiv(S, 256), cdiv(Cp, 64), N) : dim3(cdiv(cdiv(S, 64), SPLIT_TILES), cdiv(Cp, 64), N);
+  // partial-sum replicas: BIAS_REPLICAS shared ones, or (deterministic mode) one per workgroup of a channel group
+  const int nrep = muvo_det() ? (int)(grid.x * grid.z) : BIAS_REPLICAS;
   if (dbias || dhead_w) {
-    rep = bias_replica_buffer(Cp, st);
-    if (rep != nullptr && dhead_w != nullptr) hw_rep = rep + (size_t)BIAS_REPLICAS * Cp;
+    rep = bias_replica_buffer(Cp, st, nrep);
+    if (rep != nullptr && dhead_w != nullptr) hw_rep = rep + (size_t)nrep * Cp;
     if (rep == nullptr) {
       muvo_set_error("bf3_split_input: cannot allocate the bias partial-sum buffer");
       return MUVO_ERR_HIP;
     }
   }
-  static const int split_v4 = getenv("MUVO_SPLIT_V4") ? atoi(getenv("MUVO_SPLIT_V4")) : 2;   // 2: also the fused dy * act'(y) form, 1: plain splits only, 0: 4-byte kernel everywhere
   if (dhead != nullptr && !(split_v4 >= 2 && S % 4 == 0 && S >= 1024 && CO >= 1 && CO <= 4 &&
                             (((uintptr_t)x | (uintptr_t)yact | (uintptr_t)dhead) & 15) == 0)) {
     muvo_set_error("bf3_split_input: the head-gradient form needs S %% 4 == 0, S >= 1024, <= 4 head channels and 16-byte aligned tensors");
     return MUVO_ERR_INVALID_ARG;
   }
-  if (split_v4 && (!yact || split_v4 >= 2) && S % 4 == 0 && S >= 1024 && (((uintptr_t)x | (uintptr_t)yact) & 15) == 0) {   // 5.5 vs 4.5 TB/s (profiles/r02b_hbm.txt)
+  if (v4) {
     static bool attr_set = false;
     constexpr int lds = 2 * 32 * SPLIT2_PS * 4;
     if (!attr_set) {
       hipFuncSetAttribute((const void*)nchw_split_nhwc_v4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       attr_set = true;
     }
-    dim3 grid(cdiv(S, 256), cdiv(Cp, 64), N);
     hipLaunchKernelGGL(nchw_split_nhwc_v4_kernel, grid, dim3(256), lds, st, x, hi, lo, C, Cp, S, yact, act, slope, dbias ? rep : nullptr,
-                       dhead, head_w, CO, hw_rep);
+                       dhead, head_w, CO, hw_rep, nrep);
   } else {
-    dim3 grid(cdiv(cdiv(S, 64), SPLIT_TILES), cdiv(Cp, 64), N);
-    hipLaunchKernelGGL(nchw_split_nhwc_kernel, grid, dim3(256), 0, st, x, hi, lo, C, Cp, S, yact, act, slope, rep);
+    hipLaunchKernelGGL(nchw_split_nhwc_kernel, grid, dim3(256), 0, st, x, hi, lo, C, Cp, S, yact, act, slope, rep, nrep);
   }
-  if (dbias) hipLaunchKernelGGL(bias_replica_reduce_kernel, dim3(cdiv(Cp, 64)), dim3(64), 0, st, rep, dbias, C, Cp);
-  if (hw_rep) hipLaunchKernelGGL(head_replica_reduce_kernel, dim3(cdiv(4 * Cp + 4, 64)), dim3(64), 0, st, hw_rep, dhead_w, dhead_b, C, Cp, CO);
+  if (dbias) hipLaunchKernelGGL(bias_replica_reduce_kernel, dim3(cdiv(Cp, 64)), dim3(64), 0, st, rep, dbias, C, Cp, nrep);
+  if (hw_rep) hipLaunchKernelGGL(head_replica_reduce_kernel, dim3(cdiv(4 * Cp + 4, 64)), dim3(64), 0, st, hw_rep, dhead_w, dhead_b, C, Cp, CO, nrep);
   MUVO_CHECK_LAUNCH("nchw_split_nhwc_kernel");
   return MUVO_OK;
 }
@@ -1448,7 +1457,7 @@ bool bf3_wgrad_uses_pp(const ConvPhase& g) { return g.M > 128 || (g.M > 64 && g.
 // the range-view stage at 2 x 32: 512 channels x 9 taps) have too few 64 x 128 tiles to fill the chip; their K range is cut
 // into >= 16-step pieces until ~512 workgroups exist.  The caller zeroes the output and runs the bias / activation pass.
 int bf3_fwd_ksplit(const ConvPhase& g) {
-  if (g.npix <= 0 || bf3_fwd_uses_pp(g)) return 1;
+  if (g.npix <= 0 || bf3_fwd_uses_pp(g) || muvo_det()) return 1;     // deterministic mode: no float atomics over K ranges
   static const int tgt = getenv("MUVO_BF3_KSPLIT_BLOCKS") ? atoi(getenv("MUVO_BF3_KSPLIT_BLOCKS")) : 512;
   static const int min_steps = getenv("MUVO_BF3_KSPLIT_MIN_STEPS") ? atoi(getenv("MUVO_BF3_KSPLIT_MIN_STEPS")) : 16;
   const long tiles = (long)cdiv(g.npix, 128) * cdiv(g.M, 64);
@@ -1489,6 +1498,7 @@ int bf3_launch_fwd_phase(const ConvPhase& g, const void* ws, const float* wp, co
 // 163 steps ran as 360 workgroups = two rounds of 33 steps; 216 workgroups are one round of 55 (tools/bf3_wgrad_stamps.py:
 // 1.2 us per step, 4 us setup + prologue, 6-10 us until the epilogue's atomics have drained and the LDS is free again).
 static int bf3_wgrad_ksplit(long tiles, int nsteps, int tgt, int minst, int slots) {
+  if (muvo_det()) return 1;           // deterministic mode: one workgroup walks all pixels of its tile (no atomics race)
   int ksplit = cdiv(tgt, tiles);
   if (ksplit > cdiv(nsteps, minst)) ksplit = cdiv(nsteps, minst);
   if (ksplit < 1) ksplit = 1;

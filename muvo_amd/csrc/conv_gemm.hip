@@ -454,7 +454,9 @@ static bool vox_uses_bf3(const muvo_conv_desc* d, int dgrad) {
 
 static double bf3_wgrad_min_gflop();
 static bool vox_wgrad_uses_bf3(const muvo_conv_desc* d) {
-  if (conv_mode() != 1 || !vox_bf3_wgrad_shape_ok(d)) return false;
+  // (deterministic mode: the bf16x3 voxel weight gradient reduces its tiles with LDS float atomics; the exact-fp32 kernel with
+  // ordered global adds takes over)
+  if (conv_mode() != 1 || !vox_bf3_wgrad_shape_ok(d) || muvo_det()) return false;
   const double gflop = 2.0 * d->Cin * d->Cout * 27.0 * (double)d->in_sz[0] * d->in_sz[1] * d->in_sz[2] * 1e-9;
   return gflop >= bf3_wgrad_min_gflop();
 }
@@ -694,7 +696,7 @@ static void launch_fwd_run(const ConvPhase& g, const float* in, const float* wp,
 
 // split-K factor of a fp32 phase: only for small grids with a long reduction
 static int phase_ksplit(const ConvPhase& g) {
-  if (g.npix <= 0) return 1;
+  if (g.npix <= 0 || muvo_det()) return 1;       // deterministic mode: no float atomics over K ranges
   if (g.bf3) return bf3_fwd_ksplit(g);
   const int bm = g.M > 64 ? 128 : (g.M > 32 ? 64 : 32);
   const long blocks = (long)cdiv(g.npix, 128) * cdiv(g.M, bm);
@@ -731,7 +733,7 @@ static int launch_wgrad_phase(const ConvPhase& g, const float* in, const float* 
   static const int mint = getenv("MUVO_F32_WGRAD_MINTILES") ? atoi(getenv("MUVO_F32_WGRAD_MINTILES")) : 4;    // measured 3.4 -> 2.9 ms/step vs (1024, 8)
   int nsplit = cdiv(tgt, gx * gy);
   if (nsplit > cdiv(ntiles, mint)) nsplit = cdiv(ntiles, mint);
-  if (nsplit < 1) nsplit = 1;
+  if (nsplit < 1 || muvo_det()) nsplit = 1;       // deterministic mode: one workgroup per tile walks all pixels
   const int tps = cdiv(ntiles, nsplit);
   nsplit = cdiv(ntiles, tps);
   dim3 grid(gx, gy, nsplit);
@@ -939,7 +941,7 @@ int muvo_conv_forward(const muvo_conv_desc* d, const float* x, const float* wp_f
 int muvo_conv_forward_head_supported(const muvo_conv_desc* d, int CO) {
   if (check_desc(d) || CO < 1 || CO > 4) return 0;
   static const int on = getenv("MUVO_CONV_HEAD_FWD") ? atoi(getenv("MUVO_CONV_HEAD_FWD")) : 1;
-  if (!on || conv_mode() != 1 || pw_applicable(d) || vox_fwd_ok(d)) return 0;
+  if (!on || muvo_det() || conv_mode() != 1 || pw_applicable(d) || vox_fwd_ok(d)) return 0;   // (deterministic mode: groups of > 64 channels add their partial logits atomically)
   ConvPlan pl;
   if (build_plan(d, &pl) != MUVO_OK || pl.nfwd < 1) return 0;
   for (int i = 0; i < pl.nfwd; ++i) {
@@ -973,6 +975,7 @@ int muvo_conv_forward_head(const muvo_conv_desc* d, const float* x, const float*
 
 int muvo_conv_forward_moments_supported(const muvo_conv_desc* d) {
   if (check_desc(d)) return 0;
+  if (muvo_det()) return 0;          // the epilogue statistics are double atomics from many workgroups
   return (!pw_applicable(d) && vox_fwd_ok(d) && vox_uses_bf3(d, 0)) ? 1 : 0;
 }
 int muvo_conv_forward_moments(const muvo_conv_desc* d, const float* x, const float* wp_fwd, const float* bias, float* y, int act,
@@ -1147,6 +1150,7 @@ int muvo_conv_wgrad(const muvo_conv_desc* d, const float* x, const float* dy, fl
   if (dbias) {
     int chunks = cdiv((long)d->N * S_out, 65536);
     if (chunks > 64) chunks = 64;
+    if (muvo_det()) chunks = 1;
     hipLaunchKernelGGL(bias_grad_kernel, dim3(d->Cout, chunks), dim3(256), 0, st, dy, dbias, d->N, d->Cout, S_out);
     MUVO_CHECK_LAUNCH("bias_grad_kernel");
   }
@@ -1164,6 +1168,7 @@ int muvo_bias_grad_nchw(const float* dy, float* db, int N, int M, int64_t S, voi
   MUVO_CHECK_ARG(dy && db && N > 0 && M > 0 && S > 0, "bias_grad_nchw: bad args");
   int chunks = cdiv((long)N * S, 65536);
   if (chunks > 64) chunks = 64;
+  if (muvo_det()) chunks = 1;
   hipLaunchKernelGGL(bias_grad_kernel, dim3(M, chunks), dim3(256), 0, (hipStream_t)stream, dy, db, N, M, (long)S);
   MUVO_CHECK_LAUNCH("bias_grad_kernel");
   return MUVO_OK;

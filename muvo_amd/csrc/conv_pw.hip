@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256) pw_dgrad_kernel(const float* __restrict__
 template <int CO>
 __global__ void __launch_bounds__(256) pw_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ dout,
                                                        float* __restrict__ dw, float* __restrict__ dbias, int Cin, long S4,
-                                                       long chunk4) {
+                                                       long chunk4, unsigned* ticket) {
   __shared__ float red[4][CO * 8 + CO];
   const int n = blockIdx.z, ci0 = blockIdx.y * 8;
   const float4* inn = (const float4*)in + ((size_t)n * Cin + ci0) * S4;
@@ -124,6 +124,7 @@ __global__ void __launch_bounds__(256) pw_wgrad_kernel(const float* __restrict__
     if (lane == 0) red[wave][CO * 8 + co] = sb;
   }
   __syncthreads();
+  det_turn_wait(ticket);      // deterministic mode: the workgroups add in block order
   if (threadIdx.x < CO * 8 + CO) {
     const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
     if (threadIdx.x < CO * 8) {
@@ -133,6 +134,7 @@ __global__ void __launch_bounds__(256) pw_wgrad_kernel(const float* __restrict__
       atomicAdd(dbias + (threadIdx.x - CO * 8), s);
     }
   }
+  det_turn_done(ticket);
 }
 
 bool pw_applicable(const muvo_conv_desc* d) {
@@ -163,7 +165,7 @@ static int pw_run(int op, const muvo_conv_desc* d, const float* a, const float* 
     if (chunks < 1) chunks = 1;
     const long chunk4 = cdiv(S4, chunks);
     hipLaunchKernelGGL((pw_wgrad_kernel<CO>), dim3(cdiv(S4, chunk4), cgroups, d->N), dim3(256), 0, st, a, b, o0, o1, d->Cin, S4,
-                       chunk4);
+                       chunk4, muvo_det_ticket(st));
   }
   MUVO_CHECK_LAUNCH("pw_kernel");
   return MUVO_OK;

@@ -29,6 +29,7 @@ struct VoxArgs {
   int xcd_order;       // bf16x3 kernels: walk (x segment, row tile, batch) in XCD order (row tiles that share halo rows share an L2)
   const float* aff;    // optional (bf16x3 forward / weight-gradient kernels): [N][Cin][2] = (scale, shift); the kernel convolves
                        // scale * x + shift (zero padding stays zero): the AdaIN of the producing layer applied while staging
+  unsigned* ticket;    // deterministic mode (exact-fp32 weight gradient): the workgroups add their tiles in block order
 };
 static thread_local const float* t_vox_aff = nullptr;   // set by vox_forward / vox_wgrad around their launches (VoxArgs::aff)
 static int vox_xcd_order() {
@@ -300,6 +301,7 @@ vox_wgrad_kernel(const VoxArgs a, const float* __restrict__ in, const float* __r
   }
 
   // reduce over the 16 blocks (lane bits 2..5), then lanes 0..3 publish
+  det_turn_wait(a.ticket);
 #pragma unroll
   for (int q = 0; q < CQR; ++q)
 #pragma unroll
@@ -327,6 +329,7 @@ vox_wgrad_kernel(const VoxArgs a, const float* __restrict__ in, const float* __r
       if (lane < 4) atomicAdd(dbias + (qc * CQB + qg * CQR + q) * 4 + lane, v);
     }
   }
+  det_turn_done(a.ticket);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1347,6 +1350,7 @@ static int launch_vox_wgrad(const muvo_conv_desc* d, const float* x, const float
     attr_set = true;
   }
   dim3 grid(a.N * a.ytiles * xsplit, nqc * nrc);
+  a.ticket = muvo_det_ticket(st);
   hipLaunchKernelGGL((vox_wgrad_kernel<RQB, CQR, Z, TYB>), grid, dim3(768), lds, st, a, x, dz, dw, dbias, xsplit, nqc);
   MUVO_CHECK_LAUNCH("vox_wgrad_kernel");
   return MUVO_OK;

@@ -864,6 +864,7 @@ int muvo_colsum_acc(const float* x, float* out, int64_t rows, int64_t cols, int6
   MUVO_CHECK_ARG(x && out && rows > 0 && cols > 0 && ld >= cols, "colsum: bad args");
   int chunks = cdiv(rows, 64);           // 16 rows per lane: enough workgroups to cover the chip even for 384 columns
   if (chunks > 1024) chunks = 1024;
+  if (muvo_det()) chunks = 1;
   hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 64), chunks), dim3(256), 0, ST, x, out, (long)rows, (long)cols, (long)ld);
   MUVO_CHECK_LAUNCH("colsum");
   return MUVO_OK;

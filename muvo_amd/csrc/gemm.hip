@@ -666,7 +666,7 @@ extern "C" int muvo_gemm(const muvo_gemm_desc* d, const float* A, const float* B
         static const int ks_tgt = getenv("MUVO_SKINNY_KS_BLOCKS") ? atoi(getenv("MUVO_SKINNY_KS_BLOCKS")) : 512;
         ks = cdiv(ks_tgt, blocks);
         if (ks > d->K / 64) ks = d->K / 64;
-        if (ks < 1) ks = 1;
+        if (ks < 1 || muvo_det()) ks = 1;
       }
       if (ks > 1 && hipMemsetAsync(C, 0, sizeof(float) * (size_t)d->M * d->N, st) != hipSuccess) {
         muvo_set_error("gemm_skinny: memset failed");
@@ -691,7 +691,7 @@ extern "C" int muvo_gemm(const muvo_gemm_desc* d, const float* A, const float* B
     static const int mint = getenv("MUVO_GEMM_KSPLIT_MINTILES") ? atoi(getenv("MUVO_GEMM_KSPLIT_MINTILES")) : 8;
     ksplit = cdiv(tgt, gx * gy * nb);
     if (ksplit > cdiv(nkt, mint)) ksplit = cdiv(nkt, mint);
-    if (ksplit < 1) ksplit = 1;
+    if (ksplit < 1 || muvo_det()) ksplit = 1;      // deterministic mode: one contributor per element of the accumulated C
   }
   g.ksplit = ksplit;
   dim3 grid(gx, gy, nb * ksplit);

@@ -23,7 +23,7 @@ __device__ __forceinline__ void block_atomic_add_d(double v, double* dst, double
 __global__ void __launch_bounds__(256) spatial_loss_fwd_kernel(const float* __restrict__ pred,
                                                                const float* __restrict__ target, long F, int Ct, long HW,
                                                                int c0, int c1, int norm, float ignore,
-                                                               double* __restrict__ stats) {
+                                                               double* __restrict__ stats, unsigned* ticket) {
   // grid = (pixel blocks, frames): no 64-bit division per pixel, four consecutive pixels per trip (16-byte loads when
   // HW % 4 == 0), ONE workgroup reduction for both sums (few hundred workgroups: the two atomics are not contended)
   __shared__ double red[2][4];
@@ -75,7 +75,9 @@ __global__ void __launch_bounds__(256) spatial_loss_fwd_kernel(const float* __re
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (lane == 0) { red[0][w] = d0; red[1][w] = d1; }
   __syncthreads();
+  det_turn_wait(ticket);      // deterministic mode: the workgroups add in block order
   if (threadIdx.x < 2) atomicAdd(&stats[threadIdx.x], red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+  det_turn_done(ticket);
 }
 __global__ void spatial_loss_finalize_kernel(const double* __restrict__ stats, float* __restrict__ loss, float weight) {
   if (threadIdx.x == 0 && blockIdx.x == 0) loss[0] = stats[1] > 0.0 ? (float)(weight * stats[0] / stats[1]) : 0.f;
@@ -110,7 +112,8 @@ __global__ void spatial_loss_bwd_kernel(const float* __restrict__ pred, const fl
 template <int CT>
 __global__ void __launch_bounds__(256) voxel_loss_fwd_kernel(const float* __restrict__ logits,
                                                              const uint8_t* __restrict__ target, long F, int C, long V,
-                                                             const float* __restrict__ class_w, double* __restrict__ stats) {
+                                                             const float* __restrict__ class_w, double* __restrict__ stats,
+                                                             unsigned* ticket) {
   constexpr int NCU = CT ? CT : MAXC;     // unrolled class loops
   const int Cc = CT ? CT : C;
   __shared__ double red[4];
@@ -208,7 +211,9 @@ __global__ void __launch_bounds__(256) voxel_loss_fwd_kernel(const float* __rest
     if (c < Cc) { put(2 + 5 * c, P[c]); put(3 + 5 * c, Nn[c]); put(4 + 5 * c, T[c]); put(5 + 5 * c, Q[c]); put(6 + 5 * c, R[c]); }
   put(2 + 5 * Cc, gI); put(3 + 5 * Cc, gA); put(4 + 5 * Cc, gB); put(5 + 5 * Cc, gS); put(6 + 5 * Cc, gR);
   __syncthreads();
+  det_turn_wait(ticket);      // deterministic mode: the workgroups add in block order
   if ((int)threadIdx.x < NV) atomicAdd(&stats[threadIdx.x], redm[threadIdx.x][0] + redm[threadIdx.x][1] + redm[threadIdx.x][2] + redm[threadIdx.x][3]);
+  det_turn_done(ticket);
   (void)red;
 }
 
@@ -536,7 +541,7 @@ int muvo_spatial_loss_fwd(const float* pred, const float* target, int64_t F, int
   long nbx = (HW / 4 + 1023) / 1024;             // ~4 trips of 4 pixels per thread
   if (nbx * F > 1024) nbx = 1024 / F > 0 ? 1024 / F : 1;
   hipLaunchKernelGGL(spatial_loss_fwd_kernel, dim3((unsigned)nbx, (unsigned)F), dim3(256), 0, ST, pred, target, (long)F, Ct, (long)HW,
-                     c0, c1, norm, ignore, stats2);
+                     c0, c1, norm, ignore, stats2, muvo_det_ticket(ST));
   hipLaunchKernelGGL(spatial_loss_finalize_kernel, dim3(1), dim3(64), 0, ST, stats2, loss, weight);
   MUVO_CHECK_LAUNCH("spatial_loss_fwd");
   return MUVO_OK;
@@ -562,8 +567,9 @@ int muvo_voxel_loss_fwd(const float* logits, const uint8_t* target, int64_t F, i
   static const long nb_cap = getenv("MUVO_VOXLOSS_BLOCKS") ? atol(getenv("MUVO_VOXLOSS_BLOCKS")) : 1280;
   if (nbx * F > nb_cap) nbx = nb_cap / F > 0 ? nb_cap / F : 1;
   const dim3 grid((unsigned)nbx, (unsigned)F);
-  if (C == 2) hipLaunchKernelGGL(voxel_loss_fwd_kernel<2>, grid, dim3(256), 0, ST, logits, target, (long)F, C, (long)V, class_w, stats);
-  else hipLaunchKernelGGL(voxel_loss_fwd_kernel<0>, grid, dim3(256), 0, ST, logits, target, (long)F, C, (long)V, class_w, stats);
+  unsigned* ticket = muvo_det_ticket(ST);
+  if (C == 2) hipLaunchKernelGGL(voxel_loss_fwd_kernel<2>, grid, dim3(256), 0, ST, logits, target, (long)F, C, (long)V, class_w, stats, ticket);
+  else hipLaunchKernelGGL(voxel_loss_fwd_kernel<0>, grid, dim3(256), 0, ST, logits, target, (long)F, C, (long)V, class_w, stats, ticket);
   hipLaunchKernelGGL(voxel_loss_finalize_kernel, dim3(1), dim3(64), 0, ST, stats, C, (double)F * (double)V, weight, loss3, coef);
   MUVO_CHECK_LAUNCH("voxel_loss_fwd");
   return MUVO_OK;

@@ -148,6 +148,7 @@ __global__ void __launch_bounds__(256) bwd_moments_kernel(const float* __restric
 }
 
 static int norm_max_chunks(int dflt) {
+  if (muvo_det()) return 1;          // deterministic mode: one workgroup per statistics group = one contributor per double
   static const int v = getenv("MUVO_NORM_MAXCHUNKS") ? atoi(getenv("MUVO_NORM_MAXCHUNKS")) : 0;
   return v > 0 ? v : dflt;
 }
@@ -186,8 +187,10 @@ static double* norm_sums(size_t n_doubles, hipStream_t st) {
   if (n_doubles > b->sums_cap) {
     if (b->sums) hipFree(b->sums);                   // synchronises the device: nobody is using the old buffer any more
     b->sums_cap = n_doubles < 65536 ? 65536 : 2 * n_doubles;
+    // cleared ON THE STREAM that uses it: PyTorch's side streams are non-blocking, a null-stream hipMemset is not ordered
+    // with them (the first statistics pass on a new stream raced with its own buffer's initialisation)
     if (hipMalloc((void**)&b->sums, b->sums_cap * sizeof(double)) != hipSuccess ||
-        hipMemset(b->sums, 0, b->sums_cap * sizeof(double)) != hipSuccess) {
+        hipMemsetAsync(b->sums, 0, b->sums_cap * sizeof(double), st) != hipSuccess) {
       b->sums = nullptr;
       b->sums_cap = 0;
     }
@@ -867,6 +870,7 @@ static int adain_head_run(int which, const float* x, const float* style, float* 
     double* hsum = sums + 2 * (size_t)G;
     int gx = cdiv(S4, 1024);                 // 4096 voxels per workgroup
     if (gx > 128) gx = 128;
+    if (muvo_det()) gx = 1;                  // one contributor per statistics word
     hipLaunchKernelGGL((adain_head_bwd_stats_kernel<C, CO>), dim3(gx, N), dim3(256), 0, st, x, (const float*)mean, (const float*)rstd,
                        style, wh, dl, sums, hsum, S);
     hipLaunchKernelGGL(adain_bwd_finalize_kernel, dim3(cdiv(G, 64)), dim3(64), 0, st, sums, ws, dstyle, N, C);
@@ -995,12 +999,10 @@ __global__ void __launch_bounds__(256) add_dropout_ln_bwd_kernel(const float* __
                                                                  float* __restrict__ da, float* __restrict__ dgamma,
                                                                  float* __restrict__ dbeta, int rows, int E,
                                                                  int rows_per_block, float p, uint64_t seed) {
-  extern __shared__ float sm[];  // [2][E]
-  float* sg = sm;
-  float* sb = sm + E;
-  for (int e = threadIdx.x; e < 2 * E; e += 256) sm[e] = 0.f;
-  __syncthreads();
+  extern __shared__ float sm[];  // [4 waves][2][E]: per-wave partial sums, added in wave order (no LDS atomics: their order varies)
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float* sg = sm + (size_t)w * 2 * E;
+  float* sb = sg + E;
   const int r0 = blockIdx.x * rows_per_block;
   float ag[MAXV], ab[MAXV];
 #pragma unroll
@@ -1073,12 +1075,12 @@ __global__ void __launch_bounds__(256) add_dropout_ln_bwd_kernel(const float* __
 #pragma unroll
   for (int k = 0; k < MAXV; ++k) {
     const int e = lane + 64 * k;
-    if (e < E) { atomicAdd(&sg[e], ag[k]); atomicAdd(&sb[e], ab[k]); }
+    if (e < E) { sg[e] = ag[k]; sb[e] = ab[k]; }
   }
   __syncthreads();
   for (int e = threadIdx.x; e < E; e += 256) {
-    atomicAdd(&dgamma[e], sg[e]);
-    atomicAdd(&dbeta[e], sb[e]);
+    atomicAdd(&dgamma[e], (sm[e] + sm[2 * E + e]) + (sm[4 * E + e] + sm[6 * E + e]));
+    atomicAdd(&dbeta[e], (sm[E + e] + sm[3 * E + e]) + (sm[5 * E + e] + sm[7 * E + e]));
   }
 }
 
@@ -1098,8 +1100,8 @@ extern "C" int muvo_add_dropout_layernorm_bwd(const float* dy, const float* z, c
                                               int rows, int E, float p, uint64_t seed, void* stream) {
   MUVO_CHECK_ARG(dy && z && mean && rstd && gamma && dx && dgamma && dbeta, "layernorm_bwd: null pointer");
   MUVO_CHECK_ARG(rows > 0 && E > 0 && E <= 512, "layernorm_bwd: E=%d unsupported (max 512)", E);
-  const int rpb = 16;       // four rows per wave; 6500 token rows -> 407 workgroups
-  hipLaunchKernelGGL((add_dropout_ln_bwd_kernel<8>), dim3(cdiv(rows, rpb)), dim3(256), 2 * E * sizeof(float),
+  const int rpb = muvo_det() ? rows : 16;       // four rows per wave; 6500 token rows -> 407 workgroups (deterministic mode: one workgroup, one contributor per dgamma / dbeta element)
+  hipLaunchKernelGGL((add_dropout_ln_bwd_kernel<8>), dim3(cdiv(rows, rpb)), dim3(256), 8 * E * sizeof(float),
                      (hipStream_t)stream, dy, z, mean, rstd, gamma, dx, da, dgamma, dbeta, rows, E, rpb, p, seed);
   MUVO_CHECK_LAUNCH("layernorm_bwd");
   return MUVO_OK;

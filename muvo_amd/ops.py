@@ -42,7 +42,7 @@ class GemmDesc(C.Structure):
 
 # every exported symbol of include/muvo_hip.h (tests/test_abi.py checks this list against the header)
 EXPORTS = [
-    'muvo_last_error', 'muvo_abi_version', 'muvo_selftest_mfma',
+    'muvo_last_error', 'muvo_abi_version', 'muvo_selftest_mfma', 'muvo_set_deterministic', 'muvo_get_deterministic',
     'muvo_conv_set_mode', 'muvo_conv_get_mode', 'muvo_conv_set_bf16x3_min_gflop', 'muvo_conv_pack_sizes', 'muvo_conv_workspace_bytes', 'muvo_conv_kernel_family', 'muvo_conv_kernel_variant', 'muvo_conv_pack_weights', 'muvo_conv_forward', 'muvo_conv_dgrad', 'muvo_conv_prepare_dy', 'muvo_conv_wgrad', 'muvo_bias_grad_nchw',
     'muvo_gemm',
     'muvo_pack_table_item_bytes', 'muvo_conv_pack_table_add', 'muvo_linear_bf16x3_pack_table_add', 'muvo_pack_table_run',
@@ -154,6 +154,22 @@ def get_conv_mode():
 
 
 _plan_epoch = [0]
+
+
+def set_deterministic(on=True):
+    """Deterministic mode (include/muvo_hip.h: muvo_set_deterministic; MUVO_DETERMINISTIC=1 at start-up): every reduction whose
+    result would depend on the arrival order of float / double atomics runs in a fixed order - two runs of the same step are
+    bit-identical.  Slower (split-K and pixel-range splits off, ordered workgroup turns, the AdaIN style projections one Linear
+    at a time); a debugging aid for parity work.  Plans and packed weights depend on it: both caches are invalidated."""
+    global GROUPED_LINEAR
+    _ck(lib().muvo_set_deterministic(1 if on else 0))
+    GROUPED_LINEAR = (not on) and os.environ.get('MUVO_GROUPED_LINEAR', '1') != '0'   # its data gradient adds 14 layers atomically
+    bump_weight_epoch()
+    _plan_epoch[0] += 1
+
+
+def get_deterministic():
+    return bool(lib().muvo_get_deterministic())
 
 
 _join_queued = [False]
@@ -543,7 +559,7 @@ class LinearFn(torch.autograd.Function):
         return dx, None, None, None, None
 
 
-GROUPED_LINEAR = os.environ.get('MUVO_GROUPED_LINEAR', '1') != '0'
+GROUPED_LINEAR = os.environ.get('MUVO_GROUPED_LINEAR', '1') != '0' and os.environ.get('MUVO_DETERMINISTIC', '0') in ('', '0')
 
 
 def _ptr_array(tensors):

