@@ -75,7 +75,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-exact-f32', action='store_true', help='skip the extra exact-fp32 steps after the timed region')
-    ap.add_argument('--conv-mfma', default=os.environ.get('MUVO_CONV_MFMA', 'bf16x3'), choices=['f32', 'bf16x3'],
+    ap.add_argument('--conv-mfma', default=os.environ.get('MUVO_CONV_MFMA', 'bf16x3'), choices=['f32', 'bf16x3', 'bf16'],
                     help='matrix-pipe arithmetic of the large convolutions (DESIGN.md section 5)')
     ap.add_argument('--layer-table', default='', help='write the per-layer conv timing table to this file')
     ap.add_argument('--workload', default='base_1d', choices=['base_1d', 'rv2048', 'vox256'],
@@ -113,7 +113,7 @@ def main():
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     from muvo_amd import ops
-    ops.set_conv_mode(ops.CONV_BF16X3 if args.conv_mfma == 'bf16x3' else ops.CONV_F32)
+    ops.set_conv_mode({'bf16x3': ops.CONV_BF16X3, 'bf16': ops.CONV_BF16, 'f32': ops.CONV_F32}[args.conv_mfma])
     from muvo_amd.config import base_1d_cfg
     from muvo_amd.data.synthetic import make_batch
     from muvo_amd.parallel import SegmentedGradReducer
@@ -156,7 +156,7 @@ def main():
         step(i)
     # inside the timed region only the dominant kernel class is bracketed with HIP events (roofline object); the per-class
     # table and the layer table come from two extra, untimed steps after it
-    dominant = 'bf16x3_implicit_gemm' if args.conv_mfma == 'bf16x3' else 'f32_implicit_gemm'
+    dominant = 'bf16x3_implicit_gemm' if args.conv_mfma in ('bf16x3', 'bf16') else 'f32_implicit_gemm'
     if not args.no_kernel_timing:
         ops.KERNEL_TIMING = ops.KernelTiming(only=dominant)
     if world > 1 or force_dist:
@@ -186,11 +186,19 @@ def main():
         tr._reducer.timing = False
     full_timing, extra_steps = None, 2
     if timing is not None:
+        # per-class table from extra steps with the side streams OFF: next to each other on several streams the kernels share
+        # the chip and every event bracket also contains its neighbours' work, so the isolated durations are the ones that say
+        # how good a kernel is (the timed region above runs with the streams on; its brackets of the dominant class are
+        # reported as roofline.achieved / frac, the isolated figures as roofline.achieved_isolated / frac_isolated)
+        streams_were = (ops.STREAMS, ops.WGRAD_STREAM)
+        ops.STREAMS = ops.WGRAD_STREAM = False
+        step(args.warmup + args.steps)            # one untimed step for the per-stream scratch of the main stream
         full_timing = ops.KERNEL_TIMING = ops.KernelTiming()
         for i in range(extra_steps):
-            step(args.warmup + args.steps + i)
+            step(args.warmup + args.steps + 1 + i)
         torch.cuda.synchronize()
         ops.KERNEL_TIMING = None
+        ops.STREAMS, ops.WGRAD_STREAM = streams_were
     if world > 1:
         t = torch.tensor([dt, median_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -198,7 +206,7 @@ def main():
     loss_val = float(loss.item())
     # the same step with every contraction on exact-fp32 MFMA, a few steps after the timed region
     exact_f32 = None
-    if args.conv_mfma != 'f32' and not args.no_exact_f32:
+    if args.conv_mfma == 'bf16x3' and not args.no_exact_f32:
         ops.set_conv_mode(ops.CONV_F32)
         step(10_000)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -224,7 +232,8 @@ def main():
             'metric': 'world-model training samples/sec (seq_len=10)', 'value': samples / dt, 'unit': 'samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if args.conv_mfma == 'f32' else 'f32 storage/accumulate; large contractions (convolutions, transformer Linear) as bf16x3 split products',
+            'dtype': {'f32': 'f32', 'bf16x3': 'f32 storage/accumulate; large contractions (convolutions, transformer Linear) as bf16x3 split products',
+                      'bf16': 'f32 storage/accumulate; large contractions with bf16 operands, ONE product (extension: not the fp32 parity arithmetic)'}[args.conv_mfma],
             'data': 'synthetic',
             'peak_hbm_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
             'config': {'workload': f'base_1d (resnet18 + range-view + transformer fusion + 1D latent), batch={args.batch} '
@@ -233,7 +242,8 @@ def main():
                                    + ('' if args.workload == 'base_1d' else f' [EXTENSION {args.workload}: MODEL.CONSTANT_SIZE, no reference code]'),
                        'global_batch': args.batch * world, 'seq_len': s, 'parallelism': f'dp{world}',
                        'conv_mfma': args.conv_mfma},
-            'parity': 'pinned by reference fixtures (tests/golden)' if args.workload == 'base_1d' else 'unpinned (extension, own oracle only)',
+            'parity': ('pinned by reference fixtures (tests/golden)' if (args.workload == 'base_1d' and args.conv_mfma != 'bf16')
+                       else 'unpinned (extension, own oracle only)'),
             'median_ms_per_step': median_ms, 'value_at_median': args.batch * world / (median_ms * 1e-3),
             'frames_per_s': samples * s / dt,
             'step_tflops_per_gpu': (GFLOP_PER_FRAME * frames_per_gpu_step / (ms * 1e-3) / 1e3) if args.workload == 'base_1d' else None,
@@ -262,7 +272,15 @@ def main():
                 f.write(full_timing.layer_table() + '\n')
         if timing is not None:
             out['roofline'], _ = timing.summary()                      # dominant class, events inside the timed region
-            _, out['kernel_classes'] = full_timing.summary()           # every class, from the extra untimed steps
+            iso, out['kernel_classes'] = full_timing.summary()         # every class, from the extra untimed steps (streams off)
+            if out['roofline'] is not None and iso is not None and iso['kernel'] == out['roofline']['kernel']:
+                out['roofline']['achieved_isolated'] = iso['achieved']
+                out['roofline']['frac_isolated'] = iso['frac']
+                out['roofline']['avg_launch_us_isolated'] = iso['avg_launch_us']
+                out['roofline']['isolation_note'] = ('achieved / frac: HIP-event brackets inside the timed region, where the class shares the '
+                                                     'chip with kernels of the side streams (muvo_amd/ops.py: branch, wgrad_stream); '
+                                                     '*_isolated: the same brackets in extra steps with MUVO_STREAMS off')
+            out['side_streams'] = dict(enabled=bool(streams_were[0]), branches=sorted(ops.BRANCHES), wgrad_stream=bool(streams_were[1]))
             out['kernel_class_steps'] = extra_steps
             if out['roofline'] is not None:
                 conv_s = sum(c['seconds'] for c in out['kernel_classes'].values())

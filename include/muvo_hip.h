@@ -60,6 +60,12 @@ typedef struct muvo_conv_desc {
 #define MUVO_CONV_F32 0
 #define MUVO_CONV_BF16X3 1
 #define MUVO_CONV_MODE_DEFAULT MUVO_CONV_BF16X3
+/* Products per fp32 product on the split-product implicit-GEMM kernels (MUVO_CONV_BF16X3 mode): 3 = hi*hi + hi*lo + lo*hi
+ * (default, fp32-equivalent); 1 = hi*hi only, i.e. plain bf16 operands with fp32 accumulation - the arithmetic of the
+ * reference's shipped PRECISION '16-mixed' (muvo/config.py:40) and of BASELINE.json configs[4] ("bf16").  An EXTENSION outside
+ * the fp32 1e-3 parity contract: a third of the MFMA work; the voxel 3x3x3 kernels keep three products. */
+int muvo_conv_set_products(int n);
+int muvo_conv_get_products(void);
 int muvo_conv_set_mode(int mode);
 int muvo_conv_get_mode(void);
 /* Which convolutions use the split-product kernels in MUVO_CONV_BF16X3 mode.  gflop_per_item >= 0: every phase with

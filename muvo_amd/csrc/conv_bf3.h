@@ -17,6 +17,8 @@ int bf3_launch_fwd_phase(const ConvPhase& g, const void* ws, const float* wp, co
                          float slope, hipStream_t st, int ksplit = 1);
 // fused 1x1 head of the NEXT forward launches on the eight-wave tiles (thread-local; co = 0 clears it): logits = b + W y, W [co][Msub]
 void bf3_set_fused_head(const float* w, const float* b, float* out, int co);
+void bf3_set_products(int n);   // 3: bf16x3 split products (default); 1: hi * hi only (plain bf16 arithmetic)
+int bf3_get_products();
 // split-K factor the caller should use for this phase (1: none; > 1: zero the output first, finish bias / activation after)
 int bf3_fwd_ksplit(const ConvPhase& g);
 // weight gradient of one forward-form phase on the split planes (ws_x: planes of x with Cin_total channels, ws_dz: planes

@@ -83,7 +83,9 @@ __device__ __forceinline__ void dma16(const uint4* g, uint4* lds_wave_base) {
 // Workgroup = WM x WN waves, each owning a 64x64 output tile (2x2 MFMA tiles of 32x32).  K loop: BK = 32 per step,
 // three LDS stages; the DMA of steps k+1 and k+2 stays in flight across the (raw) barrier of step k — each wave waits
 // only for its own copies of step k with a counted vmcnt before the barrier.
-template <int BM, int BN, int WM, int WN, int BKC, int NST>
+// ONE: single-product bf16 arithmetic (muvo_conv_set_products(1), the "bf16" mode of BASELINE configs[4]): only hi * hi is
+// accumulated - a third of the MFMA work, operands rounded to bf16 like the reference's '16-mixed' autocast; staging unchanged.
+template <int BM, int BN, int WM, int WN, int BKC, int NST, bool ONE = false>
 __global__ void __launch_bounds__(64 * WM * WN)
 conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, const uint4* __restrict__ wp,
                 const float* __restrict__ bias, float* __restrict__ out, int act, float slope,
@@ -219,10 +221,11 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
       const int a = wave * APW + q;
       const int pc = a / RG, rg = a % RG;           // pc = plane * BKC + chunk
       const int plane = pc / BKC, ch = pc % BKC;
-      R[P][q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, lane * 16, ((k32 * 8 + plane * 4 + c4 + ch) * g.Mp + rg * 64) * 16, 0));
+      // (ONE: the lo plane is never multiplied - an out-of-range offset makes the load return zeros without touching memory)
+      R[P][q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (ONE && plane == 1) ? OOB : lane * 16, ((k32 * 8 + plane * 4 + c4 + ch) * g.Mp + rg * 64) * 16, 0));
     } else {
       const int plane = (q - APW) & 1, sidx = (q - APW) >> 1;
-      const bool ok = b_tval && (vmask[sidx] & b_bit);
+      const bool ok = b_tval && (vmask[sidx] & b_bit) && !(ONE && plane == 1);
       const int off = ok ? (pixoff[sidx] + b_uoff + plane * (int)plane_u4) * 16 : OOB;
       R[P][q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
     }
@@ -288,8 +291,10 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
   auto mma_row = [&](int i, const bf16x8 (&ah)[TM], const bf16x8 (&al)[TM], const bf16x8 (&bh)[TN], const bf16x8 (&bl)[TN]) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+      if constexpr (!ONE) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+      }
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
     }
   };
@@ -382,8 +387,10 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
       for (int i = 0; i < TM; ++i)
   #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l[i], b0h[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h[i], b0l[j], acc[i][j], 0, 0, 0);
+          if constexpr (!ONE) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0l[i], b0h[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h[i], b0l[j], acc[i][j], 0, 0, 0);
+          }
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0h[i], b0h[j], acc[i][j], 0, 0, 0);
   #pragma unroll
           for (int u = 0; u < PPP; ++u)      // past the end of K these read zeros (range check), nobody consumes them
@@ -399,8 +406,10 @@ conv_bf3_kernel(const ConvPhase g, const uint4* __restrict__ xs, long plane_u4, 
       for (int i = 0; i < TM; ++i)
   #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l[i], b1h[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h[i], b1l[j], acc[i][j], 0, 0, 0);
+          if constexpr (!ONE) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1l[i], b1h[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h[i], b1l[j], acc[i][j], 0, 0, 0);
+          }
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1h[i], b1h[j], acc[i][j], 0, 0, 0);
   #pragma unroll
           for (int u = 0; u < PPP; ++u)      // stage P is free (mid-step barrier); past the end of K nobody reads it again
@@ -477,7 +486,7 @@ __device__ __forceinline__ WgradBlock wgrad_block(int xcd_order) {
   return b;
 }
 
-template <int BM, int BN, int WM, int WN, int WK>
+template <int BM, int BN, int WM, int WN, int WK, bool ONE = false>
 __global__ void __launch_bounds__(64 * WM * WN * WK)
 conv_bf3_wgrad_kernel(const ConvPhase g, const uint4* __restrict__ xs, long xplane_u4, int xc8, const uint4* __restrict__ dzs,
                       long dzplane_u4, int dzc8, float* __restrict__ wg, int steps_per_split,
@@ -621,8 +630,10 @@ conv_bf3_wgrad_kernel(const ConvPhase g, const uint4* __restrict__ xs, long xpla
       for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          if constexpr (!ONE) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          }
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
@@ -651,7 +662,7 @@ conv_bf3_wgrad_kernel(const ConvPhase g, const uint4* __restrict__ xs, long xpla
 // transpose reads from the same [plane][chunk][32 pixels ^ swizzle] image as conv_bf3_wgrad_kernel.
 // Wave w stages the pixel half (w & 1) of every step, A roles [(w >> 1) * APW, +APW), B roles likewise; a role is a
 // (plane, 32-channel group) pair, fixed for the whole kernel.
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool ONE = false>
 __global__ void __launch_bounds__(64 * WM * WN)
 conv_bf3_wgrad_pp_kernel(const ConvPhase g, const uint4* __restrict__ xs, long xplane_u4, int xc8, const uint4* __restrict__ dzs,
                          long dzplane_u4, int dzc8, float* __restrict__ wg, int steps_per_split, int xcd_order) {
@@ -703,7 +714,7 @@ conv_bf3_wgrad_pp_kernel(const ConvPhase g, const uint4* __restrict__ xs, long x
     const int lc8 = (row - grp * g.Msub) >> 3;
     const int resid = (g.mop[gi][0] * g.OH + g.mop[gi][1]) * g.OW + g.mop[gi][2];
     const bool inb = row < g.M && lc8 < dzc8;
-    a_base[q] = inb ? (unsigned)(resid * dzc8 + lc8) + (unsigned)plane * (unsigned)dzplane_u4 : OOB;
+    a_base[q] = (inb && !(ONE && plane == 1)) ? (unsigned)(resid * dzc8 + lc8) + (unsigned)plane * (unsigned)dzplane_u4 : OOB;   // (ONE: lo planes are not read)
     a_lds[q] = (plane * CA + chunk) * 32 + (p ^ (c4 << 2));
   }
   const int ct8 = c_tile >> 3;
@@ -712,7 +723,7 @@ conv_bf3_wgrad_pp_kernel(const ConvPhase g, const uint4* __restrict__ xs, long x
     const int k = ridx * BPW + q;
     const int plane = k / (BN / 32), chunk = (k % (BN / 32)) * 4 + c4;
     const bool inb = c_tile + chunk * 8 < g.Cp;
-    b_base[q] = inb ? (unsigned)(ct8 + chunk) + (unsigned)plane * (unsigned)xplane_u4 : OOB;
+    b_base[q] = (inb && !(ONE && plane == 1)) ? (unsigned)(ct8 + chunk) + (unsigned)plane * (unsigned)xplane_u4 : OOB;
     b_lds[q] = 2 * CA * 32 + (plane * CB + chunk) * 32 + (p ^ (c4 << 2));
   }
   // pixel of this lane in the current load step; advanced by 32 per step with small exact magic divisions
@@ -830,8 +841,10 @@ conv_bf3_wgrad_pp_kernel(const ConvPhase g, const uint4* __restrict__ xs, long x
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bl[ks][j], acc[i][j], 0, 0, 0);
+          if constexpr (!ONE) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bl[ks][j], acc[i][j], 0, 0, 0);
+          }
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
         }
     __builtin_amdgcn_sched_barrier(0);
@@ -1416,9 +1429,14 @@ int bf3_split_rows(const float* x, void* ws, long rows, int C, hipStream_t st) {
 struct Bf3Head { const float* w; const float* b; float* out; int co; };     // fused 1x1 head of a forward launch (co = 0: none)
 static thread_local Bf3Head t_bf3_head = {nullptr, nullptr, nullptr, 0};
 
-template <int BM, int BN, int WM, int WN, int BKC, int NST>
-static int bf3_launch(const ConvPhase& g, const void* ws, const float* wp, const float* bias, float* out, int act,
-                      float slope, hipStream_t st, int ksplit = 1) {
+// products per fp32 product: 3 (default, fp32-equivalent) or 1 (plain bf16: muvo_conv_set_products)
+static int g_bf3_products = 3;
+void bf3_set_products(int n) { g_bf3_products = n == 1 ? 1 : 3; }
+int bf3_get_products() { return g_bf3_products; }
+
+template <int BM, int BN, int WM, int WN, int BKC, int NST, bool ONE>
+static int bf3_launch_t(const ConvPhase& g, const void* ws, const float* wp, const float* bias, float* out, int act,
+                        float slope, hipStream_t st, int ksplit) {
   constexpr size_t lds0 = (size_t)NST * 2 * BKC * (BM + BN) * 16 + 512 + 4 * BM * WN;   // stages + tap tables + bias rows per wave
   static_assert(lds0 <= 160 * 1024, "LDS budget");
   constexpr size_t HEAD_LDS = NST == 3 ? 4096 : 0;        // eight-wave tiles: room for the weights of a fused head (<= 1024 floats)
@@ -1428,7 +1446,7 @@ static int bf3_launch(const ConvPhase& g, const void* ws, const float* wp, const
   static bool attr_set = false;
   static const uint4* zero16 = nullptr;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv_bf3_kernel<BM, BN, WM, WN, BKC, NST>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)conv_bf3_kernel<BM, BN, WM, WN, BKC, NST, ONE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(lds0 + HEAD_LDS)) != hipSuccess ||
         hipGetSymbolAddress((void**)&zero16, HIP_SYMBOL(g_zero16)) != hipSuccess) {
       muvo_set_error("conv_bf3: kernel attribute / symbol setup failed");
@@ -1438,10 +1456,16 @@ static int bf3_launch(const ConvPhase& g, const void* ws, const float* wp, const
   }
   const long plane_u4 = (long)g.N * g.ID * g.IH * g.IW * (g.Cp / 8);
   dim3 grid(cdiv(g.npix, BN) * cdiv(g.M, BM), ksplit, 1);
-  hipLaunchKernelGGL((conv_bf3_kernel<BM, BN, WM, WN, BKC, NST>), grid, dim3(64 * WM * WN), lds, st, g, (const uint4*)ws, plane_u4,
+  hipLaunchKernelGGL((conv_bf3_kernel<BM, BN, WM, WN, BKC, NST, ONE>), grid, dim3(64 * WM * WN), lds, st, g, (const uint4*)ws, plane_u4,
                      (const uint4*)wp, bias, out, act, slope, zero16, ksplit, hd.w, hd.b, hd.out, hd.co);
   MUVO_CHECK_LAUNCH("conv_bf3_kernel");
   return MUVO_OK;
+}
+template <int BM, int BN, int WM, int WN, int BKC, int NST>
+static int bf3_launch(const ConvPhase& g, const void* ws, const float* wp, const float* bias, float* out, int act,
+                      float slope, hipStream_t st, int ksplit = 1) {
+  return g_bf3_products == 1 ? bf3_launch_t<BM, BN, WM, WN, BKC, NST, true>(g, ws, wp, bias, out, act, slope, st, ksplit)
+                             : bf3_launch_t<BM, BN, WM, WN, BKC, NST, false>(g, ws, wp, bias, out, act, slope, st, ksplit);
 }
 
 // does this phase run on the eight-wave ping-pong tiles (256x128 / 128x256) or on the four-wave 64x128 tile?
@@ -1521,13 +1545,13 @@ static int bf3_wgrad_xcd_order() {
   return v;
 }
 
-template <int BM, int BN, int WM, int WN>
-static int bf3_wgrad_pp_launch(const ConvPhase& g, const void* ws_x, int Cin_total, const void* ws_dz, int Cout_total,
-                               float* wg, hipStream_t st) {
+template <int BM, int BN, int WM, int WN, bool ONE>
+static int bf3_wgrad_pp_launch_t(const ConvPhase& g, const void* ws_x, int Cin_total, const void* ws_dz, int Cout_total,
+                                 float* wg, hipStream_t st) {
   constexpr size_t lds = (size_t)3 * 2 * 32 * (BM / 8 + BN / 8) * 16;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv_bf3_wgrad_pp_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)conv_bf3_wgrad_pp_kernel<BM, BN, WM, WN, ONE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) {
       muvo_set_error("conv_bf3_wgrad_pp: kernel attribute setup failed");
       return MUVO_ERR_HIP;
@@ -1546,20 +1570,26 @@ static int bf3_wgrad_pp_launch(const ConvPhase& g, const void* ws_x, int Cin_tot
   const int sps = cdiv(nsteps, ksplit);
   ksplit = cdiv(nsteps, sps);
   dim3 grid(ctiles * g.T, mtiles, ksplit);
-  hipLaunchKernelGGL((conv_bf3_wgrad_pp_kernel<BM, BN, WM, WN>), grid, dim3(64 * WM * WN), lds, st, p, (const uint4*)ws_x, xplane,
+  hipLaunchKernelGGL((conv_bf3_wgrad_pp_kernel<BM, BN, WM, WN, ONE>), grid, dim3(64 * WM * WN), lds, st, p, (const uint4*)ws_x, xplane,
                      xc8, (const uint4*)ws_dz, dzplane, dzc8, wg, sps, bf3_wgrad_xcd_order());
   MUVO_CHECK_LAUNCH("conv_bf3_wgrad_pp_kernel");
   return MUVO_OK;
 }
+template <int BM, int BN, int WM, int WN>
+static int bf3_wgrad_pp_launch(const ConvPhase& g, const void* ws_x, int Cin_total, const void* ws_dz, int Cout_total,
+                               float* wg, hipStream_t st) {
+  return g_bf3_products == 1 ? bf3_wgrad_pp_launch_t<BM, BN, WM, WN, true>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st)
+                             : bf3_wgrad_pp_launch_t<BM, BN, WM, WN, false>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st);
+}
 
-template <int BM, int BN, int WM, int WN, int WK>
-static int bf3_wgrad_launch(const ConvPhase& g, const void* ws_x, int Cin_total, const void* ws_dz, int Cout_total,
-                            float* wg, hipStream_t st) {
+template <int BM, int BN, int WM, int WN, int WK, bool ONE>
+static int bf3_wgrad_launch_t(const ConvPhase& g, const void* ws_x, int Cin_total, const void* ws_dz, int Cout_total,
+                              float* wg, hipStream_t st) {
   constexpr size_t lds = (size_t)3 * 2 * 32 * (BM / 8 + BN / 8) * 16;
   static bool attr_set = false;
   static const uint4* zero16 = nullptr;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)conv_bf3_wgrad_kernel<BM, BN, WM, WN, WK>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)conv_bf3_wgrad_kernel<BM, BN, WM, WN, WK, ONE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess ||
         hipGetSymbolAddress((void**)&zero16, HIP_SYMBOL(g_zero16)) != hipSuccess) {
       muvo_set_error("conv_bf3_wgrad: kernel attribute / symbol setup failed");
@@ -1579,10 +1609,16 @@ static int bf3_wgrad_launch(const ConvPhase& g, const void* ws_x, int Cin_total,
   const int sps = cdiv(nsteps, ksplit);
   ksplit = cdiv(nsteps, sps);
   dim3 grid(ctiles * g.T, mtiles, ksplit);
-  hipLaunchKernelGGL((conv_bf3_wgrad_kernel<BM, BN, WM, WN, WK>), grid, dim3(64 * WM * WN * WK), lds, st, p, (const uint4*)ws_x, xplane,
+  hipLaunchKernelGGL((conv_bf3_wgrad_kernel<BM, BN, WM, WN, WK, ONE>), grid, dim3(64 * WM * WN * WK), lds, st, p, (const uint4*)ws_x, xplane,
                      xc8, (const uint4*)ws_dz, dzplane, dzc8, wg, sps, zero16, bf3_wgrad_xcd_order());
   MUVO_CHECK_LAUNCH("conv_bf3_wgrad_kernel");
   return MUVO_OK;
+}
+template <int BM, int BN, int WM, int WN, int WK>
+static int bf3_wgrad_launch(const ConvPhase& g, const void* ws_x, int Cin_total, const void* ws_dz, int Cout_total,
+                            float* wg, hipStream_t st) {
+  return g_bf3_products == 1 ? bf3_wgrad_launch_t<BM, BN, WM, WN, WK, true>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st)
+                             : bf3_wgrad_launch_t<BM, BN, WM, WN, WK, false>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st);
 }
 
 // g: a forward-form phase with the fp32-plan wp_off replaced by the float offset of its [T][M][C] slab in wg

@@ -752,6 +752,12 @@ int muvo_conv_set_mode(int mode) {
   return MUVO_OK;
 }
 int muvo_conv_get_mode(void) { return conv_mode(); }
+int muvo_conv_set_products(int n) {
+  MUVO_CHECK_ARG(n == 1 || n == 3, "conv_set_products: 1 (bf16) or 3 (bf16x3), got %d", n);
+  bf3_set_products(n);
+  return MUVO_OK;
+}
+int muvo_conv_get_products(void) { return bf3_get_products(); }
 int muvo_conv_set_bf16x3_min_gflop(double gflop_per_item) {
   g_bf3_min_gflop = gflop_per_item < 0.0 ? -1.0 : gflop_per_item;   // negative: back to the built-in policy
   return MUVO_OK;

@@ -43,6 +43,7 @@ class GemmDesc(C.Structure):
 # every exported symbol of include/muvo_hip.h (tests/test_abi.py checks this list against the header)
 EXPORTS = [
     'muvo_last_error', 'muvo_abi_version', 'muvo_selftest_mfma', 'muvo_set_deterministic', 'muvo_get_deterministic',
+    'muvo_conv_set_products', 'muvo_conv_get_products',
     'muvo_conv_set_mode', 'muvo_conv_get_mode', 'muvo_conv_set_bf16x3_min_gflop', 'muvo_conv_pack_sizes', 'muvo_conv_workspace_bytes', 'muvo_conv_kernel_family', 'muvo_conv_kernel_variant', 'muvo_conv_pack_weights', 'muvo_conv_forward', 'muvo_conv_dgrad', 'muvo_conv_prepare_dy', 'muvo_conv_wgrad', 'muvo_bias_grad_nchw',
     'muvo_gemm',
     'muvo_pack_table_item_bytes', 'muvo_conv_pack_table_add', 'muvo_linear_bf16x3_pack_table_add', 'muvo_pack_table_run',
@@ -135,14 +136,15 @@ def bump_weight_epoch():
     _weight_epoch[0] += 1
 
 
-CONV_F32, CONV_BF16X3 = 0, 1
+CONV_F32, CONV_BF16X3, CONV_BF16 = 0, 1, 2     # CONV_BF16: the bf16x3 kernels with ONE product (extension, see include/muvo_hip.h)
 
 
 def set_conv_mode(mode, min_gflop=None):
     """Select the matrix-pipe arithmetic of the large convolutions (CONV_F32 exact / CONV_BF16X3 split products;
     min_gflop = per-item work below which a phase stays on fp32 MFMA; negative = the library's built-in per-layer policy).  Packed weights and plans depend on it, so both
     caches are invalidated."""
-    _ck(lib().muvo_conv_set_mode(int(mode)))
+    _ck(lib().muvo_conv_set_mode(CONV_BF16X3 if int(mode) == CONV_BF16 else int(mode)))
+    _ck(lib().muvo_conv_set_products(1 if int(mode) == CONV_BF16 else 3))
     if min_gflop is not None:
         _ck(lib().muvo_conv_set_bf16x3_min_gflop(C.c_double(min_gflop)))
     bump_weight_epoch()
@@ -150,7 +152,8 @@ def set_conv_mode(mode, min_gflop=None):
 
 
 def get_conv_mode():
-    return lib().muvo_conv_get_mode()
+    m = lib().muvo_conv_get_mode()
+    return CONV_BF16 if (m == CONV_BF16X3 and lib().muvo_conv_get_products() == 1) else m
 
 
 _plan_epoch = [0]
@@ -282,7 +285,7 @@ def join_side_streams(device=None, into=None):
         (into if into is not None else torch.cuda.current_stream(st.device)).wait_stream(st)
 
 
-BRANCHES = set(os.environ.get('MUVO_STREAM_BRANCHES', 'route,lidar,decoders').split(','))
+BRANCHES = set(os.environ.get('MUVO_STREAM_BRANCHES', 'route,lidar,decoders,wgrad').split(','))
 
 
 def stream_event(device):
@@ -461,6 +464,8 @@ class KernelTiming:
             f = mfma[dom]
             alg = f['tflop'] / max(f['seconds'], 1e-12)
             mult = MFMA_FLOPS_PER_ALGORITHMIC_FLOP[dom]
+            if dom in ('bf16x3_implicit_gemm', 'bf16x3_small_tile') and lib().muvo_conv_get_products() == 1:
+                mult = 1.0        # CONV_BF16: one MFMA product per algorithmic product
             roof = dict(bound='mfma', kernel=KERNEL_NAMES[dom], achieved=alg * mult, peak=PEAK_TFLOPS[dom], unit='TFLOP/s',
                         frac=alg * mult / PEAK_TFLOPS[dom], traffic=None, algorithmic_tflops=alg,
                         mfma_flops_per_algorithmic_flop=mult, launches=f['launches'],

@@ -97,3 +97,46 @@ def test_hip_step_with_extension_matches_own_oracle(dev, mode):
         if abs(got_g[n] - r) > tol * r + 1e-7:
             bad.append((n, got_g[n], r))
     assert not bad, f'{len(bad)} gradient norms off, first {bad[:4]}'
+
+
+@pytest.mark.gpu
+def test_bf16_single_product_mode(dev):
+    """CONV_BF16 (muvo_conv_set_products(1)): the split-product kernels with ONE product - plain bf16 operands, fp32
+    accumulation.  One ConvTranspose stage, one 3x3 convolution and one token-matrix Linear against fp32 PyTorch on the same
+    operands ROUNDED TO BF16 (what the mode computes: 1e-5 relative) and against the unrounded fp32 result (bf16 operand
+    rounding: 2e-2 of the tensor maximum), forward, data and weight gradient; then the mode is switched back."""
+    import torch.nn.functional as F
+    from muvo_amd import nn as hnn
+    from muvo_amd import ops
+    old = ops.get_conv_mode()
+    torch.manual_seed(3)
+    bf = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    try:
+        ops.set_conv_mode(ops.CONV_BF16, min_gflop=0.0)
+        assert ops.get_conv_mode() == ops.CONV_BF16
+        with torch.device(dev):
+            convt = hnn.ConvTranspose2d(128, 64, 6, 2, 2)
+            conv = hnn.Conv2d(64, 64, 3, 1, 1)
+        for m, x, fn in ((convt, torch.randn(4, 128, 20, 52), lambda x, w, b: F.conv_transpose2d(x, w, b, 2, 2)),
+                         (conv, torch.randn(4, 64, 40, 104), lambda x, w, b: F.conv2d(x, w, b, 1, 1))):
+            xg = x.to(dev).requires_grad_(True)
+            m.weight.grad, m.bias.grad = torch.zeros_like(m.weight), torch.zeros_like(m.bias)
+            y = m(xg)
+            g = torch.randn_like(y)
+            y.backward(g)
+            w, b = m.weight.detach().cpu(), m.bias.detach().cpu()
+            for rounded, tol in ((True, 1e-4), (False, 2e-2)):
+                xc = (bf(x) if rounded else x.clone()).requires_grad_(True)
+                wc = (bf(w) if rounded else w.clone()).requires_grad_(True)
+                yr = fn(xc, wc, b)
+                gc = g.cpu()
+                yr.backward(bf(gc) if rounded else gc)
+                for name, got, ref in (('fwd', y, yr), ('dgrad', xg.grad, xc.grad), ('wgrad', m.weight.grad, wc.grad)):
+                    err = (got.detach().cpu() - ref.detach()).abs().max().item()
+                    assert err <= tol * ref.abs().max().item(), (type(m).__name__, name, rounded, err, ref.abs().max().item())
+        # the exact-fp32 and three-product results must differ from the one-product result by about the bf16 rounding
+        ops.set_conv_mode(ops.CONV_BF16X3, min_gflop=0.0)
+        y3 = conv(xg.detach())
+        assert 1e-4 < ((y3 - y.detach()).abs().max() / y3.abs().max()).item() < 2e-2
+    finally:
+        ops.set_conv_mode(old, min_gflop=-1.0)
