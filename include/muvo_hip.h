@@ -366,6 +366,13 @@ int muvo_spatial_loss_fwd(const float* pred, const float* target, int64_t F, int
                           float ignore, float weight, double* stats2, float* loss, void* stream);
 int muvo_spatial_loss_bwd(const float* pred, const float* target, float* dpred, int64_t F, int Ct, int64_t HW, int c0, int c1,
                           int norm, float ignore, float weight, const double* stats2, const float* gout, void* stream);
+/* the same with an explicit pixel mask (F, HW) uint8 instead of `target[:, c0] != ignore` (instance_mask argument of
+ * SpatialRegressionLoss.forward, muvo/losses.py:87-90: LOSSES.RGB_INSTANCE, muvo/trainer.py:303-321); mask NULL = the plain form */
+int muvo_spatial_loss_masked_fwd(const float* pred, const float* target, const uint8_t* mask, int64_t F, int Ct, int64_t HW, int c0,
+                                 int c1, int norm, float ignore, float weight, double* stats2, float* loss, void* stream);
+int muvo_spatial_loss_masked_bwd(const float* pred, const float* target, const uint8_t* mask, float* dpred, int64_t F, int Ct,
+                                 int64_t HW, int c0, int c1, int norm, float ignore, float weight, const double* stats2,
+                                 const float* gout, void* stream);
 /* VoxelLoss (CE mean) + SemScalLoss + GeoScalLoss in one pass; loss3 = {ce, sem_scal, geo_scal} * weight */
 int muvo_voxel_loss_stats_doubles(int C);
 int muvo_voxel_loss_coef_floats(int C);

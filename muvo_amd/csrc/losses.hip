@@ -23,7 +23,8 @@ __device__ __forceinline__ void block_atomic_add_d(double v, double* dst, double
 __global__ void __launch_bounds__(256) spatial_loss_fwd_kernel(const float* __restrict__ pred,
                                                                const float* __restrict__ target, long F, int Ct, long HW,
                                                                int c0, int c1, int norm, float ignore,
-                                                               double* __restrict__ stats, unsigned* ticket) {
+                                                               double* __restrict__ stats, unsigned* ticket,
+                                                               const uint8_t* __restrict__ imask) {
   // grid = (pixel blocks, frames): no 64-bit division per pixel, four consecutive pixels per trip (16-byte loads when
   // HW % 4 == 0), ONE workgroup reduction for both sums (few hundred workgroups: the two atomics are not contended)
   __shared__ double red[2][4];
@@ -47,7 +48,11 @@ __global__ void __launch_bounds__(256) spatial_loss_fwd_kernel(const float* __re
     }
     bool on[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { on[e] = m[e] != ignore && (vec || p0 + e < HW); cnt += on[e] ? 1.f : 0.f; }
+    for (int e = 0; e < 4; ++e) {
+      on[e] = m[e] != ignore && (vec || p0 + e < HW);
+      if (imask != nullptr) on[e] = p0 + e < HW && imask[f * HW + p0 + e] != 0;       // explicit instance mask (losses.py:87-90)
+      cnt += on[e] ? 1.f : 0.f;
+    }
     for (int c = c0; c < c1; ++c) {
       float pv[4], tv[4];
       if (vec) {
@@ -86,13 +91,13 @@ __global__ void spatial_loss_finalize_kernel(const double* __restrict__ stats, f
 __global__ void spatial_loss_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target,
                                         float* __restrict__ dpred, long F, int Ct, long HW, int c0, int c1, int norm,
                                         float ignore, const double* __restrict__ stats, const float* __restrict__ gout,
-                                        float weight) {
+                                        float weight, const uint8_t* __restrict__ imask) {
   const long n = F * HW;
   const float scale = stats[1] > 0.0 ? (float)((double)weight * (double)gout[0] / stats[1]) : 0.f;
   GRID_STRIDE(i, n) {
     const long f = i / HW, p = i - f * HW;
     const long base = f * Ct * HW + p;
-    const bool m = target[base + (long)c0 * HW] != ignore;
+    const bool m = imask != nullptr ? imask[i] != 0 : target[base + (long)c0 * HW] != ignore;
     for (int c = c0; c < c1; ++c) {
       const long idx = base + (long)c * HW;
       const float d = pred[idx] - target[idx];
@@ -532,25 +537,40 @@ seg_ce_bwd_kernel(const float* __restrict__ logits, const unsigned char* __restr
 #define ST ((hipStream_t)stream)
 extern "C" {
 
+int muvo_spatial_loss_masked_fwd(const float* pred, const float* target, const uint8_t* mask, int64_t F, int Ct, int64_t HW, int c0,
+                                 int c1, int norm, float ignore, float weight, double* stats2, float* loss, void* stream);
 int muvo_spatial_loss_fwd(const float* pred, const float* target, int64_t F, int Ct, int64_t HW, int c0, int c1, int norm,
                           float ignore, float weight, double* stats2, float* loss, void* stream) {
+  return muvo_spatial_loss_masked_fwd(pred, target, nullptr, F, Ct, HW, c0, c1, norm, ignore, weight, stats2, loss, stream);
+}
+int muvo_spatial_loss_masked_fwd(const float* pred, const float* target, const uint8_t* mask, int64_t F, int Ct, int64_t HW, int c0,
+                                 int c1, int norm, float ignore, float weight, double* stats2, float* loss, void* stream) {
   MUVO_CHECK_ARG(pred && target && stats2 && loss, "spatial_loss_fwd: null pointer");
   MUVO_CHECK_ARG(F > 0 && HW > 0 && 0 <= c0 && c0 < c1 && c1 <= Ct && (norm == 1 || norm == 2), "spatial_loss_fwd: bad args");
   hipMemsetAsync(stats2, 0, 2 * sizeof(double), ST);
   MUVO_CHECK_ARG(F <= 65535, "spatial_loss_fwd: more than 65535 frames");
   long nbx = (HW / 4 + 1023) / 1024;             // ~4 trips of 4 pixels per thread
   if (nbx * F > 1024) nbx = 1024 / F > 0 ? 1024 / F : 1;
+  if (nbx < 1) nbx = 1;
   hipLaunchKernelGGL(spatial_loss_fwd_kernel, dim3((unsigned)nbx, (unsigned)F), dim3(256), 0, ST, pred, target, (long)F, Ct, (long)HW,
-                     c0, c1, norm, ignore, stats2, muvo_det_ticket(ST));
+                     c0, c1, norm, ignore, stats2, muvo_det_ticket(ST), mask);
   hipLaunchKernelGGL(spatial_loss_finalize_kernel, dim3(1), dim3(64), 0, ST, stats2, loss, weight);
   MUVO_CHECK_LAUNCH("spatial_loss_fwd");
   return MUVO_OK;
 }
+int muvo_spatial_loss_masked_bwd(const float* pred, const float* target, const uint8_t* mask, float* dpred, int64_t F, int Ct,
+                                 int64_t HW, int c0, int c1, int norm, float ignore, float weight, const double* stats2,
+                                 const float* gout, void* stream);
 int muvo_spatial_loss_bwd(const float* pred, const float* target, float* dpred, int64_t F, int Ct, int64_t HW, int c0, int c1,
                           int norm, float ignore, float weight, const double* stats2, const float* gout, void* stream) {
+  return muvo_spatial_loss_masked_bwd(pred, target, nullptr, dpred, F, Ct, HW, c0, c1, norm, ignore, weight, stats2, gout, stream);
+}
+int muvo_spatial_loss_masked_bwd(const float* pred, const float* target, const uint8_t* mask, float* dpred, int64_t F, int Ct,
+                                 int64_t HW, int c0, int c1, int norm, float ignore, float weight, const double* stats2,
+                                 const float* gout, void* stream) {
   MUVO_CHECK_ARG(pred && target && dpred && stats2 && gout, "spatial_loss_bwd: null pointer");
   hipLaunchKernelGGL(spatial_loss_bwd_kernel, dim3(ew_grid(F * HW)), dim3(256), 0, ST, pred, target, dpred, (long)F, Ct,
-                     (long)HW, c0, c1, norm, ignore, stats2, gout, weight);
+                     (long)HW, c0, c1, norm, ignore, stats2, gout, weight, mask);
   MUVO_CHECK_LAUNCH("spatial_loss_bwd");
   return MUVO_OK;
 }

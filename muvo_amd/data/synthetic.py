@@ -116,3 +116,18 @@ def make_bev_labels(b, s, seed, size=(192, 192), n_classes=8, n_instances=6, dev
             inst[f // s, f % s, 0, y0:y0 + hh, x0:x0 + ww] = i + 1
     out = {'birdview_label': bev, 'instance_label': inst}
     return {kk: v.to(device) for kk, v in out.items()} if device != 'cpu' else out
+
+
+def make_image_instance_mask(b, s, seed, image_hw=(600, 960), n_boxes=5, device='cpu'):
+    """`image_instance_mask` (b, s, 1, H, W) bool of LOSSES.RGB_INSTANCE (dataset.py:335-338: vehicle | pedestrian pixels of the
+    camera's semantic image): a few axis-aligned boxes per frame."""
+    k = detinit.name_key(f'imask:{seed}')
+    n = b * s
+    r = detinit.hash_u64(k + 1, n * n_boxes * 4).reshape(n, n_boxes, 4)
+    m = torch.zeros(b, s, 1, *image_hw, dtype=torch.bool)
+    for f in range(n):
+        for i in range(n_boxes):
+            y0, x0 = int(r[f, i, 0] % np.uint64(image_hw[0] - 120)), int(r[f, i, 1] % np.uint64(image_hw[1] - 160))
+            hh, ww = 20 + int(r[f, i, 2] % np.uint64(100)), 30 + int(r[f, i, 3] % np.uint64(130))
+            m[f // s, f % s, 0, y0:y0 + hh, x0:x0 + ww] = True
+    return m.to(device) if device != 'cpu' else m

@@ -6,16 +6,30 @@ import torch.nn as nn
 
 from muvo_amd import ops
 
+VOXEL_SEG_WEIGHTS = (1.0, 1.0, 1.0, 1.5, 2.0, 3.0, 1.0, 1.0, 1.0)      # constants.py:39
+SEMANTIC_SEG_WEIGHTS = (1.0, 1.0, 1.0, 2.0, 3.0, 1.0, 1.0, 1.0)        # constants.py:33
+
 
 class RegressionLoss(nn.Module):
+    """muvo/losses.py:53-71: |d| (norm 1) or d^2 (norm 2) summed over the channel dimension, mean over the rest."""
+
     def __init__(self, norm, channel_dim=-1):
         super().__init__()
-        if norm != 1:
-            raise NotImplementedError('hot path uses RegressionLoss(norm=1) only (trainer.py:57)')
+        if norm not in (1, 2):
+            raise ValueError(f'Expected norm 1 or 2, but got norm={norm}')
+        if channel_dim != -1:
+            raise NotImplementedError('the reference only ever uses the last dimension (trainer.py:57)')
         self.norm = norm
 
     def forward(self, prediction, target):
-        return ops.l1_rows_loss(prediction, target, 1.0)[0]
+        if self.norm == 1:
+            return ops.l1_rows_loss(prediction, target, 1.0)[0]
+        # norm 2 on the masked spatial-loss kernel: rows = "frames" of one pixel, every row counted (all-ones mask)
+        rows = prediction.numel() // prediction.shape[-1]
+        p = prediction.reshape(1, rows, prediction.shape[-1], 1, 1)
+        t = target.reshape(1, rows, prediction.shape[-1], 1, 1).float()
+        ones = torch.ones(1, rows, 1, 1, 1, device=p.device, dtype=torch.uint8)
+        return ops.spatial_losses(p, t, [(0, prediction.shape[-1], 2, 1.0)], mask=ones)[0]
 
 
 class SpatialRegressionLoss(nn.Module):
@@ -27,10 +41,8 @@ class SpatialRegressionLoss(nn.Module):
 
     def forward(self, prediction, target, instance_mask=None):
         assert prediction.dim() == 5, 'Must be a 5D tensor'
-        if instance_mask is not None:
-            raise NotImplementedError('instance_mask (LOSSES.RGB_INSTANCE) is outside the base_1d path')
         c = prediction.shape[2]
-        return ops.spatial_losses(prediction, target, [(0, c, self.norm, 1.0)], float(self.ignore_index))[0]
+        return ops.spatial_losses(prediction, target, [(0, c, self.norm, 1.0)], float(self.ignore_index), mask=instance_mask)[0]
 
 
 class KLLoss(nn.Module):
@@ -53,12 +65,27 @@ class _VoxelTriple(nn.Module):
 
 
 class VoxelLoss(_VoxelTriple):
+    """muvo/losses.py:144-186.  Plain / class-weighted mean: the fused voxel-loss kernel.  Top-k: the per-voxel (weighted) cross
+    entropy map from the segmentation kernels, `topk` over every frame's voxels (a selection), mean."""
     index = 0
 
     def __init__(self, use_top_k=False, top_k_ratio=1.0, use_weights=False, poly_one=False, poly_one_coefficient=0.0):
         super().__init__()
-        if use_top_k or use_weights or poly_one:
-            raise NotImplementedError('VoxelLoss top-k / class weights / poly-1 are off in base_1d (muvo.yml:56-60)')
+        if poly_one:
+            raise NotImplementedError('poly-1 is never enabled by the reference trainer (trainer.py:163-170)')
+        self.use_top_k, self.top_k_ratio = use_top_k, top_k_ratio
+        self.weights = VOXEL_SEG_WEIGHTS if use_weights else None
+
+    def forward(self, prediction, target):
+        cw = torch.tensor(self.weights, dtype=torch.float32, device=prediction.device) if self.weights is not None else None
+        if cw is not None and prediction.shape[2] != len(self.weights):
+            raise ValueError(f'VOXEL_SEG.USE_WEIGHTS needs the {len(self.weights)}-class head (constants.py:39), got {prediction.shape[2]} classes')
+        if not self.use_top_k:
+            return ops.voxel_losses(prediction, target, 1.0, cw)[0]
+        b, s, c = prediction.shape[:3]
+        loss = ops.seg_ce_pixel_loss(prediction.reshape(b * s, c, -1), target.reshape(b * s, -1), cw).view(b, s, -1)
+        k = int(self.top_k_ratio * loss.shape[2])
+        return torch.mean(loss.topk(k, dim=-1)[0])
 
 
 class SemScalLoss(_VoxelTriple):
@@ -69,8 +96,6 @@ class GeoScalLoss(_VoxelTriple):
     index = 2
 
 
-VOXEL_SEG_WEIGHTS = (1.0, 1.0, 1.0, 1.5, 2.0, 3.0, 1.0, 1.0, 1.0)      # constants.py:39
-SEMANTIC_SEG_WEIGHTS = (1.0, 1.0, 1.0, 2.0, 3.0, 1.0, 1.0, 1.0)        # constants.py:33
 
 
 class SegmentationLoss(nn.Module):

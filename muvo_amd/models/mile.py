@@ -41,8 +41,6 @@ class Mile(nn.Module):
             unsupported.append('LIDAR off / POINT_PILLAR')
         if m.MEASUREMENTS.ENABLED or m.REWARD.ENABLED or not m.TRANSITION.ENABLED or not m.ROUTE.ENABLED:
             unsupported.append('MEASUREMENTS/REWARD/TRANSITION off/ROUTE off')
-        if cfg.SEMANTIC_SEG.ENABLED and cfg.EVAL.MASK_VIEW:
-            unsupported.append('EVAL.MASK_VIEW')
         if unsupported:
             raise NotImplementedError('muvo_amd implements the base_1d hot path (SURVEY.md §8); not in scope: '
                                       + ', '.join(unsupported))

@@ -13,6 +13,24 @@ import torch.nn as nn
 from muvo_amd import ops
 
 
+def bev_out_of_view_mask(fov, image_width, resolution, crop_left, crop_right, bev_w, bev_h, offset_forward, camera_forward):
+    """(bev_h, bev_w) bool: True = this bird's-eye-view cell is outside the camera's horizontal field of view or behind the ego
+    vehicle (EVAL.MASK_VIEW; muvo/utils/geometry_utils.py:37-61).  Column u of a ground point (x right, z forward) through a
+    pinhole with the principal point moved by the crop: u = x / z * f + c_u; visible when 0 <= u < cropped width.  Rows run
+    from the far end of the grid towards the vehicle; the rows between camera and grid end are all masked."""
+    import numpy as np
+    f = image_width / (2 * np.tan(fov * np.pi / 360.0))
+    c_u = image_width / 2 - crop_left
+    half = np.round((bev_w // 2) * resolution, decimals=1)
+    cam_off = (bev_h / 2 + offset_forward) * resolution + camera_forward
+    top = np.round(bev_h * resolution - cam_off, decimals=1)
+    x, z = np.arange(-half, half, resolution), np.arange(0.01, top, resolution)
+    u = x / z[:, None] * f + c_u
+    visible = (u >= 0) & (u < crop_right - crop_left)
+    behind = np.ones((int(cam_off / resolution), visible.shape[1]), dtype=bool)
+    return np.vstack([~visible[::-1], behind])
+
+
 class PreProcess(nn.Module):
     def __init__(self, cfg):
         super().__init__()
@@ -25,6 +43,11 @@ class PreProcess(nn.Module):
             raise NotImplementedError('EVAL.RESOLUTION.ENABLED (preprocess.py:209-210: antialiased down-scaling of the input '
                                       'for evaluation) is outside the training hot path (SURVEY.md §8)')
         self._pins = {}
+        self.bev_out_of_view_mask = None
+        if cfg.EVAL.MASK_VIEW:        # preprocess.py:20-21
+            self.bev_out_of_view_mask = torch.from_numpy(bev_out_of_view_mask(
+                cfg.IMAGE.FOV, cfg.IMAGE.SIZE[1], cfg.BEV.RESOLUTION, cfg.IMAGE.CROP[0], cfg.IMAGE.CROP[2], cfg.BEV.SIZE[0],
+                cfg.BEV.SIZE[1], cfg.BEV.OFFSET_FORWARD, cfg.IMAGE.CAMERA_POSITION[0]))
         # state_dict parity with the reference module (preprocess.py:42-43); the kernels take the values as scalars
         self.register_buffer('image_mean', torch.tensor(self.mean).unsqueeze(1).unsqueeze(1))
         self.register_buffer('image_std', torch.tensor(self.std).unsqueeze(1).unsqueeze(1))
@@ -80,6 +103,13 @@ class PreProcess(nn.Module):
             h, w = label1.shape[-2:]
             for f in (2, 4):
                 batch[f'rgb_label_{f}'] = ops.resize_bilinear(batch[f'rgb_label_{f // 2}'], h // f, w // f)
+        if cfg.LOSSES.RGB_INSTANCE and 'image_instance_mask' in batch:     # preprocess.py:115-125,242-243: crop, nearest pyramid
+            left, top, right, bottom = self.crop
+            im = batch['image_instance_mask'][..., top:bottom, left:right].to(torch.uint8).contiguous()
+            batch['image_instance_mask'] = batch['image_instance_mask_1'] = im
+            h, w = im.shape[-2:]
+            for f in (2, 4):
+                batch[f'image_instance_mask_{f}'] = ops.resize_nearest(batch[f'image_instance_mask_{f // 2}'], (h // f, w // f))
         # PixelAugmentation: after the label pyramid, in place on the [0,1] image = rgb_label_1, re-normalising `image`
         if pix_aug is not None and bool(((pix_aug[:, 0] != 0) | (pix_aug[:, 2] != 0)).any()):
             pix_aug = pix_aug if pix_aug.is_cuda else self._to_device(pix_aug, dev)
@@ -94,6 +124,8 @@ class PreProcess(nn.Module):
         # bird's-eye-view labels (preprocess.py:50-100; EVAL.MASK_VIEW off): rotate 90 degrees clockwise, nearest pyramids,
         # instance ids -> centre heat map + offsets at every scale (sigma / scale)
         if cfg.SEMANTIC_SEG.ENABLED and 'birdview_label' in batch:
+            if self.bev_out_of_view_mask is not None:      # preprocess.py:52-54: cells the camera cannot see -> class 0, in place
+                batch['birdview_label'][:, :, :, self.bev_out_of_view_mask.to(batch['birdview_label'].device)] = 0
             bev = torch.rot90(batch['birdview_label'], k=-1, dims=[3, 4]).to(torch.uint8).contiguous()
             batch['birdview_label'] = bev
             batch['birdview_label_1'] = bev
@@ -101,6 +133,8 @@ class PreProcess(nn.Module):
             for f in (2, 4):
                 batch[f'birdview_label_{f}'] = ops.resize_nearest(batch[f'birdview_label_{f // 2}'], (h // f, w // f))
         if cfg.SEMANTIC_SEG.ENABLED and 'instance_label' in batch:
+            if self.bev_out_of_view_mask is not None:      # preprocess.py:70-72
+                batch['instance_label'][:, :, :, self.bev_out_of_view_mask.to(batch['instance_label'].device)] = 0
             inst = torch.rot90(batch['instance_label'], k=-1, dims=[3, 4]).to(torch.uint8).contiguous()
             batch['instance_label'] = inst
             sigma, ign = cfg.INSTANCE_SEG.CENTER_LABEL_SIGMA_PX, cfg.INSTANCE_SEG.IGNORE_INDEX

@@ -57,7 +57,7 @@ EXPORTS = [
     'muvo_preprocess_route', 'muvo_divide_scalar', 'muvo_resize_bilinear', 'muvo_resize_nearest_f32',
     'muvo_resize_nearest_u8', 'muvo_softmax_dropout_fwd', 'muvo_softmax_dropout_bwd', 'muvo_gru_fwd', 'muvo_gru_bwd',
     'muvo_rssm_sample_fwd', 'muvo_rssm_sample_bwd',
-    'muvo_spatial_loss_fwd', 'muvo_spatial_loss_bwd', 'muvo_voxel_loss_stats_doubles', 'muvo_voxel_loss_coef_floats',
+    'muvo_spatial_loss_fwd', 'muvo_spatial_loss_bwd', 'muvo_spatial_loss_masked_fwd', 'muvo_spatial_loss_masked_bwd', 'muvo_voxel_loss_stats_doubles', 'muvo_voxel_loss_coef_floats',
     'muvo_voxel_loss_fwd', 'muvo_voxel_loss_bwd', 'muvo_l1_rows_fwd', 'muvo_l1_rows_bwd', 'muvo_kl_loss_fwd',
     'muvo_kl_loss_bwd', 'muvo_adamw_step',
     'muvo_ssim_frames', 'muvo_sqdiff_frames', 'muvo_chamfer_sums', 'muvo_ssc_counts',
@@ -2176,36 +2176,40 @@ class SpatialLossFn(torch.autograd.Function):
     `parts` = list of (c0, c1, norm, weight); returns one scalar per part (stacked 1-D tensor)."""
 
     @staticmethod
-    def forward(ctx, pred, target, parts, ignore):
+    def forward(ctx, pred, target, parts, ignore, mask=None):
+        # mask: optional explicit (B, S, 1, H, W) uint8 / bool pixel mask (SpatialRegressionLoss(..., instance_mask), losses.py:87-90)
         pred, target = pred.contiguous(), target.contiguous()
         b, s, c, h, w = pred.shape
         f, hw = b * s, h * w
+        if mask is not None:
+            mask = mask.to(torch.uint8).contiguous()
+            assert mask.numel() == f * hw
         losses = torch.empty(len(parts), device=pred.device, dtype=torch.float32)
         stats = torch.empty(len(parts), 2, device=pred.device, dtype=torch.float64)
         for i, (c0, c1, norm, weight) in enumerate(parts):
-            _ck(lib().muvo_spatial_loss_fwd(_f(pred), _f(target), _i64(f), c, _i64(hw), c0, c1, norm, _fl(ignore),
-                                            _fl(weight), C.c_void_p(stats.data_ptr() + 16 * i),
-                                            C.c_void_p(losses.data_ptr() + 4 * i), _st()))
+            _ck(lib().muvo_spatial_loss_masked_fwd(_f(pred), _f(target), _p(mask), _i64(f), c, _i64(hw), c0, c1, norm, _fl(ignore),
+                                                   _fl(weight), C.c_void_p(stats.data_ptr() + 16 * i),
+                                                   C.c_void_p(losses.data_ptr() + 4 * i), _st()))
         ctx.parts, ctx.ignore, ctx.dims = parts, ignore, (f, c, hw)
-        ctx.save_for_backward(pred, target, stats)
+        ctx.save_for_backward(pred, target, stats, mask)
         return losses
 
     @staticmethod
     def backward(ctx, g):
-        pred, target, stats = ctx.saved_tensors
+        pred, target, stats, mask = ctx.saved_tensors
         f, c, hw = ctx.dims
         g = g.contiguous()
         covered = sum(c1 - c0 for c0, c1, _, _ in ctx.parts)
         dpred = torch.empty_like(pred) if covered == c else torch.zeros_like(pred)
         for i, (c0, c1, norm, weight) in enumerate(ctx.parts):
-            _ck(lib().muvo_spatial_loss_bwd(_f(pred), _f(target), _f(dpred), _i64(f), c, _i64(hw), c0, c1, norm,
-                                            _fl(ctx.ignore), _fl(weight), C.c_void_p(stats.data_ptr() + 16 * i),
-                                            C.c_void_p(g.data_ptr() + 4 * i), _st()))
-        return dpred, None, None, None
+            _ck(lib().muvo_spatial_loss_masked_bwd(_f(pred), _f(target), _p(mask), _f(dpred), _i64(f), c, _i64(hw), c0, c1, norm,
+                                                   _fl(ctx.ignore), _fl(weight), C.c_void_p(stats.data_ptr() + 16 * i),
+                                                   C.c_void_p(g.data_ptr() + 4 * i), _st()))
+        return dpred, None, None, None, None
 
 
-def spatial_losses(pred, target, parts, ignore=255.0):
-    return SpatialLossFn.apply(pred, target, parts, ignore)
+def spatial_losses(pred, target, parts, ignore=255.0, mask=None):
+    return SpatialLossFn.apply(pred, target, parts, ignore, mask)
 
 
 class VoxelLossFn(torch.autograd.Function):

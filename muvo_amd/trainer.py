@@ -215,6 +215,9 @@ class WorldModelTrainer(_Base):
                 w = 0.1 * (1 / f)  # rgb_weight literal 0.1 (trainer.py:296)
                 pred = output[f'rgb_{f}']
                 losses[f'rgb_{f}'] = ops.spatial_losses(pred, batch[f'rgb_label_{f}'], [(0, pred.shape[2], 1, w)])[0]
+                if cfg.LOSSES.RGB_INSTANCE:       # trainer.py:303-321: + 0.5 x the same L1 over the vehicle / pedestrian pixels
+                    losses[f'rgb_{f}'] = losses[f'rgb_{f}'] + ops.spatial_losses(
+                        pred, batch[f'rgb_label_{f}'], [(0, pred.shape[2], 1, 0.5 * w)], mask=batch[f'image_instance_mask_{f}'])[0]
                 if cfg.LOSSES.SSIM:               # trainer.py:312-318: 0.6 * (1 - mean SSIM), same rgb weight and discount
                     if '_ssim_loss' not in self.__dict__:
                         from .losses import SSIMLoss
@@ -246,8 +249,17 @@ class WorldModelTrainer(_Base):
         if cfg.VOXEL_SEG.ENABLED:
             for f in (1, 2, 4):
                 w = (1 / f) * cfg.LOSSES.WEIGHT_VOXEL
-                three = ops.voxel_losses(output[f'voxel_{f}'], batch[f'voxel_label_{f}'], w)
+                vs = cfg.VOXEL_SEG
+                cw = None
+                if vs.USE_WEIGHTS:                # constants.py:39 through VoxelLoss(use_weights) (losses.py:155-165)
+                    from .losses import VOXEL_SEG_WEIGHTS
+                    cw = torch.tensor(VOXEL_SEG_WEIGHTS, dtype=torch.float32, device=output[f'voxel_{f}'].device)
+                three = ops.voxel_losses(output[f'voxel_{f}'], batch[f'voxel_label_{f}'], w, cw)
                 losses[f'voxel_{f}'] = three[0]
+                if vs.USE_TOP_K:                  # losses.py:179-184: the k hardest voxels of every frame
+                    from .losses import VoxelLoss
+                    crit = self.__dict__.setdefault('_voxel_topk', VoxelLoss(True, vs.TOP_K_RATIO, vs.USE_WEIGHTS))
+                    losses[f'voxel_{f}'] = crit(output[f'voxel_{f}'], batch[f'voxel_label_{f}']) * w
                 losses[f'sem_scal_{f}'] = three[1]
                 losses[f'geo_scal_{f}'] = three[2]
         return losses

@@ -33,6 +33,24 @@ def base_1d_cfg() -> dict:
     )
 
 
+def bev_out_of_view_mask(fov, image_width, resolution, crop_left, crop_right, bev_w, bev_h, offset_forward, camera_forward):
+    """(bev_h, bev_w) bool: True = this bird's-eye-view cell is outside the camera's horizontal field of view or behind the ego
+    vehicle (EVAL.MASK_VIEW; muvo/utils/geometry_utils.py:37-61).  Column u of a ground point (x right, z forward) through a
+    pinhole with the principal point moved by the crop: u = x / z * f + c_u; visible when 0 <= u < cropped width.  Rows run
+    from the far end of the grid towards the vehicle; the rows between camera and grid end are all masked."""
+    import numpy as np
+    f = image_width / (2 * np.tan(fov * np.pi / 360.0))
+    c_u = image_width / 2 - crop_left
+    half = np.round((bev_w // 2) * resolution, decimals=1)
+    cam_off = (bev_h / 2 + offset_forward) * resolution + camera_forward
+    top = np.round(bev_h * resolution - cam_off, decimals=1)
+    x, z = np.arange(-half, half, resolution), np.arange(0.01, top, resolution)
+    u = x / z[:, None] * f + c_u
+    visible = (u >= 0) & (u < crop_right - crop_left)
+    behind = np.ones((int(cam_off / resolution), visible.shape[1]), dtype=bool)
+    return np.vstack([~visible[::-1], behind])
+
+
 # --------------------------------------------------------------------------- preprocess
 def _tv_blend(a, b, ratio):
     """torchvision _blend for float images: clamp(ratio*a + (1-ratio)*b, 0, 1)."""
@@ -154,6 +172,15 @@ def preprocess(batch: Dict[str, torch.Tensor], cfg: dict, pixel_aug=None, route_
         prev = F.interpolate(prev.flatten(0, 1), size=(h // f, w // f), mode='bilinear',
                              align_corners=False).view(b, s, 3, h // f, w // f)
         out[f'rgb_label_{f}'] = prev
+    # LOSSES.RGB_INSTANCE (preprocess.py:115-125,242-243): the instance mask is cropped like the image, nearest pyramid
+    if 'image_instance_mask' in batch:
+        im = batch['image_instance_mask'][..., top:bottom, left:right]
+        out['image_instance_mask'] = out['image_instance_mask_1'] = im
+        h, w = im.shape[-2:]
+        prev = im
+        for f in (2, 4):
+            prev = F.interpolate(prev.flatten(0, 1).float(), size=(h // f, w // f), mode='nearest').to(im.dtype).view(b, s, 1, h // f, w // f)
+            out[f'image_instance_mask_{f}'] = prev
     # range view (preprocess.py:150-162)
     rv = batch['range_view_pcd_xyzd'].float() / cfg['LIDAR_RE_SCALE']
     out['range_view_pcd_xyzd'] = rv
@@ -173,7 +200,12 @@ def preprocess(batch: Dict[str, torch.Tensor], cfg: dict, pixel_aug=None, route_
             b, s, 1, x // f, y // f, z // f)
         out[f'voxel_label_{f}'] = prev
     # bird's-eye-view labels, when present (preprocess.py:50-100, EVAL.MASK_VIEW off)
+    view_mask = None
+    if cfg.get('MASK_VIEW'):         # EVAL.MASK_VIEW (preprocess.py:20-21,52-54,70-72) with the default geometry (config.py:111-141)
+        view_mask = torch.from_numpy(bev_out_of_view_mask(*cfg.get('MASK_VIEW_GEOMETRY', (100, 960, 0.2, 64, 896, 192, 192, -64, 1.0))))
     if 'birdview_label' in batch:
+        if view_mask is not None:
+            batch['birdview_label'][:, :, :, view_mask] = 0
         bev = torch.rot90(batch['birdview_label'], k=-1, dims=[3, 4]).contiguous()
         out['birdview_label'] = out['birdview_label_1'] = bev
         h, w = bev.shape[-2:]
@@ -182,6 +214,8 @@ def preprocess(batch: Dict[str, torch.Tensor], cfg: dict, pixel_aug=None, route_
             prev = F.interpolate(prev.flatten(0, 1).float(), size=(h // f, w // f), mode='nearest').to(bev.dtype).view(b, s, 1, h // f, w // f)
             out[f'birdview_label_{f}'] = prev
     if 'instance_label' in batch:
+        if view_mask is not None:
+            batch['instance_label'][:, :, :, view_mask] = 0
         inst = torch.rot90(batch['instance_label'], k=-1, dims=[3, 4]).contiguous()
         out['instance_label'] = out['instance_label_1'] = inst
         out['center_label_1'], out['offset_label_1'] = instance_center_offset(inst, 255, 4.0)    # config.py:234-235
@@ -783,9 +817,9 @@ def imagine(model, state, future_horizon, noise):
 
 
 # --------------------------------------------------------------------------- losses
-def _spatial_regression(pred, target, norm):
-    """losses.py:74-99 (mask = target channel 0 != 255; channel-sum; masked mean)."""
-    mask = target[:, :, :1] != 255
+def _spatial_regression(pred, target, norm, instance_mask=None):
+    """losses.py:74-99 (mask = the given instance mask, else target channel 0 != 255; channel-sum; masked mean)."""
+    mask = instance_mask.bool() if instance_mask is not None else target[:, :, :1] != 255
     if mask.sum() == 0:
         return pred.new_zeros(())
     loss = (pred - target).abs() if norm == 1 else (pred - target) ** 2
@@ -859,7 +893,10 @@ def compute_losses(batch, out, cfg) -> Dict[str, torch.Tensor]:
         L['probabilistic'] = cfg['W_PROB'] * kl
     for f in (1, 2, 4):
         d = 1 / f
-        L[f'rgb_{f}'] = cfg['W_RGB'] * d * _spatial_regression(out[f'rgb_{f}'], batch[f'rgb_label_{f}'], 1)
+        rgb = _spatial_regression(out[f'rgb_{f}'], batch[f'rgb_label_{f}'], 1)
+        if cfg.get('RGB_INSTANCE'):              # LOSSES.RGB_INSTANCE (trainer.py:303-321): + 0.5 x the same L1 over the instance pixels
+            rgb = rgb + 0.5 * _spatial_regression(out[f'rgb_{f}'], batch[f'rgb_label_{f}'], 1, batch[f'image_instance_mask_{f}'])
+        L[f'rgb_{f}'] = cfg['W_RGB'] * d * rgb
         if cfg.get('SSIM'):                      # LOSSES.SSIM (trainer.py:312-318): 0.6 * (1 - mean SSIM)
             L[f'ssim_{f}'] = cfg['W_RGB'] * d * (1 - ssim_frames(out[f'rgb_{f}'], batch[f'rgb_label_{f}']).mean()) * 0.6
     for f in (1, 2, 4):
@@ -871,7 +908,15 @@ def compute_losses(batch, out, cfg) -> Dict[str, torch.Tensor]:
         d = 1 / f
         logits = out[f'voxel_{f}'].flatten(0, 1)
         tgt = batch[f'voxel_label_{f}'].flatten(0, 1)[:, 0]
-        L[f'voxel_{f}'] = d * cfg['W_VOXEL'] * F.cross_entropy(logits, tgt.long(), reduction='none').mean()
+        # VoxelLoss (losses.py:144-186): VOXEL_SEG.USE_WEIGHTS -> VOXEL_SEG_WEIGHTS (needs the 9-class head), USE_TOP_K -> mean of the
+        # k = int(ratio * voxels) hardest voxels of every frame
+        vw = torch.tensor(VOXEL_SEG_WEIGHTS, dtype=logits.dtype) if cfg.get('VOXEL_USE_WEIGHTS') else None
+        ce = F.cross_entropy(logits, tgt.long(), reduction='none', weight=vw)
+        if cfg.get('VOXEL_USE_TOP_K'):
+            bb, ss = out[f'voxel_{f}'].shape[:2]
+            ce = ce.view(bb, ss, -1)
+            ce = ce.topk(int(cfg.get('VOXEL_TOP_K_RATIO', 0.5) * ce.shape[2]), dim=-1)[0]
+        L[f'voxel_{f}'] = d * cfg['W_VOXEL'] * ce.mean()
         L[f'sem_scal_{f}'] = d * cfg['W_VOXEL'] * _sem_scal(logits, tgt)
         L[f'geo_scal_{f}'] = d * cfg['W_VOXEL'] * _geo_scal(logits, tgt)
     # config-off heads (trainer.py:266-291,338-365), when the model produced them

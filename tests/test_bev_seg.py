@@ -109,3 +109,54 @@ def test_hip_bev_seg_step_matches_reference(dev):
     bad = [f'{n} x{params[n].grad.double().pow(2).sum().sqrt().item() / max(ref, 1e-30):.4f}' for n, ref in fx['grad_l2'].items()
            if abs(params[n].grad.double().pow(2).sum().sqrt().item() - ref) > 5e-3 * max(ref, 1e-12) + 1e-7]
     assert not bad, '; '.join(bad)
+
+
+def test_mask_view_matches_reference_function():
+    """EVAL.MASK_VIEW: the out-of-view mask of the oracle and of the product against the REAL reference function
+    (tests/golden/maskview.npz: geometry_utils.get_out_of_view_mask for three geometries), bit for bit; PreProcess applies it to
+    the bird's-eye-view and instance labels before the rotation (preprocess.py:52-54,70-72)."""
+    from muvo_amd.models.preprocess import bev_out_of_view_mask as prod
+    from oracle.muvo_ref import bev_out_of_view_mask as orc
+    fx = np.load(os.path.join(GOLD, 'maskview.npz'))
+    for tag in ('default', 'fov60', 'offset'):
+        shape = tuple(int(v) for v in fx[f'{tag}_shape'])
+        ref = np.unpackbits(fx[f'{tag}_bits'])[:shape[0] * shape[1]].astype(bool).reshape(shape)
+        c = fx[f'{tag}_cfg']
+        args = (c[0], c[1], c[2], c[3], c[4], int(c[5]), int(c[6]), c[7], c[8])
+        for fn in (prod, orc):
+            got = fn(*args)
+            assert got.shape == shape and got.dtype == bool
+            assert np.array_equal(got, ref), (tag, fn.__module__, int((got != ref).sum()))
+
+
+def test_oracle_preprocess_applies_mask_view():
+    import torch
+    from oracle import muvo_ref as R
+    from muvo_amd.data.synthetic import make_batch, make_bev_labels
+    batch = make_batch(1, 1, seed=5)
+    batch.update(make_bev_labels(1, 1, 5))
+    plain = R.preprocess({k: v.clone() for k, v in batch.items()}, R.base_1d_cfg())
+    masked = R.preprocess({k: v.clone() for k, v in batch.items()}, dict(R.base_1d_cfg(), MASK_VIEW=True))
+    m = torch.rot90(torch.from_numpy(R.bev_out_of_view_mask(100, 960, 0.2, 64, 896, 192, 192, -64, 1.0)), k=-1, dims=[0, 1])
+    assert (masked['birdview_label_1'][0, 0, 0][m] == 0).all() and (masked['instance_label_1'][0, 0, 0][m] == 0).all()
+    assert torch.equal(masked['birdview_label_1'][0, 0, 0][~m], plain['birdview_label_1'][0, 0, 0][~m])
+
+
+@pytest.mark.gpu
+def test_hip_preprocess_mask_view(dev):
+    """PreProcess with EVAL.MASK_VIEW + SEMANTIC_SEG on the GPU against the oracle's preprocess: label pyramids bit-exact."""
+    import torch
+    from muvo_amd.config import base_1d_cfg
+    from muvo_amd.data.synthetic import make_batch, make_bev_labels
+    from muvo_amd.models.preprocess import PreProcess
+    from oracle import muvo_ref as R
+    cfg = base_1d_cfg()
+    cfg.SEMANTIC_SEG.ENABLED, cfg.EVAL.MASK_VIEW = True, True
+    pp = PreProcess(cfg).to(dev).eval()
+    batch = make_batch(1, 2, seed=9)
+    batch.update(make_bev_labels(1, 2, 9))
+    ref = R.preprocess({k: v.clone() for k, v in batch.items()}, dict(R.base_1d_cfg(), MASK_VIEW=True))
+    got = pp({k: v.to(dev) for k, v in batch.items()})
+    for k in ('birdview_label_1', 'birdview_label_2', 'birdview_label_4', 'instance_label_1', 'instance_label_4'):
+        assert torch.equal(got[k].cpu().long(), ref[k].long()), k
+    assert (ref['birdview_label_1'] == 0).sum() > (R.preprocess({k: v.clone() for k, v in batch.items()}, R.base_1d_cfg())['birdview_label_1'] == 0).sum()
