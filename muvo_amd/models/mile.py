@@ -105,6 +105,9 @@ class Mile(nn.Module):
         # data-parallel gradient overlap: called with a segment name (muvo_amd/param_store.SEGMENTS) from autograd
         # hooks the moment backward has finished that segment's parameters
         self.segment_done = None
+        # latent memory of deployment_forward / sim_forward (mile.py:399-402)
+        self.last_h = self.last_sample = self.last_action = None
+        self.count = 0
         self._step_seed = 0
         self.dropout_seed = 0x5EED
         self.dropout_rank = 0     # data-parallel rank (set by WorldModelTrainer.configure_optimizers)
@@ -138,7 +141,8 @@ class Mile(nn.Module):
 
     def forward(self, batch, deployment=False, noise=None, use_prior=None):
         if deployment:
-            raise NotImplementedError('deployment_forward is outside the training hot path')
+            raise NotImplementedError('Mile.forward(deployment=True) (mile.py:404-489: the whole-sequence deployment variant) is not '
+                                      'built; the closed-loop callers use deployment_forward / sim_forward, which are')
         dev = batch['image'].device
         embedding = self.encode(batch)
         b, s = batch['image'].shape[:2]
@@ -173,6 +177,84 @@ class Mile(nn.Module):
         for br in joins:
             br.join()
         return output, state_dict
+
+    # ------------------------------------------------------------------ closed-loop inference (mile.py:852-1032)
+    CARLA_FPS = 10              # constants.py:3
+
+    def _advance_latent(self, batch, action_prev, is_dreaming, frame):
+        """encode frame `frame` of the (past-free) batch and advance (last_h, last_sample) one step with `action_prev`"""
+        b = batch['image'].shape[0]
+        embedding_t = self.encode({k: v[:, frame:frame + 1].contiguous() if frame is not None else v for k, v in batch.items()})[:, -1]
+        m = self.cfg.MODEL.TRANSITION
+        if self.last_h is None:
+            h_t = action_prev.new_zeros(b, m.HIDDEN_STATE_DIM)
+            sample_t = action_prev.new_zeros(b, m.STATE_DIM)
+        else:
+            h_t, sample_t = self.last_h, self.last_sample
+        if is_dreaming:
+            out = self.rssm.imagine_step(h_t, sample_t, action_prev.contiguous(), use_sample=False, policy=self.policy)
+        else:
+            out = self.rssm.observe_step(h_t, sample_t, action_prev.contiguous(), embedding_t, use_sample=False,
+                                         policy=self.policy)['posterior']
+        self.last_h, self.last_sample = out['hidden_state'], out['sample']
+        self.count = int(self.CARLA_FPS * self.cfg.DATASET.STRIDE_SEC) - 1
+
+    def _policy_output(self, b):
+        state = ops.cat_last([self.last_h, self.last_sample])
+        pol = self.policy(state)
+        return state, {'throttle_brake': unpack_sequence_dim(ops.slice_last(pol, 0, 1), b, 1),
+                       'steering': unpack_sequence_dim(ops.slice_last(pol, 1, 2), b, 1),
+                       'hidden_state': self.last_h, 'sample': self.last_sample}
+
+    @torch.no_grad()
+    def deployment_forward(self, batch, is_dreaming):
+        """mile.py:852-923: keep the latent state between calls; every int(CARLA_FPS * DATASET.STRIDE_SEC) calls the newest
+        frame is encoded and the state advanced with batch['action'][:, -2]; the other calls only re-evaluate the policy."""
+        assert self.cfg.MODEL.TRANSITION.ENABLED
+        b = batch['image'].shape[0]
+        if self.count == 0:
+            s = batch['image'].shape[1]
+            action_t = batch['action'][:, -2]
+            cut = {k: v[:, s - 1:].contiguous() for k, v in batch.items()}       # remove_past(batch, s)
+            self._advance_latent(cut, action_t, is_dreaming, None)
+        else:
+            self.count -= 1
+        state, output = self._policy_output(b)
+        if self.cfg.SEMANTIC_SEG.ENABLED:                                        # constants.DISPLAY_SEGMENTATION = True
+            output.update(unpack_sequence_dim(self.bev_decoder(state), b, 1))
+        return output
+
+    @torch.no_grad()
+    def sim_forward(self, batch, is_dreaming, noise=None):
+        """mile.py:925-1032 (sim_run.py:72-73): like deployment_forward, but the state advances with the action of the PREVIOUS
+        call, every decoder renders the current state, and the remaining frames of the batch are imagined from it."""
+        assert self.cfg.MODEL.TRANSITION.ENABLED
+        b = batch['image'].shape[0]
+        if self.count == 0:
+            s = self.receptive_field
+            batch = {k: v[:, s - 1:].contiguous() for k, v in batch.items()}     # remove_past(batch, receptive_field)
+            action_t = ops.cat_last([batch['throttle_brake'][:, 0].contiguous(), batch['steering'][:, 0].contiguous()])
+            action_last = torch.zeros_like(action_t) if self.last_action is None else self.last_action
+            self._advance_latent(batch, action_last, is_dreaming, 0)
+            self.last_action = action_t
+        else:
+            self.count -= 1
+        state, output = self._policy_output(b)
+        if self.cfg.SEMANTIC_SEG.ENABLED:
+            output.update(unpack_sequence_dim(self.bev_decoder(state), b, 1))
+        if self.cfg.EVAL.RGB_SUPERVISION:
+            output.update(unpack_sequence_dim(self.rgb_decoder(state), b, 1))
+        if self.cfg.LIDAR_RE.ENABLED:
+            output.update(unpack_sequence_dim(self.lidar_re(state), b, 1))
+        output.update(self._aux_heads(state, b, 1))
+        if self.cfg.VOXEL_SEG.ENABLED:
+            output.update(unpack_sequence_dim(self.voxel_decoder(state), b, 1))
+        state_imagine = {'hidden_state': self.last_h, 'sample': self.last_sample, 'throttle_brake': batch['throttle_brake'],
+                         'steering': batch['steering']}
+        fh = batch['image'].shape[1] - 1
+        # (noise: optional explicit (b, fh, S) draws of the imagined steps for parity runs; the reference draws them)
+        output_imagine = self.imagine(state_imagine, predict_action=False, future_horizon=fh, noise=noise) if fh > 0 else {}
+        return output, output_imagine
 
     def imagine(self, batch, predict_action=False, future_horizon=None, noise=None):
         """Mile.imagine (mile.py:771-850): roll the prior forward from (hidden_state, sample) with the recorded actions (or

@@ -80,6 +80,15 @@ class RSSM(nn.Module):
         return {'prior': {k: ops.stack_time(v) for k, v in prior.items()},
                 'posterior': {k: ops.stack_time(v) for k, v in post.items()}}
 
+    def observe_step(self, h_t, sample_t, action_t, embedding_t, use_sample=True, policy=None, eps=None, eps_prior=None):
+        """transition.py:130-149: the imagine step, then the posterior from (h, embedding, action latent)."""
+        prior = self.imagine_step(h_t, sample_t, action_t, use_sample, policy=policy, eps=eps_prior)
+        la = self.posterior_action_module[0](action_t)
+        if use_sample and eps is None:
+            eps = torch.randn(h_t.shape[0], self.state_dim, device=h_t.device)
+        mu, sigma, sample = self.posterior(ops.cat_last([prior['hidden_state'], embedding_t.contiguous(), la]), eps if use_sample else None)
+        return {'prior': prior, 'posterior': {'hidden_state': prior['hidden_state'], 'sample': sample, 'mu': mu, 'sigma': sigma}}
+
     def imagine_step(self, h_t, sample_t, action_t, use_sample=True, policy=None, eps=None):
         """transition.py:151-173: one prior roll-out step (eps: the explicit N(0,1) draw, generated when None)."""
         if self.active_inference:

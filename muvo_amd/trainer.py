@@ -93,6 +93,12 @@ class WorldModelTrainer(_Base):
         output, state_dict = self.model.forward(batch, deployment=deployment, noise=noise, use_prior=use_prior)
         return output, state_dict
 
+    def deployment_forward(self, batch, is_dreaming):
+        """trainer.py:218-221"""
+        ops.repack_all()
+        batch = self.preprocess(batch)
+        return self.model.deployment_forward(batch, is_dreaming)
+
     def shared_step(self, batch, mode='train', predict_action=False, noise=None, use_prior=None):
         """trainer.py:223-249.  mode='train': reconstruction of the whole sequence.  Otherwise: reconstruct the first
         RECEPTIVE_FIELD frames, then imagine FUTURE_HORIZON steps from the last posterior state and score them against the

@@ -421,6 +421,59 @@ class RSSM(nn.Module):
         return h, pm + ps * eps, pm, ps
 
 
+def rssm_observe_step(rssm, h, z, a, emb, eps_prior, eps_post):
+    """RSSM.observe_step (transition.py:130-149): the imagine step, then the posterior from (h, embedding, action latent).
+    eps = 0 reproduces use_sample=False (the sample is the mean).  Returns (h, prior sample, posterior sample, mu_q, sigma_q)."""
+    h, zp, _, _ = rssm.imagine_step(h, z, a, eps_prior)
+    qm, qs = rssm.posterior(torch.cat([h, emb, rssm.posterior_action_module(a)], -1))
+    return h, zp, qm + qs * eps_post, qm, qs
+
+
+class SimState:
+    """the latent memory deployment_forward / sim_forward keep between calls (mile.py:399-402)"""
+
+    def __init__(self):
+        self.last_h = self.last_sample = self.last_action = None
+        self.count = 0
+
+
+def sim_forward(model, state: SimState, batch, is_dreaming, receptive_field, stride_frames):
+    """Mile.sim_forward (mile.py:925-1032) on a preprocessed batch, use_sample=False everywhere except the imagination, whose
+    noise is zero here too (deterministic restatement: the reference draws it).  Every `stride_frames` calls (int(CARLA_FPS *
+    DATASET.STRIDE_SEC), constants.py:3) the newest frame is encoded and the latent state advanced with the PREVIOUS call's
+    action; the calls in between only count down.  Returns (output, output_imagine)."""
+    b = batch['image'].shape[0]
+    if state.count == 0:
+        cut = {k: v[:, receptive_field - 1:].contiguous() for k, v in batch.items()}      # remove_past
+        action_t = torch.cat([cut['throttle_brake'][:, 0], cut['steering'][:, 0]], -1)
+        emb = model.encode({k: v[:, :1] for k, v in cut.items()})[:, -1]
+        a_last = torch.zeros_like(action_t) if state.last_action is None else state.last_action
+        H, S = model.cfg['HIDDEN_STATE_DIM'], model.cfg['STATE_DIM']
+        h = action_t.new_zeros(b, H) if state.last_h is None else state.last_h
+        z = action_t.new_zeros(b, S) if state.last_h is None else state.last_sample
+        zero = torch.zeros(b, S)
+        if is_dreaming:
+            h, z, _, _ = model.rssm.imagine_step(h, z, a_last, zero)
+        else:
+            h, _, z, _, _ = rssm_observe_step(model.rssm, h, z, a_last, emb, zero, zero)
+        state.last_h, state.last_sample, state.last_action = h, z, action_t
+        state.count = stride_frames - 1
+        batch = cut
+    else:
+        state.count -= 1
+    st = torch.cat([state.last_h, state.last_sample], -1)
+    pol = model.policy(st)
+    out = {'throttle_brake': pol[:, :1].view(b, 1, 1), 'steering': pol[:, 1:].view(b, 1, 1), 'hidden_state': state.last_h,
+           'sample': state.last_sample}
+    for dec in (model.rgb_decoder, model.lidar_re, model.voxel_decoder) + model.aux_decoders():
+        for k, v in dec(st).items():
+            out[k] = v.view(b, 1, *v.shape[1:])
+    fh = batch['image'].shape[1] - 1
+    imag = imagine(model, {'hidden_state': state.last_h, 'sample': state.last_sample, 'throttle_brake': batch['throttle_brake'],
+                           'steering': batch['steering']}, fh, torch.zeros(b, max(fh, 1), model.cfg['STATE_DIM'])) if fh > 0 else {}
+    return out, imag
+
+
 class Policy(nn.Module):
     """common.py:53-68."""
 
