@@ -11,10 +11,10 @@ import os
 import sys
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import muvo_amd  # noqa: E402,F401  (sets GPU_MAX_HW_QUEUES before the HIP runtime initialises)
+import torch  # noqa: E402
 
 GFLOP_PER_FRAME = 794.36       # fwd 265.35 + bwd 529.01 (2*MAC, conv/convT/matmul)
 
@@ -137,6 +137,8 @@ def main():
     assert (tr._reducer is not None) == (world > 1 or force_dist)
     if tr._reducer is not None:
         tr._reducer.timing = True             # per-segment all-reduce time and exposed (not overlapped) time in the JSON line
+        if os.environ.get('MUVO_DP_OVERLAP') == '0':
+            tr._reducer.overlap = False       # A/B: every segment sent after backward
     torch.manual_seed(1234 + 7919 * rank)    # RSSM noise / use-prior coins differ per rank from here on
 
     # two distinct synthetic batches per rank, staged in HBM before the timed region
@@ -165,6 +167,7 @@ def main():
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     if tr._reducer is not None:
         tr._reducer._steps_timed = []          # exchange timing: the timed steps only
+        tr._reducer.host_s = 0.0
     c0 = time.process_time()
     t0 = time.perf_counter()
     marks[0].record()
@@ -280,7 +283,8 @@ def main():
                 out['roofline']['isolation_note'] = ('achieved / frac: HIP-event brackets inside the timed region, where the class shares the '
                                                      'chip with kernels of the side streams (muvo_amd/ops.py: branch, wgrad_stream); '
                                                      '*_isolated: the same brackets in extra steps with MUVO_STREAMS off')
-            out['side_streams'] = dict(enabled=bool(streams_were[0]), branches=sorted(ops.BRANCHES), wgrad_stream=bool(streams_were[1]))
+            out['side_streams'] = dict(enabled=bool(streams_were[0]), branches=sorted(ops.BRANCHES), wgrad_stream=bool(streams_were[1]),
+                                       budget=ops.STREAM_BUDGET[0], hw_queues=os.environ.get('GPU_MAX_HW_QUEUES'))
             out['kernel_class_steps'] = extra_steps
             if out['roofline'] is not None:
                 conv_s = sum(c['seconds'] for c in out['kernel_classes'].values())

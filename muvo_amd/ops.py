@@ -256,8 +256,36 @@ _side_streams = {}
 _inputs_ready = {}
 
 
+# Which logical branch runs on which HIP stream.  Measured on MI355X (profiles/r03i_stream_queues.txt): concurrency pays as long
+# as the process keeps AT MOST FOUR streams busy (the current stream included) - a fifth concurrently active queue does not
+# serialise gracefully, the step falls from 84 to 104-111 ms - and with the runtime's default of four hardware queues the
+# streams of other libraries (RCCL) push ours onto shared queues in an order nobody controls.  So: muvo_amd/__init__.py asks for
+# eight hardware queues (GPU_MAX_HW_QUEUES, before HIP initialises) so that every stream below owns one, and the logical
+# branches are folded onto a BUDGET of side streams: three alone on the GPU (encoders + range-view decoder | voxel decoder |
+# weight gradients: 83.3 ms/step), one when a gradient exchange is attached (its communication stream and RCCL's own stream take
+# two of the four: set_stream_budget(1), 85.5 ms/step instead of 92.8 with colliding queues).  MUVO_STREAM_MAP overrides single
+# entries ("voxel_decoder=main,wgrad=s0").
+_STREAM_PLANS = {
+    3: {'lidar_encoder': 's0', 'route_encoder': 's0', 'lidar_decoder': 's0', 'voxel_decoder': 's1', 'wgrad': 's2'},
+    2: {'lidar_encoder': 's0', 'route_encoder': 's0', 'lidar_decoder': 's0', 'voxel_decoder': 'main', 'wgrad': 's1'},
+    1: {'lidar_encoder': 's0', 'route_encoder': 's0', 'lidar_decoder': 's0', 'voxel_decoder': 'main', 'wgrad': 's0'},
+    0: {},
+}
+STREAM_BUDGET = [int(os.environ.get('MUVO_STREAM_BUDGET', '3'))]
+STREAM_MAP = dict(kv.split('=') for kv in os.environ.get('MUVO_STREAM_MAP', '').split(',') if '=' in kv)
+
+
+def set_stream_budget(n):
+    """number of side streams the model may use (0..3); WorldModelTrainer lowers it to 1 when it attaches a gradient exchange"""
+    STREAM_BUDGET[0] = max(0, min(3, int(n)))
+
+
 def side_stream(name, device):
     device = torch.device(device)
+    plan = _STREAM_PLANS[max(0, min(3, STREAM_BUDGET[0]))]
+    name = STREAM_MAP.get(name, plan.get(name, 'main' if name in _STREAM_PLANS[3] else name))
+    if name == 'main':
+        return torch.cuda.current_stream(device)
     key = (name, device.index)
     st = _side_streams.get(key)
     if st is None:

@@ -30,6 +30,14 @@ class SegmentedGradReducer:
         self.accumulating = False     # True while backward runs for a non-final micro-batch of gradient accumulation
         self.is_cuda = store.flat_grad.is_cuda
         self.side = torch.cuda.Stream() if (self.is_cuda and (self.world > 1 or self.force)) else None
+        if self.side is not None:
+            # the communication stream and RCCL's own stream are two of the four streams the chip runs well side by side
+            # (muvo_amd/ops.py: side_stream; the communication stream itself only carries waits): the model folds its
+            # branches onto TWO side streams from now on
+            import os
+            from muvo_amd import ops
+            if 'MUVO_STREAM_BUDGET' not in os.environ:
+                ops.set_stream_budget(2)
         self._done = []
         self._handles = []
         self._snap = {}
@@ -64,6 +72,16 @@ class SegmentedGradReducer:
     def _launch(self, name, from_hook):
         if name in self._done or name not in self.ranges:
             return
+        if self.timing:
+            import time
+            t0 = time.perf_counter()
+            try:
+                return self._launch_impl(name, from_hook)
+            finally:
+                self.host_s = getattr(self, 'host_s', 0.0) + time.perf_counter() - t0
+        return self._launch_impl(name, from_hook)
+
+    def _launch_impl(self, name, from_hook):
         self._done.append(name)
         self.launch_log.append((name, from_hook))
         if self.world == 1 and not self.force:
@@ -163,4 +181,6 @@ class SegmentedGradReducer:
                               busbw_gbs=round(2.0 * (g - 1) / max(g, 1) * a['bytes'] / max(ms, 1e-6) / 1e6, 1),
                               from_hook=a['from_hook'], exposed_ms=round(a['exposed_ms'] / a['n'], 3))
         self._steps_timed = []
-        return dict(steps=len(exposed), exposed_ms_per_step=round(sum(exposed) / len(exposed), 3), segments=segs)
+        host_ms = round(getattr(self, 'host_s', 0.0) * 1e3 / max(len(exposed), 1), 3)     # host time inside the collective calls
+        self.host_s = 0.0
+        return dict(steps=len(exposed), exposed_ms_per_step=round(sum(exposed) / len(exposed), 3), host_ms_per_step=host_ms, segments=segs)
