@@ -32,9 +32,16 @@ for r in range(3):
     opt.zero_grad()
     batch = make_batch(b, s, seed=1234, device=dev)
     losses, output, _, _ = tr.shared_step(batch, mode='train', noise=eps, use_prior=use_prior)
+    torch.cuda.synchronize()
+    pre = {'pre.' + k: v.detach().clone() for k, v in output.items() if torch.is_tensor(v)}      # outputs BEFORE backward
+    torch.cuda.synchronize()
     tr.loss_reducing(losses).backward()
     torch.cuda.synchronize()
     rec = {'loss.' + k: v.detach().clone() for k, v in losses.items()}
+    rec.update(pre)
+    for k, v in output.items():
+        if torch.is_tensor(v) and not torch.equal(v, pre['pre.' + k]):
+            print(f'run {r}: output {k} CHANGED during backward: {(v - pre["pre." + k]).abs().gt(0).sum().item()} elements')
     rec.update({'out.' + k: v.detach().clone() for k, v in output.items() if torch.is_tensor(v)})
     rec.update({'grad.' + n: p.grad.detach().clone() for n, p in tr.model.named_parameters() if p.grad is not None})
     rec.update({'buf.' + n: v.detach().clone() for n, v in tr.model.named_buffers()})
@@ -51,6 +58,18 @@ for k in runs[0]:
             bad.append((k, d))
             break
 print(f'{mode} b{b}s{s}: {len(runs[0])} tensors compared over 3 runs, {len(bad)} differ')
+for k, _ in bad[:4]:
+    if runs[0][k].numel() > 1:
+        for r_i, r in enumerate(runs[1:], 1):
+            d = (runs[0][k] - r[k]).abs()
+            nz = torch.nonzero(d.reshape(-1)).reshape(-1)
+            if nz.numel():
+                idx = nz[:6].tolist()
+                print(f'   {k} run0 vs run{r_i}: {nz.numel()} of {d.numel()} elements differ, max {d.max().item():.3e}; shape {tuple(d.shape)}; first flat idx {idx}; '
+                      f'unravel {[tuple(int(v) for v in torch.unravel_index(torch.tensor(i), d.shape)) for i in idx[:3]]}')
+                a, b_ = runs[0][k].reshape(-1), r[k].reshape(-1)
+                print('      run0 values', [round(float(a[i]), 5) for i in nz[:8].tolist()], ' other', [round(float(b_[i]), 5) for i in nz[:8].tolist()],
+                      ' last idx', nz[-3:].tolist(), ' gaps', sorted(set((nz[1:] - nz[:-1]).tolist()))[:6])
 thr = 0.0 if DET else 1e-3
 shown = [(k, d) for k, d in bad if d > thr]
 print(f'   ({len(shown)} above {thr})')
