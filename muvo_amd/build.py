@@ -13,7 +13,16 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-munsafe-fp-ato
          # A by-value kernel argument struct (ConvPhase, 2.8 KB) is first copied to a private alloca by the front end; InstCombine
          # forwards its loads to the kernel-argument segment only while the alloca has <= this many users (default 300).  The
          # unrolled epilogues (x 6 activations) read `g` more often than that: beyond the limit the whole struct lands in scratch.
-         '-mllvm', '-instcombine-max-copied-from-constant-users=8000']
+         '-mllvm', '-instcombine-max-copied-from-constant-users=8000',
+         # No packed fp32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32).  Measured on MI355X (tools/dev/
+         # coresidency_repro.py, profiles/r03j_lidar_decoder_stream.txt): `v_pk_mul_f32 d, a, b op_sel:[0,1]` whose b is a register
+         # pair filled by ds_read2_b32 returned 0 for the low half in lanes 48-63 while a big-LDS MFMA workgroup of ANOTHER
+         # stream was resident on the same compute unit - one product missing from a 1x1 head's sum, in every launch that
+         # overlapped, never on an idle GPU or next to other workgroups of the same stream.  The same code with scalar
+         # v_mul_f32 / v_add_f32 (this flag) never showed it (0 of 400 launches against 200 of 400); the step time is unchanged
+         # (84.5 vs 84.4 ms): nothing here is bound by the fp32 VALU rate.  The flag is a device target feature; the host pass
+         # of hipcc reports it as unknown (filtered below).
+         '-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
 # Kernels allowed to use scratch memory (bytes per lane).  Everything else must stay in registers: a kernel that silently
 # picks up scratch (an argument struct captured by reference and copied to the stack, register spills after a small edit)
 # loses tens of microseconds per workgroup launch — the build fails instead.
@@ -46,7 +55,8 @@ def _stale(out, deps):
 
 def build(force=False, verbose=True):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    hdrs = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_vox.h'), os.path.join(CSRC, 'conv_pw.h'), os.path.join(CSRC, 'conv_plan.h'), os.path.join(CSRC, 'conv_bf3.h'), os.path.join(HERE, '..', 'include', 'muvo_hip.h')]
+    hdrs = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_vox.h'), os.path.join(CSRC, 'conv_pw.h'), os.path.join(CSRC, 'conv_plan.h'), os.path.join(CSRC, 'conv_bf3.h'), os.path.join(HERE, '..', 'include', 'muvo_hip.h'),
+            os.path.abspath(__file__)]   # the flags are part of the recipe
     objdir = os.path.join(HERE, 'build')
     os.makedirs(objdir, exist_ok=True)
     objs, jobs = [], []
@@ -55,7 +65,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(objdir, s.replace('.hip', '.o'))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([hipcc, *FLAGS, '-c', src, '-o', obj])
+            jobs.append([hipcc, *FLAGS, *os.environ.get('MUVO_HIPCC_EXTRA', '').split(), '-c', src, '-o', obj])
 
     def run(cmd):
         if verbose:
@@ -69,7 +79,7 @@ def build(force=False, verbose=True):
                 os.remove(cmd[-1])
             raise RuntimeError('kernels use scratch memory (see muvo_amd/build.py SCRATCH_ALLOWED): ' +
                                ', '.join(f'{n}: {b} B/lane' for n, b in bad))
-        rest = '\n'.join(l for l in r.stderr.splitlines() if 'kernel-resource-usage' not in l and not l.lstrip().startswith(('|', '^')) and
+        rest = '\n'.join(l for l in r.stderr.splitlines() if 'kernel-resource-usage' not in l and 'is not a recognized feature for this target' not in l and not l.lstrip().startswith(('|', '^')) and
                          not (l.strip()[:1].isdigit() and ' | ' in l))
         if verbose and rest.strip():
             print(rest)

@@ -15,7 +15,7 @@ template <int CO>
 __global__ void __launch_bounds__(256) pw_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                      const float* __restrict__ bias, float* __restrict__ out, int Cin,
                                                      long S4, int act, float slope) {
-  extern __shared__ float s_w[];  // [CO][Cin] (+ PW_LDS_RESERVE, see pw_run)
+  extern __shared__ float s_w[];  // [CO][Cin]
   for (int i = threadIdx.x; i < CO * Cin; i += 256) s_w[i] = w[i];
   __syncthreads();
   const int n = blockIdx.y;
@@ -149,12 +149,9 @@ template <int CO>
 static int pw_run(int op, const muvo_conv_desc* d, const float* a, const float* b, const float* w, const float* bias, float* o0,
                   float* o1, int act, float slope, hipStream_t st) {
   const long S4 = (long)d->in_sz[0] * d->in_sz[1] * d->in_sz[2] / 4;
-  // PW_LDS_RESERVE: the forward kernel asks for 20 KB more LDS than it uses so that its workgroups never share a compute unit
-  // with a 147-150 KB workgroup of the eight-wave convolution tiles.  Next to such a workgroup OF ANOTHER STREAM (side streams,
-  // muvo_amd/ops.py) single 16-lane groups of one output channel came out off by ~1e-2 in about half of all processes; any
-  // reservation that rules out the co-residency removes it, guard words around the weights do not
-  // (profiles/r03j_lidar_decoder_stream.txt).  Cause unknown; the reservation costs nothing (the kernel is HBM-bound).
-  constexpr size_t PW_LDS_RESERVE = 20 * 1024;
+  // MUVO_PW_LDS_RESERVE: unused LDS added to the forward kernel's allocation (diagnostic, tools/dev/coresidency_repro.py: keeps its
+  // workgroups off compute units that hold a big-LDS workgroup of another stream)
+  static const size_t PW_LDS_RESERVE = getenv("MUVO_PW_LDS_RESERVE") ? (size_t)atol(getenv("MUVO_PW_LDS_RESERVE")) : 0;
   const size_t lds = sizeof(float) * CO * d->Cin + (op == 0 ? PW_LDS_RESERVE : 0);
   int gx = cdiv(S4, 256);
   if (gx > 2048) gx = 2048;
