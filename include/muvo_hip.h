@@ -18,7 +18,7 @@ extern "C" {
 #define MUVO_OK 0
 #define MUVO_ERR_INVALID_ARG (-1)
 #define MUVO_ERR_HIP (-2)
-#define MUVO_ERR_RCCL (-3)
+/* (no collective error code: the library launches no collectives - gradient exchange is torch.distributed over RCCL, muvo_amd/parallel.py) */
 
 #define MUVO_ACT_NONE 0
 #define MUVO_ACT_RELU 1
