@@ -457,7 +457,7 @@ def test_loss_curve_matches_reference(dev, mode):
         opt, sched = opts[0], scheds[0]['scheduler']
         eps, use_prior = make_noise(b, s, seed=seed)
         eps = eps.to(dev)
-        lines, worst = [], []
+        lines, worst, worst_total = [], [], []
         for step, g in enumerate(fx['steps']):
             opt.zero_grad()
             total = tr.training_step(make_batch(b, s, seed=seed + step, device=dev), step, noise=eps, use_prior=use_prior)
@@ -467,6 +467,7 @@ def test_loss_curve_matches_reference(dev, mode):
             dev_k = {k: _rel(tr.last_losses[k].item(), v) for k, v in g['losses'].items()}
             w = max(dev_k, key=dev_k.get)
             worst.append(dev_k[w])
+            worst_total.append(_rel(total.item(), g['total']))
             lines.append(f'{mode} step {step}: total {total.item():.6f} vs {g["total"]:.6f} (rel {_rel(total.item(), g["total"]):.2e}); '
                          f'worst term {w} {dev_k[w]:.2e}')
         with open(os.path.join(os.path.dirname(GOLD), '..', 'gpurun_out', 'loss_curve.txt'), 'a') as f:
@@ -474,6 +475,7 @@ def test_loss_curve_matches_reference(dev, mode):
         print('\n'.join(lines))
         for step, wv in enumerate(worst):
             assert wv < 1e-3 * (step + 1), lines[step]
+            assert worst_total[step] < 1e-3, lines[step]       # the curve of the total loss itself: 1e-3 at every step
         bad = [n for n, (s_ref, a_ref) in fx['steps'][-1]['param_checksums_after_step'].items()
                if abs(dict(tr.model.named_parameters())[n].detach().double().abs().sum().item() - a_ref) > 1e-4 * a_ref + 8 * 1e-4]
         assert not bad, bad[:5]
