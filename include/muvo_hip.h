@@ -37,6 +37,10 @@ int muvo_selftest_mfma(void* stream);
  * aid for parity work - slower (the affected kernels lose their split parallelism).  The reference has no counterpart
  * (torch.use_deterministic_algorithms plays this role for its cuDNN / ATen kernels). */
 int muvo_set_deterministic(int on);
+/* Clears the library-owned statistics accumulators of every stream (all-zero between operations by construction: the consuming
+   kernel clears what it read).  For the caller's error path: an exception between a statistics pass and its consumer leaves
+   partial sums behind that every later normalisation on that stream would add to (muvo_amd/ops.py: reset_accumulators). */
+int muvo_reset_accumulators(void);
 int muvo_get_deterministic(void);
 
 /* ---- convolution family (conv_gemm.hip) -------------------------------------------------------

@@ -222,6 +222,19 @@ static double* bn_slot(size_t n_doubles, hipStream_t st) {
   return p;
 }
 
+// After a failed step (exception between a statistics pass and the kernel that consumes and clears its sums) the accumulators
+// may hold stale partial sums: clear every stream's accumulator and ring, each on its own stream (include/muvo_hip.h).
+extern "C" int muvo_reset_accumulators(void) {
+  for (int i = 0; i < NORM_MAX_STREAMS; ++i) {
+    NormStreamBufs* b = &g_norm_bufs[i];
+    if (!b->used) continue;
+    if (b->sums && hipMemsetAsync(b->sums, 0, b->sums_cap * sizeof(double), b->st) != hipSuccess) return MUVO_ERR_HIP;
+    if (b->ring && hipMemsetAsync(b->ring, 0, BN_RING * sizeof(double), b->st) != hipSuccess) return MUVO_ERR_HIP;
+    b->ring_pos = 0;
+  }
+  return MUVO_OK;
+}
+
 // ------------------------------------------------------------------------------------------ BN
 // per-channel statistics from the slot totals; `first` (one thread per channel) also stores them for the backward pass and
 // updates the running statistics (nn.BatchNorm2d train mode: unbiased variance, momentum)

@@ -42,7 +42,7 @@ class GemmDesc(C.Structure):
 
 # every exported symbol of include/muvo_hip.h (tests/test_abi.py checks this list against the header)
 EXPORTS = [
-    'muvo_last_error', 'muvo_abi_version', 'muvo_selftest_mfma', 'muvo_set_deterministic', 'muvo_get_deterministic',
+    'muvo_last_error', 'muvo_abi_version', 'muvo_selftest_mfma', 'muvo_set_deterministic', 'muvo_get_deterministic', 'muvo_reset_accumulators',
     'muvo_conv_set_products', 'muvo_conv_get_products',
     'muvo_conv_set_mode', 'muvo_conv_get_mode', 'muvo_conv_set_bf16x3_min_gflop', 'muvo_conv_pack_sizes', 'muvo_conv_workspace_bytes', 'muvo_conv_kernel_family', 'muvo_conv_kernel_variant', 'muvo_conv_pack_weights', 'muvo_conv_forward', 'muvo_conv_dgrad', 'muvo_conv_prepare_dy', 'muvo_conv_wgrad', 'muvo_bias_grad_nchw',
     'muvo_gemm',
@@ -100,7 +100,31 @@ def lib():
 
 def _ck(rc):
     if rc != 0:
-        raise RuntimeError(f'muvo_hip error {rc}: {lib().muvo_last_error().decode()}')
+        msg = lib().muvo_last_error().decode()
+        reset_accumulators()
+        raise RuntimeError(f'muvo_hip error {rc}: {msg}')
+
+
+_MOMENT_BUFS = []      # weak references to the per-layer float64 moments buffers (conv_moments_buffer)
+
+
+def reset_accumulators():
+    """Error path: buffers that are all-zero between uses by construction - the library's per-stream statistics accumulators and
+    the per-layer moments buffers a convolution epilogue fills for the AdaIN that follows - may hold partial sums when an
+    exception interrupted a step between producer and consumer.  Called by _ck on every library error and by the trainer when
+    a step raises; a no-op cost otherwise (never on the success path)."""
+    try:
+        if _lib is not None:
+            _lib.muvo_reset_accumulators()
+        live = []
+        for r in _MOMENT_BUFS:
+            t = r()
+            if t is not None:
+                t.zero_()
+                live.append(r)
+        _MOMENT_BUFS[:] = live
+    except Exception:          # the original error is the one to report
+        pass
 
 
 def _st():
@@ -1146,7 +1170,16 @@ def conv_moments_buffer(x, geom):
     buf = cache.get((n, x.device))
     if buf is None:
         buf = cache[(n, x.device)] = torch.zeros(n, geom.cout, 2, device=x.device, dtype=torch.float64)
+        _MOMENT_BUFS.append(weakref.ref(buf))
     return buf
+
+
+def _grad_is_private(g):
+    """May a backward function write into the gradient tensor it was handed?  Only if nobody else holds it: autograd hands the SAME
+    tensor to several consumers when a gradient is shared (both inputs of an add, expand views, retained grads / hooks).  Inside
+    backward() a tensor made for this one consumer has two owners (the engine's input buffer and the Python argument); a shared
+    one has more, or is a view (tests/test_kernels_gpu.py::test_head_branch_shared_gradient)."""
+    return g._base is None and g._use_count() <= 2
 
 
 class HeadBranchFn(torch.autograd.Function):
@@ -1179,7 +1212,7 @@ class HeadBranchFn(torch.autograd.Function):
             if packed.dgr_key != k or packed.dgr_plan != pkey:
                 _ck(L.muvo_conv_pack_weights(C.byref(d), _f(weight), None, _f(packed.dgr), _st()))
                 packed.dgr_key, packed.dgr_plan = k, pkey
-            if gx is not None and gx.is_contiguous():
+            if gx is not None and gx.is_contiguous() and _grad_is_private(gx):
                 dx = gx            # a fresh tensor made by the trunk's backward for this one consumer: accumulated in place
                 _ck(L.muvo_conv_dgrad_accumulate(C.byref(d), _f(gy), _f(packed.dgr), _f(dx), _st()))
             else:

@@ -46,6 +46,9 @@ class SegmentedGradReducer:
         self.order = [name for name, _, _ in store.segment_ranges]
         from muvo_amd.param_store import SEGMENTS
         self._rank = {name: i for i, (name, _) in enumerate(SEGMENTS)}     # completion order, also of absent segments
+        # parameters per segment: a gradient tensor that is not the flat view (installed by AccumulateGrad after something set
+        # p.grad to None) is copied into its slot BEFORE the segment is exchanged - afterwards it would never be reduced
+        self._seg_params = {name: [p for p in store.params if a <= store._off[id(p)] < b] for name, (a, b) in self.ranges.items()}
         self.launch_log = []          # (segment, was launched from a backward hook) of the last step
         self.late_writes = {}         # verify: segment -> max |difference|
         # timing (bench.py, MUVO_DP_TIMING=1): HIP events around every segment's collective on the side stream and at the
@@ -87,6 +90,7 @@ class SegmentedGradReducer:
         if self.world == 1 and not self.force:
             return
         a, b = self.ranges[name]
+        self.store.settle_grads(self._seg_params[name])
         buf = self.store.flat_grad[a:b]
         if self.verify:
             from muvo_amd import ops

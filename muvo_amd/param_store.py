@@ -89,15 +89,18 @@ class ParamStore:
             p._muvo_flat_grad = self.flat_grad[o:o + p.numel()].view(p.shape)   # ops.grad_of re-binds to it
 
     def zero_grad(self):
+        """All gradients zero, every p.grad the flat view again.  A foreign gradient tensor (installed by AccumulateGrad after
+        `p.grad = None`, or assigned from outside) is DISCARDED here, like torch's zero_grad discards it: copying it back would
+        put the old gradient into the freshly zeroed slot."""
         self.flat_grad.zero_()
-        self.rebind_grads()
+        self.rebind_grads(copy_foreign=False)
         for _, p in self.unused:
             p.grad = None
 
-    def rebind_grads(self):
+    def rebind_grads(self, copy_foreign=True):
         """Re-attach the p.grad views after something replaced them (nn.Module.zero_grad() / `p.grad = None` set them to
         None; a kernel that found None re-binds through ops.grad_of).  A gradient tensor that is NOT the flat view (assigned
-        from outside) is copied into its slot first, so its contents are not lost."""
+        from outside) is copied into its slot first, so its contents are not lost (copy_foreign; zero_grad passes False)."""
         base = self.flat_grad.data_ptr()
         for p in self.params:
             view = p._muvo_flat_grad
@@ -105,14 +108,16 @@ class ParamStore:
             if g is None:
                 p.grad = view
             elif g.data_ptr() != base + 4 * self._off[id(p)]:
-                view.copy_(g)
+                if copy_foreign:
+                    view.copy_(g)
                 p.grad = view
 
-    def settle_grads(self):
-        """Before the optimizer reads flat_grad: a parameter whose .grad is None got no gradient since something reset it
-        (its slot may hold the previous step's values) -> zero the slot; foreign gradient tensors are copied in."""
+    def settle_grads(self, params=None):
+        """Before the optimizer (or, per segment, the gradient exchange: parallel.SegmentedGradReducer) reads flat_grad: a
+        parameter whose .grad is None got no gradient since something reset it (its slot may hold the previous step's values)
+        -> zero the slot; foreign gradient tensors are copied in."""
         base = self.flat_grad.data_ptr()
-        for p in self.params:
+        for p in (self.params if params is None else params):
             g = p.grad
             if g is None:
                 p._muvo_flat_grad.zero_()

@@ -105,8 +105,12 @@ class WorldModelTrainer(_Base):
         remaining frames.  noise (b, rf + N_SAMPLES*fh, 2, S) / use_prior (rf,) make the RNG explicit: [:, t < rf] feed the
         observe steps, [:, rf + k*fh + t, 0] step t of imagined sample k."""
         if mode == 'train':
-            output, state_dict = self.forward(batch, noise=noise, use_prior=use_prior)
-            losses = self.compute_loss(batch, output)
+            try:
+                output, state_dict = self.forward(batch, noise=noise, use_prior=use_prior)
+                losses = self.compute_loss(batch, output)
+            except BaseException:
+                ops.reset_accumulators()      # zero-between-uses buffers may hold partial sums of the interrupted step
+                raise
             return losses, output, [], []
         rf, fh = self.rf, self.fh
         batch = self.preprocess(batch)

@@ -45,7 +45,12 @@ def _worker(rank, world, port, overlap, q):
         store.zero_grad()
         for n, p in m.named_parameters():
             if n in used:
-                p.grad.add_(float(rank + 1) * (step + 1))
+                if step == 1 and n == 'encoder.weight':
+                    # a FOREIGN gradient tensor (what AccumulateGrad installs after `p.grad = None`): the reducer must copy it
+                    # into the flat slot before the segment is exchanged, or it is never reduced
+                    p.grad = torch.full_like(p, float(rank + 1) * (step + 1))
+                else:
+                    p.grad.add_(float(rank + 1) * (step + 1))
         if overlap:
             red.segment_done('policy')   # no such segment in the toy: everything before it in layout order = 'rgb_decoder'
             red.segment_done('fusion')   # implies 'rssm'
@@ -56,6 +61,7 @@ def _worker(rank, world, port, overlap, q):
         assert torch.all(store.flat_grad[~pad] == expect), (store.flat_grad, expect)
         assert torch.all(store.flat_grad[pad] == 0) and torch.all(store.flat_param[pad] == 0)
         assert m.encoder_layer.weight.grad is None
+        assert m.encoder.weight.grad.data_ptr() == store.flat_grad.data_ptr() + 4 * store.offsets['encoder.weight'][0]
     assert red.grad_scale == 1.0 / world
     q.put(rank)
     dist.destroy_process_group()
@@ -115,3 +121,26 @@ def test_optimizer_state_dict_format_cpu():
     assert torch.all(store.flat_grad[o:o + k] == 2.0) and m.rssm.weight.grad.data_ptr() == store.flat_grad.data_ptr() + 4 * o
     o, k = store.offsets['encoder.bias']
     assert torch.all(store.flat_grad[o:o + k] == 0.0)      # got no gradient since the reset: treated as zero
+
+
+def test_zero_grad_discards_foreign_gradients():
+    """ParamStore.zero_grad(): a gradient tensor that is not the flat view is dropped, not copied back into the zeroed slot
+    (a skipped optimizer step followed by zero_grad must not leave the old gradient behind); settle_grads() - the optimizer's
+    and the reducer's entry - copies foreign tensors in and zeroes the slots of parameters without a gradient."""
+    sys.path.insert(0, ROOT)
+    from muvo_amd.param_store import ParamStore
+    torch.manual_seed(0)
+    m = _Toy()
+    store = ParamStore(m)
+    p = m.encoder.weight
+    o, k = store.offsets['encoder.weight']
+    p.grad = torch.full_like(p, 2.0)
+    store.zero_grad()
+    assert torch.all(store.flat_grad == 0)
+    assert p.grad.data_ptr() == store.flat_grad.data_ptr() + 4 * o
+    p.grad = torch.full_like(p, 3.0)
+    m.encoder.bias.grad = None
+    store.flat_grad[store.offsets['encoder.bias'][0]] = 7.0          # stale value of an earlier step
+    store.settle_grads([p, m.encoder.bias])
+    assert torch.all(store.flat_grad[o:o + k] == 3.0)
+    assert torch.all(m.encoder.bias.grad == 0) and p.grad.data_ptr() == store.flat_grad.data_ptr() + 4 * o

@@ -208,6 +208,68 @@ def test_conv_stage_with_head(dev, trunk_used, shape):
         ops.set_conv_mode(old, min_gflop=-1.0)
 
 
+def test_reset_accumulators_after_interrupted_step(dev):
+    """A step interrupted between a convolution epilogue that fills a layer's moments buffer and the AdaIN that consumes and
+    clears it leaves partial sums behind; ops.reset_accumulators() (called by ops._ck on library errors and by the trainer when a
+    step raises) restores the all-zero state, so the next forward gives the same result as before."""
+    from muvo_amd import ops
+    from muvo_amd.models.common import DecoderBlock3d
+    old = ops.get_conv_mode()
+    ops.set_conv_mode(ops.CONV_BF16X3, min_gflop=0.0)
+    try:
+        torch.manual_seed(3)
+        with torch.device(dev):
+            blk = DecoderBlock3d(16, 8, 24, upsample=False)
+        x, w = torch.randn(2, 16, 24, 24, 32, device=dev), torch.randn(2, 24, device=dev)
+        with torch.no_grad():
+            ref = blk(x, w).clone()
+            real = ops.adain_lazy, ops.adain
+
+            def boom(*a, **k):
+                raise MemoryError('injected between the convolution and its AdaIN')
+            ops.adain_lazy = ops.adain = boom
+            try:
+                with pytest.raises(MemoryError):
+                    blk(x, w)
+            finally:
+                ops.adain_lazy, ops.adain = real
+            buf = ops.conv_moments_buffer(x, blk.conv1.conv_act[0].geom)
+            assert buf is not None and float(buf.abs().sum()) > 0, 'the interrupted forward left no partial sums: test is vacuous'
+            ops.reset_accumulators()
+            assert float(buf.abs().sum()) == 0
+            assert torch.equal(blk(x, w), ref)
+        with pytest.raises(RuntimeError):           # a library error takes the same path by itself
+            ops._ck(-1)
+    finally:
+        ops.set_conv_mode(old, min_gflop=-1.0)
+
+
+def test_head_branch_shared_gradient(dev):
+    """ops.HeadBranchFn adds the head's data gradient into the trunk's gradient tensor IN PLACE - allowed only when that tensor
+    belongs to this consumer alone.  Here the trunk's gradient is shared: `a + c` hands the same tensor object to both inputs,
+    so an in-place accumulate would corrupt c's gradient (ops._grad_is_private)."""
+    from muvo_amd import nn as hnn
+    from muvo_amd import ops
+    torch.manual_seed(5)
+    with torch.device(dev):
+        head = hnn.Conv2d(64, 3, 1, 1, 0)
+    for p in (head.weight, head.bias):
+        p.grad = torch.zeros_like(p)
+    x = torch.randn(2, 64, 32, 64, device=dev)
+    for shared in (True, False):
+        t = x.clone().requires_grad_(True)
+        c = torch.randn_like(x).requires_grad_(True)
+        a, logits = ops.head_branch(t * 1.0, head.weight, head.bias, head.geom, head._packed)
+        assert type(logits.grad_fn).__name__.startswith('HeadBranchFn')
+        up = torch.randn_like(x)
+        gl = torch.randn_like(logits)
+        trunk = (a + c) if shared else (a * 1.0 + c * 1.0)
+        torch.autograd.backward([trunk, logits], [up, gl])
+        assert torch.equal(c.grad, up), 'the shared gradient tensor was modified in place'
+        ref = up + torch.einsum('nkhw,kc->nchw', gl, head.weight.detach().view(3, 64))
+        _close(t.grad, ref, rtol=1e-5, atol=1e-5, name='trunk gradient')
+
+
 def test_grouped_linear(dev):
     """All style projections of a decoder in one launch per pass (ops.grouped_linear; common.py:205-246: each
     AdaptiveInstanceNorm applies its own Linear to the same latent): outputs, the summed data gradient and the per-layer
