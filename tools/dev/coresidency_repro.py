@@ -2,7 +2,11 @@
 (profiles/r03j_lidar_decoder_stream.txt.)  Stream A loops a 3x3 convolution that runs on the 256x128 eight-wave tile (150 KB of
 LDS per workgroup); the current stream runs a victim kernel (the 1x1 head, an activation, ...) over and over and compares every
 result bit for bit with the result it gave on an idle GPU.
-    MUVO_PW_LDS_RESERVE=0 python tools/dev/coresidency_repro.py [victim=head|act|head_big] [aggressor=conv|vox|none] [iters]"""
+    python tools/dev/coresidency_repro.py [victim=head|head_nobias|head_direct|act] [aggressor=vox|conv|gemm|gemm32|ew|none] [iters]
+The shipped library (built without packed fp32 instructions, muvo_amd/build.py) gives 0 differing launches.  To see the failure,
+build a library WITH them and point MUVO_HIP_LIB at it:
+    MUVO_HIPCC_EXTRA="-Xclang -target-feature -Xclang +packed-fp32-ops" python -c "from muvo_amd.build import build; build(force=True)"
+(every run is listed in profiles/r03j_lidar_decoder_stream.txt)."""
 import os, sys, torch
 sys.path.insert(0, '/root/repo')
 from muvo_amd import nn as hnn, ops
