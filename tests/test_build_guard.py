@@ -28,3 +28,10 @@ def test_allow_list_has_a_size_limit():
 
 def test_flags_request_the_remarks():
     assert '-Rpass-analysis=kernel-resource-usage' in b.FLAGS and '--offload-arch=gfx950' in b.FLAGS
+
+
+def test_flags_switch_packed_fp32_off():
+    """The library is built without packed fp32 VALU instructions (build.py explains why; the GPU-side check is
+    tests/test_kernels_gpu.py::test_head_next_to_a_convolution_of_another_stream)."""
+    i = b.FLAGS.index('-packed-fp32-ops')
+    assert b.FLAGS[i - 3:i] == ['-Xclang', '-target-feature', '-Xclang']

@@ -208,6 +208,39 @@ def test_conv_stage_with_head(dev, trunk_used, shape):
         ops.set_conv_mode(old, min_gflop=-1.0)
 
 
+def test_head_next_to_a_convolution_of_another_stream(dev):
+    """A 1x1 output head must give bit-identical results whether or not a convolution of ANOTHER stream shares the chip with it.
+    With packed fp32 VALU instructions in the head kernel about half of such launches lost one product in lanes 48-63
+    (tools/dev/coresidency_repro.py, profiles/r03j_lidar_decoder_stream.txt); the library is built without them."""
+    from muvo_amd import nn as hnn
+    from muvo_amd import ops
+    old = ops.get_conv_mode()
+    ops.set_conv_mode(ops.CONV_BF16X3, min_gflop=0.0)
+    try:
+        torch.manual_seed(0)
+        with torch.device(dev):
+            vox = hnn.Conv3d(32, 32, 3, 1, 1, bias=True)
+            head = hnn.Conv2d(64, 3, 1, 1, 0, bias=True)
+        xv3 = torch.randn(2, 32, 96, 96, 32, device=dev)
+        xv = torch.randn(20, 64, 160, 800, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        with torch.no_grad():
+            vox(xv3, act=2, slope=0.2)
+            ref = head(xv).clone()
+            torch.cuda.synchronize()
+            bad = 0
+            for _ in range(25):
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        vox(xv3, act=2, slope=0.2)
+                outs = [head(xv) for _ in range(4)]
+                torch.cuda.synchronize()
+                bad += sum(0 if torch.equal(o, ref) else 1 for o in outs)
+        assert bad == 0, f'{bad} of 100 head launches differ from the idle-GPU result'
+    finally:
+        ops.set_conv_mode(old, min_gflop=-1.0)
+
+
 def test_reset_accumulators_after_interrupted_step(dev):
     """A step interrupted between a convolution epilogue that fills a layer's moments buffer and the AdaIN that consumes and
     clears it leaves partial sums behind; ops.reset_accumulators() (called by ops._ck on library errors and by the trainer when a
@@ -256,6 +289,9 @@ def test_head_branch_shared_gradient(dev):
     for p in (head.weight, head.bias):
         p.grad = torch.zeros_like(p)
     x = torch.randn(2, 64, 32, 64, device=dev)
+    seen = []
+    real = ops._grad_is_private
+    ops._grad_is_private = lambda g: (seen.append(real(g)), seen[-1])[1]
     for shared in (True, False):
         t = x.clone().requires_grad_(True)
         c = torch.randn_like(x).requires_grad_(True)
@@ -268,6 +304,8 @@ def test_head_branch_shared_gradient(dev):
         assert torch.equal(c.grad, up), 'the shared gradient tensor was modified in place'
         ref = up + torch.einsum('nkhw,kc->nchw', gl, head.weight.detach().view(3, 64))
         _close(t.grad, ref, rtol=1e-5, atol=1e-5, name='trunk gradient')
+    ops._grad_is_private = real
+    assert seen == [False, True], seen       # shared -> fresh tensor; a gradient made for this consumer alone -> in place
 
 
 def test_grouped_linear(dev):
