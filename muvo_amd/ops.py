@@ -416,7 +416,7 @@ class branch:
 # gradient - come from a ring of WGRAD_RING buffers, a buffer is rewritten only after the weight gradient that read it has
 # finished (event); tensors owned by autograd (x, y, dy, kept planes of x) are marked with record_stream.
 WGRAD_STREAM = STREAMS and 'wgrad' in set(os.environ.get('MUVO_STREAM_BRANCHES', 'route,lidar,decoders,wgrad').split(','))
-WGRAD_RING = 3
+WGRAD_RING = int(os.environ.get('MUVO_WGRAD_RING', '8'))      # same-box A/B, ms/step: 3 slots 86.8, 6: 86.4, 8: 85.95, 12: 85.9 (+8.6 GB of HBM at 8)
 _dy_rings = {}
 
 
