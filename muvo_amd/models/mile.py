@@ -154,26 +154,33 @@ class Mile(nn.Module):
         post = state_dict['posterior']
         state = ops.cat_last([pack_sequence_dim(post['hidden_state']), pack_sequence_dim(post['sample'])])
         self._hook(state, 'policy')        # d(state) complete: every decoder and the policy are done
-        # The decoders only share their input: the range-view and voxel decoders run on side streams next to the RGB decoder
-        # (ops.branch; host order - and with it the order in which backward finishes the parameter segments - is unchanged)
+        # The decoders only share their input: the voxel decoder runs on a side stream next to the RGB / range-view decoders
+        # (ops.branch).  HOST ORDER MATTERS for backward: autograd executes the most recently recorded nodes first and makes the
+        # stream of a gradient's CONSUMER wait for its producer the moment the gradient is handed over - every AdaIN of the voxel
+        # decoder hands a contribution to d(state), whose consumer lives on the main stream.  Recorded last (the reference's
+        # order), the voxel decoder ran its backward first and the main stream queued the RGB decoder's backward behind a wait
+        # for the voxel stream's top level; recorded FIRST, its backward is issued after the other decoders' and that wait lands
+        # behind them.  Same-box A/B: 82.86 -> 82.45 ms/step (under rocprofv3, where the host is slower than the GPU, the wait
+        # showed as 7 ms of main-stream idle time per step: tools/rocpd_queues.py).
+        # (param_store.SEGMENTS lists the segments in the order backward completes them: voxel_decoder after rgb_decoder.)
         state_ready = ops.stream_event(dev)
         pol = self.policy(state)
         output['throttle_brake'] = unpack_sequence_dim(ops.slice_last(pol, 0, 1), b, s)
         output['steering'] = unpack_sequence_dim(ops.slice_last(pol, 1, 2), b, s)
+        joins = []
+        if self.cfg.VOXEL_SEG.ENABLED:
+            br = ops.branch('decoders', 'voxel_decoder', dev, inputs=(state,), after=state_ready)
+            with br:
+                output.update(br.out(unpack_sequence_dim(self.voxel_decoder(self._mark(state, 'voxel_decoder')), b, s)))
+            joins.append(br)
         if self.cfg.EVAL.RGB_SUPERVISION:
             output.update(unpack_sequence_dim(self.rgb_decoder(self._mark(state, 'rgb_decoder')), b, s))
-        joins = []
         if self.cfg.LIDAR_RE.ENABLED:
             br = ops.branch('decoders', 'lidar_decoder', dev, inputs=(state,), after=state_ready)
             with br:
                 output.update(br.out(unpack_sequence_dim(self.lidar_re(self._mark(state, 'lidar_re')), b, s)))
             joins.append(br)
         output.update(self._aux_heads(state, b, s))
-        if self.cfg.VOXEL_SEG.ENABLED:
-            br = ops.branch('decoders', 'voxel_decoder', dev, inputs=(state,), after=state_ready)
-            with br:
-                output.update(br.out(unpack_sequence_dim(self.voxel_decoder(self._mark(state, 'voxel_decoder')), b, s)))
-            joins.append(br)
         for br in joins:
             br.join()
         return output, state_dict
