@@ -161,8 +161,9 @@ class Mile(nn.Module):
         # order), the voxel decoder ran its backward first and the main stream queued the RGB decoder's backward behind a wait
         # for the voxel stream's top level; recorded FIRST, its backward is issued after the other decoders' and that wait lands
         # behind them.  Same-box A/B: 82.86 -> 82.45 ms/step (under rocprofv3, where the host is slower than the GPU, the wait
-        # showed as 7 ms of main-stream idle time per step: tools/rocpd_queues.py).
-        # (param_store.SEGMENTS lists the segments in the order backward completes them: voxel_decoder after rgb_decoder.)
+        # showed as 7 ms of main-stream idle time per step: tools/rocpd_queues.py).  The same holds for the range-view decoder
+        # (its own stream, ops._STREAM_PLANS): recorded before the RGB decoder.  Record order voxel, range-view, RGB => backward
+        # order RGB, range-view, voxel = the order of param_store.SEGMENTS.
         state_ready = ops.stream_event(dev)
         pol = self.policy(state)
         output['throttle_brake'] = unpack_sequence_dim(ops.slice_last(pol, 0, 1), b, s)
@@ -173,13 +174,13 @@ class Mile(nn.Module):
             with br:
                 output.update(br.out(unpack_sequence_dim(self.voxel_decoder(self._mark(state, 'voxel_decoder')), b, s)))
             joins.append(br)
-        if self.cfg.EVAL.RGB_SUPERVISION:
-            output.update(unpack_sequence_dim(self.rgb_decoder(self._mark(state, 'rgb_decoder')), b, s))
         if self.cfg.LIDAR_RE.ENABLED:
             br = ops.branch('decoders', 'lidar_decoder', dev, inputs=(state,), after=state_ready)
             with br:
                 output.update(br.out(unpack_sequence_dim(self.lidar_re(self._mark(state, 'lidar_re')), b, s)))
             joins.append(br)
+        if self.cfg.EVAL.RGB_SUPERVISION:
+            output.update(unpack_sequence_dim(self.rgb_decoder(self._mark(state, 'rgb_decoder')), b, s))
         output.update(self._aux_heads(state, b, s))
         for br in joins:
             br.join()

@@ -285,18 +285,18 @@ _inputs_ready = {}
 # serialise gracefully, the step falls from 84 to 104-111 ms - and with the runtime's default of four hardware queues the
 # streams of other libraries (RCCL) push ours onto shared queues in an order nobody controls.  So: muvo_amd/__init__.py asks for
 # eight hardware queues (GPU_MAX_HW_QUEUES, before HIP initialises) so that every stream below owns one, and the logical
-# branches are folded onto a BUDGET of side streams: three alone on the GPU (encoders + range-view decoder | voxel decoder |
-# weight gradients: 83.3 ms/step), one when a gradient exchange is attached (its communication stream and RCCL's own stream take
-# two of the four: set_stream_budget(1), 85.5 ms/step instead of 92.8 with colliding queues).  MUVO_STREAM_MAP overrides single
-# entries ("voxel_decoder=main,wgrad=s0").
-# The range-view decoder stays on the current stream: next to the RGB decoder (two ConvDecoder stacks with the same layer types
-# on two queues) single heads of either decoder came out with a few 16-element groups off by ~1e-2 in about half of all processes
-# - found by the deterministic mode (tools/det_repeat.py), reproducible only for that pair (every other pairing: 0 of 10
-# processes), cause not found (the stage output and the head's inputs are unchanged afterwards; a host synchronisation between
-# stage and head hides it) - profiles/r03j_lidar_decoder_stream.txt.
+# branches are folded onto a BUDGET of side streams: three alone on the GPU ({encoders, then the range-view decoder} | voxel
+# decoder | weight gradients), two when a gradient exchange is attached (its communication stream only carries waits, RCCL's
+# own stream is the fourth busy one; the voxel decoder then follows the range-view decoder's stream).  Same-box A/Bs: range-view
+# decoder on s0 instead of the main stream 83.3 -> 82.3 ms/step; with a one-rank RCCL group 84.7 -> 83.1.  MUVO_STREAM_MAP
+# overrides single entries ("voxel_decoder=main,wgrad=s0").
+# (History: the range-view decoder had to leave its side stream for a while - next to the RGB decoder single heads came out with
+# a few 16-element groups off by ~1e-2 in about half of all processes.  That was the packed-fp32 instruction finding of
+# muvo_amd/build.py; since the library is built without those instructions: 0 of 30 processes, profiles/r03j_lidar_decoder_stream.txt.)
+# The ORDER in which the decoders are recorded in forward matters for backward, see models/mile.py.
 _STREAM_PLANS = {
-    3: {'lidar_encoder': 's0', 'route_encoder': 's0', 'lidar_decoder': 'main', 'voxel_decoder': 's1', 'wgrad': 's2'},
-    2: {'lidar_encoder': 's0', 'route_encoder': 's0', 'lidar_decoder': 'main', 'voxel_decoder': 'main', 'wgrad': 's1'},
+    3: {'lidar_encoder': 's0', 'route_encoder': 's0', 'lidar_decoder': 's0', 'voxel_decoder': 's1', 'wgrad': 's2'},
+    2: {'lidar_encoder': 's0', 'route_encoder': 's0', 'lidar_decoder': 's0', 'voxel_decoder': 's0', 'wgrad': 's1'},
     1: {'lidar_encoder': 's0', 'route_encoder': 's0', 'lidar_decoder': 'main', 'voxel_decoder': 'main', 'wgrad': 's0'},
     0: {},
 }

@@ -3,7 +3,7 @@
 
 The reference has no explicit collective (Lightning's implicit DDP would all-reduce ~440 tensors in 25 MB
 buckets, train.py:93-98).  Here the gradient buffer is laid out in the order backward completes it
-(param_store.SEGMENTS: range-view decoder 135 MB, RGB decoder 186 MB, voxel decoder 12 MB, policy 24 MB, RSSM
+(param_store.SEGMENTS: RGB decoder 186 MB, range-view decoder 135 MB, voxel decoder 12 MB, policy 24 MB, RSSM
 53 MB, fusion ~210 MB, the two encoder branches ~57 MB each at base_1d), so each segment is ONE contiguous
 sum-all-reduce, issued on a side HIP stream the moment autograd leaves the segment and overlapped with the rest
 of backward: the first 333 MB are in flight while the RGB decoder (the longest stretch of backward) still runs, and

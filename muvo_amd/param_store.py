@@ -12,15 +12,15 @@ import torch
 
 # Order in which backward finishes the parameters of the model (autograd runs the most recently recorded forward nodes
 # first: the reference, mile.py:437-487, calls policy, rgb, lidar_re, the config-off heads and the voxel decoder in that order;
-# muvo_amd/models/mile.py records the voxel decoder FIRST - see the comment there - so it completes last of the decoders).  Each entry is one contiguous range of the flat gradient buffer = ONE all-reduce, launched
+# muvo_amd/models/mile.py records voxel, range-view, RGB decoder - see the comment there - so backward completes RGB, range-view, voxel).  Each entry is one contiguous range of the flat gradient buffer = ONE all-reduce, launched
 # by the hook named in the comment (muvo_amd/models/mile.py `_mark` / `_hook`).
 SEGMENTS = (
     ('depth_image_decoder', ('depth_image_decoder.',)),
     ('sem_image_decoder', ('sem_image_decoder.',)),
     ('lidar_segmentation', ('lidar_segmentation.',)),
     ('bev_decoder', ('bev_decoder.',)),
-    ('lidar_re', ('lidar_re.',)),
     ('rgb_decoder', ('rgb_decoder.',)),
+    ('lidar_re', ('lidar_re.',)),
     ('voxel_decoder', ('voxel_decoder.',)),                      # recorded first in forward (models/mile.py), so finished last of the decoders
     ('policy', ('policy.',)),                                    # d(state) complete (every consumer of the state done)
     ('rssm', ('rssm.',)),                                        # d(embedding) arrives

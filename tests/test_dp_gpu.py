@@ -114,7 +114,7 @@ def test_segment_hooks_on_one_rank_group(dev):
             tr.on_after_backward()
             torch.cuda.synchronize()
             names = [n for n, _ in red.launch_log]
-            assert names == red.order == ['lidar_re', 'rgb_decoder', 'voxel_decoder', 'policy', 'rssm', 'fusion',
+            assert names == red.order == ['rgb_decoder', 'lidar_re', 'voxel_decoder', 'policy', 'rssm', 'fusion',
                                           'lidar_branch', 'image_branch']
             assert [h for _, h in red.launch_log] == [True] * 7 + [False], red.launch_log
             assert red.late_writes and max(red.late_writes.values()) == 0.0, red.late_writes
@@ -318,6 +318,6 @@ def test_two_processes_share_the_gpu(dev):
             assert _rel(got, want) < 2e-3, r['losses']
         assert not r['bad'], r['bad'][:3]
         for log in r['hooks']:
-            assert [n for n, _ in log] == ['lidar_re', 'rgb_decoder', 'voxel_decoder', 'policy', 'rssm', 'fusion', 'lidar_branch', 'image_branch']
+            assert [n for n, _ in log] == ['rgb_decoder', 'lidar_re', 'voxel_decoder', 'policy', 'rssm', 'fusion', 'lidar_branch', 'image_branch']
             assert [h for _, h in log] == [True] * 7 + [False]
     assert out[0]['digest'] == out[1]['digest'], (out[0]['digest'], out[1]['digest'])
