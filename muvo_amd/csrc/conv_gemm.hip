@@ -172,10 +172,33 @@ __global__ void __launch_bounds__(256) bias_act_kernel(float* __restrict__ y, co
 // GEMM rows = (t,c) (BM), cols = m (BN), reduction over BK = 32 pixels per tile, split-K over pixel
 // tiles with float atomics into the packed (zero-initialised) dWp.
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN>
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+// eight fp32 -> bf16 hi / lo fragments (RNE both, lo = bf16(x - hi)): the split of conv_bf3.hip, in registers
+__device__ __forceinline__ void wg_split8(const float (&v)[8], wg_bf16x8& hi, wg_bf16x8& lo) {
+  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const b2 hh = __builtin_convertvector((f2){v[2 * p], v[2 * p + 1]}, b2);
+    h[p] = __builtin_bit_cast(unsigned, hh);
+    const float h0 = __uint_as_float(h[p] << 16), h1 = __uint_as_float(h[p] & 0xffff0000u);
+    const b2 ll = __builtin_convertvector((f2){v[2 * p] - h0, v[2 * p + 1] - h1}, b2);
+    l[p] = __builtin_bit_cast(unsigned, ll);
+  }
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  hi = __builtin_bit_cast(wg_bf16x8, (u4){h[0], h[1], h[2], h[3]});
+  lo = __builtin_bit_cast(wg_bf16x8, (u4){l[0], l[1], l[2], l[3]});
+}
+
+template <int BM, int BN, int WM, int WN, bool BF3>
 __global__ void __launch_bounds__(256)
 conv_wgrad_kernel(const ConvPhase g, const float* __restrict__ in, const float* __restrict__ dout,
                   float* __restrict__ dwp, int tiles_per_split) {
+  // BF3: the same fp32 staging, but the products run as three bf16 MFMAs (hi*hi + lo*hi + hi*lo, split in registers from the
+  // fp32 LDS tile: the "bf16x3" arithmetic of conv_bf3.hip) instead of fp32 MFMAs - for the shapes the bf16x3 weight-gradient
+  // kernels do not take (fewer than 32 channels: the 7x7 stems, whose weight gradient is the last kernel of every backward
+  // pass and runs alone on the chip).  32 fp32 MFMAs of 64 clocks per 32-pixel step become 12 bf16 MFMAs of 32.
   constexpr int BK = 32;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   constexpr int LDA = BM + 1, LDB = BN + 1;
@@ -268,19 +291,49 @@ conv_wgrad_kernel(const ConvPhase g, const float* __restrict__ in, const float* 
     if (pt + 1 < t_end) load_tile(pt + 1);
     const float* As = As0 + buf * BK * LDA + wm * (TM * 32) + (lane & 31);
     const float* Bs = Bs0 + buf * BK * LDB + wn * (TN * 32) + (lane & 31);
+    if constexpr (BF3) {
 #pragma unroll
-    for (int k2 = 0; k2 < BK / 2; ++k2) {
-      const int kr = 2 * k2 + (lane >> 5);
-      float a[TM], b[TN];
+      for (int s16 = 0; s16 < BK / 16; ++s16) {
+        const int kb = 16 * s16 + 8 * (lane >> 5);      // this lane's 8 consecutive k of the 32x32x16 operand fragment
+        wg_bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = As[kr * LDA + i * 32];
+        for (int i = 0; i < TM; ++i) {
+          float v[8];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = Bs[kr * LDB + j * 32];
+          for (int e = 0; e < 8; ++e) v[e] = As[(kb + e) * LDA + i * 32];
+          wg_split8(v, ah[i], al[i]);
+        }
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < TN; ++j) {
+          float v[8];
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          for (int e = 0; e < 8; ++e) v[e] = Bs[(kb + e) * LDB + j * 32];
+          wg_split8(v, bh[j], bl[j]);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          }
+      }
+    } else {
+#pragma unroll
+      for (int k2 = 0; k2 < BK / 2; ++k2) {
+        const int kr = 2 * k2 + (lane >> 5);
+        float a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = As[kr * LDA + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = Bs[kr * LDB + j * 32];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
     }
     if (pt + 1 < t_end) store_tile(buf ^ 1);
     __syncthreads();
@@ -737,9 +790,18 @@ static int launch_wgrad_phase(const ConvPhase& g, const float* in, const float* 
   const int tps = cdiv(ntiles, nsplit);
   nsplit = cdiv(ntiles, tps);
   dim3 grid(gx, gy, nsplit);
-  if (bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, g, in, dout, dwp, tps);
-  else if (bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 2, 2>), grid, dim3(256), 0, st, g, in, dout, dwp, tps);
-  else hipLaunchKernelGGL((conv_wgrad_kernel<128, 32, 4, 1>), grid, dim3(256), 0, st, g, in, dout, dwp, tps);
+  // bf16x3 mode: the products of this kernel run as three bf16 MFMAs too (MUVO_F32_WGRAD_BF3=0: fp32 MFMAs as in the exact mode)
+  static const bool want_bf3 = !getenv("MUVO_F32_WGRAD_BF3") || atoi(getenv("MUVO_F32_WGRAD_BF3")) != 0;
+  const bool b3 = want_bf3 && conv_mode() == 1;
+  if (b3) {
+    if (bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, true>), grid, dim3(256), 0, st, g, in, dout, dwp, tps);
+    else if (bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 2, 2, true>), grid, dim3(256), 0, st, g, in, dout, dwp, tps);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<128, 32, 4, 1, true>), grid, dim3(256), 0, st, g, in, dout, dwp, tps);
+  } else {
+    if (bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, false>), grid, dim3(256), 0, st, g, in, dout, dwp, tps);
+    else if (bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 2, 2, false>), grid, dim3(256), 0, st, g, in, dout, dwp, tps);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<128, 32, 4, 1, false>), grid, dim3(256), 0, st, g, in, dout, dwp, tps);
+  }
   MUVO_CHECK_LAUNCH("conv_wgrad_kernel");
   return MUVO_OK;
 }

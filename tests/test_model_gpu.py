@@ -434,8 +434,10 @@ def test_loss_curve_matches_reference(dev, mode):
     """Eight optimizer steps of the REAL reference (tests/golden/base1d_b1s2_curve.json: make_golden.py --steps 8, a new batch
     every step, OneCycleLR running) against the HIP step: every one of the 21 loss terms at every step, and the parameters after
     the last step.  The trajectories separate slowly (each step feeds the previous step's rounding differences through
-    Adam's g/|g|): the bar is 1e-3 on the first step and grows by 1e-3 per step; the measured deviations are written to
-    gpurun_out/loss_curve.txt."""
+    Adam's g/|g|): the bar on a single term is 1e-3 on the first step and grows by 1e-3 per step, the TOTAL stays within 1e-3
+    at every step; the measured deviations are written to gpurun_out/loss_curve.txt.  The bf16x3 case runs in the deterministic
+    mode, so its numbers are the same in every run (total 2.8e-4 at step 7; with float atomics the same curve lands between
+    4.8e-4 and 5.9e-4 from run to run)."""
     from muvo_amd import ops
     from muvo_amd.config import base_1d_cfg
     from muvo_amd.data.synthetic import make_batch, make_noise
@@ -445,7 +447,9 @@ def test_loss_curve_matches_reference(dev, mode):
     b, s, seed = fx['b'], fx['s'], fx['seed']
     assert len(fx['steps']) == 8
     old = ops.get_conv_mode()
+    was_det = ops.get_deterministic()
     ops.set_conv_mode(ops.CONV_F32 if mode == 'f32' else ops.CONV_BF16X3, min_gflop=-1.0)
+    ops.set_deterministic(mode != 'f32')
     try:
         tr = WorldModelTrainer(base_1d_cfg(RECEPTIVE_FIELD=s, FUTURE_HORIZON=0, STEPS=100000).convert_to_dict(), device=dev)
         tr.train()
@@ -480,4 +484,5 @@ def test_loss_curve_matches_reference(dev, mode):
                if abs(dict(tr.model.named_parameters())[n].detach().double().abs().sum().item() - a_ref) > 1e-4 * a_ref + 8 * 1e-4]
         assert not bad, bad[:5]
     finally:
+        ops.set_deterministic(was_det)
         ops.set_conv_mode(old, min_gflop=-1.0)
