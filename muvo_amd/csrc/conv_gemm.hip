@@ -20,10 +20,32 @@
 #include "conv_plan.h"
 #include "conv_bf3.h"
 
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+// eight fp32 -> bf16 hi / lo fragments (RNE both, lo = bf16(x - hi)): the split of conv_bf3.hip, in registers
+__device__ __forceinline__ void wg_split8(const float (&v)[8], wg_bf16x8& hi, wg_bf16x8& lo) {
+  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const b2 hh = __builtin_convertvector((f2){v[2 * p], v[2 * p + 1]}, b2);
+    h[p] = __builtin_bit_cast(unsigned, hh);
+    const float h0 = __uint_as_float(h[p] << 16), h1 = __uint_as_float(h[p] & 0xffff0000u);
+    const b2 ll = __builtin_convertvector((f2){v[2 * p] - h0, v[2 * p + 1] - h1}, b2);
+    l[p] = __builtin_bit_cast(unsigned, ll);
+  }
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  hi = __builtin_bit_cast(wg_bf16x8, (u4){h[0], h[1], h[2], h[3]});
+  lo = __builtin_bit_cast(wg_bf16x8, (u4){l[0], l[1], l[2], l[3]});
+}
+
 // ------------------------------------------------------------------------------------------------
 // Forward-type kernel.  256 threads = 4 waves arranged WM x WN; each wave owns TM x TN MFMA tiles of
 // 32x32.  BK = 16, double-buffered LDS, register-staged prefetch (one barrier per K tile).
 // RUN = number of consecutive k (channels) that share one tap within a thread's k-run.
+// (A bf16x3 form of the inner loop as in conv_wgrad_kernel was tried for the 7x7 stems: -0.2 ms/step, but the stems' rounding
+// then propagates into every gradient and flipped the sign of a few zero-expectation bias gradients against the reference's first
+// AdamW step, tests/test_dp_gpu.py::test_two_rank_step_matches_reference; the forward / data-gradient kernel stays exact.)
 // ------------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, int RUN>
 __global__ void __launch_bounds__(256)
@@ -172,25 +194,6 @@ __global__ void __launch_bounds__(256) bias_act_kernel(float* __restrict__ y, co
 // GEMM rows = (t,c) (BM), cols = m (BN), reduction over BK = 32 pixels per tile, split-K over pixel
 // tiles with float atomics into the packed (zero-initialised) dWp.
 // ------------------------------------------------------------------------------------------------
-typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
-// eight fp32 -> bf16 hi / lo fragments (RNE both, lo = bf16(x - hi)): the split of conv_bf3.hip, in registers
-__device__ __forceinline__ void wg_split8(const float (&v)[8], wg_bf16x8& hi, wg_bf16x8& lo) {
-  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
-  typedef float f2 __attribute__((ext_vector_type(2)));
-  unsigned h[4], l[4];
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const b2 hh = __builtin_convertvector((f2){v[2 * p], v[2 * p + 1]}, b2);
-    h[p] = __builtin_bit_cast(unsigned, hh);
-    const float h0 = __uint_as_float(h[p] << 16), h1 = __uint_as_float(h[p] & 0xffff0000u);
-    const b2 ll = __builtin_convertvector((f2){v[2 * p] - h0, v[2 * p + 1] - h1}, b2);
-    l[p] = __builtin_bit_cast(unsigned, ll);
-  }
-  typedef unsigned u4 __attribute__((ext_vector_type(4)));
-  hi = __builtin_bit_cast(wg_bf16x8, (u4){h[0], h[1], h[2], h[3]});
-  lo = __builtin_bit_cast(wg_bf16x8, (u4){l[0], l[1], l[2], l[3]});
-}
-
 template <int BM, int BN, int WM, int WN, bool BF3>
 __global__ void __launch_bounds__(256)
 conv_wgrad_kernel(const ConvPhase g, const float* __restrict__ in, const float* __restrict__ dout,
@@ -734,6 +737,12 @@ static int build_plan(const muvo_conv_desc* d, ConvPlan* pl, int mode = -1, bool
   return MUVO_OK;
 }
 
+// work threshold (per launch) above which the fp32-staged kernels use bf16x3 products in the bf16x3 mode
+static double f32_bf3_min_gflop() {
+  static const double v = getenv("MUVO_F32_BF3_MIN_GFLOP") ? atof(getenv("MUVO_F32_BF3_MIN_GFLOP")) : 2.0;
+  return v;
+}
+
 template <int BM, int BN, int WM, int WN>
 static void launch_fwd_run(const ConvPhase& g, const float* in, const float* wp, const float* bias, float* out,
                            int act, float slope, hipStream_t st, int ksplit) {
@@ -792,7 +801,8 @@ static int launch_wgrad_phase(const ConvPhase& g, const float* in, const float* 
   dim3 grid(gx, gy, nsplit);
   // bf16x3 mode: the products of this kernel run as three bf16 MFMAs too (MUVO_F32_WGRAD_BF3=0: fp32 MFMAs as in the exact mode)
   static const bool want_bf3 = !getenv("MUVO_F32_WGRAD_BF3") || atoi(getenv("MUVO_F32_WGRAD_BF3")) != 0;
-  const bool b3 = want_bf3 && conv_mode() == 1;
+  const bool b3 = want_bf3 && conv_mode() == 1 &&
+                  2e-9 * (double)g.M * (double)g.npix * (double)g.T * (double)g.C >= f32_bf3_min_gflop();   // large launches only (the stems)
   if (b3) {
     if (bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 2, true>), grid, dim3(256), 0, st, g, in, dout, dwp, tps);
     else if (bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64, 2, 2, true>), grid, dim3(256), 0, st, g, in, dout, dwp, tps);
