@@ -900,13 +900,68 @@ int muvo_maxpool2d_fwd(const float* x, float* y, uint8_t* idx, int64_t NC, int H
   MUVO_CHECK_LAUNCH("maxpool2d_fwd");
   return MUVO_OK;
 }
+// 3x3 stride-2 pad-1 form for W % 8 == 0, OW % 4 == 0, H = 2 OH (the ResNet stems): a lane owns EIGHT consecutive input columns
+// of the ROW PAIR (2r, 2r+1).  They are touched by the five windows 4l .. 4l+4 of the window rows r (rows 2r-1 .. 2r+1) and r+1
+// (row 2r+1 only): per window row one 16-byte gradient load, one 4-byte winner load and one scalar pair for the fifth window -
+// instead of 2 x 3 scalar pairs per four columns of one row - and four 16-byte stores.  Standalone on 20 x 64 x 160 x 416:
+// 96 us against 134 us with one row per lane (tools/dev/maxpool_bwd_probe.hip; stores alone 54 us); it is the last memory-bound
+// pass on the main stream before the stem's weight gradient.
+__global__ void __launch_bounds__(256) maxpool3s2_bwd_v8_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                                 float* __restrict__ dx, int H, int W, int OH, int OW) {
+  const int l = blockIdx.x * 64 + threadIdx.x, w0 = 8 * l, r = blockIdx.y * 4 + threadIdx.y;
+  if (w0 >= W || 2 * r >= H) return;
+  const long nc = blockIdx.z;
+  float g0[8], g1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) g0[e] = g1[e] = 0.f;
+  const int j4 = min(4 * l + 4, OW - 1);                              // fifth window (clamped; masked below)
+  const bool live4 = 4 * l + 4 <= OW - 1;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int oh = min(r + i, OH - 1);
+    const bool live = r + i <= OH - 1;
+    const long ro = (nc * OH + oh) * (long)OW;
+    const float4 d4 = *(const float4*)(dy + ro + 4 * l);
+    const uchar4 i4 = *(const uchar4*)(idx + ro + 4 * l);
+    const float dd[5] = {d4.x, d4.y, d4.z, d4.w, dy[ro + j4]};
+    const int ww[5] = {i4.x, i4.y, i4.z, i4.w, idx[ro + j4]};
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const bool lv = live && (j < 4 || live4);
+      const int a0 = ww[j] / 3, b0 = ww[j] - 3 * a0;                   // winner (row, column) inside the window
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const int e = 2 * j - 1 + b;                                   // window 4l+j covers columns 2j-1 .. 2j+1 of this lane
+        if (e >= 0 && e < 8 && lv && b0 == b) {
+          // window row r: input rows 2r-1 (a = 0, another lane's pair), 2r (a = 1), 2r+1 (a = 2); window row r+1: row 2r+1 is a = 0
+          if (i == 0) {
+            if (a0 == 1) g0[e] += dd[j];
+            if (a0 == 2) g1[e] += dd[j];
+          } else if (a0 == 0) {
+            g1[e] += dd[j];
+          }
+        }
+      }
+    }
+  }
+  float* o = dx + (nc * H + 2 * r) * (long)W + w0;
+  *(float4*)o = make_float4(g0[0], g0[1], g0[2], g0[3]);
+  *(float4*)(o + 4) = make_float4(g0[4], g0[5], g0[6], g0[7]);
+  *(float4*)(o + W) = make_float4(g1[0], g1[1], g1[2], g1[3]);
+  *(float4*)(o + W + 4) = make_float4(g1[4], g1[5], g1[6], g1[7]);
+}
+
 int muvo_maxpool2d_bwd(const float* dy, const uint8_t* idx, float* dx, int64_t NC, int H, int W, int OH, int OW, int k,
                        int s, int p, void* stream) {
   MUVO_CHECK_ARG(dy && dx && idx && NC > 0 && NC <= 2147483647L, "maxpool2d_bwd: bad args");
   MUVO_CHECK_ARG((k == 3 && s == 2 && p == 1) || (k == 2 && s == 2 && p == 0), "maxpool2d: only 3x3 s2 p1 and 2x2 s2 p0 are on the path");
   MUVO_CHECK_ARG(cdiv(H, 4) <= 65535, "maxpool2d_bwd: image too tall");
   dim3 grid(cdiv(W, 256), cdiv(H, 4), (unsigned)NC), block(64, 4);
-  if (k == 3) hipLaunchKernelGGL((maxpool2d_bwd_t_kernel<3, 2, 1>), grid, block, 0, ST, dy, idx, dx, H, W, OH, OW);
+  static const bool v8 = !getenv("MUVO_MAXPOOL_BWD_V8") || atoi(getenv("MUVO_MAXPOOL_BWD_V8")) != 0;   // A/B switch
+  if (k == 3 && v8 && W % 8 == 0 && OW % 4 == 0 && 2 * OW == W && 2 * OH == H && ((((uintptr_t)dy) | ((uintptr_t)dx)) & 15) == 0 &&
+      (((uintptr_t)idx) & 3) == 0) {
+    hipLaunchKernelGGL(maxpool3s2_bwd_v8_kernel, dim3(cdiv(W / 8, 64), cdiv(H / 2, 4), (unsigned)NC), block, 0, ST, dy, idx, dx, H, W, OH, OW);
+  } else if (k == 3) hipLaunchKernelGGL((maxpool2d_bwd_t_kernel<3, 2, 1>), grid, block, 0, ST, dy, idx, dx, H, W, OH, OW);
   else hipLaunchKernelGGL((maxpool2d_bwd_t_kernel<2, 2, 0>), grid, block, 0, ST, dy, idx, dx, H, W, OH, OW);
   MUVO_CHECK_LAUNCH("maxpool2d_bwd");
   return MUVO_OK;

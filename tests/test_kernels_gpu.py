@@ -753,7 +753,8 @@ def test_pooling_and_upsample(dev):
     from muvo_amd import ops
     torch.manual_seed(7)
     shapes = {'plain': torch.randn(2, 5, 13, 18), 'ties': (torch.randn(2, 3, 33, 70) * 2).round() / 2,   # many equal maxima
-              'wide': torch.randn(1, 2, 64, 1024), 'tiny': torch.randn(3, 2, 2, 2)}
+              'wide': torch.randn(1, 2, 64, 1024), 'tiny': torch.randn(3, 2, 2, 2),
+              'ties8': (torch.randn(2, 3, 32, 72) * 2).round() / 2, 'stem': torch.randn(2, 4, 160, 416)}   # eight-column backward kernel
     for name, (k, s, p) in [(n_, c_) for n_ in shapes for c_ in ((3, 2, 1), (2, 2, 0))]:
         x = shapes[name]
         xg, xc = x.to(dev).requires_grad_(True), x.clone().requires_grad_(True)

@@ -53,13 +53,13 @@ def main():
         y = ops.max_pool2d(x, 3, 2, 1)
         g = torch.randn_like(y)
         report('maxpool3s2 fwd 20x64x160x416', timeit(lambda: ops.max_pool2d(x.detach(), 3, 2, 1)), x.numel() * 4 + y.numel() * 8)
-        report('maxpool3s2 bwd', timeit(lambda: y.backward(g, retain_graph=True)), x.numel() * 4 + y.numel() * 8)
+        report('maxpool3s2 bwd', timeit(lambda: torch.autograd.grad(y, x, g, retain_graph=True)), x.numel() * 4 + y.numel() * 8)   # (autograd.grad: no AccumulateGrad add pass in the timing)
     if on('upsample'):
         x = torch.randn(20, 16, 96, 96, 32, device=dev, requires_grad=True)
         y = ops.upsample3d_x2(x)
         g = torch.randn_like(y)
         report('upsample3d fwd 20x16x96x96x32', timeit(lambda: ops.upsample3d_x2(x.detach())), x.numel() * 4 + y.numel() * 4)
-        report('upsample3d bwd', timeit(lambda: y.backward(g, retain_graph=True)), x.numel() * 4 + y.numel() * 4)
+        report('upsample3d bwd', timeit(lambda: torch.autograd.grad(y, x, g, retain_graph=True)), x.numel() * 4 + y.numel() * 4)
     if on('voxloss'):
         lg = torch.randn(2, 10, 2, 192, 192, 64, device=dev, requires_grad=True)
         lab = (torch.rand(2, 10, 1, 192, 192, 64, device=dev) < 0.1).to(torch.uint8)
