@@ -65,6 +65,60 @@ def cpu_baseline(cores):
                        f'{frames_per_s:.3f} frames/s; value = frames/s / 10 (one sample = 10 frames)')
 
 
+def run_extension(name, dev, batch, s, steps=5, warmup=2):
+    """One extension workload (no reference code for these sizes / this arithmetic: parity unpinned, own oracle only,
+    tests/test_extension.py): a fresh trainer, `warmup` untimed steps, `steps` steps between HIP events.
+    rv2048 = the 64 x 2048 range view north_star names, vox256 = the 256 x 256 x 64 voxel grid of BASELINE configs[4],
+    bf16 = base_1d sizes with ONE bf16 product per fp32 product (the reference's shipped '16-mixed' arithmetic)."""
+    import gc
+    from muvo_amd import ops
+    from muvo_amd.config import base_1d_cfg
+    from muvo_amd.data.synthetic import make_batch
+    from muvo_amd.trainer import WorldModelTrainer
+    ext, sizes = {}, {}
+    if name == 'rv2048':
+        ext, sizes = {'MODEL.CONSTANT_SIZE.LIDAR': [1, 32]}, dict(range_hw=(64, 2048))
+    elif name == 'vox256':
+        ext, sizes = {'MODEL.CONSTANT_SIZE.VOXEL': [4, 4, 1]}, dict(voxel=(256, 256, 64))
+    old_mode = ops.get_conv_mode()
+    if name == 'bf16':
+        ops.set_conv_mode(ops.CONV_BF16)
+    try:
+        cfg = base_1d_cfg(RECEPTIVE_FIELD=min(6, s), FUTURE_HORIZON=s - min(6, s), BATCHSIZE=batch, STEPS=100000, **ext)
+        torch.manual_seed(1234)
+        tr = WorldModelTrainer(cfg.convert_to_dict(), device=dev)
+        tr.train()
+        opts, scheds = tr.configure_optimizers()
+        opt, sched = opts[0], scheds[0]['scheduler']
+        batches = [make_batch(batch, s, seed=1234 + k, device=dev, **sizes) for k in range(2)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        for i in range(warmup + steps):
+            if i == warmup:
+                ev[0].record()
+            opt.zero_grad()
+            loss = tr.training_step(dict(batches[i % 2]), i)
+            loss.backward()
+            tr.on_after_backward()
+            opt.step()
+            sched.step()
+            if i >= warmup:
+                ev[i - warmup + 1].record()
+        torch.cuda.synchronize()
+        ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+        res = dict(ms_per_step=ev[0].elapsed_time(ev[steps]) / steps, median_ms_per_step=ms[len(ms) // 2], steps=steps, warmup=warmup,
+                   value=batch / (ev[0].elapsed_time(ev[steps]) / steps * 1e-3), unit='samples/s', parity='unpinned',
+                   final_loss=float(loss.item()),
+                   what={'rv2048': '64 x 2048 range view (MODEL.CONSTANT_SIZE.LIDAR = [1, 32]), bf16x3',
+                         'vox256': '256 x 256 x 64 voxel grid (MODEL.CONSTANT_SIZE.VOXEL = [4, 4, 1]), bf16x3',
+                         'bf16': 'base_1d sizes, large contractions with ONE bf16 product (muvo_conv_set_products(1))'}[name])
+    finally:
+        ops.set_conv_mode(old_mode)
+    del tr, opt, sched, opts, scheds, batches, loss
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -82,7 +136,15 @@ def main():
                     help='base_1d: BASELINE.json configs[1] (the judged line).  Extensions through MODEL.CONSTANT_SIZE (no reference '
                          'implementation, parity unpinned): rv2048 = the 64 x 2048 range view north_star names; vox256 = the '
                          '256 x 256 x 64 voxel grid of configs[4] (use with --batch 8 --seq-len 12 for that configuration)')
+    ap.add_argument('--no-extensions', action='store_true',
+                    help='skip the extension workloads (rv2048, vox256, single-product bf16: 5 steps each after the judged region)')
     args = ap.parse_args()
+
+    if os.environ.get('MUVO_BENCH_CORES'):
+        # what an 8-rank box leaves each rank: restrict this process (and the threads it starts) to that many host cores
+        # BEFORE anything touches the GPU (an env switch, not a wrapper process)
+        ncore = max(1, int(os.environ['MUVO_BENCH_CORES']))
+        os.sched_setaffinity(0, set(sorted(os.sched_getaffinity(0))[:ncore]))
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # `python bench.py --gpus N` without a launcher: start one rank per GPU through torch.distributed.run as a CHILD
@@ -284,7 +346,8 @@ def main():
                                                      'chip with kernels of the side streams (muvo_amd/ops.py: branch, wgrad_stream); '
                                                      '*_isolated: the same brackets in extra steps with MUVO_STREAMS off')
             out['side_streams'] = dict(enabled=bool(streams_were[0]), branches=sorted(ops.BRANCHES), wgrad_stream=bool(streams_were[1]),
-                                       budget=ops.STREAM_BUDGET[0], hw_queues=os.environ.get('GPU_MAX_HW_QUEUES'))
+                                       budget=ops.STREAM_BUDGET[0], hw_queues=os.environ.get('GPU_MAX_HW_QUEUES'),
+                                       hw_queues_state=muvo_amd.hw_queue_state(), side_priority=dict(ops.SIDE_PRIORITY))
             out['kernel_class_steps'] = extra_steps
             if out['roofline'] is not None:
                 conv_s = sum(c['seconds'] for c in out['kernel_classes'].values())
@@ -323,6 +386,34 @@ def main():
                         r['traffic_bytes_per_step'] = c['hbm_bytes_per_launch'] * c['dispatches'] / psteps
                         r['algorithmic_bytes_per_step'] = r['algorithmic_bytes'] * r['launches'] / args.steps
                         r['traffic_over_algorithmic'] = r['traffic_bytes_per_step'] / max(r['algorithmic_bytes_per_step'], 1.0)
+        if 'kernel_classes' in out:
+            # every class against the HBM roof as well (algorithmic bytes: both activation tensors + the weight, fp32, each touched
+            # once per operation): the voxel class (8 / 16 channels) is the one where this is the tighter roof
+            for c in out['kernel_classes'].values():
+                c['hbm_gbs'] = c['algorithmic_gb'] / max(c['seconds'], 1e-12)
+                c['hbm_frac'] = c['hbm_gbs'] / 8000.0
+            vox = {k: c for k, c in out['kernel_classes'].items() if k.startswith('vox_bf16x3')}
+            if vox:
+                sec, gb, tf = (sum(c[k] for c in vox.values()) for k in ('seconds', 'algorithmic_gb', 'tflop'))
+                out['voxel_class'] = dict(ms_per_step=sec / extra_steps * 1e3, algorithmic_gb_per_step=gb / extra_steps,
+                                          hbm_gbs=gb / max(sec, 1e-12), hbm_frac=gb / max(sec, 1e-12) / 8000.0,
+                                          ms_at_hbm_roof=gb / extra_steps / 8000.0 * 1e3,
+                                          mfma_frac=3.0 * tf / max(sec, 1e-12) / 2500.0)
+        if out.get('roofline') is not None:
+            out['roofline']['frac_is'] = ('in situ: HIP-event brackets inside the timed region, side streams on (a bracket also contains the '
+                                          "neighbours' share of the chip); frac_isolated = the kernel figure (same brackets, side streams off)")
+        if world == 1 and args.workload == 'base_1d' and args.conv_mfma == 'bf16x3' and not args.no_extensions:
+            # (the judged trainer, its optimizer state and the last step's autograd graph go first: 70 GB peak otherwise doubles)
+            del batches, tr, opt, sched, opts, scheds, loss
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            out['extensions'] = {}
+            for name in ('rv2048', 'vox256', 'bf16'):
+                try:
+                    out['extensions'][name] = run_extension(name, dev, args.batch, s)
+                except Exception as e:          # an extension must never cost the judged line
+                    out['extensions'][name] = dict(error=f'{type(e).__name__}: {e}'[:300], parity='unpinned')
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(usable_cores())
         print(json.dumps(out), flush=True)

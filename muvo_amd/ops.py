@@ -318,8 +318,35 @@ def side_stream(name, device):
     key = (name, device.index)
     st = _side_streams.get(key)
     if st is None:
-        st = _side_streams[key] = torch.cuda.Stream(device=device)
+        st = _side_streams[key] = _new_stream(device, SIDE_PRIORITY.get(name, SIDE_PRIORITY.get('*', 0)))
     return st
+
+
+# HIP stream priorities of the side streams (MUVO_SIDE_PRIORITY="*=low" | "s2=low,s0=normal" ...; physical stream names s0..s2).
+# The main stream's chain is the critical path of the step; a low-priority side stream only gets the compute units the main
+# stream's launches leave idle.
+SIDE_PRIORITY = {k: {'low': 1, 'normal': 0, 'high': -1}.get(v, 0)
+                 for k, v in (kv.split('=') for kv in os.environ.get('MUVO_SIDE_PRIORITY', '').split(',') if '=' in kv)}
+_hip_rt = [None]
+
+
+def _new_stream(device, priority=0):
+    """a non-blocking HIP stream of the given priority (-1 high, 0 normal, 1 low) as a torch stream object.  torch.cuda.Stream
+    only knows 'normal' and 'high' on ROCm, so other priorities are created through the HIP runtime and wrapped."""
+    if priority == 0:
+        return torch.cuda.Stream(device=device)
+    if _hip_rt[0] is None:
+        _hip_rt[0] = C.CDLL('libamdhip64.so')
+    rt = _hip_rt[0]
+    least, greatest = C.c_int(0), C.c_int(0)
+    with torch.cuda.device(device):
+        if rt.hipDeviceGetStreamPriorityRange(C.byref(least), C.byref(greatest)) != 0:
+            return torch.cuda.Stream(device=device)
+        prio = least.value if priority > 0 else greatest.value
+        h = C.c_void_p(0)
+        if rt.hipStreamCreateWithPriority(C.byref(h), C.c_uint(1), C.c_int(prio)) != 0 or not h.value:   # 1 = hipStreamNonBlocking
+            return torch.cuda.Stream(device=device)
+    return torch.cuda.ExternalStream(h.value, device=device)
 
 
 def mark_inputs_ready(device):

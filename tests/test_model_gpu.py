@@ -349,6 +349,56 @@ def test_deterministic_mode_is_bit_reproducible(dev, mode):
         ops.set_conv_mode(old, min_gflop=-1.0)
 
 
+def _check_headline_gradients(mode, grads):
+    """The gradients of the BASELINE workload (batch 2 x 10 frames: BatchNorm statistics over 20 frames, the tile / split-K
+    choices of the full-size launches) against the float32 backward pass of the REAL reference on the same batch
+    (tests/golden/base1d_b2s10_bwd*: oracle/refimport/make_golden_bwd.py, muvo/trainer.py:392-402 with the big sub-networks
+    checkpointed).  Both sides are fp32 evaluations of an ill-conditioned chain; the b2s4 fixture knows how far the
+    reference's own fp32 gradients are from its float64 truth per tensor (grad_l2_ref32_err / grad_l2_fp64) and, for the
+    default arithmetic, how far the reference moves under bf16x3-sized rounding (base1d_b2s4_rounding.json).  Bar on the
+    L2 norm of each of the 440 tensors: 2e-3 relative, or 8x that relative noise floor (two fp32 evaluations), or 2x the
+    rounding response; strided samples of the ten largest + named tensors: 5e-3 relative L2 of the sample vector or the
+    same floors."""
+    fx = json.load(open(os.path.join(GOLD, 'base1d_b2s10_bwd.json')))['steps'][0]
+    smp = np.load(os.path.join(GOLD, 'base1d_b2s10_bwd_samples.npz'))
+    small = json.load(open(os.path.join(GOLD, 'base1d_b2s4.json')))['steps'][0]
+    rnd = json.load(open(os.path.join(GOLD, 'base1d_b2s4_rounding.json'))) if mode == 'policy' else None
+    assert sum(v is not None for v in fx['grad_l2'].values()) == 440 == len(grads)
+    bad, worst = [], (0.0, None)
+    for n, ref in fx['grad_l2'].items():
+        if ref is None:
+            assert n not in grads, n
+            continue
+        got = grads[n].double().pow(2).sum().sqrt().item()
+        floor = small['grad_l2_ref32_err'][n] / max(small['grad_l2_fp64'][n], 1e-30)
+        tol = max(2e-3, 8.0 * floor)
+        if rnd:
+            tol = max(tol, 2.0 * rnd['grad_l2_err'][n] / max(small['grad_l2_fp64'][n], 1e-30))
+        dev_rel = abs(got - ref) / max(ref, 1e-30)
+        if dev_rel / tol > worst[0]:
+            worst = (dev_rel / tol, f'{n}: {dev_rel:.2e} of a bar of {tol:.2e}')
+        if dev_rel > tol and abs(got - ref) > 1e-6:
+            bad.append((n, got, ref, tol))
+    line = f'b2s10 {mode} gradients: {len(bad)} of 440 L2 norms outside their bar; closest to it {worst[1]}'
+    print(line)
+    os.makedirs(os.path.join(os.path.dirname(GOLD), '..', 'gpurun_out'), exist_ok=True)
+    with open(os.path.join(os.path.dirname(GOLD), '..', 'gpurun_out', 'headline_parity.txt'), 'a') as f:
+        f.write(line + '\n')
+    assert not bad, f'{len(bad)} gradient norms off, first: {bad[:5]}'
+    for key in smp.files:
+        n = key[5:]
+        ref = torch.from_numpy(smp[key]).double()
+        t = grads[n].double().contiguous().view(-1)
+        stride = max(1, t.numel() // 1024)
+        got = t[::stride][:ref.numel()].cpu()
+        floor = small['grad_l2_ref32_err'][n] / max(small['grad_l2_fp64'][n], 1e-30)
+        tol = max(5e-3, 8.0 * floor)
+        if rnd:
+            tol = max(tol, 3.0 * rnd['grad_l2_err'][n] / max(small['grad_l2_fp64'][n], 1e-30))
+        err = (got - ref).norm().item() / max(ref.norm().item(), 1e-30)
+        assert err <= tol, f'{n}: sample L2 err {err:.3e} > {tol:.3e}'
+
+
 @pytest.mark.parametrize('mode', ['f32', 'policy'])
 def test_headline_workload_matches_reference(dev, mode):
     """The BASELINE workload itself - base_1d, batch 2 x seq_len 10, full sizes - against the REAL reference run on the same
@@ -380,11 +430,21 @@ def test_headline_workload_matches_reference(dev, mode):
         eps, use_prior = make_noise(b, s, seed=seed)
         assert use_prior == fx['use_prior']
         batch = make_batch(b, s, seed=seed, device=dev)
-        with torch.no_grad():
-            losses, output, _, _ = tr.shared_step(batch, mode='train', noise=eps.to(dev), use_prior=use_prior)
-            total = tr.loss_reducing(losses)
+        # grad mode (the path bench.py runs: activations saved, split planes kept), then the backward pass of the same step
+        opt = tr.configure_optimizers()[0][0]
+        opt.zero_grad()
+        losses, output, _, _ = tr.shared_step(batch, mode='train', noise=eps.to(dev), use_prior=use_prior)
+        total = tr.loss_reducing(losses)
+        total.backward()
+        ops.join_side_streams()
+        grads = {n: p.grad.detach() for n, p in tr.model.named_parameters() if p.grad is not None}
+        losses = {k: v.detach() for k, v in losses.items()}
+        total = total.detach()
+        output = {k: (v.detach() if torch.is_tensor(v) else ({kk: vv.detach() for kk, vv in v.items()} if isinstance(v, dict) else v))
+                  for k, v in output.items()}
     finally:
         ops.set_conv_mode(old, min_gflop=-1.0)
+    _check_headline_gradients(mode, grads)
     assert set(losses) == set(g['losses']) and len(losses) == 21
     lines = [f'{mode}: total {total.item():.7f} vs {g["total"]:.7f} (rel {_rel(total.item(), g["total"]):.2e})']
     for k, v in g['losses'].items():
@@ -429,15 +489,16 @@ def test_headline_workload_matches_reference(dev, mode):
         assert tot <= 2e-4 * n, lines[-1]
 
 
-@pytest.mark.parametrize('mode', ['f32', 'policy'])
+@pytest.mark.parametrize('mode', ['f32', 'policy', 'policy_default'])
 def test_loss_curve_matches_reference(dev, mode):
-    """Eight optimizer steps of the REAL reference (tests/golden/base1d_b1s2_curve.json: make_golden.py --steps 8, a new batch
+    """32 optimizer steps of the REAL reference (tests/golden/base1d_b1s2_curve.json: make_golden.py --steps 32, a new batch
     every step, OneCycleLR running) against the HIP step: every one of the 21 loss terms at every step, and the parameters after
-    the last step.  The trajectories separate slowly (each step feeds the previous step's rounding differences through
-    Adam's g/|g|): the bar on a single term is 1e-3 on the first step and grows by 1e-3 per step, the TOTAL stays within 1e-3
-    at every step; the measured deviations are written to gpurun_out/loss_curve.txt.  The bf16x3 case runs in the deterministic
-    mode, so its numbers are the same in every run (total 2.8e-4 at step 7; with float atomics the same curve lands between
-    4.8e-4 and 5.9e-4 from run to run)."""
+    steps 8 and 32.  The trajectories separate slowly (each step feeds the previous step's rounding differences through
+    Adam's g/|g|): the bar on a single term is 1e-3 on the first step and grows by 1e-3 per step up to 8e-3, the TOTAL stays
+    within 1e-3 at every step (north_star: "loss curves matching reference to 1e-3"); the measured deviations are written to
+    gpurun_out/loss_curve.txt.  'policy' = the default arithmetic (bf16x3) in the deterministic mode, so its numbers are the
+    same in every run; 'policy_default' = the same arithmetic exactly as bench.py runs it (float atomics, split-K, side
+    streams on), whose curve differs from run to run inside the same bar."""
     from muvo_amd import ops
     from muvo_amd.config import base_1d_cfg
     from muvo_amd.data.synthetic import make_batch, make_noise
@@ -445,11 +506,11 @@ def test_loss_curve_matches_reference(dev, mode):
     from muvo_amd.utils import detinit
     fx = json.load(open(os.path.join(GOLD, 'base1d_b1s2_curve.json')))
     b, s, seed = fx['b'], fx['s'], fx['seed']
-    assert len(fx['steps']) == 8
+    assert len(fx['steps']) == 32
     old = ops.get_conv_mode()
     was_det = ops.get_deterministic()
     ops.set_conv_mode(ops.CONV_F32 if mode == 'f32' else ops.CONV_BF16X3, min_gflop=-1.0)
-    ops.set_deterministic(mode != 'f32')
+    ops.set_deterministic(mode == 'policy')
     try:
         tr = WorldModelTrainer(base_1d_cfg(RECEPTIVE_FIELD=s, FUTURE_HORIZON=0, STEPS=100000).convert_to_dict(), device=dev)
         tr.train()
@@ -462,6 +523,12 @@ def test_loss_curve_matches_reference(dev, mode):
         eps, use_prior = make_noise(b, s, seed=seed)
         eps = eps.to(dev)
         lines, worst, worst_total = [], [], []
+
+        def check_params(g, step):
+            named = dict(tr.model.named_parameters())
+            bad = [n for n, (s_ref, a_ref) in g['param_checksums_after_step'].items()
+                   if abs(named[n].detach().double().abs().sum().item() - a_ref) > 1e-4 * (step / 8) * a_ref + step * 1e-4]
+            assert not bad, (step, bad[:5])
         for step, g in enumerate(fx['steps']):
             opt.zero_grad()
             total = tr.training_step(make_batch(b, s, seed=seed + step, device=dev), step, noise=eps, use_prior=use_prior)
@@ -474,15 +541,17 @@ def test_loss_curve_matches_reference(dev, mode):
             worst_total.append(_rel(total.item(), g['total']))
             lines.append(f'{mode} step {step}: total {total.item():.6f} vs {g["total"]:.6f} (rel {_rel(total.item(), g["total"]):.2e}); '
                          f'worst term {w} {dev_k[w]:.2e}')
+            if 'param_checksums_after_step' in g:
+                check_params(g, step + 1)
+        lines.append(f'{mode} drift: max total deviation steps 1-8 {max(worst_total[:8]):.2e}, 9-16 {max(worst_total[8:16]):.2e}, '
+                     f'17-24 {max(worst_total[16:24]):.2e}, 25-32 {max(worst_total[24:]):.2e}; worst single term {max(worst):.2e}')
+        os.makedirs(os.path.join(os.path.dirname(GOLD), '..', 'gpurun_out'), exist_ok=True)
         with open(os.path.join(os.path.dirname(GOLD), '..', 'gpurun_out', 'loss_curve.txt'), 'a') as f:
             f.write('\n'.join(lines) + '\n')
         print('\n'.join(lines))
         for step, wv in enumerate(worst):
-            assert wv < 1e-3 * (step + 1), lines[step]
+            assert wv < min(1e-3 * (step + 1), 8e-3), lines[step]
             assert worst_total[step] < 1e-3, lines[step]       # the curve of the total loss itself: 1e-3 at every step
-        bad = [n for n, (s_ref, a_ref) in fx['steps'][-1]['param_checksums_after_step'].items()
-               if abs(dict(tr.model.named_parameters())[n].detach().double().abs().sum().item() - a_ref) > 1e-4 * a_ref + 8 * 1e-4]
-        assert not bad, bad[:5]
     finally:
         ops.set_deterministic(was_det)
         ops.set_conv_mode(old, min_gflop=-1.0)

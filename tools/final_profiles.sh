@@ -23,14 +23,14 @@ echo "bench rc=$?"; cut -c1-300 gpurun_out/${tag}_bench.json | tail -1
 } > gpurun_out/${tag}_force_dist.txt 2>&1
 cat gpurun_out/${tag}_force_dist.txt
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${tag} -o p -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-exact-f32 > $R/gpurun_out/${tag}_prof.log 2>&1
+GPU_MAX_HW_QUEUES=8 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${tag} -o p -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-exact-f32 > $R/gpurun_out/${tag}_prof.log 2>&1
 cd $R
 db=$(ls gpurun_out/prof_${tag}/*/p_results.db gpurun_out/prof_${tag}/p_results.db 2>/dev/null | head -1)
 python tools/rocpd_stats.py $db --top 90 > gpurun_out/${tag}_kernel_stats.txt
 python tools/rocpd_timeline.py $db > gpurun_out/${tag}_timeline.txt 2>&1
 rm -rf gpurun_out/prof_${tag}
 cd /tmp
-MUVO_STREAMS=0 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${tag}_off -o p -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-exact-f32 > $R/gpurun_out/${tag}_prof_off.log 2>&1
+GPU_MAX_HW_QUEUES=8 MUVO_STREAMS=0 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${tag}_off -o p -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-exact-f32 > $R/gpurun_out/${tag}_prof_off.log 2>&1
 cd $R
 db=$(ls gpurun_out/prof_${tag}_off/*/p_results.db gpurun_out/prof_${tag}_off/p_results.db 2>/dev/null | head -1)
 python tools/rocpd_stats.py $db --top 60 > gpurun_out/${tag}_kernel_stats_streams_off.txt

@@ -16,7 +16,7 @@ tail -5 gpurun_out/${tag}_tests.log
 python bench.py --steps 10 --warmup 3 --layer-table gpurun_out/${tag}_conv_layers.txt > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 echo "bench rc=$?"; cut -c1-600 gpurun_out/${tag}_bench.json
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${tag} -o p -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-exact-f32 > $R/gpurun_out/${tag}_prof.log 2>&1
+GPU_MAX_HW_QUEUES=8 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${tag} -o p -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-exact-f32 > $R/gpurun_out/${tag}_prof.log 2>&1
 cd $R
 db=$(ls gpurun_out/prof_${tag}/*/p_results.db gpurun_out/prof_${tag}/p_results.db 2>/dev/null | head -1)
 python tools/rocpd_stats.py $db --top 90 > gpurun_out/${tag}_kernel_stats.txt

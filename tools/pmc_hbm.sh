@@ -6,6 +6,6 @@ set -uo pipefail
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/hbm_${tag}_rd -o p -- python3 $R/tools/layer_bench.py "$@" > $R/gpurun_out/hbm_${tag}_rd.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/hbm_${tag}_wr -o p -- python3 $R/tools/layer_bench.py "$@" > $R/gpurun_out/hbm_${tag}_wr.log 2>&1
+GPU_MAX_HW_QUEUES=8 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/hbm_${tag}_rd -o p -- python3 $R/tools/layer_bench.py "$@" > $R/gpurun_out/hbm_${tag}_rd.log 2>&1
+GPU_MAX_HW_QUEUES=8 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/hbm_${tag}_wr -o p -- python3 $R/tools/layer_bench.py "$@" > $R/gpurun_out/hbm_${tag}_wr.log 2>&1
 ls $R/gpurun_out/hbm_${tag}_rd $R/gpurun_out/hbm_${tag}_wr

@@ -6,8 +6,8 @@ set -uo pipefail
 tag=$1
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/pmc_${tag}_rd -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact-f32 --no-kernel-timing > $R/gpurun_out/pmc_${tag}_rd.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/pmc_${tag}_wr -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact-f32 --no-kernel-timing > $R/gpurun_out/pmc_${tag}_wr.log 2>&1
+GPU_MAX_HW_QUEUES=8 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/pmc_${tag}_rd -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact-f32 --no-kernel-timing > $R/gpurun_out/pmc_${tag}_rd.log 2>&1
+GPU_MAX_HW_QUEUES=8 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/pmc_${tag}_wr -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-exact-f32 --no-kernel-timing > $R/gpurun_out/pmc_${tag}_wr.log 2>&1
 cd $R
 rd=$(ls gpurun_out/pmc_${tag}_rd/*/p_results.db gpurun_out/pmc_${tag}_rd/p_results.db 2>/dev/null | head -1)
 wr=$(ls gpurun_out/pmc_${tag}_wr/*/p_results.db gpurun_out/pmc_${tag}_wr/p_results.db 2>/dev/null | head -1)
