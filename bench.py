@@ -119,6 +119,108 @@ def run_extension(name, dev, batch, s, steps=5, warmup=2):
     return res
 
 
+def dry_run(args):
+    """`python bench.py --gpus N --dry-run`: everything of the N-rank run that does not need a GPU, on CPU over gloo - launched
+    exactly like the real run (self-launch through torch.distributed.run or the driver's launcher; RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* from the environment), replicated initial weights (seed 1234) and per-rank data seeds (1234 + 7919 * rank), the REAL
+    ParamStore / SegmentedGradReducer with backward hooks on a toy model whose sub-module names are the real segment prefixes,
+    barrier + max-over-ranks timing, rank 0 prints one JSON line of the same shape.  NOT a measurement (`dry_run: true`)."""
+    import torch.distributed as dist
+    from muvo_amd.parallel import SegmentedGradReducer
+    from muvo_amd.param_store import ParamStore
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.set_num_threads(1)
+    if world > 1:
+        dist.init_process_group('gloo')
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    assert 0 <= local_rank < max(world, 1)
+
+    class Toy(torch.nn.Module):
+        def __init__(self, d=32):
+            super().__init__()
+            L = torch.nn.Linear
+            self.encoder, self.range_view_encoder, self.transformer_encoder = L(d, d), L(d, d), L(2 * d, d)
+            self.rssm, self.policy = L(d, d), L(d, 2)
+            self.rgb_decoder, self.lidar_re, self.voxel_decoder = L(d, 3 * d), L(d, 2 * d), L(d, d)
+            self.encoder_layer = L(d, d)          # registered, never used (reference: mile.py:96, SURVEY App. B 2)
+
+    torch.manual_seed(1234)                       # replicated initial weights
+    m = Toy()
+    store = ParamStore(m)
+    red = SegmentedGradReducer(store)
+    torch.manual_seed(1234 + 7919 * rank)         # data / noise differ per rank from here on
+    batches = [torch.randn(args.batch * args.seq_len, 32) for _ in range(2)]
+
+    def step(i):
+        x = batches[i % 2]
+        red.begin_step()
+        store.zero_grad()
+        img = torch.tanh(m.encoder(x))
+        rv = torch.tanh(m.range_view_encoder(x))
+        tok = torch.cat([img, rv], 1)
+        tok.register_hook(lambda g: red.segment_done('fusion'))            # d(tokens) arrives: fusion (and everything before) is complete
+        emb = torch.tanh(m.transformer_encoder(tok))
+        emb.register_hook(lambda g: red.segment_done('rssm'))
+        state = torch.tanh(m.rssm(emb))
+        state.register_hook(lambda g: red.segment_done('policy'))
+        # decoders recorded in the order of muvo_amd/models/mile.py (voxel, range view, RGB): backward completes RGB first
+        sv = state + 0
+        sv.register_hook(lambda g: red.segment_done('voxel_decoder'))
+        lv = m.voxel_decoder(sv).pow(2).mean()
+        sl = state + 0
+        sl.register_hook(lambda g: red.segment_done('lidar_re'))
+        ll = m.lidar_re(sl).pow(2).mean()
+        sr = state + 0
+        sr.register_hook(lambda g: red.segment_done('rgb_decoder'))
+        lr_ = m.rgb_decoder(sr).pow(2).mean()
+        loss = lv + ll + lr_ + m.policy(state).abs().mean()
+        loss.backward()
+        red.finish()
+        with torch.no_grad():
+            store.flat_param.add_(store.flat_grad, alpha=-1e-2 * red.grad_scale)
+        return loss.detach()
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    log = list(red.launch_log)
+    t = torch.tensor([dt, float(loss), float(store.flat_param.double().sum()), float(store.flat_param.double().abs().sum())], dtype=torch.float64)
+    if world > 1:
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+    else:
+        gathered = [t]
+    if rank == 0:
+        dt = max(float(g[0]) for g in gathered)
+        losses = [float(g[1]) for g in gathered]
+        sums = {(float(g[2]), float(g[3])) for g in gathered}
+        out = {'metric': 'world-model training samples/sec (seq_len=10)', 'value': args.batch * world * args.steps / dt, 'unit': 'samples/s',
+               'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'dry_run': True,
+               'config': {'workload': 'DRY RUN on CPU over gloo: toy model with the real segment names - launch, seeds, timing protocol and '
+                                      'gradient exchange only, not a measurement', 'global_batch': args.batch * world,
+                          'seq_len': args.seq_len, 'parallelism': f'dp{world}'},
+               'n_ranks_seen': dist.get_world_size() if dist.is_initialized() else 1,
+               'per_rank_final_loss': losses, 'per_rank_losses_distinct': len({round(v, 9) for v in losses}) == world,
+               'params_identical_across_ranks': len(sums) == 1,
+               'gradient_exchange': {'segments': {name: dict(mbytes=round((b - a) * 4 / 2 ** 20, 6), from_hook=dict(log).get(name))
+                                                  for name, a, b in store.segment_ranges},
+                                     'order': [n for n, _ in log], 'grad_scale': red.grad_scale}}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -136,6 +238,10 @@ def main():
                     help='base_1d: BASELINE.json configs[1] (the judged line).  Extensions through MODEL.CONSTANT_SIZE (no reference '
                          'implementation, parity unpinned): rv2048 = the 64 x 2048 range view north_star names; vox256 = the '
                          '256 x 256 x 64 voxel grid of configs[4] (use with --batch 8 --seq-len 12 for that configuration)')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='CPU rehearsal of the multi-rank control flow (no GPU, no measurement): the same self-launch, environment, seeds, '
+                         'barrier / max-over-ranks timing and segmented gradient exchange over gloo on a toy model whose parameter '
+                         'names follow the real segments (tests/test_bench_dry_run.py)')
     ap.add_argument('--no-extensions', action='store_true',
                     help='skip the extension workloads (rv2048, vox256, single-product bf16: 5 steps each after the judged region)')
     args = ap.parse_args()
@@ -158,6 +264,8 @@ def main():
                '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
 
+    if args.dry_run:
+        return dry_run(args)
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -193,10 +301,12 @@ def main():
     tr.train()
     opts, scheds = tr.configure_optimizers()
     opt, sched = opts[0], scheds[0]['scheduler']
-    if tr._reducer is None and force_dist:   # one-rank RCCL group: same wiring as WorldModelTrainer._attach_reducer
-        tr._reducer = SegmentedGradReducer(tr.store, force_collectives=True)
+    fake_peers = int(os.environ.get('MUVO_DP_FAKE_PEERS', '0')) if world == 1 else 0
+    if tr._reducer is None and (force_dist or fake_peers > 1):
+        # one-rank RCCL group / stand-in kernel with a collective's footprint: same wiring as WorldModelTrainer._attach_reducer
+        tr._reducer = SegmentedGradReducer(tr.store, force_collectives=force_dist, fake_peers=fake_peers)
         tr.model.segment_done = tr._reducer.segment_done
-    assert (tr._reducer is not None) == (world > 1 or force_dist)
+    assert (tr._reducer is not None) == (world > 1 or force_dist or fake_peers > 1)
     if tr._reducer is not None:
         tr._reducer.timing = True             # per-segment all-reduce time and exposed (not overlapped) time in the JSON line
         if os.environ.get('MUVO_DP_OVERLAP') == '0':
@@ -328,6 +438,11 @@ def main():
             out['step_frac_fp32_exact'] = out['step_tflops_per_gpu'] / 157.3
         if dp_report is not None:
             out['gradient_exchange'] = dp_report     # rank 0's view: per-segment RCCL time, bus bandwidth, exposed time
+            if fake_peers > 1:
+                dp_report['fake_peers'] = fake_peers
+                dp_report['fake_peers_calibration'] = ops.fake_allreduce_calibration()
+                dp_report['note'] = ('one GPU: every segment all-reduce replaced by muvo_fake_allreduce (a kernel with a ring '
+                                     "collective's local footprint at the xGMI rate, values unchanged) on the communication stream")
         if exact_f32 is not None:
             exact_f32['step_tflops_per_gpu'] = GFLOP_PER_FRAME * frames_per_gpu_step / (exact_f32['ms_per_step'] * 1e-3) / 1e3
             out['exact_f32'] = exact_f32

@@ -471,6 +471,15 @@ int muvo_voxel_grid(const int64_t* rows, int64_t Q, const uint8_t* remap, int X,
 int muvo_instance_labels(const uint8_t* instance, int64_t F, int H, int W, float sigma, float ignore, double* scratch, float* center,
                          float* offset, void* stream);
 
+/* ---- measurement aid for the data-parallel path on ONE GPU (muvo_amd/parallel.py: SegmentedGradReducer(fake_peers=G)) ----
+ * Lightning's implicit DDP (train.py:93-98) all-reduces the gradients; on a one-GPU box a one-rank RCCL all-reduce is a no-op, so
+ * nothing ever ran beside the big-LDS convolution tiles and the persistent recurrent kernels.  muvo_fake_allreduce stands in for
+ * the collective's LOCAL footprint: `workgroups` resident workgroups of 256 threads (RCCL's channels) walk buf (n floats, n % 4 == 0,
+ * 16-byte aligned), read every element twice (own copy + "received" copy: two uncached loads), write 0.5 * (a + b) - bit-identical
+ * to the input, so parity is unchanged - and sleep `sleep` x 64 clocks per 16-KB round, which sets the rate (calibrated by the
+ * caller to the xGMI ring's ~1 ms per 100 MB).  The loop has a fixed trip count: every wave terminates. */
+int muvo_fake_allreduce(float* buf, int64_t n, int workgroups, int sleep, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1125,3 +1125,32 @@ int muvo_rssm_sample_bwd(const float* mu_logsigma, const float* eps, int64_t eps
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Stand-in for the local footprint of a ring all-reduce on a one-GPU box (include/muvo_hip.h: muvo_fake_allreduce)
+__global__ void __launch_bounds__(256) fake_allreduce_kernel(f32x4* __restrict__ buf, long n4, int sleep) {
+  const long stride = (long)gridDim.x * 256;
+  for (long i0 = (long)blockIdx.x * 256; i0 < n4; i0 += 4 * stride) {
+    f32x4 a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long i = i0 + u * stride + threadIdx.x;
+      const long ic = i < n4 ? i : 0;
+      a[u] = __builtin_nontemporal_load(buf + ic);
+      b[u] = *(volatile f32x4*)(buf + ic);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long i = i0 + u * stride + threadIdx.x;
+      if (i < n4) __builtin_nontemporal_store(0.5f * (a[u] + b[u]), buf + i);
+    }
+    for (int k = 0; k < sleep; ++k) __builtin_amdgcn_s_sleep(1);
+  }
+}
+extern "C" int muvo_fake_allreduce(float* buf, int64_t n, int workgroups, int sleep, void* stream) {
+  MUVO_CHECK_ARG(buf && n > 0 && n % 4 == 0 && ((uintptr_t)buf & 15) == 0, "fake_allreduce: n %% 4 == 0 and a 16-byte aligned buffer");
+  MUVO_CHECK_ARG(workgroups >= 1 && workgroups <= 256 && sleep >= 0 && sleep <= 100000, "fake_allreduce: bad launch parameters");
+  hipLaunchKernelGGL(fake_allreduce_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, (f32x4*)buf, (long)(n / 4), sleep);
+  MUVO_CHECK_LAUNCH("fake_allreduce_kernel");
+  return MUVO_OK;
+}

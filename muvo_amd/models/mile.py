@@ -312,10 +312,15 @@ class Mile(nn.Module):
         return out
 
     def encode(self, batch):
-        ops.mark_inputs_ready(batch['image'].device)   # packed weights + preprocessed batch are queued: side-stream branches start here
         b, s = batch['image'].shape[:2]
         image = pack_sequence_dim(batch['image'])
-        speed = pack_sequence_dim(batch['speed'])
+        speed = pack_sequence_dim(batch['speed']).contiguous()
+        # every branch input is packed BEFORE the inputs-ready event: for a non-contiguous batch tensor (sliced batch, custom
+        # collate) pack_sequence_dim is a copy kernel on the main stream, and a side stream that waits only for the event
+        # would read the buffer before it is written
+        rv_packed = pack_sequence_dim(batch['range_view_pcd_xyzd']).contiguous() if 'range_view_pcd_xyzd' in batch else None
+        route_packed = {k: pack_sequence_dim(batch[k]).contiguous() for k in ('route_map',) if k in batch}
+        ops.mark_inputs_ready(batch['image'].device)   # packed weights + preprocessed batch are queued: side-stream branches start here
         xs = self.encoder(image)
         x = self.feat_decoder(xs)
         if self.bev:                                                     # mile.py:506-524
@@ -330,7 +335,7 @@ class Mile(nn.Module):
             x = self.bev_down_sample_4[2](self.bev_down_sample_4[0](x, act=ops.ACT_RELU))
         # recorded before the range-view branch: its backward fires when that branch (and the token gradient) is done
         x = self._mark(x, 'lidar_branch')
-        rv = pack_sequence_dim(batch['range_view_pcd_xyzd'])
+        rv = rv_packed
         br_lidar = ops.branch('lidar', 'lidar_encoder', x.device, inputs=(rv,))
         with br_lidar:                 # next to the image encoder's kernels still queued on the main stream
             lidar_features = br_lidar.out(self.range_view_decoder(self.range_view_encoder(rv)))
@@ -346,7 +351,7 @@ class Mile(nn.Module):
         lidar_tokens_out = ops.untoken(tokens_out, hi * wi, hl, wl)
         # route-map encoder (ResNet-18 on 64 x 64 pixels) and speed encoder: ~300 launches of 5-50 us that occupy a few compute
         # units - on a side stream, next to whatever the main stream has queued (they depend on the preprocessed batch only)
-        route_map = pack_sequence_dim(batch['route_map'])
+        route_map = route_packed['route_map']
         br_route = ops.branch('route', 'route_encoder', x.device, inputs=(route_map, speed))
         with br_route:
             route_features = br_route.out(self.backbone_route(route_map))

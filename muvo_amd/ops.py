@@ -71,6 +71,7 @@ EXPORTS = [
     'muvo_grouped_linear_fwd', 'muvo_grouped_linear_bwd', 'muvo_conv_prepare_dy_head', 'muvo_conv_prepare_dy_head_supported',
     'muvo_conv_forward_head_supported', 'muvo_conv_forward_head',
     'muvo_adain_affine', 'muvo_conv_affine_supported', 'muvo_conv_forward_affine', 'muvo_conv_wgrad_affine',
+    'muvo_fake_allreduce',
     'muvo_rssm_supported', 'muvo_rssm_transposed_floats', 'muvo_rssm_scratch_floats', 'muvo_rssm_forward', 'muvo_rssm_backward',
 ]
 
@@ -305,7 +306,8 @@ STREAM_MAP = dict(kv.split('=') for kv in os.environ.get('MUVO_STREAM_MAP', '').
 
 
 def set_stream_budget(n):
-    """number of side streams the model may use (0..3); WorldModelTrainer lowers it to 1 when it attaches a gradient exchange"""
+    """number of side streams the model may use (0..3); SegmentedGradReducer lowers it to 2 when a gradient exchange is attached
+    (its communication stream only carries waits, RCCL's own stream is the fourth busy one)"""
     STREAM_BUDGET[0] = max(0, min(3, int(n)))
 
 
@@ -2040,9 +2042,15 @@ class RSSMFusedFn(torch.autograd.Function):
         keep = [new(n) for n in (H, S, AD, H, 3 * H, 3 * H, H + A, H + E + A, H + A, H + E + A, 2 * S, 2 * S)]
         bar = rssm_barrier_words(dev)
         rssm_check(dev, post=False)
+        if get_deterministic():
+            # deterministic mode runs single-workgroup weight-gradient kernels on the side streams that can hold a compute unit for
+            # a long time: the persistent grid must not wait for them inside its bounded barrier spin
+            join_side_streams(dev)
         w = rssm_weights(rssm)
         _ck(lib().muvo_rssm_forward(B, T, H, S, E, A, AD, _ptr_table(w), _f(emb), _f(act), _f(noise), C.c_uint64(mask),
                                     _ptr_table(out), _ptr_table(keep), _p(bar), _fl(rssm.prior.min_std), _st()))
+        if not any(ctx.needs_input_grad):
+            rssm_check(dev)        # no backward will follow (validation / imagination): post the error-word copy here
         ctx.rssm, ctx.mask, ctx.dims = rssm, mask, (B, T, H, S, E, A, AD)
         ctx.save_for_backward(noise, *keep)
         return tuple(out)
@@ -2061,6 +2069,8 @@ class RSSMFusedFn(torch.autograd.Function):
         wt = scratch('rssm_wt', L.muvo_rssm_transposed_floats(H, S, E, A), dev)
         sc = scratch('rssm_scratch', L.muvo_rssm_scratch_floats(B, H, S, E, A), dev)
         bar = rssm_barrier_words(dev)
+        if get_deterministic():
+            join_side_streams(dev)
         w = rssm_weights(rssm)
         _ck(L.muvo_rssm_backward(B, T, H, S, E, A, AD, _ptr_table(w), _f(wt), _f(noise), C.c_uint64(ctx.mask),
                                  _ptr_table([hprev, gi, gh, mls_p, mls_q]), _ptr_table(gout),
@@ -2102,6 +2112,11 @@ def rssm_check(dev, post=True):
         w = _rssm_watch[dev] = dict(host=torch.zeros(1, dtype=torch.int32).pin_memory(), ev=None)
     if w['ev'] is not None and w['ev'].query():
         if int(w['host'][0]) != 0:
+            # the word is sticky on the device (every later fused launch would leave at its first barrier): clear it and the
+            # host copy, so that a caller who catches this and switches to MUVO_FUSED_RSSM=0 / a smaller grid can go on
+            w['host'].zero_()
+            w['ev'] = None
+            rssm_barrier_words(dev)[1:2].zero_()
             raise RuntimeError('muvo_rssm: a persistent RSSM kernel timed out in its grid barrier (its workgroups were not '
                                'co-resident: another persistent kernel or a CU mask is holding compute units); set '
                                'MUVO_FUSED_RSSM=0 or lower MUVO_RSSM_GRID')
@@ -2529,3 +2544,43 @@ class SumScalarsFn(torch.autograd.Function):
 
 def sum_scalars(vals):
     return SumScalarsFn.apply(*vals)
+
+
+# ------------------------------------------------------------------------------------------------
+# one-GPU stand-in for a gradient all-reduce among `peers` GPUs (include/muvo_hip.h: muvo_fake_allreduce)
+_FAKE_AR = {}
+
+
+def fake_allreduce(buf, peers=8, workgroups=None, ms_per_100mb=None):
+    """Runs on the current stream; leaves buf bit-identical.  Rate: 1 ms per 100 MB (an 8-GPU xGMI ring at ~175 GB/s of bus
+    bandwidth: 2 (G-1)/G x 100 MB / 175 GB/s; RCCL reaches more on large messages, so this is the pessimistic side;
+    MUVO_DP_FAKE_MS_PER_100MB overrides).  The sleep count that gives this rate with
+    `workgroups` resident workgroups (RCCL-like: MUVO_DP_FAKE_WGS, default 32) is calibrated once per device on a scratch buffer."""
+    dev = buf.device
+    wgs = int(workgroups or os.environ.get('MUVO_DP_FAKE_WGS', '32'))
+    target = float(ms_per_100mb or os.environ.get('MUVO_DP_FAKE_MS_PER_100MB', '1.0'))
+    key = (dev.index, wgs, round(target, 4))
+    sleep = _FAKE_AR.get(key)
+    L = lib()
+    if sleep is None:
+        probe = torch.zeros(16 * 2 ** 20, device=dev, dtype=torch.float32)        # 64 MB
+        ms = {}
+        for sl in (0, 64):
+            for _ in range(2):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                _ck(L.muvo_fake_allreduce(_f(probe), _i64(probe.numel()), wgs, sl, _st()))
+                e1.record()
+                e1.synchronize()
+                ms[sl] = e0.elapsed_time(e1) * 100.0 / 64.0            # per 100 MB
+        per = max((ms[64] - ms[0]) / 64.0, 1e-6)
+        sleep = int(max(0, round((target - ms[0]) / per)))
+        _FAKE_AR[key] = sleep
+        _FAKE_AR[('calibration',) + key] = dict(ms_per_100mb_sleep0=ms[0], ms_per_100mb_sleep64=ms[64], sleep=sleep, target=target, workgroups=wgs)
+    n = buf.numel() & ~3
+    if n:
+        _ck(L.muvo_fake_allreduce(_f(buf), _i64(n), wgs, sleep, _st()))
+
+
+def fake_allreduce_calibration():
+    return [v for k, v in _FAKE_AR.items() if k and k[0] == 'calibration']

@@ -15,16 +15,22 @@ import torch.distributed as dist
 
 
 class SegmentedGradReducer:
-    def __init__(self, store, group=None, overlap=True, force_collectives=False, verify=False):
+    def __init__(self, store, group=None, overlap=True, force_collectives=False, verify=False, fake_peers=0):
         """force_collectives: issue the all-reduces even in a one-rank group (exercises the RCCL / side-stream path on a
         single GPU; `bench.py` sets it when MUVO_BENCH_FORCE_DIST=1).
         verify: keep a copy of every segment as it is handed to the collective and compare it in finish() with what the
         segment holds once backward has ended (one-rank groups only: a sum over one rank changes nothing) — proves that
-        no kernel wrote into a segment after its hook fired (tests/test_dp_gpu.py)."""
+        no kernel wrote into a segment after its hook fired (tests/test_dp_gpu.py).
+        fake_peers = G > 1 (MUVO_DP_FAKE_PEERS on a one-GPU box, no process group needed): every segment's all-reduce is
+        replaced by ops.fake_allreduce on the communication stream - a kernel with a collective's local footprint (a few
+        resident workgroups, the segment read twice and written once at the xGMI ring's rate, values unchanged) - so the
+        overlap with the big-LDS convolution tiles and the persistent recurrent kernels is MEASURED with `exposed_ms` per
+        segment instead of being a no-op (a one-rank RCCL all-reduce moves no byte)."""
         self.store = store
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.force = bool(force_collectives) and dist.is_initialized()
+        self.fake_peers = int(fake_peers) if (int(fake_peers) > 1 and self.world == 1) else 0
+        self.force = (bool(force_collectives) and dist.is_initialized()) or self.fake_peers > 0
         self.overlap = overlap
         self.verify = verify
         self.accumulating = False     # True while backward runs for a non-final micro-batch of gradient accumulation
@@ -104,7 +110,11 @@ class SegmentedGradReducer:
                 if self.timing:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(self.side)
-                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+                if self.fake_peers:
+                    from muvo_amd import ops
+                    ops.fake_allreduce(buf, self.fake_peers)
+                else:
+                    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
                 if self.timing:
                     e1.record(self.side)
                     self._ev.append((name, from_hook, e0, e1, (b - a) * 4))
@@ -177,7 +187,7 @@ class SegmentedGradReducer:
                 a['n'] += 1
                 worst = max(worst, ex)
             exposed.append(worst)
-        g = self.world
+        g = self.fake_peers or self.world
         segs = {}
         for name, a in acc.items():
             ms = a['ms'] / a['n']

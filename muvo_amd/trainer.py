@@ -263,13 +263,22 @@ class WorldModelTrainer(_Base):
                 cw = None
                 if vs.USE_WEIGHTS:                # constants.py:39 through VoxelLoss(use_weights) (losses.py:155-165)
                     from .losses import VOXEL_SEG_WEIGHTS
-                    cw = torch.tensor(VOXEL_SEG_WEIGHTS, dtype=torch.float32, device=output[f'voxel_{f}'].device)
+                    logits_f = output[f'voxel_{f}']
+                    if len(VOXEL_SEG_WEIGHTS) != logits_f.shape[2]:      # F.cross_entropy of the reference raises here as well
+                        raise RuntimeError(f'VOXEL_SEG.USE_WEIGHTS: {len(VOXEL_SEG_WEIGHTS)} class weights (constants.py:39) for '
+                                           f'{logits_f.shape[2]} voxel classes')
+                    cache = self.__dict__.setdefault('_voxel_class_weights', {})     # one H2D copy per device, not three per step
+                    cw = cache.get(logits_f.device)
+                    if cw is None:
+                        cw = cache[logits_f.device] = torch.tensor(VOXEL_SEG_WEIGHTS, dtype=torch.float32, device=logits_f.device)
+                # (USE_TOP_K replaces the cross-entropy term: the fused kernel then only delivers the two scaling terms)
                 three = ops.voxel_losses(output[f'voxel_{f}'], batch[f'voxel_label_{f}'], w, cw)
-                losses[f'voxel_{f}'] = three[0]
                 if vs.USE_TOP_K:                  # losses.py:179-184: the k hardest voxels of every frame
                     from .losses import VoxelLoss
                     crit = self.__dict__.setdefault('_voxel_topk', VoxelLoss(True, vs.TOP_K_RATIO, vs.USE_WEIGHTS))
                     losses[f'voxel_{f}'] = crit(output[f'voxel_{f}'], batch[f'voxel_label_{f}']) * w
+                else:
+                    losses[f'voxel_{f}'] = three[0]
                 losses[f'sem_scal_{f}'] = three[1]
                 losses[f'geo_scal_{f}'] = three[2]
         return losses
