@@ -9,7 +9,8 @@ gradient depends on).  Written: the 21 losses (they must equal the forward-only 
 of all 440 parameter gradients, 1024 strided samples of the ten largest gradient tensors and of six named ones.
 
 Writes tests/golden/base1d_b2s10_bwd.json, base1d_b2s10_bwd_samples.npz.
-Usage: python oracle/refimport/make_golden_bwd.py [--b 2 --s 10]"""
+Usage: python oracle/refimport/make_golden_bwd.py --fp64   (2 min for the float32 pass, 14 min and 48.5 GB for the float64 one; the
+committed fixture was written with --fp64: keys grad_l2_fp64 / grad_l2_ref32_err / grad64.*)"""
 import argparse
 import json
 import os
@@ -97,7 +98,6 @@ def main():
         samples['grad.' + n] = smp
     if args.fp64:
         g32 = {n: p.grad.detach().clone() for n, p in params.items() if p.grad is not None}
-        state = {k: v.clone() for k, v in model.state_dict().items()}
         del output, losses, total, trainer, model, params
         import gc
         gc.collect()

@@ -351,51 +351,52 @@ def test_deterministic_mode_is_bit_reproducible(dev, mode):
 
 def _check_headline_gradients(mode, grads):
     """The gradients of the BASELINE workload (batch 2 x 10 frames: BatchNorm statistics over 20 frames, the tile / split-K
-    choices of the full-size launches) against the float32 backward pass of the REAL reference on the same batch
-    (tests/golden/base1d_b2s10_bwd*: oracle/refimport/make_golden_bwd.py, muvo/trainer.py:392-402 with the big sub-networks
-    checkpointed).  Both sides are fp32 evaluations of an ill-conditioned chain; the b2s4 fixture knows how far the
-    reference's own fp32 gradients are from its float64 truth per tensor (grad_l2_ref32_err / grad_l2_fp64) and, for the
-    default arithmetic, how far the reference moves under bf16x3-sized rounding (base1d_b2s4_rounding.json).  Bar on the
-    L2 norm of each of the 440 tensors: 2e-3 relative, or 8x that relative noise floor (two fp32 evaluations), or 2x the
-    rounding response; strided samples of the ten largest + named tensors: 5e-3 relative L2 of the sample vector or the
-    same floors."""
+    choices of the full-size launches) against the backward pass of the REAL reference on the same batch
+    (tests/golden/base1d_b2s10_bwd*: oracle/refimport/make_golden_bwd.py --fp64, muvo/trainer.py:392-402 with the big
+    sub-networks checkpointed): its float32 run and its float64 run.  As in test_gradients_match_reference the truth is the
+    float64 gradient; the reference's own float32 gradients deviate from it by a median of 1.5e-3 and up to 9e-3 relative
+    per tensor at this size (grad_l2_ref32_err).  Bar on the L2 norm of each of the 440 tensors: within 2e-3 relative of
+    the truth, or 6x the reference's own fp32 error on that tensor; default arithmetic: or 2x the reference's response to
+    bf16x3-sized rounding (relative, measured at b2s4: base1d_b2s4_rounding.json).  Strided samples of the ten largest +
+    named tensors: 5e-3 relative L2 of the sample vector against the float64 sample, or the same floors."""
     fx = json.load(open(os.path.join(GOLD, 'base1d_b2s10_bwd.json')))['steps'][0]
     smp = np.load(os.path.join(GOLD, 'base1d_b2s10_bwd_samples.npz'))
     small = json.load(open(os.path.join(GOLD, 'base1d_b2s4.json')))['steps'][0]
     rnd = json.load(open(os.path.join(GOLD, 'base1d_b2s4_rounding.json'))) if mode == 'policy' else None
-    assert sum(v is not None for v in fx['grad_l2'].values()) == 440 == len(grads)
+    assert sum(v is not None for v in fx['grad_l2_fp64'].values()) == 440 == len(grads)
     bad, worst = [], (0.0, None)
-    for n, ref in fx['grad_l2'].items():
+    for n, ref in fx['grad_l2_fp64'].items():
         if ref is None:
             assert n not in grads, n
             continue
         got = grads[n].double().pow(2).sum().sqrt().item()
-        floor = small['grad_l2_ref32_err'][n] / max(small['grad_l2_fp64'][n], 1e-30)
-        tol = max(2e-3, 8.0 * floor)
+        tol = max(2e-3 * ref, 6.0 * fx['grad_l2_ref32_err'][n], 1e-5)
         if rnd:
-            tol = max(tol, 2.0 * rnd['grad_l2_err'][n] / max(small['grad_l2_fp64'][n], 1e-30))
-        dev_rel = abs(got - ref) / max(ref, 1e-30)
-        if dev_rel / tol > worst[0]:
-            worst = (dev_rel / tol, f'{n}: {dev_rel:.2e} of a bar of {tol:.2e}')
-        if dev_rel > tol and abs(got - ref) > 1e-6:
+            tol = max(tol, 2.0 * rnd['grad_l2_err'][n] / max(small['grad_l2_fp64'][n], 1e-30) * ref)
+        d = abs(got - ref)
+        if d / tol > worst[0]:
+            worst = (d / tol, f'{n}: off by {d / max(ref, 1e-30):.2e} relative, {d / tol:.2f} of its bar')
+        if d > tol:
             bad.append((n, got, ref, tol))
-    line = f'b2s10 {mode} gradients: {len(bad)} of 440 L2 norms outside their bar; closest to it {worst[1]}'
+    line = f'b2s10 {mode} gradients vs the float64 reference: {len(bad)} of 440 L2 norms outside their bar; closest to it {worst[1]}'
     print(line)
     os.makedirs(os.path.join(os.path.dirname(GOLD), '..', 'gpurun_out'), exist_ok=True)
     with open(os.path.join(os.path.dirname(GOLD), '..', 'gpurun_out', 'headline_parity.txt'), 'a') as f:
         f.write(line + '\n')
     assert not bad, f'{len(bad)} gradient norms off, first: {bad[:5]}'
     for key in smp.files:
-        n = key[5:]
+        if not key.startswith('grad64.'):
+            continue
+        n = key[7:]
         ref = torch.from_numpy(smp[key]).double()
+        ref32 = torch.from_numpy(smp['grad.' + n]).double()
         t = grads[n].double().contiguous().view(-1)
         stride = max(1, t.numel() // 1024)
         got = t[::stride][:ref.numel()].cpu()
-        floor = small['grad_l2_ref32_err'][n] / max(small['grad_l2_fp64'][n], 1e-30)
-        tol = max(5e-3, 8.0 * floor)
+        tol = max(5e-3 * ref.norm().item(), 6.0 * (ref32 - ref).norm().item(), 1e-12)
         if rnd:
-            tol = max(tol, 3.0 * rnd['grad_l2_err'][n] / max(small['grad_l2_fp64'][n], 1e-30))
-        err = (got - ref).norm().item() / max(ref.norm().item(), 1e-30)
+            tol = max(tol, 3.0 * rnd['grad_l2_err'][n] / max(small['grad_l2_fp64'][n], 1e-30) * ref.norm().item())
+        err = (got - ref).norm().item()
         assert err <= tol, f'{n}: sample L2 err {err:.3e} > {tol:.3e}'
 
 
