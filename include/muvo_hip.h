@@ -480,6 +480,13 @@ int muvo_instance_labels(const uint8_t* instance, int64_t F, int H, int W, float
  * caller to the xGMI ring's ~1 ms per 100 MB).  The loop has a fixed trip count: every wave terminates. */
 int muvo_fake_allreduce(float* buf, int64_t n, int workgroups, int sleep, void* stream);
 
+/* antialiased linear resize of (NC, H, W) float planes: EVAL.RESOLUTION of PreProcess.forward (muvo/models/preprocess.py:209-210,
+ * functional_resize_batch :252-273: torchvision 0.15.2 `resize(image, size, antialias=True)`, i.e. ATen's _upsample_bilinear2d_aa -
+ * per axis the triangle filter of width in/out around scale * (i + 0.5), weights normalised, horizontal pass first).  ynorm (may be
+ * NULL): (y - mean[c]) / std[c] with c = plane index % C (the ImageNet normalisation that follows, preprocess.py:217; host arrays). */
+int muvo_resize_bilinear_aa(const float* x, float* y, float* ynorm, const float* mean, const float* std, int64_t NC, int C, int H,
+                            int W, int OH, int OW, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,7 +22,15 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-munsafe-fp-ato
          # v_mul_f32 / v_add_f32 (this flag) never showed it (0 of 400 launches against 200 of 400); the step time is unchanged
          # (84.5 vs 84.4 ms): nothing here is bound by the fp32 VALU rate.  The flag is a device target feature; the host pass
          # of hipcc reports it as unknown (filtered below).
-         '-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
+         ]
+NO_PACKED_FP32 = ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
+# Translation units that MAY use packed fp32 VALU instructions: the finding above is about a packed product whose operand pair
+# came from LDS and is broadcast with op_sel - a VALU dot product against LDS-resident weights.  A unit is listed here only if
+# its device code contains NO packed fp32 instruction with an op_sel / op_sel_hi modifier (checked after every build, below):
+# conv_gemm.hip (exact-fp32 implicit GEMM: 66 plain v_pk_*_f32 in epilogues and index-free accumulator arithmetic, none with
+# op_sel).  gemm.hip (1622 with op_sel: the skinny GEMMs ARE dot products against LDS vectors), conv_vox.hip (486) and
+# attention.hip (192) stay without them.
+PACKED_FP32_OK = {'conv_gemm.hip'}
 # Kernels allowed to use scratch memory (bytes per lane).  Everything else must stay in registers: a kernel that silently
 # picks up scratch (an argument struct captured by reference and copied to the stack, register spills after a small edit)
 # loses tens of microseconds per workgroup launch — the build fails instead.
@@ -46,6 +54,35 @@ def _check_resources(src, stderr):
     return bad
 
 
+def _check_packed_fp32(obj, src_name):
+    """Disassembles the gfx950 code object inside `obj` and fails the build if the packed-fp32 workaround is not in effect: no
+    v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 at all in a unit built with NO_PACKED_FP32 (a future hipcc that renames or ignores
+    the target feature would silently bring them back), none with an op_sel modifier in a unit listed in PACKED_FP32_OK."""
+    import re
+    import tempfile
+    llvm = os.environ.get('MUVO_LLVM_BIN', '/opt/rocm/lib/llvm/bin')
+    with tempfile.TemporaryDirectory() as td:
+        co, fat = os.path.join(td, 'dev.co'), os.path.join(td, 'fat.bin')
+        r = subprocess.run([os.path.join(llvm, 'llvm-objcopy'), f'--dump-section=.hip_fatbin={fat}', obj], capture_output=True, text=True)
+        if r.returncode == 0:
+            r = subprocess.run([os.path.join(llvm, 'clang-offload-bundler'), '--type=o', '--unbundle', f'--input={fat}', f'--output={co}',
+                                '--targets=hipv4-amdgcn-amd-amdhsa--gfx950'], capture_output=True, text=True)
+        if r.returncode != 0 or not os.path.exists(co) or os.path.getsize(co) == 0:
+            raise RuntimeError(f'packed-fp32 guard: cannot extract the gfx950 code object of {obj}: {r.stderr[-300:]}')
+        d = subprocess.run([os.path.join(llvm, 'llvm-objdump'), '-d', '--mcpu=gfx950', co], capture_output=True, text=True)
+        if d.returncode != 0:
+            raise RuntimeError(f'packed-fp32 guard: llvm-objdump failed on {obj}: {d.stderr[-300:]}')
+    pk = [l for l in d.stdout.splitlines() if re.search(r'\bv_pk_(mul|add|fma)_f32\b', l)]
+    if src_name in PACKED_FP32_OK:
+        bad = [l for l in pk if 'op_sel' in l]
+        if bad:
+            raise RuntimeError(f'{src_name} is listed in PACKED_FP32_OK but contains {len(bad)} packed fp32 instructions with op_sel '
+                               f'(muvo_amd/build.py), e.g. {bad[0].strip()[:120]}')
+    elif pk:
+        raise RuntimeError(f'{src_name}: {len(pk)} packed fp32 VALU instructions although the unit is built without them '
+                           f'(muvo_amd/build.py: NO_PACKED_FP32 no longer takes effect?), e.g. {pk[0].strip()[:120]}')
+
+
 def _stale(out, deps):
     if not os.path.exists(out):
         return True
@@ -65,7 +102,8 @@ def build(force=False, verbose=True):
         obj = os.path.join(objdir, s.replace('.hip', '.o'))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([hipcc, *FLAGS, *os.environ.get('MUVO_HIPCC_EXTRA', '').split(), '-c', src, '-o', obj])
+            extra = [] if s in PACKED_FP32_OK else NO_PACKED_FP32
+            jobs.append([hipcc, *FLAGS, *extra, *os.environ.get('MUVO_HIPCC_EXTRA', '').split(), '-c', src, '-o', obj])
 
     def run(cmd):
         if verbose:
@@ -85,6 +123,8 @@ def build(force=False, verbose=True):
             print(rest)
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
+    for job in jobs:
+        _check_packed_fp32(job[-1], os.path.basename(job[-3]))
     if jobs or force or not os.path.exists(LIB):
         run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB, *objs])
     return LIB

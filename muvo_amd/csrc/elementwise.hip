@@ -1154,3 +1154,69 @@ extern "C" int muvo_fake_allreduce(float* buf, int64_t n, int workgroups, int sl
   MUVO_CHECK_LAUNCH("fake_allreduce_kernel");
   return MUVO_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Antialiased linear resize of (NC, H, W) float planes (include/muvo_hip.h: muvo_resize_bilinear_aa): EVAL.RESOLUTION of
+// PreProcess.forward (preprocess.py:209-210,252-273: torchvision 0.15.2 resize(antialias=True) = ATen _upsample_bilinear2d_aa).
+// One thread per output pixel; per axis the taps [lo, hi) and triangle weights of ATen's _compute_indices_min_size_weights_aa in
+// float32, normalised; horizontal sums first, then the vertical combination (the order of the separable reference kernel).
+struct AaTaps { int lo, n; float center, inv, total; };
+__device__ __forceinline__ AaTaps aa_taps(int o, int in_size, float scale) {
+  const float support = scale >= 1.f ? scale : 1.f;
+  AaTaps t;
+  t.inv = scale >= 1.f ? 1.f / scale : 1.f;
+  t.center = scale * ((float)o + 0.5f);
+  int lo = (int)(t.center - support + 0.5f), hi = (int)(t.center + support + 0.5f);
+  lo = lo < 0 ? 0 : lo;
+  hi = hi > in_size ? in_size : hi;
+  t.lo = lo;
+  t.n = hi - lo;
+  float tot = 0.f;
+  for (int j = 0; j < t.n; ++j) {
+    const float w = 1.f - fabsf(((float)(j + lo) - t.center + 0.5f) * t.inv);
+    tot += w > 0.f ? w : 0.f;
+  }
+  t.total = tot;
+  return t;
+}
+__device__ __forceinline__ float aa_weight(const AaTaps& t, int j) {
+  const float w = 1.f - fabsf(((float)(j + t.lo) - t.center + 0.5f) * t.inv);
+  return (w > 0.f ? w : 0.f) / t.total;
+}
+__global__ void __launch_bounds__(256) resize_bilinear_aa_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                 float* __restrict__ ynorm, float m0, float m1, float m2, float s0,
+                                                                 float s1, float s2, long NC, int C, int H, int W, int OH, int OW) {
+  const float sh = (float)H / (float)OH, sw = (float)W / (float)OW;
+  const long total = NC * OH * OW;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int ox = (int)(i % OW), oy = (int)((i / OW) % OH);
+    const long nc = i / ((long)OW * OH);
+    const AaTaps tx = aa_taps(ox, W, sw), ty = aa_taps(oy, H, sh);
+    const float* p = x + nc * (long)H * W;
+    float acc = 0.f;
+    for (int r = 0; r < ty.n; ++r) {
+      const float* row = p + (long)(ty.lo + r) * W + tx.lo;
+      float rs = 0.f;
+      for (int j = 0; j < tx.n; ++j) rs += row[j] * aa_weight(tx, j);
+      acc += rs * aa_weight(ty, r);
+    }
+    y[i] = acc;
+    if (ynorm) {
+      const int c = (int)(nc % C);
+      const float m = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+      ynorm[i] = (acc - m) / sd;
+    }
+  }
+}
+extern "C" int muvo_resize_bilinear_aa(const float* x, float* y, float* ynorm, const float* mean, const float* std, int64_t NC, int C, int H,
+                                       int W, int OH, int OW, void* stream) {
+  MUVO_CHECK_ARG(x && y && NC > 0 && C > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, "resize_bilinear_aa: bad args");
+  MUVO_CHECK_ARG(ynorm == nullptr || (mean && std && C <= 3), "resize_bilinear_aa: the normalised copy needs mean / std of <= 3 channels");
+  float m[3] = {0.f, 0.f, 0.f}, s[3] = {1.f, 1.f, 1.f};
+  if (ynorm) for (int c = 0; c < C; ++c) { m[c] = mean[c]; s[c] = std[c]; }
+  const long total = (long)NC * OH * OW;
+  hipLaunchKernelGGL(resize_bilinear_aa_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, y, ynorm, m[0], m[1], m[2],
+                     s[0], s[1], s[2], (long)NC, C, H, W, OH, OW);
+  MUVO_CHECK_LAUNCH("resize_bilinear_aa_kernel");
+  return MUVO_OK;
+}

@@ -39,9 +39,13 @@ class PreProcess(nn.Module):
         self.route_map_size = cfg.ROUTE.SIZE
         self.mean = tuple(float(v) for v in cfg.IMAGE.IMAGENET_MEAN)
         self.std = tuple(float(v) for v in cfg.IMAGE.IMAGENET_STD)
-        if cfg.EVAL.RESOLUTION.ENABLED:
-            raise NotImplementedError('EVAL.RESOLUTION.ENABLED (preprocess.py:209-210: antialiased down-scaling of the input '
-                                      'for evaluation) is outside the training hot path (SURVEY.md §8)')
+        # EVAL.RESOLUTION (preprocess.py:209-210): antialiased down-scaling of the cropped image by 1 / FACTOR before the model sees
+        # it (the reference's RGB losses then compare 320 x 832 predictions with the smaller label and fail to broadcast: the
+        # switch only works with EVAL.RGB_SUPERVISION off, here as there)
+        self.eval_scale = 1.0 / cfg.EVAL.RESOLUTION.FACTOR if cfg.EVAL.RESOLUTION.ENABLED else None
+        if self.eval_scale is not None and self.eval_scale != 1.0 and cfg.EVAL.RGB_SUPERVISION:
+            raise ValueError('EVAL.RESOLUTION with FACTOR != 1 needs EVAL.RGB_SUPERVISION = False: the RGB decoder reconstructs the '
+                             'full-size image while rgb_label_1 is the down-scaled one (the reference fails in its loss, trainer.py:296-302)')
         self._pins = {}
         self.bev_out_of_view_mask = None
         if cfg.EVAL.MASK_VIEW:        # preprocess.py:20-21
@@ -86,6 +90,13 @@ class PreProcess(nn.Module):
             if 'route_map' in batch and route_aug is None:
                 route_aug = augment.draw_route_params(cfg, b, self.route_map_size)
         label1, image = ops.preprocess_image(batch['image'], self.crop, self.mean, self.std)
+        scale = self.eval_scale
+        if scale is not None and scale != 1.0:          # functional_resize_batch (preprocess.py:252-273)
+            h, w = label1.shape[-2:]
+            label1, image = ops.resize_bilinear_aa(label1, int(round(h * scale)), int(round(w * scale)), self.mean, self.std)
+            for k in ('image_instance_mask', 'semantic_image'):
+                if k in batch:
+                    raise NotImplementedError(f'EVAL.RESOLUTION: antialiased resize of `{k}` is not built')
         batch['image'] = image
         if 'route_map' in batch:
             if route_aug is not None and bool((route_aug[:, 0] != 0).any()):
@@ -97,6 +108,8 @@ class PreProcess(nn.Module):
             intr = batch['intrinsics'].clone()
             intr[..., 0, 2] -= self.crop[0]
             intr[..., 1, 2] -= self.crop[1]
+            if scale is not None and scale != 1.0:
+                intr[..., :2, :] *= scale
             batch['intrinsics'] = intr
         if cfg.EVAL.RGB_SUPERVISION:
             batch['rgb_label_1'] = label1

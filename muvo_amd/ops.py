@@ -71,7 +71,7 @@ EXPORTS = [
     'muvo_grouped_linear_fwd', 'muvo_grouped_linear_bwd', 'muvo_conv_prepare_dy_head', 'muvo_conv_prepare_dy_head_supported',
     'muvo_conv_forward_head_supported', 'muvo_conv_forward_head',
     'muvo_adain_affine', 'muvo_conv_affine_supported', 'muvo_conv_forward_affine', 'muvo_conv_wgrad_affine',
-    'muvo_fake_allreduce',
+    'muvo_fake_allreduce', 'muvo_resize_bilinear_aa',
     'muvo_rssm_supported', 'muvo_rssm_transposed_floats', 'muvo_rssm_scratch_floats', 'muvo_rssm_forward', 'muvo_rssm_backward',
 ]
 
@@ -320,11 +320,15 @@ def side_stream(name, device):
     key = (name, device.index)
     st = _side_streams.get(key)
     if st is None:
-        st = _side_streams[key] = _new_stream(device, SIDE_PRIORITY.get(name, SIDE_PRIORITY.get('*', 0)))
+        # default: the stream that carries ONLY the weight gradients (leaves of the backward graph: nothing waits for them before
+        # the optimizer) runs at low priority - the main stream's chain is the critical path of the step and gets the compute
+        # units first (same-box A/Bs, profiles/r04a_priority.txt: 80.9 -> 79.9 and 80.6 -> 80.3 ms/step)
+        dflt = 1 if (plan.get('wgrad') == name and list(plan.values()).count(name) == 1) else 0
+        st = _side_streams[key] = _new_stream(device, SIDE_PRIORITY.get(name, SIDE_PRIORITY.get('*', dflt)))
     return st
 
 
-# HIP stream priorities of the side streams (MUVO_SIDE_PRIORITY="*=low" | "s2=low,s0=normal" ...; physical stream names s0..s2).
+# HIP stream priorities of the side streams (MUVO_SIDE_PRIORITY="*=normal" | "s2=low,s0=normal" ...; physical stream names s0..s2).
 # The main stream's chain is the critical path of the step; a low-priority side stream only gets the compute units the main
 # stream's launches leave idle.
 SIDE_PRIORITY = {k: {'low': 1, 'normal': 0, 'high': -1}.get(v, 0)
@@ -2150,6 +2154,19 @@ def preprocess_image(img_u8, crop, mean, std):
     _ck(lib().muvo_preprocess_image(_p(img_u8), _f(label), _f(norm), _i64(b * s * c), c, h, w, top, left, ch, cw, m, sd,
                                     _st()))
     return label, norm
+
+
+def resize_bilinear_aa(x, oh, ow, mean=None, std=None):
+    """(..., C, H, W) float -> antialiased linear resize to (oh, ow) (torchvision resize(antialias=True)); with mean / std also
+    the ImageNet-normalised copy (returns (y, ynorm))."""
+    x = x.contiguous()
+    c, h, w = x.shape[-3:]
+    y = torch.empty(*x.shape[:-2], oh, ow, device=x.device, dtype=torch.float32)
+    yn = torch.empty_like(y) if mean is not None else None
+    m = (C.c_float * 3)(*mean) if mean is not None else None
+    sd = (C.c_float * 3)(*std) if mean is not None else None
+    _ck(lib().muvo_resize_bilinear_aa(_f(x), _f(y), _f(yn), m, sd, _i64(x.numel() // (h * w)), c, h, w, oh, ow, _st()))
+    return (y, yn) if mean is not None else y
 
 
 def preprocess_route(route_u8, size, mean, std):

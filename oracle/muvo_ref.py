@@ -147,6 +147,35 @@ def route_augmentation(route: torch.Tensor, params: torch.Tensor) -> torch.Tenso
     return out
 
 
+def _aa_weights(in_size: int, out_size: int):
+    """Per output index: (first input index, normalised triangle-filter weights) of the antialiased linear resize -
+    torchvision 0.15.2 `resize(tensor, size, antialias=True)` = torch `F.interpolate(mode='bilinear', antialias=True,
+    align_corners=False)` = ATen `_compute_indices_min_size_weights_aa` with the linear filter (third-party: torch 2.0,
+    aten/src/ATen/native/cpu/UpSampleKernel.cpp): scale = in / out; support = scale when down-scaling, else 1; centre =
+    scale * (i + 0.5); taps [int(centre - support + 0.5), int(centre + support + 0.5)) clipped to the image; weight of tap j =
+    max(0, 1 - |(j - centre + 0.5) / max(scale, 1)|), normalised to sum 1.  float32 arithmetic."""
+    scale = torch.tensor(in_size / out_size, dtype=torch.float32)
+    support = scale if scale >= 1.0 else torch.tensor(1.0)
+    inv = 1.0 / scale if scale >= 1.0 else torch.tensor(1.0)
+    rows = []
+    for i in range(out_size):
+        center = scale * (i + 0.5)
+        lo = max(int(center - support + 0.5), 0)
+        hi = min(int(center + support + 0.5), in_size)
+        j = torch.arange(lo, hi, dtype=torch.float32)
+        w = (1.0 - ((j - center + 0.5) * inv).abs()).clamp(min=0.0)
+        rows.append((lo, (w / w.sum()).float()))
+    return rows
+
+
+def resize_bilinear_aa(x: torch.Tensor, size) -> torch.Tensor:
+    """(N, C, H, W) float -> (N, C, h, w): horizontal pass first, then vertical (the order of ATen's separable kernel)."""
+    h, w = size
+    wx, wy = _aa_weights(x.shape[-1], w), _aa_weights(x.shape[-2], h)
+    tmp = torch.stack([(x[..., lo:lo + len(k)] * k).sum(-1) for lo, k in wx], -1)
+    return torch.stack([(tmp[..., lo:lo + len(k), :] * k[:, None]).sum(-2) for lo, k in wy], -2)
+
+
 def preprocess(batch: Dict[str, torch.Tensor], cfg: dict, pixel_aug=None, route_aug=None) -> Dict[str, torch.Tensor]:
     """muvo/models/preprocess.py:201-225 (+ prepare_bev_labels :102-186).  pixel_aug / route_aug: the training-time
     augmentation (preprocess.py:213-214) with its random draws as explicit tables (None = off); it runs after the label
@@ -163,6 +192,11 @@ def preprocess(batch: Dict[str, torch.Tensor], cfg: dict, pixel_aug=None, route_
     intr = batch['intrinsics'].clone()
     intr[..., 0, 2] -= left
     intr[..., 1, 2] -= top
+    if cfg.get('EVAL_RESOLUTION_FACTOR', 1) != 1:       # EVAL.RESOLUTION (preprocess.py:209-210, functional_resize_batch :252-273)
+        sc = 1 / cfg['EVAL_RESOLUTION_FACTOR']
+        h1, w1 = int(round(img.shape[-2] * sc)), int(round(img.shape[-1] * sc))
+        img = resize_bilinear_aa(img.flatten(0, 1), (h1, w1)).view(b, s, 3, h1, w1)
+        intr[..., :2, :] *= sc
     out['intrinsics'] = intr
     # rgb labels: bilinear (no antialias), each level from the previous (preprocess.py:104-113)
     out['rgb_label_1'] = img
@@ -465,7 +499,7 @@ def sim_forward(model, state: SimState, batch, is_dreaming, receptive_field, str
     pol = model.policy(st)
     out = {'throttle_brake': pol[:, :1].view(b, 1, 1), 'steering': pol[:, 1:].view(b, 1, 1), 'hidden_state': state.last_h,
            'sample': state.last_sample}
-    for dec in (model.rgb_decoder, model.lidar_re, model.voxel_decoder) + model.aux_decoders():
+    for dec in model.main_decoders() + model.aux_decoders():
         for k, v in dec(st).items():
             out[k] = v.view(b, 1, *v.shape[1:])
     fh = batch['image'].shape[1] - 1
@@ -780,7 +814,8 @@ class MileRef(nn.Module):
         # muvo_amd/config.py is in use (cfg keys RGB_CONST / LIDAR_CONST / VOXEL_CONST; no reference counterpart: unpinned)
         cs_rgb, cs_lidar = tuple(cfg.get('RGB_CONST', (5, 13))), tuple(cfg.get('LIDAR_CONST', (1, 16)))
         cs_voxel = tuple(cfg.get('VOXEL_CONST', (3, 3, 1)))
-        self.rgb_decoder = ConvDecoder(sd, 3, cs_rgb, 'rgb_head', 'rgb')
+        if cfg.get('RGB_SUPERVISION', True):     # EVAL.RGB_SUPERVISION (mile.py:315-321)
+            self.rgb_decoder = ConvDecoder(sd, 3, cs_rgb, 'rgb_head', 'rgb')
         self.lidar_re = ConvDecoder(sd, cfg['LIDAR_RE_CHANNELS'], cs_lidar, 'lidar_re_head', 'lidar_reconstruction')
         self.voxel_decoder = VoxelDecoder1(sd, cfg['VOXEL_N_CLASSES'], cfg['VOXEL_DIMENSION'], cs_voxel)
         if 'bev' in self.aux_heads:             # SEMANTIC_SEG (mile.py:307-313)
@@ -838,10 +873,13 @@ class MileRef(nn.Module):
         pol = self.policy(state)
         out['throttle_brake'] = pol[:, :1].view(b, s, 1)
         out['steering'] = pol[:, 1:].view(b, s, 1)
-        for dec in (self.rgb_decoder, self.lidar_re, self.voxel_decoder) + self.aux_decoders():
+        for dec in self.main_decoders() + self.aux_decoders():
             for k, v in dec(state).items():
                 out[k] = v.view(b, s, *v.shape[1:])
         return out
+
+    def main_decoders(self):
+        return tuple(getattr(self, n) for n in ('rgb_decoder', 'lidar_re', 'voxel_decoder') if hasattr(self, n))
 
     def aux_decoders(self):
         return tuple(getattr(self, n) for n in ('bev_decoder', 'lidar_segmentation', 'sem_image_decoder', 'depth_image_decoder')
@@ -863,7 +901,7 @@ def imagine(model, state, future_horizon, noise):
     pol = model.policy(flat)
     out = {'state': st, 'throttle_brake': pol[:, :1].view(b, future_horizon, 1),
            'steering': pol[:, 1:].view(b, future_horizon, 1)}
-    for dec in (model.rgb_decoder, model.lidar_re, model.voxel_decoder) + model.aux_decoders():
+    for dec in model.main_decoders() + model.aux_decoders():
         for k, v in dec(flat).items():
             out[k] = v.view(b, future_horizon, *v.shape[1:])
     return out
@@ -944,7 +982,7 @@ def compute_losses(batch, out, cfg) -> Dict[str, torch.Tensor]:
         kl = a * _kl(pr['mu'], pr['sigma'], po['mu'].detach(), po['sigma'].detach()) + \
             (1 - a) * _kl(pr['mu'].detach(), pr['sigma'].detach(), po['mu'], po['sigma'])
         L['probabilistic'] = cfg['W_PROB'] * kl
-    for f in (1, 2, 4):
+    for f in ((1, 2, 4) if cfg.get('RGB_SUPERVISION', True) else ()):
         d = 1 / f
         rgb = _spatial_regression(out[f'rgb_{f}'], batch[f'rgb_label_{f}'], 1)
         if cfg.get('RGB_INSTANCE'):              # LOSSES.RGB_INSTANCE (trainer.py:303-321): + 0.5 x the same L1 over the instance pixels

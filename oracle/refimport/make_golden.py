@@ -117,10 +117,11 @@ def main():
     ap.add_argument('--fp64-checkpoint', action='store_true',
                     help='float64 run: recompute the three decoders in backward (b*s > 4 does not fit 62 GB otherwise)')
     ap.add_argument('--no-fp64', action='store_true', help='skip the float64 run of the reference (gradient noise floor)')
+    ap.add_argument('--threads', type=int, default=8, help='CPU threads (another count = another summation order in the reference\'s own reductions)')
     args = ap.parse_args()
     tag = args.tag or f'b{args.b}s{args.s}'
     torch.manual_seed(0)
-    torch.set_num_threads(8)
+    torch.set_num_threads(args.threads)
 
     ref_trainer, ref_config = import_reference()
     cfg_dict = effective_cfg_dict(ref_config)

@@ -1,5 +1,5 @@
 // Standalone reproducer of the packed-fp32 finding - no library code, two kernels, two streams.
-//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/dev/pk_f32_repro.hip -o /tmp/pk_repro && /tmp/pk_repro [launches] [aggressor_lds_kb]
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/dev/pk_f32_repro.hip -o /tmp/pk_repro && /tmp/pk_repro [launches] [aggressor_lds_kb] [aggressor_mode]
 //   (-ffp-contract=off as in muvo_amd/build.py: v_pk_mul_f32 + v_pk_add_f32; without it the products are v_pk_fma_f32)
 //   control: add  -Xclang -target-feature -Xclang -packed-fp32-ops   (the flag the library is built with) -> 0 wrong launches
 // aggressor (stream A): workgroups of 8 waves that reserve `aggressor_lds_kb` KB of LDS (default 150: one workgroup per CU) and
@@ -20,13 +20,25 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 2; } } while (0)
 
-__global__ void __launch_bounds__(512) aggressor_kernel(float* __restrict__ sink, int iters, int lds_words) {
+// mode 0: MFMA + LDS fragment reads only.  mode 1: the K-loop shape of the eight-wave convolution tiles - every step streams 16 bytes
+// per lane from global memory, stages them with ds_write_b128, meets at a workgroup barrier, reads two fragments back and issues
+// six MFMAs.
+__global__ void __launch_bounds__(512) aggressor_kernel(float* __restrict__ sink, const uint4* __restrict__ src, long src_n4, int iters,
+                                                        int lds_words, int mode) {
   extern __shared__ unsigned lds[];
   for (int i = threadIdx.x; i < lds_words; i += 512) lds[i] = 0x3f803f80u + (unsigned)(i & 7);   // bf16 pairs near 1.0
   __syncthreads();
   f32x16 acc = {};
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int stage_words = 512 * 4;
+  const int nstage = (lds_words - 8) / stage_words > 0 ? (lds_words - 8) / stage_words : 1;
   for (int it = 0; it < iters; ++it) {
+    if (mode == 1 && lds_words >= stage_words + 8) {
+      const long gi = ((long)blockIdx.x * iters + it) * 512 + threadIdx.x;
+      const uint4 g = src[gi % src_n4];
+      *(uint4*)(lds + (it % nstage) * stage_words + threadIdx.x * 4) = make_uint4(g.x | 0x3f803f80u, g.y & 0x3fff3fffu, g.z & 0x3fff3fffu, g.w & 0x3fff3fffu);
+      __syncthreads();
+    }
     const int base = ((it * 8 + wave) * 64 + lane) * 4 % (lds_words - 8);
     const uint4 a = *(const uint4*)(lds + (base & ~3));
     const uint4 b = *(const uint4*)(lds + ((base + 2048) % (lds_words - 8) & ~3));
@@ -70,6 +82,7 @@ __global__ void __launch_bounds__(256) victim_kernel(const float* __restrict__ i
 int main(int argc, char** argv) {
   const int launches = argc > 1 ? atoi(argv[1]) : 200;
   const int lds_kb = argc > 2 ? atoi(argv[2]) : 150;
+  const int mode = argc > 3 ? atoi(argv[3]) : 1;
   const int N = 4, Cin = 64, H = 160, W = 800;
   const long S = (long)H * W, S4 = S / 4;
   const size_t in_n = (size_t)N * Cin * S, out_n = (size_t)N * CO * S;
@@ -96,7 +109,7 @@ int main(int argc, char** argv) {
   int lane_hist[64] = {0};
   for (int l = 0; l < launches; ++l) {
     // ~2 ms of aggressor work on stream A: 1024 workgroups (4 rounds of 256 CUs), then the victim on stream B in the middle of it
-    hipLaunchKernelGGL(aggressor_kernel, dim3(1024), dim3(512), lds_bytes, sa, d_sink, 6000, lds_bytes / 4);
+    hipLaunchKernelGGL(aggressor_kernel, dim3(1024), dim3(512), lds_bytes, sa, d_sink, (const uint4*)d_in, (long)(in_n / 4), mode ? 3000 : 6000, lds_bytes / 4, mode);
     CK(hipMemsetAsync(d_out, 0, out_n * 4, sb));
     hipLaunchKernelGGL(victim_kernel, vgrid, dim3(256), CO * Cin * 4, sb, d_in, d_w, d_out, Cin, S4);
     CK(hipStreamSynchronize(sb));
@@ -111,8 +124,8 @@ int main(int argc, char** argv) {
       }
     if (bad) { ++wrong_launches; wrong_values += bad; }
   }
-  printf("victim launches next to the %d-KB-LDS aggressor: %d, with wrong values: %d (%ld values in all)\n", lds_kb, launches,
-         wrong_launches, wrong_values);
+  printf("victim launches next to the %d-KB-LDS aggressor (mode %d): %d, with wrong values: %d (%ld values in all)\n", lds_kb, mode,
+         launches, wrong_launches, wrong_values);
   if (wrong_values) {
     printf("wrong values by lane of the wave:");
     for (int i = 0; i < 64; ++i) if (lane_hist[i]) printf(" %d:%d", i, lane_hist[i]);

@@ -11,9 +11,9 @@ for v in packed fma control; do
     control) flags="-ffp-contract=off -Xclang -target-feature -Xclang -packed-fp32-ops" ;;
   esac
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $flags "$here/pk_f32_repro.hip" -o /tmp/pk_repro_$v 2>/dev/null || { echo "$v: build failed"; continue; }
-  for kb in 150 64 8; do
-    echo -n "$v, aggressor LDS ${kb} KB: "
-    timeout 300 /tmp/pk_repro_$v $n $kb | tail -2 | tr '\n' ' '
+  for cfg in "150 1" "150 0" "64 1"; do
+    echo -n "$v, aggressor (LDS KB, mode) = ($cfg): "
+    timeout 300 /tmp/pk_repro_$v $n $cfg | tail -2 | tr '\n' ' '
     echo
   done
 done
