@@ -12,7 +12,7 @@ from muvo_amd.models.common import (BevDecoder, ConvDecoder, Decoder, DecoderDS,
                                     position_embedding_sine)
 from muvo_amd.models.resnet import ResNet18Features
 from muvo_amd.models.transition import RSSM
-from muvo_amd.utils.network_utils import pack_sequence_dim, unpack_sequence_dim
+from muvo_amd.utils.network_utils import pack_sequence_dim, remove_past, unpack_sequence_dim
 
 
 class _FeatureConv(nn.Sequential):
@@ -141,8 +141,7 @@ class Mile(nn.Module):
 
     def forward(self, batch, deployment=False, noise=None, use_prior=None):
         if deployment:
-            raise NotImplementedError('Mile.forward(deployment=True) (mile.py:404-489: the whole-sequence deployment variant) is not '
-                                      'built; the closed-loop callers use deployment_forward / sim_forward, which are')
+            return self._forward_deployment(batch, use_prior)
         dev = batch['image'].device
         embedding = self.encode(batch)
         b, s = batch['image'].shape[:2]
@@ -184,6 +183,42 @@ class Mile(nn.Module):
         output.update(self._aux_heads(state, b, s))
         for br in joins:
             br.join()
+        return output, state_dict
+
+    def _forward_deployment(self, batch, use_prior=None):
+        """Mile.forward(batch, deployment=True) (mile.py:404-489): the whole observed sequence through the encoder and the RSSM with the
+        recorded `batch['action']` and the distribution MEANS instead of samples (use_sample=False), then everything but the last time
+        step is dropped (remove_past, network_utils.py:30-38) and the policy and every decoder run on that last state only (s = 1).
+        No caller of the reference uses it (deployment goes through deployment_forward / sim_forward); inference-only here as well."""
+        assert self.cfg.MODEL.TRANSITION.ENABLED
+        with torch.no_grad():
+            embedding = self.encode(batch)
+            b, s = batch['image'].shape[:2]
+            action = batch['action'].float().contiguous().view(b, s, -1)
+            # (in train() mode the RSSM still draws its prior-substitution coin per step, transition.py:118-124, unless `use_prior` says)
+            state_dict = self.rssm(embedding, action, use_sample=False, policy=self.policy, use_prior=use_prior)
+            state_dict = remove_past(state_dict, s)
+            output = {**state_dict}
+            post = state_dict['posterior']
+            state = ops.cat_last([pack_sequence_dim(post['hidden_state']), pack_sequence_dim(post['sample'])])
+            pol = self.policy(state)
+            output['throttle_brake'] = unpack_sequence_dim(ops.slice_last(pol, 0, 1), b, 1)
+            output['steering'] = unpack_sequence_dim(ops.slice_last(pol, 1, 2), b, 1)
+            # reference order (mile.py:448-487); DISPLAY_SEGMENTATION is True (constants.py:4): the BEV decoder runs as well
+            if self.cfg.SEMANTIC_SEG.ENABLED:
+                output.update(unpack_sequence_dim(self.bev_decoder(state), b, 1))
+            if self.cfg.EVAL.RGB_SUPERVISION:
+                output.update(unpack_sequence_dim(self.rgb_decoder(state), b, 1))
+            if self.cfg.LIDAR_RE.ENABLED:
+                output.update(unpack_sequence_dim(self.lidar_re(state), b, 1))
+            if self.cfg.LIDAR_SEG.ENABLED:
+                output.update(unpack_sequence_dim(self.lidar_segmentation(state), b, 1))
+            if self.cfg.SEMANTIC_IMAGE.ENABLED:
+                output.update(unpack_sequence_dim(self.sem_image_decoder(state), b, 1))
+            if self.cfg.DEPTH.ENABLED:
+                output.update(unpack_sequence_dim(self.depth_image_decoder(state), b, 1))
+            if self.cfg.VOXEL_SEG.ENABLED:
+                output.update(unpack_sequence_dim(self.voxel_decoder(state), b, 1))
         return output, state_dict
 
     # ------------------------------------------------------------------ closed-loop inference (mile.py:852-1032)

@@ -878,6 +878,26 @@ class MileRef(nn.Module):
                 out[k] = v.view(b, s, *v.shape[1:])
         return out
 
+    def forward_deployment(self, batch):
+        """Mile.forward(batch, deployment=True) (mile.py:404-489): the recorded `batch['action']`, distribution means instead of
+        samples (use_sample=False = zero noise, no prior substitution outside training dropout), then remove_past(state_dict, s)
+        (network_utils.py:30-38): only the last time step is kept and decoded (s = 1)."""
+        b, s = batch['image'].shape[:2]
+        emb = self.encode(batch)
+        zero = emb.new_zeros(b, s, 2, self.cfg['STATE_DIM'])
+        prior, post = self.rssm(emb, batch['action'].float(), zero, [False] * s)
+        prior = {k: v[:, s - 1:].contiguous() for k, v in prior.items()}
+        post = {k: v[:, s - 1:].contiguous() for k, v in post.items()}
+        out = {'prior': prior, 'posterior': post}
+        state = torch.cat([post['hidden_state'], post['sample']], -1).flatten(0, 1)
+        pol = self.policy(state)
+        out['throttle_brake'] = pol[:, :1].view(b, 1, 1)
+        out['steering'] = pol[:, 1:].view(b, 1, 1)
+        for dec in self.main_decoders() + self.aux_decoders():
+            for k, v in dec(state).items():
+                out[k] = v.view(b, 1, *v.shape[1:])
+        return out
+
     def main_decoders(self):
         return tuple(getattr(self, n) for n in ('rgb_decoder', 'lidar_re', 'voxel_decoder') if hasattr(self, n))
 

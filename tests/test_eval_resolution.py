@@ -1,0 +1,122 @@
+"""EVAL.RESOLUTION (muvo/models/preprocess.py:209-210,252-273): PreProcess.forward down-scales the cropped image by 1 / FACTOR with
+torchvision's antialiased resize before the model sees it; the smaller image runs through the same encoder (5 x 13 feature map at
+FACTOR 2).  Pinned by one training step of the REAL reference with EVAL.RESOLUTION.{ENABLED, FACTOR=2} and EVAL.RGB_SUPERVISION off
+(tests/golden/evalres_b1s2.*, oracle/refimport/make_golden_evalres.py - with the RGB decoder on the reference's own loss fails to
+broadcast).  CPU: the oracle's restatement of the antialiased filter against torch's own, and the oracle step.  GPU: the HIP kernel
+against torch for several size pairs, and the HIP model against the fixture (18 losses 1e-3, outputs and the resized image 2e-3 /
+1e-5, gradient norms of the image branch 5e-3)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+SIZES = [(320, 832, 160, 416), (320, 832, 107, 277), (64, 64, 48, 40), (33, 47, 66, 94), (20, 20, 20, 20)]
+
+
+def _fixture():
+    return json.load(open(os.path.join(GOLD, 'evalres_b1s2.json'))), np.load(os.path.join(GOLD, 'evalres_b1s2_samples.npz'))
+
+
+def _check_outputs(fx, smp, out, batch, tol, tol_image):
+    for k, st in fx['outputs'].items():
+        t = batch[k[6:]] if k.startswith('batch.') else out[k]
+        assert list(t.shape) == st['shape'], k
+        f = t.detach().float().contiguous().view(-1)
+        ref = torch.from_numpy(smp[('' if k.startswith('batch.') else 'out.') + k])
+        got = f[::st['stride']][:ref.numel()].cpu()
+        err = (got - ref).abs().max().item()
+        bar = tol_image if k.startswith('batch.') else tol
+        assert err <= bar * max(st['absmean'], ref.abs().max().item(), 1e-6), f'{k}: {err}'
+
+
+def test_oracle_antialiased_resize_is_torchs():
+    from oracle import muvo_ref as R
+    torch.manual_seed(0)
+    for h, w, oh, ow in SIZES:
+        x = torch.rand(2, 3, h, w)
+        want = F.interpolate(x, size=(oh, ow), mode='bilinear', antialias=True, align_corners=False)
+        assert (R.resize_bilinear_aa(x, (oh, ow)) - want).abs().max() < 1e-6, (h, w, oh, ow)
+
+
+def test_oracle_eval_resolution_matches_reference():
+    from muvo_amd.data.synthetic import make_batch, make_noise
+    from muvo_amd.utils import detinit
+    from oracle import muvo_ref as R
+    fx, smp = _fixture()
+    b, s = fx['b'], fx['s']
+    model = R.MileRef(dict(R.base_1d_cfg(), EVAL_RESOLUTION_FACTOR=2, RGB_SUPERVISION=False))
+    assert sum(1 for _ in model.parameters()) == fx['n_parameters'] and not hasattr(model, 'rgb_decoder')
+    detinit.fill_state_dict_(model)
+    model.train()
+    model.set_dropout(0.0)
+    eps, use_prior = make_noise(b, s, seed=fx['seed'])
+    with torch.no_grad():
+        total, losses, out, pb = R.training_step(model, make_batch(b, s, seed=fx['seed']), eps, use_prior)
+    assert set(losses) == set(fx['losses']) and len(losses) == 18
+    for k, val in fx['losses'].items():
+        assert abs(float(losses[k]) - val) <= 2e-5 * max(abs(val), 1e-12), k
+    _check_outputs(fx, smp, out, pb, 2e-4, 1e-5)
+
+
+def test_product_refuses_the_combination_the_reference_cannot_run():
+    from muvo_amd.config import base_1d_cfg
+    from muvo_amd.models.preprocess import PreProcess
+    cfg = base_1d_cfg()
+    cfg.EVAL.RESOLUTION.ENABLED, cfg.EVAL.RESOLUTION.FACTOR = True, 2
+    with pytest.raises(ValueError, match='RGB_SUPERVISION'):
+        PreProcess(cfg)
+    cfg.EVAL.RGB_SUPERVISION = False
+    assert PreProcess(cfg).eval_scale == 0.5
+
+
+@pytest.mark.gpu
+def test_hip_antialiased_resize_kernel(dev):
+    from muvo_amd import ops
+    torch.manual_seed(1)
+    for h, w, oh, ow in SIZES:
+        x = torch.rand(2, 2, 3, h, w)
+        want = F.interpolate(x.flatten(0, 1), size=(oh, ow), mode='bilinear', antialias=True, align_corners=False).view(2, 2, 3, oh, ow)
+        mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+        y, yn = ops.resize_bilinear_aa(x.to(dev), oh, ow, mean, std)
+        assert (y.cpu() - want).abs().max() < 2e-6, (h, w, oh, ow)
+        wn = (want - torch.tensor(mean).view(3, 1, 1)) / torch.tensor(std).view(3, 1, 1)
+        assert (yn.cpu() - wn).abs().max() < 1e-5
+        assert (ops.resize_bilinear_aa(x.to(dev), oh, ow).cpu() - want).abs().max() < 2e-6
+
+
+@pytest.mark.gpu
+def test_hip_eval_resolution_matches_reference(dev):
+    from muvo_amd.config import base_1d_cfg
+    from muvo_amd.data.synthetic import make_batch, make_noise
+    from muvo_amd.trainer import WorldModelTrainer
+    from muvo_amd.utils import detinit
+    fx, smp = _fixture()
+    b, s = fx['b'], fx['s']
+    cfg = base_1d_cfg(RECEPTIVE_FIELD=s, FUTURE_HORIZON=0, STEPS=100000)
+    cfg.EVAL.RESOLUTION.ENABLED, cfg.EVAL.RESOLUTION.FACTOR, cfg.EVAL.RGB_SUPERVISION = True, 2, False
+    tr = WorldModelTrainer(cfg.convert_to_dict(), device=dev)
+    tr.train()
+    tr.preprocess.augment = False
+    assert sum(1 for _ in tr.model.parameters()) == fx['n_parameters']
+    detinit.fill_state_dict_(tr.model)
+    for layer in tr.model.transformer_encoder.layers:
+        layer.p = 0.0
+    opts, _ = tr.configure_optimizers()
+    eps, use_prior = make_noise(b, s, seed=fx['seed'])
+    batch = make_batch(b, s, seed=fx['seed'], device=dev)
+    opts[0].zero_grad()
+    losses, output, _, _ = tr.shared_step(batch, mode='train', noise=eps.to(dev), use_prior=use_prior)
+    tr.loss_reducing(losses).backward()
+    assert set(losses) == set(fx['losses']) and len(losses) == 18
+    for k, val in fx['losses'].items():
+        assert abs(losses[k].item() - val) <= 1e-3 * max(abs(val), 1e-12), (k, losses[k].item(), val)
+    assert tuple(batch['image'].shape[-2:]) == (160, 416)
+    _check_outputs(fx, smp, output, batch, 2e-3, 1e-5)
+    named = dict(tr.model.named_parameters())
+    for n, ref in fx['grad_l2'].items():
+        got = named[n].grad.double().pow(2).sum().sqrt().item()
+        assert abs(got - ref) <= max(5e-3 * ref, 1e-6), (n, got, ref)

@@ -89,3 +89,67 @@ def test_hip_sim_and_deployment_forward_match_reference(dev):
         raw['action'] = torch.cat([raw['throttle_brake'], raw['steering']], -1)
         out = tr.deployment_forward(raw, is_dreaming=False)
         _check(f'dep{call}', fx['deploy'][call], smp, out, {}, 1e-3, 2e-3)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Mile.forward(batch, deployment=True) (muvo/models/mile.py:404-489): the whole-sequence deployment variant, pinned by the REAL
+# reference at batch 2 x 3 frames (tests/golden/deploy_fwd_b2s3.*, oracle/refimport/make_golden_deploy_fwd.py)
+DKEYS = ['rgb_1', 'rgb_4', 'lidar_reconstruction_1', 'voxel_1', 'voxel_4', 'throttle_brake', 'steering']
+
+
+def _deploy_fixture():
+    return (json.load(open(os.path.join(GOLD, 'deploy_fwd_b2s3.json'))), np.load(os.path.join(GOLD, 'deploy_fwd_b2s3_samples.npz')))
+
+
+def _check_deploy(fx, smp, out, tol):
+    flat = {k: out[k] for k in DKEYS}
+    for grp in ('prior', 'posterior'):
+        for k, v in out[grp].items():
+            flat[f'{grp}.{k}'] = v
+    assert set(flat) == set(fx['outputs'])
+    for k, st in fx['outputs'].items():
+        t = flat[k]
+        assert list(t.shape) == st['shape'] and t.shape[1] == 1, k          # remove_past: one time step left
+        f = t.detach().float().contiguous().view(-1)
+        ref = torch.from_numpy(smp['out.' + k])
+        got = f[::st['stride']][:ref.numel()].cpu()
+        assert (got - ref).abs().max().item() <= tol * max(st['absmean'], ref.abs().max().item(), 1e-6), k
+
+
+def test_oracle_forward_deployment_matches_reference():
+    from muvo_amd.data.synthetic import make_batch
+    from muvo_amd.utils import detinit
+    from oracle import muvo_ref as R
+    fx, smp = _deploy_fixture()
+    model = R.MileRef()
+    detinit.fill_state_dict_(model)
+    model.train()
+    model.set_dropout(0.0)
+    raw = make_batch(fx['b'], fx['s'], seed=fx['seed'])
+    with torch.no_grad():
+        pb = R.preprocess(raw, model.cfg)
+        pb['action'] = torch.cat([raw['throttle_brake'], raw['steering']], -1)
+        out = model.forward_deployment(pb)
+    _check_deploy(fx, smp, out, 2e-5)
+
+
+@pytest.mark.gpu
+def test_hip_forward_deployment_matches_reference(dev):
+    from muvo_amd.config import base_1d_cfg
+    from muvo_amd.data.synthetic import make_batch
+    from muvo_amd.trainer import WorldModelTrainer
+    from muvo_amd.utils import detinit
+    fx, smp = _deploy_fixture()
+    b, s = fx['b'], fx['s']
+    tr = WorldModelTrainer(base_1d_cfg(RECEPTIVE_FIELD=s, FUTURE_HORIZON=0, STEPS=100000).convert_to_dict(), device=dev)
+    tr.train()
+    tr.preprocess.augment = False
+    detinit.fill_state_dict_(tr.model)
+    for layer in tr.model.transformer_encoder.layers:
+        layer.p = 0.0
+    raw = make_batch(b, s, seed=fx['seed'], device=dev)
+    raw['action'] = torch.cat([raw['throttle_brake'], raw['steering']], -1)
+    batch = tr.preprocess(raw)
+    out, state_dict = tr.model(batch, deployment=True, use_prior=[False] * s)
+    assert set(state_dict) == {'prior', 'posterior'} and not any(v.requires_grad for v in out.values() if torch.is_tensor(v))
+    _check_deploy(fx, smp, out, 2e-3)
