@@ -487,6 +487,23 @@ int muvo_fake_allreduce(float* buf, int64_t n, int workgroups, int sleep, void* 
 int muvo_resize_bilinear_aa(const float* x, float* y, float* ynorm, const float* mean, const float* std, int64_t NC, int C, int H,
                             int W, int OH, int OW, void* stream);
 
+/* ---- BatchNorm that writes its consumer's operand format (round 4; muvo/layers/layers.py:9-66, muvo/models/common.py:102-130, timm
+ * ResNet-18: conv -> BatchNorm2d (train mode) -> ReLU -> conv) ----
+ * muvo_bn_train_fwd_planes = muvo_bn_train_fwd that ALSO stores the channels-last bf16 hi / lo planes of its result into `planes`
+ * (muvo_split_planes_bytes(N, C, S) bytes: what the bf16x3 convolution kernels read, otherwise made by a separate split pass over
+ * y); y may be NULL when the planes are the only thing the consumers need.  muvo_bn_train_bwd_planes = muvo_bn_train_bwd whose dx
+ * goes out as planes (dx may be NULL): the operand of the data- and weight-gradient kernels of the convolution that produced x
+ * (muvo_conv_dgrad with ws_valid, muvo_conv_wgrad with flag 2) - muvo_conv_prepare_dy is not needed.  Same arithmetic per element
+ * as the unfused kernels (bit-identical results).  muvo_conv_forward_planes: muvo_conv_forward with ws_valid (x may be NULL then). */
+int muvo_bn_train_fwd_planes(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+                             float* save_mean, float* save_rstd, float* running_mean, float* running_var, int N, int C,
+                             int64_t S, float eps, float momentum, int res_mode, int relu, void* planes, void* stream);
+int muvo_bn_train_bwd_planes(const float* x, const float* y, const float* dy, const float* gamma, const float* beta,
+                             const float* save_mean, const float* save_rstd, float* dx, float* dres, float* dgamma,
+                             float* dbeta, int N, int C, int64_t S, int mask_mode, void* planes, void* stream);
+int muvo_conv_forward_planes(const muvo_conv_desc* d, const float* x, const float* wp_fwd, const float* bias, float* y, int act,
+                             float slope, void* ws, int ws_valid, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1011,6 +1011,23 @@ int muvo_conv_forward(const muvo_conv_desc* d, const float* x, const float* wp_f
   return run_phases(pl.fwd, pl.nfwd, x, wp_fwd, bias, y, act, slope, ws, (hipStream_t)stream);
 }
 
+// muvo_conv_forward whose workspace may ALREADY hold the split planes of x (ws_valid != 0): written by the producer of x - the fused
+// BatchNorm apply (muvo_bn_train_fwd_planes) or an earlier consumer of the same tensor - so the split pass is skipped.  x may then
+// be NULL if every phase of the operation runs on the bf16x3 kernels (they read the planes only).
+int muvo_conv_forward_planes(const muvo_conv_desc* d, const float* x, const float* wp_fwd, const float* bias, float* y, int act,
+                             float slope, void* ws, int ws_valid, void* stream) {
+  if (!ws_valid) return muvo_conv_forward(d, x, wp_fwd, bias, y, act, slope, ws, stream);
+  ConvPlan pl;
+  int rc = build_plan(d, &pl);
+  if (rc) return rc;
+  MUVO_CHECK_ARG(wp_fwd && y && ws, "conv_forward_planes: null pointer");
+  MUVO_CHECK_ARG(!pw_applicable(d) && !vox_fwd_ok(d), "conv_forward_planes: this shape does not read split planes");
+  bool all_bf3 = pl.nfwd > 0;
+  for (int i = 0; i < pl.nfwd; ++i) all_bf3 = all_bf3 && pl.fwd[i].bf3;
+  MUVO_CHECK_ARG(all_bf3, "conv_forward_planes: ws_valid needs every phase on the bf16x3 kernels (muvo_conv_kernel_family == 1)");
+  return run_phases(pl.fwd, pl.nfwd, x, wp_fwd, bias, y, act, slope, ws, (hipStream_t)stream, true);
+}
+
 // A decoder stage and the 1x1 head on its output in one launch per phase (ConvDecoder: trans_conv1/2/3 + head_4/2/1,
 // common.py:608-632): y = act(conv(x)) as muvo_conv_forward, logits[n][k][pixel] = head_b[k] + sum_c head_w[k][c] y[n][c][pixel]
 // formed in the epilogue of the eight-wave bf16x3 tiles from the values being stored - no pass over y for the head's forward.

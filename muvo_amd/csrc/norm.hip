@@ -471,6 +471,291 @@ extern "C" int muvo_bn_train_bwd(const float* x, const float* y, const float* dy
   return MUVO_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// BatchNorm apply that WRITES THE CONSUMER'S OPERAND FORMAT (round 4): the convolution that follows a BatchNorm on the bf16x3
+// kernels reads channels-last bf16 hi / lo planes of its input, which used to be made by a separate pass over the fp32 NCHW
+// result (nchw_split_nhwc_*, conv_bf3.hip).  These kernels apply the normalisation (+ residual, + ReLU) on the 64-channel x
+// 256-pixel tile of that split pass and store the planes directly - the fp32 tensor is written only when somebody else needs it
+// (y == nullptr: not at all).  The backward form does the same for dx = gamma * rstd * (dz - mean(dz) - xhat * mean(dz * xhat)):
+// the planes are what the data- and weight-gradient kernels of the PRODUCING convolution read (muvo_conv_prepare_dy disappears).
+// Arithmetic per element is the expression of bn_apply_vec_kernel / bn_bwd_apply_vec_kernel: results are bit-identical.
+// Layout of `planes` = bf3_workspace_bytes (conv_bf3.hip): hi plane [N][S][Cp] bf16, lo plane, one zero uint4.
+typedef __bf16 nbf16x2 __attribute__((ext_vector_type(2)));
+typedef float nf32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void nsplit2(float x0, float x1, unsigned& hi, unsigned& lo) {
+  const nbf16x2 h = __builtin_convertvector((nf32x2){x0, x1}, nbf16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  const float h0 = __uint_as_float(hi << 16), h1 = __uint_as_float(hi & 0xffff0000u);
+  const nbf16x2 l = __builtin_convertvector((nf32x2){x0 - h0, x1 - h1}, nbf16x2);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+#define NSPLIT_PS 258
+struct BnSplitArgs {
+  const float* x; const float* res; const float* yin; const float* dy;      // fwd: x, res;  bwd: x, yin (mask_mode 1), dy
+  float* out; float* dres;                                                 // fp32 result (y / dx) or nullptr; bwd: dres or nullptr
+  uint4* hi; uint4* lo;
+  const float* gamma; const float* beta; float* mean; float* rstd;         // fwd writes mean / rstd, bwd reads them
+  float* run_mean; float* run_var; float* dgamma; float* dbeta;
+  const double* sums; double cnt; float eps, momentum;
+  int C, Cp, res_mode, relu, mask_mode;
+  long S;
+};
+// per-channel constants of the 64 channels of this workgroup: fwd (sc, sh); bwd (mu, rs, ga, be, m1, m2)
+template <bool BWD>
+__device__ __forceinline__ void bn_split_consts(const BnSplitArgs& a, int c0, float* s_k) {
+  const int t = threadIdx.x;
+  if (t < 64) {
+    const int c = c0 + t;
+    float k[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c < a.C) {
+      const bool first = blockIdx.x == 0 && blockIdx.z == 0;
+      if (!BWD) {
+        const BnStat bs = bn_stat(a.sums, c, a.cnt, a.eps, first, a.mean, a.rstd, a.run_mean, a.run_var, a.momentum);
+        k[0] = bs.rstd * a.gamma[c];
+        k[1] = a.beta[c] - bs.mean * k[0];
+      } else {
+        const double s1 = a.sums[2 * c], s2 = a.sums[2 * c + 1];
+        if (first) {
+          a.dbeta[c] += (float)s1;
+          a.dgamma[c] += (float)s2;
+        }
+        k[0] = a.mean[c]; k[1] = a.rstd[c]; k[2] = a.gamma[c]; k[3] = a.beta[c];
+        k[4] = (float)(s1 / a.cnt); k[5] = (float)(s2 / a.cnt);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) s_k[i * 64 + t] = k[i];
+  }
+  __syncthreads();
+}
+template <bool BWD>
+__device__ __forceinline__ float bn_split_value(const BnSplitArgs& a, const float* s_k, int cl, float xv, float rv, float yv, float dv,
+                                                float& dm) {
+  if (!BWD) {
+    const float sc = s_k[cl], sh = s_k[64 + cl];
+    float o = xv * sc + sh;
+    if (a.res_mode == 1) o += rv;
+    if (a.relu) o = o > 0.f ? o : 0.f;
+    if (a.res_mode == 2) o += rv;
+    return o;
+  } else {
+    const float mu = s_k[cl], rs = s_k[64 + cl], ga = s_k[128 + cl], be = s_k[192 + cl], m1 = s_k[256 + cl], m2 = s_k[320 + cl];
+    const float xh = (xv - mu) * rs;
+    float d = dv;
+    if (a.mask_mode == 1) d = yv > 0.f ? d : 0.f;
+    else if (a.mask_mode == 2) d = (xv * (rs * ga) + (be - mu * (rs * ga))) > 0.f ? d : 0.f;
+    dm = d;
+    return ga * rs * (d - m1 - xh * m2);
+  }
+}
+// S % 4 == 0, S >= 1024, 16-byte aligned tensors: 64 channels x 256 pixels per workgroup, float4 per lane and channel
+template <bool BWD>
+__global__ void __launch_bounds__(256) bn_split_v4_kernel(const BnSplitArgs a) {
+  extern __shared__ unsigned nsp_lds[];
+  __shared__ float s_k[6 * 64];
+  unsigned* th = nsp_lds;
+  unsigned* tl = nsp_lds + 32 * NSPLIT_PS;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c0 = blockIdx.y * 64, n = blockIdx.z;
+  const long S = a.S, s0 = (long)blockIdx.x * 256, s = s0 + 4 * lane;
+  const bool sin = s < S;
+  const long sc = sin ? s : s0;
+  bn_split_consts<BWD>(a, c0, s_k);
+  const size_t nbase = (size_t)n * a.C * S;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    f32x4 xv[8], rv[8], yv[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int c = c0 + 16 * w + 8 * h + r;
+      const size_t o = nbase + (size_t)(c < a.C ? c : a.C - 1) * S + sc;
+      xv[r] = *(const f32x4*)(a.x + o);
+      rv[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      yv[r] = (f32x4){1.f, 1.f, 1.f, 1.f};
+      if (!BWD) { if (a.res_mode) rv[r] = *(const f32x4*)(a.res + o); }
+      else {
+        rv[r] = *(const f32x4*)(a.dy + o);
+        if (a.mask_mode == 1) yv[r] = *(const f32x4*)(a.yin + o);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int cl = 16 * w + 8 * h + r, c = c0 + cl;
+      const bool ok = sin && c < a.C;
+      f32x4 o, dm;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float d = 0.f;
+        o[j] = bn_split_value<BWD>(a, s_k, cl, xv[r][j], BWD ? 0.f : rv[r][j], yv[r][j], BWD ? rv[r][j] : 0.f, d);
+        dm[j] = d;
+      }
+      if (ok) {
+        const size_t oo = nbase + (size_t)c * S + s;
+        if (a.out) *(f32x4*)(a.out + oo) = o;
+        if (BWD && a.dres) *(f32x4*)(a.dres + oo) = dm;
+      } else {
+        o = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      xv[r] = o;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = w * 8 + 4 * h + r;
+      unsigned hi[4], lo[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) nsplit2(xv[2 * r][j], xv[2 * r + 1][j], hi[j], lo[j]);
+      uint2* ph = (uint2*)(th + k * NSPLIT_PS + 4 * lane);
+      uint2* pq = (uint2*)(tl + k * NSPLIT_PS + 4 * lane);
+      ph[0] = make_uint2(hi[0], hi[1]);
+      ph[1] = make_uint2(hi[2], hi[3]);
+      pq[0] = make_uint2(lo[0], lo[1]);
+      pq[1] = make_uint2(lo[2], lo[3]);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int item = tid + 256 * r;
+    const int pix = item >> 3, ch = item & 7;
+    const long so = s0 + pix;
+    const int c = c0 + ch * 8;
+    if (so < S && c < a.Cp) {
+      const unsigned* ph = th + (4 * ch) * NSPLIT_PS + pix;
+      const unsigned* pq = tl + (4 * ch) * NSPLIT_PS + pix;
+      const size_t o = (((size_t)n * S + so) * a.Cp + c) >> 3;
+      a.hi[o] = make_uint4(ph[0], ph[NSPLIT_PS], ph[2 * NSPLIT_PS], ph[3 * NSPLIT_PS]);
+      a.lo[o] = make_uint4(pq[0], pq[NSPLIT_PS], pq[2 * NSPLIT_PS], pq[3 * NSPLIT_PS]);
+    }
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0)
+    a.hi[2 * ((size_t)gridDim.z * S * a.Cp >> 3)] = make_uint4(0u, 0u, 0u, 0u);       // zero page behind the two planes
+}
+// any S: 64 channels x 64 pixels per workgroup, one pixel per lane
+template <bool BWD>
+__global__ void __launch_bounds__(256) bn_split_kernel(const BnSplitArgs a) {
+  constexpr int RS = 33;
+  __shared__ unsigned th[64 * RS], tl[64 * RS];
+  __shared__ float s_k[6 * 64];
+  const int tid = threadIdx.x, pl = tid & 63, w = tid >> 6;
+  const int c0 = blockIdx.y * 64, n = blockIdx.z;
+  const long S = a.S, s0 = (long)blockIdx.x * 64, s = s0 + pl;
+  bn_split_consts<BWD>(a, c0, s_k);
+  const size_t nbase = (size_t)n * a.C * S;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int k = w + 4 * r;
+    float v[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int cl = 2 * k + e, c = c0 + cl;
+      const bool ok = c < a.C && s < S;
+      const size_t o = nbase + (size_t)(c < a.C ? c : a.C - 1) * S + (s < S ? s : s0);
+      const float xv = a.x[o];
+      float rv = 0.f, yv = 1.f, dv = 0.f;
+      if (!BWD) { if (a.res_mode) rv = a.res[o]; }
+      else {
+        dv = a.dy[o];
+        if (a.mask_mode == 1) yv = a.yin[o];
+      }
+      float dm = 0.f;
+      float t = bn_split_value<BWD>(a, s_k, cl, xv, rv, yv, dv, dm);
+      if (ok) {
+        if (a.out) a.out[o] = t;
+        if (BWD && a.dres) a.dres[o] = dm;
+      } else {
+        t = 0.f;
+      }
+      v[e] = t;
+    }
+    unsigned hi, lo;
+    nsplit2(v[0], v[1], hi, lo);
+    th[pl * RS + k] = hi;
+    tl[pl * RS + k] = lo;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int item = tid + 256 * r;
+    const int pix = item >> 3, ch = item & 7;
+    const long so = s0 + pix;
+    const int c = c0 + ch * 8;
+    if (so < S && c < a.Cp) {
+      const unsigned* ph = th + pix * RS + ch * 4;
+      const unsigned* pq = tl + pix * RS + ch * 4;
+      const size_t o = (((size_t)n * S + so) * a.Cp + c) >> 3;
+      a.hi[o] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+      a.lo[o] = make_uint4(pq[0], pq[1], pq[2], pq[3]);
+    }
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0)
+    a.hi[2 * ((size_t)gridDim.z * S * a.Cp >> 3)] = make_uint4(0u, 0u, 0u, 0u);
+}
+template <bool BWD>
+static int bn_split_launch(BnSplitArgs& a, int N, void* planes, hipStream_t st) {
+  a.Cp = (a.C + 7) & ~7;
+  a.hi = (uint4*)planes;
+  a.lo = a.hi + (size_t)N * a.S * a.Cp / 8;
+  const uintptr_t al = (uintptr_t)a.x | (uintptr_t)(a.res ? a.res : a.x) | (uintptr_t)(a.yin ? a.yin : a.x) |
+                       (uintptr_t)(a.dy ? a.dy : a.x) | (uintptr_t)(a.out ? a.out : a.x) | (uintptr_t)(a.dres ? a.dres : a.x);
+  if (a.S % 4 == 0 && a.S >= 1024 && (al & 15) == 0) {
+    constexpr int lds = 2 * 32 * NSPLIT_PS * 4;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[BWD]) {
+      hipFuncSetAttribute((const void*)bn_split_v4_kernel<BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      attr_set[BWD] = true;
+    }
+    hipLaunchKernelGGL(bn_split_v4_kernel<BWD>, dim3(cdiv(a.S, 256), cdiv(a.Cp, 64), N), dim3(256), lds, st, a);
+  } else {
+    hipLaunchKernelGGL(bn_split_kernel<BWD>, dim3(cdiv(a.S, 64), cdiv(a.Cp, 64), N), dim3(256), 0, st, a);
+  }
+  MUVO_CHECK_LAUNCH("bn_split_kernel");
+  return MUVO_OK;
+}
+
+extern "C" int muvo_bn_train_fwd_planes(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+                                        float* save_mean, float* save_rstd, float* running_mean, float* running_var, int N, int C,
+                                        int64_t S, float eps, float momentum, int res_mode, int relu, void* planes, void* stream) {
+  MUVO_CHECK_ARG(x && gamma && beta && save_mean && save_rstd && planes, "bn_train_fwd_planes: null pointer");
+  MUVO_CHECK_ARG(N > 0 && C > 0 && S > 0 && N <= 65535, "bn_train_fwd_planes: bad sizes");
+  MUVO_CHECK_ARG(res_mode >= 0 && res_mode <= 2 && (res_mode == 0 || residual), "bn_train_fwd_planes: bad residual mode");
+  hipStream_t st = (hipStream_t)stream;
+  const long cnt = (long)N * S;
+  int chunks = cdiv(cnt, norm_chunk_elems());
+  if (chunks > norm_max_chunks(256)) chunks = norm_max_chunks(256);
+  double* sums = bn_slot(2 * (size_t)C, st);
+  MUVO_CHECK_ARG(sums != nullptr, "bn_train_fwd_planes: cannot allocate the statistics ring");
+  hipLaunchKernelGGL(moments_kernel, dim3(C, chunks), dim3(256), 0, st, x, sums, (long)S, (long)C * S, cnt,
+                     (int)(S % 4 == 0 && ((uintptr_t)x & 15) == 0));
+  BnSplitArgs a = {};
+  a.x = x; a.res = res_mode ? residual : nullptr; a.out = y;
+  a.gamma = gamma; a.beta = beta; a.mean = save_mean; a.rstd = save_rstd; a.run_mean = running_mean; a.run_var = running_var;
+  a.sums = sums; a.cnt = (double)cnt; a.eps = eps; a.momentum = momentum;
+  a.C = C; a.res_mode = res_mode; a.relu = relu; a.S = (long)S;
+  return bn_split_launch<false>(a, N, planes, st);
+}
+
+extern "C" int muvo_bn_train_bwd_planes(const float* x, const float* y, const float* dy, const float* gamma, const float* beta,
+                                        const float* save_mean, const float* save_rstd, float* dx, float* dres, float* dgamma,
+                                        float* dbeta, int N, int C, int64_t S, int mask_mode, void* planes, void* stream) {
+  MUVO_CHECK_ARG(x && dy && gamma && beta && save_mean && save_rstd && dgamma && dbeta && planes, "bn_train_bwd_planes: null pointer");
+  MUVO_CHECK_ARG(mask_mode >= 0 && mask_mode <= 2 && (mask_mode != 1 || y) && N > 0 && N <= 65535 && C > 0 && S > 0,
+                 "bn_train_bwd_planes: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const long cnt = (long)N * S;
+  int chunks = cdiv(cnt, norm_chunk_elems());
+  if (chunks > norm_max_chunks(256)) chunks = norm_max_chunks(256);
+  double* sums = bn_slot(2 * (size_t)C, st);
+  MUVO_CHECK_ARG(sums != nullptr, "bn_train_bwd_planes: cannot allocate the statistics ring");
+  hipLaunchKernelGGL(bwd_moments_kernel, dim3(C, chunks), dim3(256), 0, st, x, y, dy, save_mean, save_rstd, gamma, beta,
+                     sums, (long)S, (long)C * S, (long)C * S, cnt, mask_mode, 0,
+                     (int)(S % 4 == 0 && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)(mask_mode == 1 ? y : x)) & 15) == 0));
+  BnSplitArgs a = {};
+  a.x = x; a.yin = mask_mode == 1 ? y : nullptr; a.dy = dy; a.out = dx; a.dres = dres;
+  a.gamma = gamma; a.beta = beta; a.mean = (float*)save_mean; a.rstd = (float*)save_rstd; a.dgamma = dgamma; a.dbeta = dbeta;
+  a.sums = sums; a.cnt = (double)cnt; a.C = C; a.mask_mode = mask_mode; a.S = (long)S;
+  return bn_split_launch<true>(a, N, planes, st);
+}
+
 // ------------------------------------------------------------------------------------- AdaIN3d
 __global__ void in_finalize_kernel(double* __restrict__ sums, float* __restrict__ mean, float* __restrict__ rstd,
                                    int G, double cnt, float eps) {

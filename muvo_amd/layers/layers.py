@@ -21,10 +21,14 @@ class BasicBlock(nn.Module):
             self.downsample = nn.Sequential(hnn.Conv2d(inplanes, planes, 1, 2, 0, bias=False), hnn.BatchNorm2d(planes))
         self.stride = stride
 
-    def forward(self, x):
+    def forward(self, x, next_convs=()):
+        """next_convs: the convolution modules that will read this block's output (the next block's conv1, a decoder's skip
+        convolution): bn2 then writes their split planes along with the fp32 result.  bn1's result has conv2 as its only consumer:
+        it exists as planes only when conv2 runs on the bf16x3 kernels; both BatchNorms hand their dx to the convolution in front
+        of them as planes (ops.bn_act)."""
         shortcut = x
-        y = self.bn1(self.conv1(x), relu=True)
+        y = self.bn1(self.conv1(x), relu=True, consumers=(self.conv2,), sole_consumer=True, from_conv=True)
         y = self.conv2(y)
         if self.downsample is not None:
-            shortcut = self.downsample[1](self.downsample[0](shortcut), relu=False)
-        return self.bn2(y, residual=shortcut, res_mode=1, relu=True)
+            shortcut = self.downsample[1](self.downsample[0](shortcut), relu=False, from_conv=True)
+        return self.bn2(y, residual=shortcut, res_mode=1, relu=True, consumers=tuple(next_convs), from_conv=True)

@@ -54,13 +54,17 @@ class DecoderDS(nn.Module):
             _conv_bn_relu(feature_info[i]['num_chs'], out_channels) for i in range(1, len(feature_info)))
         self.out_channels = out_channels
 
+    def feat_consumers(self):
+        """the convolution that reads each input feature map (ResNet18Features.forward(feat_consumers=...))"""
+        return [(self.conv1[0],)] + [(c[0],) for c in self.downsample_skip_convs]
+
     def forward(self, xs):
-        x = self.conv1[1](self.conv1[0](xs[0]), relu=True)
+        x = self.conv1[1](self.conv1[0](xs[0]), relu=True, from_conv=True)
         for i, conv in enumerate(self.downsample_skip_convs):
             stride = xs[i].shape[-1] // xs[i + 1].shape[-1]
             pooled = ops.max_pool2d(x, stride)
             # relu(bn(conv(x_{i+1}))) + max_pool(x): residual added AFTER the ReLU (common.py:128)
-            x = conv[1](conv[0](xs[i + 1]), residual=pooled, res_mode=2, relu=True)
+            x = conv[1](conv[0](xs[i + 1]), residual=pooled, res_mode=2, relu=True, from_conv=True)
         return x
 
 

@@ -23,7 +23,7 @@ class _FeatureConv(nn.Sequential):
                          hnn.Placeholder(), hnn.Placeholder())
 
     def forward(self, x):
-        return ops.global_avg_pool(self[1](self[0](x)))
+        return ops.global_avg_pool(self[1](self[0](x, next_convs=(self[1].conv1,))))
 
 
 class Mile(nn.Module):
@@ -356,7 +356,8 @@ class Mile(nn.Module):
         rv_packed = pack_sequence_dim(batch['range_view_pcd_xyzd']).contiguous() if 'range_view_pcd_xyzd' in batch else None
         route_packed = {k: pack_sequence_dim(batch[k]).contiguous() for k in ('route_map',) if k in batch}
         ops.mark_inputs_ready(batch['image'].device)   # packed weights + preprocessed batch are queued: side-stream branches start here
-        xs = self.encoder(image)
+        fc = self.feat_decoder.feat_consumers() if hasattr(self.feat_decoder, 'feat_consumers') else None
+        xs = self.encoder(image, feat_consumers=fc)
         x = self.feat_decoder(xs)
         if self.bev:                                                     # mile.py:506-524
             depth = ops.softmax_channel(self.depth(self.depth_decoder(xs)))
@@ -373,7 +374,8 @@ class Mile(nn.Module):
         rv = rv_packed
         br_lidar = ops.branch('lidar', 'lidar_encoder', x.device, inputs=(rv,))
         with br_lidar:                 # next to the image encoder's kernels still queued on the main stream
-            lidar_features = br_lidar.out(self.range_view_decoder(self.range_view_encoder(rv)))
+            lidar_features = br_lidar.out(self.range_view_decoder(
+                self.range_view_encoder(rv, feat_consumers=self.range_view_decoder.feat_consumers())))
         br_lidar.join()
         hi, wi = x.shape[-2:]
         hl, wl = lidar_features.shape[-2:]

@@ -34,12 +34,20 @@ class ResNet18Features(nn.Module):
         self.out_indices = tuple(out_indices)
         self.feature_info = FeatureInfo([_FEATURE_INFO[i] for i in self.out_indices])
 
-    def forward(self, x):
+    def forward(self, x, feat_consumers=None):
+        """feat_consumers: per returned feature map (order of out_indices) the convolution modules outside this network that read
+        it (the skip convolutions of DecoderDS): the last BatchNorm of that stage writes their split planes too."""
         feats = []
-        x = self.bn1(self.conv1(x), relu=True)
+        x = self.bn1(self.conv1(x), relu=True, from_conv=True)
         feats.append(x)
         x = ops.max_pool2d(x, 3, 2, 1)
-        for i in range(4):
-            x = getattr(self, f'layer{i + 1}')(x)
-            feats.append(x)
+        blocks = [b for i in range(4) for b in getattr(self, f'layer{i + 1}')]
+        ext = {idx: tuple(feat_consumers[k]) for k, idx in enumerate(self.out_indices)} if feat_consumers is not None else {}
+        for j, blk in enumerate(blocks):
+            nxt = (blocks[j + 1].conv1,) if j + 1 < len(blocks) else ()
+            if j % 2 == 1:                      # last block of stage j // 2 + 1 = feature index j // 2 + 1
+                nxt = nxt + ext.get(j // 2 + 1, ())
+            x = blk(x, next_convs=nxt)
+            if j % 2 == 1:
+                feats.append(x)
         return [feats[i] for i in self.out_indices]

@@ -73,8 +73,10 @@ class BatchNorm2d(nn.Module):
         self.register_buffer('running_var', torch.ones(c))
         self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
 
-    def forward(self, x, residual=None, res_mode=1, relu=False):
-        return ops.bn_act(x, self, residual, res_mode, relu)
+    def forward(self, x, residual=None, res_mode=1, relu=False, consumers=(), sole_consumer=False, from_conv=False):
+        """consumers / sole_consumer / from_conv: see ops.bn_act (the result written as the consumers' split planes, dx handed to
+        the producing convolution as planes)"""
+        return ops.bn_act(x, self, residual, res_mode, relu, consumers, sole_consumer, from_conv)
 
     def _save_to_state_dict(self, destination, prefix, keep_vars):
         ops.flush_bn_counters()          # num_batches_tracked increments are applied lazily, in one fused launch

@@ -71,7 +71,7 @@ EXPORTS = [
     'muvo_grouped_linear_fwd', 'muvo_grouped_linear_bwd', 'muvo_conv_prepare_dy_head', 'muvo_conv_prepare_dy_head_supported',
     'muvo_conv_forward_head_supported', 'muvo_conv_forward_head',
     'muvo_adain_affine', 'muvo_conv_affine_supported', 'muvo_conv_forward_affine', 'muvo_conv_wgrad_affine',
-    'muvo_fake_allreduce', 'muvo_resize_bilinear_aa',
+    'muvo_fake_allreduce', 'muvo_resize_bilinear_aa', 'muvo_bn_train_fwd_planes', 'muvo_bn_train_bwd_planes', 'muvo_conv_forward_planes',
     'muvo_rssm_supported', 'muvo_rssm_transposed_floats', 'muvo_rssm_scratch_floats', 'muvo_rssm_forward', 'muvo_rssm_backward',
 ]
 
@@ -967,7 +967,11 @@ class ConvFn(torch.autograd.Function):
         ctx.aff = aff
         if aff is not None:
             x = aff_src
-        x = x.contiguous()
+        # split planes that came with the tensor (written by its producer: BNActFn with planes=True): (workspace, stream key)
+        xp = getattr(x, '_muvo_planes', None)
+        x_is_placeholder = getattr(x, '_muvo_planes_only', False)
+        if not x_is_placeholder:
+            x = x.contiguous()
         ctx.act_bwd_fused = act_bwd_fused
         n = x.shape[0]
         in_sz = tuple(x.shape[2:]) if geom.nd == 3 else (1,) + tuple(x.shape[2:])
@@ -992,14 +996,22 @@ class ConvFn(torch.autograd.Function):
                                 _conv_bytes(geom, n, in_sz, out_sz))
             e0.record()
         wsb = geom.ws_bytes[(n, in_sz, _plan_epoch[0])]
+        hf = getattr(ctx, '_head_fwd', None)
+        use_xp = (xp is not None and wsb[0] > 0 and geom.family[(n, in_sz, _plan_epoch[0])][0] == 1 and hf is None and aff is None
+                  and moments is None and xp[1] == _stream_key(x.device) and xp[0].numel() * 4 >= wsb[0])
+        if x_is_placeholder and not (use_xp and (wsb[2] > 0 or not ctx.needs_input_grad[1])):
+            raise RuntimeError('muvo_hip: a planes-only tensor (BNActFn keep_f32=False) reached a convolution that needs its fp32 values')
         # wgrad reuses the split copy of x (grad mode is off inside forward: needs_input_grad says whether a backward follows)
         keep_ws = wsb[0] > 0 and wsb[2] > 0 and ctx.needs_input_grad[1] and _KEEP_WS
-        if keep_ws:
+        if use_xp:
+            ws = xp[0]
+            keep_ws = wsb[2] > 0 and ctx.needs_input_grad[1] and (_KEEP_WS or x_is_placeholder)
+        elif keep_ws:
             ws = torch.empty((wsb[0] + 3) // 4, device=x.device, dtype=torch.float32)
         else:
             ws = scratch('conv_ws', (wsb[0] + 3) // 4, x.device) if wsb[0] else None
         ctx.ws_x = ws if keep_ws else None
-        hf = getattr(ctx, '_head_fwd', None)
+        ctx.x_is_placeholder = x_is_placeholder
         if hf is not None:
             _ck(L.muvo_conv_forward_head(C.byref(d), _f(x), _f(packed.fwd), _f(bias), _f(y), act, _fl(slope), _p(ws),
                                          _f(hf[0]), _f(hf[1]), hf[0].shape[0], _f(hf[2]), _st()))
@@ -1007,6 +1019,9 @@ class ConvFn(torch.autograd.Function):
             _ck(L.muvo_conv_forward_affine(C.byref(d), _f(x), _f(aff), _f(packed.fwd), _f(bias), _f(y), act, _fl(slope), _p(moments), _st()))
         elif moments is not None:     # instance-norm statistics of y from the epilogue registers (voxel bf16x3 kernels)
             _ck(L.muvo_conv_forward_moments(C.byref(d), _f(x), _f(packed.fwd), _f(bias), _f(y), act, _fl(slope), _p(moments), _st()))
+        elif use_xp:
+            _ck(L.muvo_conv_forward_planes(C.byref(d), None if x_is_placeholder else _f(x), _f(packed.fwd), _f(bias), _f(y), act,
+                                           _fl(slope), _p(ws), 1, _st()))
         else:
             _ck(L.muvo_conv_forward(C.byref(d), _f(x), _f(packed.fwd), _f(bias), _f(y), act, _fl(slope), _p(ws), _st()))
         if kt is not None:
@@ -1029,10 +1044,13 @@ class ConvFn(torch.autograd.Function):
         geom, packed, weight, bias = ctx.geom, ctx.packed, ctx.weight, ctx.bias
         d, out_sz, ff, df = geom.plan(x.shape[0], ctx.in_sz)
         L = lib()
-        if dy is not None:
+        dyp = getattr(dy, '_muvo_planes', None) if dy is not None else None     # dy arrives as split planes (BNActFn.backward)
+        if dy is not None and dyp is None:
             dy = dy.contiguous()
         key = (x.shape[0], ctx.in_sz, _plan_epoch[0])
         fam, wsb = geom.family[key], geom.ws_bytes[key]
+        x_ph = getattr(ctx, 'x_is_placeholder', False)
+        xptr = ctx.ws_x if x_ph else x            # a planes-only input has no fp32 storage: the kernels read ctx.ws_x (flags bit 0)
         # both gradient kernels read dy through the channels-last split planes: one fused pass makes them from (y, dy)
         # together with the activation derivative and the bias gradient
         fused_dy = (fam[1] == 1 and fam[2] == 1 and ctx.needs_input_grad[0] and weight.requires_grad and wsb[1] > 0
@@ -1060,7 +1078,13 @@ class ConvFn(torch.autograd.Function):
                 dy_slot = _dy_ws_acquire(nfloats, x.device)
             assert dy_slot.t.numel() >= nfloats
             return dy_slot.t
-        if fused_dy:
+        if dyp is not None:
+            if not (fused_dy and head is None and bias is None and (ctx.act == ACT_NONE or ctx.act_bwd_fused)
+                    and dyp[0].numel() * 4 >= max(wsb[1], wsb[3]) and dyp[1] == _stream_key(x.device)):
+                raise RuntimeError('muvo_hip: a gradient that exists only as split planes reached a convolution backward that cannot read them')
+            ws_dy_fused = dyp[0]
+            dz = dy = dyp[0]          # (pointer stand-in: the bf16x3 kernels read the planes only)
+        elif fused_dy:
             ws_dy_fused = dy_workspace((max(wsb[1], wsb[3]) + 3) // 4)
             use_act = ctx.act != ACT_NONE and not ctx.act_bwd_fused
             if head is not None:
@@ -1096,7 +1120,7 @@ class ConvFn(torch.autograd.Function):
             if packed.dgr_key != k or packed.dgr_plan != key[1:]:
                 _ck(L.muvo_conv_pack_weights(C.byref(d), _f(weight), None, _f(packed.dgr), _st()))
                 packed.dgr_key, packed.dgr_plan = k, key[1:]
-            dx = torch.empty_like(x)
+            dx = torch.empty(x.shape, device=dz.device, dtype=torch.float32)
             kt = KERNEL_TIMING
             if kt is not None:
                 import math
@@ -1106,7 +1130,7 @@ class ConvFn(torch.autograd.Function):
                                     _conv_bytes(geom, x.shape[0], ctx.in_sz, out_sz))
                 e0.record()
             nb = max(wsb[1], wsb[3])
-            ws_dy = dy_workspace((nb + 3) // 4) if nb else None
+            ws_dy = (ws_dy_fused if dyp is not None else dy_workspace((nb + 3) // 4)) if nb else None
             dy_split = wsb[1] > 0
             _ck(L.muvo_conv_dgrad(C.byref(d), _f(dz), _f(packed.dgr), _f(dx), _p(ws_dy), 1 if fused_dy else 0, _st()))
             if kt is not None:
@@ -1120,7 +1144,7 @@ class ConvFn(torch.autograd.Function):
             if wst is not None and wst != cur:
                 # everything the weight gradient reads is queued on the current stream by now; it starts behind that point
                 wst.wait_stream(cur)
-                for t in (x, y, dz, ctx.ws_x, ctx.aff):
+                for t in (xptr, y, dz, ctx.ws_x, ctx.aff):
                     if t is not None:
                         t.record_stream(wst)
                 wctx = torch.cuda.stream(wst)
@@ -1144,7 +1168,8 @@ class ConvFn(torch.autograd.Function):
                 if ctx.aff is not None:
                     _ck(L.muvo_conv_wgrad_affine(C.byref(d), _f(x), _f(ctx.aff), _f(dz), _f(gw), _f(db), _st()))
                 else:
-                    _ck(L.muvo_conv_wgrad(C.byref(d), _f(x), _f(dz), _f(ws), _f(gw), _f(db), _p(ws_x), _p(ws_dy), flags, _st()))
+                    assert not x_ph or (flags & 1)
+                    _ck(L.muvo_conv_wgrad(C.byref(d), _f(xptr), _f(dz), _f(ws), _f(gw), _f(db), _p(ws_x), _p(ws_dy), flags, _st()))
                 if kt is not None:
                     e1.record()
                 if wctx is not None and dy_slot is not None:
@@ -1160,7 +1185,18 @@ def conv(x, weight, bias, geom, packed, act=ACT_NONE, slope=0.0, act_bwd_fused=F
     """lazy: (raw, aff) of a lazy AdaIN whose placeholder output is x (adain_lazy); the convolution applies the AdaIN itself."""
     if lazy is not None:
         return ConvFn.apply(x, weight, bias, geom, packed, act, slope, act_bwd_fused, moments, lazy[0], lazy[1])
-    return ConvFn.apply(x, weight, bias, geom, packed, act, slope, act_bwd_fused, moments)
+    y = ConvFn.apply(x, weight, bias, geom, packed, act, slope, act_bwd_fused, moments)
+    if (BN_PLANES and bias is None and act == ACT_NONE and moments is None and x.requires_grad and weight.requires_grad
+            and torch.is_grad_enabled()):
+        # the backward of this convolution reads dy as split planes (ConvFn._backward: fused_dy): a BatchNorm behind it may hand
+        # its dx over in that form (bn_act(from_conv=True))
+        n = x.shape[0]
+        in_sz = tuple(x.shape[2:]) if geom.nd == 3 else (1,) + tuple(x.shape[2:])
+        key = (n, in_sz, _plan_epoch[0])
+        fam, wsb = geom.family.get(key), geom.ws_bytes.get(key)
+        if fam is not None and fam[1] == 1 and fam[2] == 1 and wsb[1] > 0 and wsb[3] > 0:
+            y._muvo_dy_planes_ok = True
+    return y
 
 
 CONV_AFFINE = os.environ.get('MUVO_CONV_AFFINE', '1') != '0'
@@ -1363,32 +1399,56 @@ def head_branch(x, weight, bias, geom, packed):
 
 
 # ================================================================================================ norms
+BN_PLANES = os.environ.get('MUVO_BN_PLANES', '1') != '0'
+
+
+def _nan_placeholder(shape, device):
+    """a tensor of `shape` without storage of its size (one NaN, expanded): stands for data that exists only as split planes
+    (attribute _muvo_planes).  Anything that reads it as numbers gets NaN - a misuse cannot go unnoticed."""
+    return torch.full((1,), float('nan'), device=device, dtype=torch.float32).expand(shape)
+
+
 class BNActFn(torch.autograd.Function):
-    """Train-mode BatchNorm2d + optional residual + ReLU.  res_mode 1: relu(bn(x)+res); 2: relu(bn(x))+res."""
+    """Train-mode BatchNorm2d + optional residual + ReLU.  res_mode 1: relu(bn(x)+res); 2: relu(bn(x))+res.
+    planes: also write the channels-last bf16 hi / lo planes of the result (what a bf16x3 convolution reads;
+    muvo_bn_train_fwd_planes) and hand them to the consumers as y._muvo_planes; keep_f32=False: ONLY the planes (y is a
+    NaN placeholder) - the caller guarantees that the sole consumer is a convolution that reads planes in forward and weight
+    gradient.  dx_planes: the input x is the output of a convolution whose backward reads split planes of its dy
+    (x._muvo_dy_planes_ok): backward writes dx as planes only (muvo_bn_train_bwd_planes)."""
 
     @staticmethod
-    def forward(ctx, x, residual, bn, res_mode, relu, training):
+    def forward(ctx, x, residual, bn, res_mode, relu, training, planes=False, keep_f32=True, dx_planes=False):
         x = x.contiguous()
         n, c = x.shape[:2]
         s = x.numel() // (n * c)
-        y = torch.empty_like(x)
         mean = torch.empty(c, device=x.device, dtype=torch.float32)
         rstd = torch.empty(c, device=x.device, dtype=torch.float32)
-        ws = torch.empty(2 * c, device=x.device, dtype=torch.float64)
         if residual is not None:
             residual = residual.contiguous()
         if not training:
             raise RuntimeError('eval-mode BatchNorm is not part of the training hot path (reference keeps train() mode '
                                'even in validation, trainer.py:405)')
-        _ck(lib().muvo_bn_train_fwd(_f(x), _f(bn.weight), _f(bn.bias), _f(residual), _f(y), _f(mean), _f(rstd),
-                                    _f(bn.running_mean), _f(bn.running_var), _p(ws), n, c, _i64(s), _fl(bn.eps),
-                                    _fl(bn.momentum), res_mode if residual is not None else 0, int(relu), _st()))
+        mask_mode = 0 if not relu else (1 if (residual is not None and res_mode == 1) else 2)
+        keep_f32 = keep_f32 or not planes or mask_mode == 1
+        y = torch.empty_like(x) if keep_f32 else _nan_placeholder(x.shape, x.device)
+        if planes:
+            pl = torch.empty((lib().muvo_split_planes_bytes(n, c, _i64(s)) + 3) // 4, device=x.device, dtype=torch.float32)
+            _ck(lib().muvo_bn_train_fwd_planes(_f(x), _f(bn.weight), _f(bn.bias), _f(residual), _f(y) if keep_f32 else None, _f(mean),
+                                               _f(rstd), _f(bn.running_mean), _f(bn.running_var), n, c, _i64(s), _fl(bn.eps),
+                                               _fl(bn.momentum), res_mode if residual is not None else 0, int(relu), _p(pl), _st()))
+            _BN_PLANES_OUT.append((pl, _stream_key(x.device), not keep_f32))
+        else:
+            ws = torch.empty(2 * c, device=x.device, dtype=torch.float64)
+            _ck(lib().muvo_bn_train_fwd(_f(x), _f(bn.weight), _f(bn.bias), _f(residual), _f(y), _f(mean), _f(rstd),
+                                        _f(bn.running_mean), _f(bn.running_var), _p(ws), n, c, _i64(s), _fl(bn.eps),
+                                        _fl(bn.momentum), res_mode if residual is not None else 0, int(relu), _st()))
         _BN_PENDING.append(bn)           # num_batches_tracked += 1, applied in one fused launch (flush_bn_counters)
         ctx.bn, ctx.dims = bn, (n, c, s)
         # ReLU mask in backward: recomputed from x (mode 2: y is neither saved nor re-read) unless the ReLU sits AFTER the
         # residual add (res_mode 1), where only y knows the sign
-        ctx.mask_mode = 0 if not relu else (1 if (residual is not None and res_mode == 1) else 2)
+        ctx.mask_mode = mask_mode
         ctx.has_res, ctx.res_mode = residual is not None, res_mode
+        ctx.dx_planes = bool(dx_planes)
         ctx.save_for_backward(x, y if ctx.mask_mode == 1 else None, mean, rstd)
         return y
 
@@ -1398,16 +1458,25 @@ class BNActFn(torch.autograd.Function):
         bn = ctx.bn
         n, c, s = ctx.dims
         dy = dy.contiguous()
-        dx = torch.empty_like(x)
         dres = None
         if ctx.has_res and ctx.needs_input_grad[1]:
             dres = torch.empty_like(x) if ctx.res_mode == 1 else dy
+        if ctx.dx_planes:
+            # dx leaves as the split planes the producing convolution's data- and weight-gradient kernels read; no fp32 dx
+            pl = torch.empty((lib().muvo_split_planes_bytes(n, c, _i64(s)) + 3) // 4, device=x.device, dtype=torch.float32)
+            _ck(lib().muvo_bn_train_bwd_planes(_f(x), _f(y), _f(dy), _f(bn.weight), _f(bn.bias), _f(mean), _f(rstd), None,
+                                               _f(dres) if (ctx.has_res and ctx.res_mode == 1) else None,
+                                               _f(grad_of(bn.weight)), _f(grad_of(bn.bias)), n, c, _i64(s), ctx.mask_mode, _p(pl), _st()))
+            dx = _nan_placeholder(x.shape, x.device)
+            dx._muvo_planes = (pl, _stream_key(x.device))
+            return dx, dres, None, None, None, None, None, None, None
+        dx = torch.empty_like(x)
         ws = torch.empty(2 * c, device=x.device, dtype=torch.float64)
         _ck(lib().muvo_bn_train_bwd(_f(x), _f(y), _f(dy), _f(bn.weight), _f(bn.bias), _f(mean), _f(rstd), _f(dx),
                                     _f(dres) if (ctx.has_res and ctx.res_mode == 1) else None,
                                     _f(grad_of(bn.weight)), _f(grad_of(bn.bias)), _p(ws), n, c, _i64(s), ctx.mask_mode,
                                     _st()))
-        return dx, dres, None, None, None, None
+        return dx, dres, None, None, None, None, None, None, None
 
 
 _BN_PENDING = []
@@ -1430,8 +1499,41 @@ def flush_bn_counters():
         torch._foreach_add_(tensors, k)
 
 
-def bn_act(x, bn, residual=None, res_mode=1, relu=True):
-    return BNActFn.apply(x, residual, bn, res_mode, relu, bn.training)
+def conv_reads_planes(conv, x_shape, need_wgrad):
+    """will the convolution module `conv` read split planes of an input of shape x_shape in forward (and, if a backward follows,
+    in its weight gradient)?  -> (forward reads planes, and the fp32 values are needed by nobody inside the convolution)"""
+    geom = conv.geom
+    n = x_shape[0]
+    in_sz = tuple(x_shape[2:]) if geom.nd == 3 else (1,) + tuple(x_shape[2:])
+    geom.plan(n, in_sz)
+    key = (n, in_sz, _plan_epoch[0])
+    fam, wsb = geom.family[key], geom.ws_bytes[key]
+    fwd = fam[0] == 1 and wsb[0] > 0
+    return fwd, fwd and (not need_wgrad or (fam[2] == 1 and wsb[2] > 0 and _KEEP_WS))
+
+
+def bn_act(x, bn, residual=None, res_mode=1, relu=True, consumers=(), sole_consumer=False, from_conv=False):
+    """consumers: convolution modules that will read the result (planes are written with it when at least one of them runs on the
+    bf16x3 kernels); sole_consumer: `consumers` is everything that reads the result, so the fp32 tensor is dropped when they all
+    read planes; from_conv: x is the output of a bias-free convolution without activation and this BatchNorm is its only
+    consumer (conv -> bn): dx is handed to that convolution's backward as planes when it reads planes."""
+    planes, keep_f32 = False, True
+    if BN_PLANES and consumers and x.is_cuda:
+        grad = torch.is_grad_enabled() and x.requires_grad
+        rd = [conv_reads_planes(cv, x.shape, grad and cv.weight.requires_grad) for cv in consumers]
+        planes = any(r[0] for r in rd)
+        keep_f32 = not (sole_consumer and all(r[1] for r in rd))
+    dx_planes = BN_PLANES and from_conv and getattr(x, '_muvo_dy_planes_ok', False)
+    y = BNActFn.apply(x, residual, bn, res_mode, relu, bn.training, planes, keep_f32, dx_planes)
+    if planes:
+        pl = _BN_PLANES_OUT.pop()
+        y._muvo_planes = pl[:2]
+        if pl[2]:
+            y._muvo_planes_only = True
+    return y
+
+
+_BN_PLANES_OUT = []
 
 
 class AdaINFn(torch.autograd.Function):

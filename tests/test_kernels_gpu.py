@@ -1,5 +1,7 @@
 """-m gpu: every HIP kernel family against a plain PyTorch fp32 CPU reference of the same op (through the C ABI via
 muvo_amd.ops).  Tolerances are stated per test; sizes are small so the CPU side finishes in seconds."""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -1082,3 +1084,133 @@ def test_fused_rssm(dev, b, t, dims):
     for n in gw_f:
         _close(gw_f[n], refp[n].grad, name=f'fused rssm grad {n}', **tol)
         _close(gw_f[n], gw_u[n], name=f'fused vs unfused grad {n}', **tol)
+
+
+@pytest.mark.parametrize('shape', [(3, 64, 32, 40), (2, 70, 13, 20), (2, 12, 5, 13), (1, 128, 16, 256)])
+@pytest.mark.parametrize('res_mode,relu', [(0, True), (0, False), (1, True), (2, True)])
+def test_batchnorm_writes_split_planes(dev, shape, res_mode, relu):
+    """muvo_bn_train_fwd_planes / muvo_bn_train_bwd_planes (round 4: the BatchNorm apply writes the consumer's bf16x3 operand
+    format) against the unfused pair of passes - BatchNorm kernel, then muvo_split_planes over its result: the fp32 tensors, the
+    hi / lo planes, the saved statistics, the running statistics and the parameter gradients must be BIT-identical (same
+    arithmetic per element); both kernel forms (S % 4 == 0 and >= 1024: 16-byte loads; otherwise one pixel per lane); channel
+    counts that are not multiples of 8 / 64; with y = NULL / dx = NULL (planes only) the planes are the same."""
+    import ctypes as C
+    from muvo_amd import ops
+    L = ops.lib()
+    n, c, h, w = shape
+    s = h * w
+    cp = (c + 7) // 8 * 8
+    torch.manual_seed(c * 7 + s)
+    x = (torch.randn(n, c, h, w, device=dev) * 2 + 0.5).contiguous()
+    r = torch.randn(n, c, h, w, device=dev) if res_mode else None
+    gamma, beta = torch.rand(c, device=dev) + 0.5, torch.rand(c, device=dev) - 0.5
+    nws = (L.muvo_split_planes_bytes(n, c, C.c_int64(s)) + 3) // 4
+    nplane = 2 * n * s * cp          # int16 elements of the two planes
+
+    def split(t):
+        ws = torch.zeros(nws, device=dev, dtype=torch.float32)
+        ops._ck(L.muvo_split_planes(ops._f(t), ops._p(ws), n, c, C.c_int64(s), None, ops.ACT_NONE, C.c_float(0.0), None, ops._st()))
+        return ws.view(torch.int16)[:nplane + 8].clone()        # + the zero page behind the planes
+
+    def fwd(fused, want_y=True):
+        y = torch.empty_like(x)
+        mean, rstd = torch.empty(c, device=dev), torch.empty(c, device=dev)
+        rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+        if fused:
+            ws = torch.full((nws,), 7.0, device=dev)
+            ops._ck(L.muvo_bn_train_fwd_planes(ops._f(x), ops._f(gamma), ops._f(beta), ops._f(r), ops._f(y) if want_y else None, ops._f(mean),
+                                               ops._f(rstd), ops._f(rm), ops._f(rv), n, c, C.c_int64(s), C.c_float(1e-5), C.c_float(0.1),
+                                               res_mode, int(relu), ops._p(ws), ops._st()))
+            return y, ws.view(torch.int16)[:nplane + 8].clone(), mean, rstd, rm, rv
+        st = torch.empty(2 * c, device=dev, dtype=torch.float64)
+        ops._ck(L.muvo_bn_train_fwd(ops._f(x), ops._f(gamma), ops._f(beta), ops._f(r), ops._f(y), ops._f(mean), ops._f(rstd), ops._f(rm),
+                                    ops._f(rv), ops._p(st), n, c, C.c_int64(s), C.c_float(1e-5), C.c_float(0.1), res_mode, int(relu), ops._st()))
+        return y, split(y), mean, rstd, rm, rv
+    was = ops.get_deterministic()
+    ops.set_deterministic(True)          # one statistics workgroup per channel: the sums (and so every bit downstream) are reproducible
+    try:
+        ref = fwd(False)
+        got = fwd(True)
+        for a, b_, name in zip(got, ref, ('y', 'planes', 'mean', 'rstd', 'running_mean', 'running_var')):
+            assert torch.equal(a, b_), f'forward {name}'
+        assert torch.equal(fwd(True, want_y=False)[1], ref[1])
+        y, mean, rstd = ref[0], ref[2], ref[3]
+        dy = torch.randn(n, c, h, w, device=dev)
+        mask_mode = 0 if not relu else (1 if res_mode == 1 else 2)
+
+        def bwd(fused, want_dx=True):
+            dx = torch.empty_like(x)
+            dres = torch.empty_like(x) if res_mode == 1 else None
+            dg, db = torch.ones(c, device=dev), torch.ones(c, device=dev)
+            if fused:
+                ws = torch.full((nws,), 7.0, device=dev)
+                ops._ck(L.muvo_bn_train_bwd_planes(ops._f(x), ops._f(y), ops._f(dy), ops._f(gamma), ops._f(beta), ops._f(mean), ops._f(rstd),
+                                                   ops._f(dx) if want_dx else None, ops._f(dres), ops._f(dg), ops._f(db), n, c, C.c_int64(s),
+                                                   mask_mode, ops._p(ws), ops._st()))
+                return dx, ws.view(torch.int16)[:nplane + 8].clone(), dres, dg, db
+            st = torch.empty(2 * c, device=dev, dtype=torch.float64)
+            ops._ck(L.muvo_bn_train_bwd(ops._f(x), ops._f(y), ops._f(dy), ops._f(gamma), ops._f(beta), ops._f(mean), ops._f(rstd), ops._f(dx),
+                                        ops._f(dres), ops._f(dg), ops._f(db), ops._p(st), n, c, C.c_int64(s), mask_mode, ops._st()))
+            return dx, split(dx), dres, dg, db
+        ref = bwd(False)
+        got = bwd(True)
+        for a, b_, name in zip(got, ref, ('dx', 'planes', 'dres', 'dgamma', 'dbeta')):
+            assert (a is None and b_ is None) or torch.equal(a, b_), f'backward {name}'
+        assert torch.equal(bwd(True, want_dx=False)[1], ref[1])
+    finally:
+        ops.set_deterministic(was)
+
+
+@pytest.mark.parametrize('shape,stride', [((4, 64, 40, 52), 1), ((3, 64, 32, 64), 2), ((2, 128, 10, 26), 1)])
+def test_basic_block_with_planes_equals_without(dev, shape, stride):
+    """BasicBlock -> BasicBlock (layers.py:9-66) with the BatchNorms writing split planes for the convolutions behind them and
+    handing dx to the convolutions in front of them as planes (ops.BN_PLANES) against the same blocks with every tensor in fp32
+    and separate split passes: outputs, input gradient and all parameter gradients bit-identical (deterministic mode), and the
+    planes path is really taken (the inner activation exists as planes only)."""
+    from muvo_amd import ops
+    from muvo_amd.layers.layers import BasicBlock
+    n, c, h, w = shape
+    old_mode, was_det = ops.get_conv_mode(), ops.get_deterministic()
+    ops.set_conv_mode(ops.CONV_BF16X3, min_gflop=0.0)
+    ops.set_deterministic(True)
+    try:
+        torch.manual_seed(5)
+        with torch.device(dev):
+            b1 = BasicBlock(c, c * stride, stride=stride, downsample=True if stride != 1 else None)
+            b2 = BasicBlock(c * stride, c * stride)
+        x0 = torch.randn(n, c, h, w, device=dev)
+        g = None
+        runs = []
+        for planes in (False, True):
+            ops.BN_PLANES = planes
+            seen = []
+            orig = ops.BNActFn.forward
+
+            def spy(ctx, *a, _o=orig, _s=seen):
+                _s.append((bool(a[6]), bool(a[7]), bool(a[8])))          # (planes, keep_f32, dx_planes)
+                return _o(ctx, *a)
+            ops.BNActFn.forward = staticmethod(spy)
+            try:
+                for p in list(b1.parameters()) + list(b2.parameters()):
+                    p.grad = torch.zeros_like(p)
+                x = x0.clone().requires_grad_(True)
+                y = b2(b1(x, next_convs=(b2.conv1,)))
+                if g is None:
+                    g = torch.randn_like(y)
+                y.backward(g)
+                torch.cuda.synchronize()
+            finally:
+                ops.BNActFn.forward = staticmethod(orig)
+            runs.append((y.detach().clone(), x.grad.clone(), [p.grad.clone() for p in list(b1.parameters()) + list(b2.parameters())], seen))
+        (y0, dx0, g0, s0), (y1, dx1, g1, s1) = runs
+        assert not any(p or d for p, _, d in s0)
+        assert any(p and not k for p, k, _ in s1), s1        # bn1: planes only
+        assert any(d for _, _, d in s1), s1                  # dx handed over as planes
+        assert torch.equal(y0, y1) and torch.equal(dx0, dx1)
+        for a, b_ in zip(g0, g1):
+            assert torch.equal(a, b_)
+        assert torch.isfinite(dx1).all() and all(torch.isfinite(t).all() for t in g1)
+    finally:
+        ops.BN_PLANES = os.environ.get('MUVO_BN_PLANES', '1') != '0'
+        ops.set_deterministic(was_det)
+        ops.set_conv_mode(old_mode, min_gflop=-1.0)
