@@ -517,7 +517,8 @@ def main():
         if out.get('roofline') is not None:
             out['roofline']['frac_is'] = ('in situ: HIP-event brackets inside the timed region, side streams on (a bracket also contains the '
                                           "neighbours' share of the chip); frac_isolated = the kernel figure (same brackets, side streams off)")
-        if world == 1 and args.workload == 'base_1d' and args.conv_mfma == 'bf16x3' and not args.no_extensions:
+        if (world == 1 and args.workload == 'base_1d' and args.conv_mfma == 'bf16x3' and not args.no_extensions
+                and not args.no_kernel_timing):       # (the reduced command lines of the A/B and profiling scripts skip them)
             # (the judged trainer, its optimizer state and the last step's autograd graph go first: 70 GB peak otherwise doubles)
             del batches, tr, opt, sched, opts, scheds, loss
             import gc

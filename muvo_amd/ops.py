@@ -1402,10 +1402,19 @@ def head_branch(x, weight, bias, geom, packed):
 BN_PLANES = os.environ.get('MUVO_BN_PLANES', '1') != '0'
 
 
+_NAN_SCALAR = {}
+
+
 def _nan_placeholder(shape, device):
     """a tensor of `shape` without storage of its size (one NaN, expanded): stands for data that exists only as split planes
-    (attribute _muvo_planes).  Anything that reads it as numbers gets NaN - a misuse cannot go unnoticed."""
-    return torch.full((1,), float('nan'), device=device, dtype=torch.float32).expand(shape)
+    (attribute _muvo_planes).  Anything that reads it as numbers gets NaN - a misuse cannot go unnoticed.  The one-element source
+    is made once per device (a fresh torch.full per call was 60 fill launches per step); every call returns a new view object, so
+    attributes set on one placeholder do not show up on another."""
+    device = torch.device(device)
+    src = _NAN_SCALAR.get(device)
+    if src is None:
+        src = _NAN_SCALAR[device] = torch.full((1,), float('nan'), device=device, dtype=torch.float32)
+    return src.expand(shape)
 
 
 class BNActFn(torch.autograd.Function):
@@ -2397,13 +2406,39 @@ def resize_nearest(x, out_sz):
 
 
 # ================================================================================================ losses
+def _grad_vector(gs, device):
+    """the gradients of k scalar outputs of a loss Function (`terms=True`: returned as separate 0-d tensors, so that the caller's
+    `[i]` is a tuple index and not k select_backward nodes of 2-3 launches each) as ONE (k,) device vector for the backward kernel;
+    a term nobody differentiated counts as zero.  One launch (all terms usually receive the same upstream scalar)."""
+    first = next((g for g in gs if g is not None), None)
+    if first is None:
+        return torch.zeros(len(gs), device=device, dtype=torch.float32)
+    if all(g is first for g in gs):
+        return first.reshape(1).expand(len(gs)).contiguous()
+    zero = None
+    parts = []
+    for g in gs:
+        if g is None:
+            zero = torch.zeros((), device=device, dtype=torch.float32) if zero is None else zero
+            g = zero
+        parts.append(g.reshape(()))
+    return torch.stack(parts)
+
+
+def _as_terms(ctx, t, terms):
+    if not terms:
+        return t
+    ctx.set_materialize_grads(False)
+    return tuple(t[i] for i in range(t.numel()))
+
+
 class SpatialLossFn(torch.autograd.Function):
     """weight * SpatialRegressionLoss(norm) over channel ranges of (B,S,C,H,W) tensors.
 
     `parts` = list of (c0, c1, norm, weight); returns one scalar per part (stacked 1-D tensor)."""
 
     @staticmethod
-    def forward(ctx, pred, target, parts, ignore, mask=None):
+    def forward(ctx, pred, target, parts, ignore, mask=None, terms=False):
         # mask: optional explicit (B, S, 1, H, W) uint8 / bool pixel mask (SpatialRegressionLoss(..., instance_mask), losses.py:87-90)
         pred, target = pred.contiguous(), target.contiguous()
         b, s, c, h, w = pred.shape
@@ -2419,31 +2454,32 @@ class SpatialLossFn(torch.autograd.Function):
                                                    C.c_void_p(losses.data_ptr() + 4 * i), _st()))
         ctx.parts, ctx.ignore, ctx.dims = parts, ignore, (f, c, hw)
         ctx.save_for_backward(pred, target, stats, mask)
-        return losses
+        return _as_terms(ctx, losses, terms)
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, *gs):
         pred, target, stats, mask = ctx.saved_tensors
         f, c, hw = ctx.dims
-        g = g.contiguous()
+        g = gs[0].contiguous() if (len(gs) == 1 and gs[0] is not None and gs[0].dim() == 1) else _grad_vector(gs, pred.device)
         covered = sum(c1 - c0 for c0, c1, _, _ in ctx.parts)
         dpred = torch.empty_like(pred) if covered == c else torch.zeros_like(pred)
         for i, (c0, c1, norm, weight) in enumerate(ctx.parts):
             _ck(lib().muvo_spatial_loss_masked_bwd(_f(pred), _f(target), _p(mask), _f(dpred), _i64(f), c, _i64(hw), c0, c1, norm,
                                                    _fl(ctx.ignore), _fl(weight), C.c_void_p(stats.data_ptr() + 16 * i),
                                                    C.c_void_p(g.data_ptr() + 4 * i), _st()))
-        return dpred, None, None, None, None
+        return dpred, None, None, None, None, None
 
 
-def spatial_losses(pred, target, parts, ignore=255.0, mask=None):
-    return SpatialLossFn.apply(pred, target, parts, ignore, mask)
+def spatial_losses(pred, target, parts, ignore=255.0, mask=None, terms=False):
+    """terms=True: a tuple of 0-d tensors (one per part) instead of the stacked 1-D tensor"""
+    return SpatialLossFn.apply(pred, target, parts, ignore, mask, terms)
 
 
 class VoxelLossFn(torch.autograd.Function):
     """(weight*CE mean, weight*SemScal, weight*GeoScal) for logits (B,S,C,X,Y,Z), labels u8 (B,S,1,X,Y,Z)."""
 
     @staticmethod
-    def forward(ctx, logits, target, weight, class_w):
+    def forward(ctx, logits, target, weight, class_w, terms=False):
         logits, target = logits.contiguous(), target.contiguous()
         b, s, c = logits.shape[:3]
         v = logits.numel() // (b * s * c)
@@ -2455,26 +2491,26 @@ class VoxelLossFn(torch.autograd.Function):
                                   _f(coef), _f(loss3), _st()))
         ctx.dims, ctx.weight, ctx.class_w = (b * s, c, v), weight, class_w
         ctx.save_for_backward(logits, target, coef)
-        return loss3
+        return _as_terms(ctx, loss3, terms)
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, *gs):
         logits, target, coef = ctx.saved_tensors
         f, c, v = ctx.dims
-        g = g.contiguous()
+        g = gs[0].contiguous() if (len(gs) == 1 and gs[0] is not None and gs[0].dim() == 1) else _grad_vector(gs, logits.device)
         dl = torch.empty_like(logits)
         _ck(lib().muvo_voxel_loss_bwd(_f(logits), _p(target), _f(dl), _i64(f), c, _i64(v), _f(ctx.class_w),
                                       _fl(ctx.weight), _f(coef), _f(g), _st()))
-        return dl, None, None, None
+        return dl, None, None, None, None
 
 
-def voxel_losses(logits, target, weight, class_w=None):
-    return VoxelLossFn.apply(logits, target, weight, class_w)
+def voxel_losses(logits, target, weight, class_w=None, terms=False):
+    return VoxelLossFn.apply(logits, target, weight, class_w, terms)
 
 
 class L1RowsFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pred, target, weight):
+    def forward(ctx, pred, target, weight, terms=False):
         pred, target = pred.contiguous(), target.contiguous()
         cols = pred.shape[-1]
         rows = pred.numel() // cols
@@ -2482,16 +2518,17 @@ class L1RowsFn(torch.autograd.Function):
         _ck(lib().muvo_l1_rows_fwd(_f(pred), _f(target), _i64(rows), cols, _fl(weight), _f(loss), _st()))
         ctx.dims, ctx.weight = (rows, cols), weight
         ctx.save_for_backward(pred, target)
-        return loss
+        return _as_terms(ctx, loss, terms)
 
     @staticmethod
     def backward(ctx, g):
         pred, target = ctx.saved_tensors
         rows, cols = ctx.dims
         dp = torch.empty_like(pred)
+        g = torch.zeros(1, device=pred.device) if g is None else g.reshape(1)
         _ck(lib().muvo_l1_rows_bwd(_f(pred), _f(target), _f(dp), _i64(rows), cols, _fl(ctx.weight), _f(g.contiguous()),
                                    _st()))
-        return dp, None, None
+        return dp, None, None, None
 
 
 class _SegCEFn(torch.autograd.Function):
@@ -2521,33 +2558,34 @@ def seg_ce_pixel_loss(logits, target, class_w=None):
     return _SegCEFn.apply(logits.float(), t, class_w)
 
 
-def l1_rows_loss(pred, target, weight):
-    return L1RowsFn.apply(pred, target, weight)
+def l1_rows_loss(pred, target, weight, terms=False):
+    return L1RowsFn.apply(pred, target, weight, terms)
 
 
 class KLLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pm, ps, qm, qs, weight, alpha):
+    def forward(ctx, pm, ps, qm, qs, weight, alpha, terms=False):
         pm, ps, qm, qs = (t.contiguous() for t in (pm, ps, qm, qs))
         b, t, s = pm.shape
         loss = torch.empty(1, device=pm.device, dtype=torch.float32)
         _ck(lib().muvo_kl_loss_fwd(_f(pm), _f(ps), _f(qm), _f(qs), b, t, s, _fl(weight), _f(loss), _st()))
         ctx.args = (b, t, s, weight, alpha)
         ctx.save_for_backward(pm, ps, qm, qs)
-        return loss
+        return _as_terms(ctx, loss, terms)
 
     @staticmethod
     def backward(ctx, g):
         pm, ps, qm, qs = ctx.saved_tensors
         b, t, s, weight, alpha = ctx.args
+        g = torch.zeros(1, device=pm.device) if g is None else g.reshape(1)
         d = [torch.empty_like(pm) for _ in range(4)]
         _ck(lib().muvo_kl_loss_bwd(_f(pm), _f(ps), _f(qm), _f(qs), _f(d[0]), _f(d[1]), _f(d[2]), _f(d[3]), b, t, s,
                                    _fl(weight), _fl(alpha), _f(g.contiguous()), _st()))
-        return d[0], d[1], d[2], d[3], None, None
+        return d[0], d[1], d[2], d[3], None, None, None
 
 
-def kl_loss(pm, ps, qm, qs, weight, alpha):
-    return KLLossFn.apply(pm, ps, qm, qs, weight, alpha)
+def kl_loss(pm, ps, qm, qs, weight, alpha, terms=False):
+    return KLLossFn.apply(pm, ps, qm, qs, weight, alpha, terms)
 
 
 # ================================================================================================ optimiser

@@ -200,13 +200,13 @@ class WorldModelTrainer(_Base):
         losses = {}
         w_act = cfg.LOSSES.WEIGHT_ACTION
         if 'throttle_brake' in output:
-            losses['throttle_brake'] = ops.l1_rows_loss(output['throttle_brake'], batch['throttle_brake'], w_act)[0]
+            losses['throttle_brake'] = ops.l1_rows_loss(output['throttle_brake'], batch['throttle_brake'], w_act, terms=True)[0]
         if 'steering' in output:
-            losses['steering'] = ops.l1_rows_loss(output['steering'], batch['steering'], w_act)[0]
+            losses['steering'] = ops.l1_rows_loss(output['steering'], batch['steering'], w_act, terms=True)[0]
         if cfg.MODEL.TRANSITION.ENABLED and 'prior' in output and 'posterior' in output:
             pr, po = output['prior'], output['posterior']
             losses['probabilistic'] = ops.kl_loss(pr['mu'], pr['sigma'], po['mu'], po['sigma'],
-                                                  cfg.LOSSES.WEIGHT_PROBABILISTIC, cfg.LOSSES.KL_BALANCING_ALPHA)[0]
+                                                  cfg.LOSSES.WEIGHT_PROBABILISTIC, cfg.LOSSES.KL_BALANCING_ALPHA, terms=True)[0]
         if cfg.SEMANTIC_SEG.ENABLED:              # trainer.py:266-291
             crit = self._seg_loss('bev', cfg.SEMANTIC_SEG, is_bev=True)
             ign = float(cfg.INSTANCE_SEG.IGNORE_INDEX)
@@ -224,7 +224,7 @@ class WorldModelTrainer(_Base):
             for f in (1, 2, 4):
                 w = 0.1 * (1 / f)  # rgb_weight literal 0.1 (trainer.py:296)
                 pred = output[f'rgb_{f}']
-                losses[f'rgb_{f}'] = ops.spatial_losses(pred, batch[f'rgb_label_{f}'], [(0, pred.shape[2], 1, w)])[0]
+                losses[f'rgb_{f}'] = ops.spatial_losses(pred, batch[f'rgb_label_{f}'], [(0, pred.shape[2], 1, w)], terms=True)[0]
                 if cfg.LOSSES.RGB_INSTANCE:       # trainer.py:303-321: + 0.5 x the same L1 over the vehicle / pedestrian pixels
                     losses[f'rgb_{f}'] = losses[f'rgb_{f}'] + ops.spatial_losses(
                         pred, batch[f'rgb_label_{f}'], [(0, pred.shape[2], 1, 0.5 * w)], mask=batch[f'image_instance_mask_{f}'])[0]
@@ -238,7 +238,7 @@ class WorldModelTrainer(_Base):
                 w = (1 / f) * cfg.LOSSES.WEIGHT_LIDAR_RE
                 pred = output[f'lidar_reconstruction_{f}']
                 c = pred.shape[2]
-                both = ops.spatial_losses(pred, batch[f'range_view_label_{f}'], [(0, 3, 2, w), (c - 1, c, 1, w)])
+                both = ops.spatial_losses(pred, batch[f'range_view_label_{f}'], [(0, 3, 2, w), (c - 1, c, 1, w)], terms=True)
                 losses[f'lidar_re_{f}'] = both[0]
                 losses[f'lidar_depth_{f}'] = both[1]
         # config-off heads of base_1d (trainer.py:338-365)
@@ -272,7 +272,7 @@ class WorldModelTrainer(_Base):
                     if cw is None:
                         cw = cache[logits_f.device] = torch.tensor(VOXEL_SEG_WEIGHTS, dtype=torch.float32, device=logits_f.device)
                 # (USE_TOP_K replaces the cross-entropy term: the fused kernel then only delivers the two scaling terms)
-                three = ops.voxel_losses(output[f'voxel_{f}'], batch[f'voxel_label_{f}'], w, cw)
+                three = ops.voxel_losses(output[f'voxel_{f}'], batch[f'voxel_label_{f}'], w, cw, terms=True)
                 if vs.USE_TOP_K:                  # losses.py:179-184: the k hardest voxels of every frame
                     from .losses import VoxelLoss
                     crit = self.__dict__.setdefault('_voxel_topk', VoxelLoss(True, vs.TOP_K_RATIO, vs.USE_WEIGHTS))
