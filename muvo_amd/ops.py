@@ -776,6 +776,7 @@ class LinearBf16x3Fn(torch.autograd.Function):
         _ck(L.muvo_linear_bf16x3_split(_f(dz), _i64(rows), out_f, _p(ws_dz), _st()))
         dx = None
         if ctx.needs_input_grad[0]:
+            _wait_dgr_pack(dy.device)
             k = _wkey(weight)
             if pk.dgr is None or pk.dgr_key != k:
                 if pk.dgr is None:
@@ -873,6 +874,17 @@ def _wkey(w):
     return (w._version, _weight_epoch[0], w.data_ptr())
 
 
+def _head_alias(geom, key, op, weight):
+    """The 1x1 head kernels (muvo_conv_kernel_family == 3, conv_pw.hip) read the weight in PyTorch's layout: their "packed copy" is
+    the parameter itself - no device-to-device copy per head, direction and optimizer step (18 launches per step at base_1d)."""
+    fam = geom.family.get(key)
+    return fam is not None and fam[op] == 3 and weight.is_contiguous()
+
+
+def _is_alias(buf, weight):
+    return buf is not None and buf.data_ptr() == weight.data_ptr()
+
+
 # ------------------------------------------------------------------------------------------------
 # Batched weight packing (include/muvo_hip.h: muvo_pack_table_*).  Layers register themselves the first time they pack;
 # repack_all() (called once per training forward) refreshes every registered copy that already exists with ONE launch and
@@ -880,7 +892,7 @@ def _wkey(w):
 class _PackRegistry:
     def __init__(self):
         self.entries, self.seen = [], set()
-        self.sig, self.dev, self.n, self.nblk, self.batched = None, None, 0, 0, []
+        self.sig, self.tabs = None, {}
 
     def register(self, key, entry):
         """entry: (kind, desc, weight, weakref to the layer's packed-copy holder, plan key)"""
@@ -918,42 +930,80 @@ def repack_all():
     ents = [(e[0], e[1], e[2], e[3](), e[4]) for e in R.entries]
     sig = tuple((ptr(e[3].fwd), ptr(e[3].dgr), e[2].data_ptr()) for e in ents)
     if sig != R.sig:
+        # two tables: the copies forward reads, and the copies only the data-gradient kernels read (needed ~40 ms later)
         item = L.muvo_pack_table_item_bytes()
         cap = 16 * len(R.entries) + 8
-        host = torch.zeros(cap * item, dtype=torch.uint8)
-        n, nblk = C.c_int(0), C.c_int64(0)
-        R.batched = []
-        for e, orig in zip(ents, R.entries):
-            kind, desc, weight, pk, _ = e
-            if pk.fwd is None and pk.dgr is None:
-                continue
-            if kind == 'conv':
-                rc = L.muvo_conv_pack_table_add(C.c_void_p(host.data_ptr()), cap, C.byref(n), C.byref(nblk), C.byref(desc),
-                                                _f(weight), _f(pk.fwd), _f(pk.dgr))
-            else:
-                rc = L.muvo_linear_bf16x3_pack_table_add(C.c_void_p(host.data_ptr()), cap, C.byref(n), C.byref(nblk),
-                                                         desc[0], desc[1], _f(weight), _f(pk.fwd), _f(pk.dgr))
-            if rc == 0:
-                R.batched.append(orig)
-            elif rc != 1:
-                _ck(rc)
-        R.n, R.nblk = n.value, nblk.value
-        R.dev = host[:max(R.n, 1) * item].to(ents[0][2].device)
+        R.tabs = {}
+        for which in ('fwd', 'dgr'):
+            host = torch.zeros(cap * item, dtype=torch.uint8)
+            n, nblk = C.c_int(0), C.c_int64(0)
+            batched = []
+            for e, orig in zip(ents, R.entries):
+                kind, desc, weight, pk, _ = e
+                buf = pk.fwd if which == 'fwd' else pk.dgr
+                if buf is None or _is_alias(buf, weight):
+                    continue
+                f_, d_ = (_f(buf), None) if which == 'fwd' else (None, _f(buf))
+                if kind == 'conv':
+                    rc = L.muvo_conv_pack_table_add(C.c_void_p(host.data_ptr()), cap, C.byref(n), C.byref(nblk), C.byref(desc),
+                                                    _f(weight), f_, d_)
+                else:
+                    rc = L.muvo_linear_bf16x3_pack_table_add(C.c_void_p(host.data_ptr()), cap, C.byref(n), C.byref(nblk),
+                                                             desc[0], desc[1], _f(weight), f_, d_)
+                if rc == 0:
+                    batched.append(orig)
+                elif rc != 1:
+                    _ck(rc)
+            R.tabs[which] = dict(n=n.value, nblk=nblk.value, batched=batched,
+                                 dev=host[:max(n.value, 1) * item].to(ents[0][2].device))
         R.sig = sig
-    if R.n:
-        _ck(L.muvo_pack_table_run(C.c_void_p(R.dev.data_ptr()), R.n, _i64(R.nblk), _st()))
-        for kind, _, weight, pkref, pkey in R.batched:
+    dev = ents[0][2].device
+    for which in ('fwd', 'dgr'):
+        T = R.tabs[which]
+        if not T['n']:
+            continue
+        wst = wgrad_stream(dev) if (which == 'dgr' and DGR_PACK_SIDE) else None
+        cur = torch.cuda.current_stream(dev)
+        if wst is not None and wst != cur:
+            # the data-gradient copies are first read in backward: packed on the weight-gradient stream, idle during forward, they
+            # leave the start of the step (where the pack ran alone on the chip); backward waits for the event (_wait_dgr_pack)
+            wst.wait_stream(cur)
+            with torch.cuda.stream(wst):
+                _ck(L.muvo_pack_table_run(C.c_void_p(T['dev'].data_ptr()), T['n'], _i64(T['nblk']), _st()))
+                ev = torch.cuda.Event()
+                ev.record(wst)
+            _DGR_PACK[dev.index] = (ev, set())
+        else:
+            _ck(L.muvo_pack_table_run(C.c_void_p(T['dev'].data_ptr()), T['n'], _i64(T['nblk']), _st()))
+            if which == 'dgr':
+                _DGR_PACK.pop(dev.index, None)
+        for kind, _, weight, pkref, pkey in T['batched']:
             pk = pkref()
             if pk is None:
                 continue
             k = _wkey(weight)
-            if pk.fwd is not None:
+            if which == 'fwd':
                 pk.fwd_key = k
-            if pk.dgr is not None:
+                if kind == 'conv':
+                    pk.fwd_plan = pkey
+            else:
                 pk.dgr_key = k
-            if kind == 'conv':
-                pk.fwd_plan = pkey if pk.fwd is not None else pk.fwd_plan
-                pk.dgr_plan = pkey if pk.dgr is not None else pk.dgr_plan
+                if kind == 'conv':
+                    pk.dgr_plan = pkey
+
+
+DGR_PACK_SIDE = os.environ.get('MUVO_DGR_PACK_SIDE', '1') != '0'
+_DGR_PACK = {}      # device index -> (event behind the data-gradient pack on the weight-gradient stream, stream keys that waited for it)
+
+
+def _wait_dgr_pack(device):
+    """called by every backward function before its first read of a packed data-gradient copy"""
+    st = _DGR_PACK.get(torch.device(device).index)
+    if st is not None:
+        key = _stream_key(device)
+        if key not in st[1]:
+            torch.cuda.current_stream(device).wait_event(st[0])
+            st[1].add(key)
 
 
 _KEEP_WS = os.environ.get('MUVO_KEEP_WS', '1') != '0'
@@ -977,15 +1027,18 @@ class ConvFn(torch.autograd.Function):
         in_sz = tuple(x.shape[2:]) if geom.nd == 3 else (1,) + tuple(x.shape[2:])
         d, out_sz, ff, df = geom.plan(n, in_sz)
         L = lib()
-        if packed.fwd is None or packed.fwd.numel() < ff:
-            packed.fwd = torch.empty(ff, device=x.device, dtype=torch.float32)
-            packed.fwd_key = None
         k = _wkey(weight)
         pkey = (in_sz, _plan_epoch[0])
-        if packed.fwd_key != k or packed.fwd_plan != pkey:
-            _ck(L.muvo_conv_pack_weights(C.byref(d), _f(weight), _f(packed.fwd), None, _st()))
-            packed.fwd_key, packed.fwd_plan = k, pkey
-            _PACKS.register((id(packed), pkey), ('conv', d, weight, weakref.ref(packed), pkey))
+        if _head_alias(geom, (n, in_sz, _plan_epoch[0]), 0, weight):
+            packed.fwd, packed.fwd_key, packed.fwd_plan = weight.detach().view(-1), k, pkey       # 1x1 heads read the PyTorch layout
+        else:
+            if packed.fwd is None or packed.fwd.numel() < ff or _is_alias(packed.fwd, weight):
+                packed.fwd = torch.empty(ff, device=x.device, dtype=torch.float32)
+                packed.fwd_key = None
+            if packed.fwd_key != k or packed.fwd_plan != pkey:
+                _ck(L.muvo_conv_pack_weights(C.byref(d), _f(weight), _f(packed.fwd), None, _st()))
+                packed.fwd_key, packed.fwd_plan = k, pkey
+                _PACKS.register((id(packed), pkey), ('conv', d, weight, weakref.ref(packed), pkey))
         oshape = (n, geom.cout) + (out_sz if geom.nd == 3 else out_sz[1:])
         y = torch.empty(oshape, device=x.device, dtype=torch.float32)
         kt = KERNEL_TIMING
@@ -1113,13 +1166,17 @@ class ConvFn(torch.autograd.Function):
         dx = None
         ws_dy, dy_split = None, False
         if ctx.needs_input_grad[0]:
-            if packed.dgr is None or packed.dgr.numel() < df:
-                packed.dgr = torch.empty(df, device=x.device, dtype=torch.float32)
-                packed.dgr_key = None
+            _wait_dgr_pack(x.device if not x_ph else dz.device)
             k = _wkey(weight)
-            if packed.dgr_key != k or packed.dgr_plan != key[1:]:
-                _ck(L.muvo_conv_pack_weights(C.byref(d), _f(weight), None, _f(packed.dgr), _st()))
-                packed.dgr_key, packed.dgr_plan = k, key[1:]
+            if _head_alias(geom, key, 1, weight):
+                packed.dgr, packed.dgr_key, packed.dgr_plan = weight.detach().view(-1), k, key[1:]
+            else:
+                if packed.dgr is None or packed.dgr.numel() < df or _is_alias(packed.dgr, weight):
+                    packed.dgr = torch.empty(df, device=x.device, dtype=torch.float32)
+                    packed.dgr_key = None
+                if packed.dgr_key != k or packed.dgr_plan != key[1:]:
+                    _ck(L.muvo_conv_pack_weights(C.byref(d), _f(weight), None, _f(packed.dgr), _st()))
+                    packed.dgr_key, packed.dgr_plan = k, key[1:]
             dx = torch.empty(x.shape, device=dz.device, dtype=torch.float32)
             kt = KERNEL_TIMING
             if kt is not None:
@@ -1274,13 +1331,17 @@ class HeadBranchFn(torch.autograd.Function):
         gy = gy.contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            if packed.dgr is None or packed.dgr.numel() < df:
-                packed.dgr = torch.empty(df, device=x.device, dtype=torch.float32)
-                packed.dgr_key = None
+            _wait_dgr_pack(x.device)
             k, pkey = _wkey(weight), (ctx.in_sz, _plan_epoch[0])
-            if packed.dgr_key != k or packed.dgr_plan != pkey:
-                _ck(L.muvo_conv_pack_weights(C.byref(d), _f(weight), None, _f(packed.dgr), _st()))
-                packed.dgr_key, packed.dgr_plan = k, pkey
+            if _head_alias(geom, (x.shape[0], ctx.in_sz, _plan_epoch[0]), 1, weight):
+                packed.dgr, packed.dgr_key, packed.dgr_plan = weight.detach().view(-1), k, pkey
+            else:
+                if packed.dgr is None or packed.dgr.numel() < df or _is_alias(packed.dgr, weight):
+                    packed.dgr = torch.empty(df, device=x.device, dtype=torch.float32)
+                    packed.dgr_key = None
+                if packed.dgr_key != k or packed.dgr_plan != pkey:
+                    _ck(L.muvo_conv_pack_weights(C.byref(d), _f(weight), None, _f(packed.dgr), _st()))
+                    packed.dgr_key, packed.dgr_plan = k, pkey
             if gx is not None and gx.is_contiguous() and _grad_is_private(gx):
                 dx = gx            # a fresh tensor made by the trunk's backward for this one consumer: accumulated in place
                 _ck(L.muvo_conv_dgrad_accumulate(C.byref(d), _f(gy), _f(packed.dgr), _f(dx), _st()))
@@ -1332,14 +1393,17 @@ class ConvHeadFn(torch.autograd.Function):
         hin = tuple(y.shape[2:]) if head_geom.nd == 3 else (1,) + tuple(y.shape[2:])
         hd, hout, hff, _ = head_geom.plan(n, hin)
         L = lib()
-        if head_packed.fwd is None or head_packed.fwd.numel() < hff:
-            head_packed.fwd = torch.empty(hff, device=x.device, dtype=torch.float32)
-            head_packed.fwd_key = None
         k, pkey = _wkey(head_w), (hin, _plan_epoch[0])
-        if head_packed.fwd_key != k or head_packed.fwd_plan != pkey:
-            _ck(L.muvo_conv_pack_weights(C.byref(hd), _f(head_w), _f(head_packed.fwd), None, _st()))
-            head_packed.fwd_key, head_packed.fwd_plan = k, pkey
-            _PACKS.register((id(head_packed), pkey), ('conv', hd, head_w, weakref.ref(head_packed), pkey))
+        if _head_alias(head_geom, (n, hin, _plan_epoch[0]), 0, head_w):
+            head_packed.fwd, head_packed.fwd_key, head_packed.fwd_plan = head_w.detach().view(-1), k, pkey
+        else:
+            if head_packed.fwd is None or head_packed.fwd.numel() < hff or _is_alias(head_packed.fwd, head_w):
+                head_packed.fwd = torch.empty(hff, device=x.device, dtype=torch.float32)
+                head_packed.fwd_key = None
+            if head_packed.fwd_key != k or head_packed.fwd_plan != pkey:
+                _ck(L.muvo_conv_pack_weights(C.byref(hd), _f(head_w), _f(head_packed.fwd), None, _st()))
+                head_packed.fwd_key, head_packed.fwd_plan = k, pkey
+                _PACKS.register((id(head_packed), pkey), ('conv', hd, head_w, weakref.ref(head_packed), pkey))
         logits = torch.empty((n, head_geom.cout) + (hout if head_geom.nd == 3 else hout[1:]), device=x.device, dtype=torch.float32)
         _ck(L.muvo_conv_forward(C.byref(hd), _f(y), _f(head_packed.fwd), _f(head_b), _f(logits), ACT_NONE, _fl(0.0), None, _st()))
         ctx.head = (head_w, head_b, head_geom, hin)

@@ -445,6 +445,7 @@ def test_batched_repack_matches_per_layer_pack(dev):
         lin.weight.mul_(0.5).sub_(0.02)
     ops.bump_weight_epoch()                         # what optimizer.step() does
     ops.repack_all()
+    ops.join_side_streams()                         # (the data-gradient copies are re-packed on the weight-gradient stream)
     L = ops.lib()
     for (m, shp), x in zip(layers, xs):
         pk = m._packed
