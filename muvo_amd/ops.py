@@ -776,7 +776,6 @@ class LinearBf16x3Fn(torch.autograd.Function):
         _ck(L.muvo_linear_bf16x3_split(_f(dz), _i64(rows), out_f, _p(ws_dz), _st()))
         dx = None
         if ctx.needs_input_grad[0]:
-            _wait_dgr_pack(dy.device)
             k = _wkey(weight)
             if pk.dgr is None or pk.dgr_key != k:
                 if pk.dgr is None:
@@ -892,7 +891,7 @@ def _is_alias(buf, weight):
 class _PackRegistry:
     def __init__(self):
         self.entries, self.seen = [], set()
-        self.sig, self.tabs = None, {}
+        self.sig, self.dev, self.n, self.nblk, self.batched = None, None, 0, 0, []
 
     def register(self, key, entry):
         """entry: (kind, desc, weight, weakref to the layer's packed-copy holder, plan key)"""
@@ -930,80 +929,44 @@ def repack_all():
     ents = [(e[0], e[1], e[2], e[3](), e[4]) for e in R.entries]
     sig = tuple((ptr(e[3].fwd), ptr(e[3].dgr), e[2].data_ptr()) for e in ents)
     if sig != R.sig:
-        # two tables: the copies forward reads, and the copies only the data-gradient kernels read (needed ~40 ms later)
         item = L.muvo_pack_table_item_bytes()
         cap = 16 * len(R.entries) + 8
-        R.tabs = {}
-        for which in ('fwd', 'dgr'):
-            host = torch.zeros(cap * item, dtype=torch.uint8)
-            n, nblk = C.c_int(0), C.c_int64(0)
-            batched = []
-            for e, orig in zip(ents, R.entries):
-                kind, desc, weight, pk, _ = e
-                buf = pk.fwd if which == 'fwd' else pk.dgr
-                if buf is None or _is_alias(buf, weight):
-                    continue
-                f_, d_ = (_f(buf), None) if which == 'fwd' else (None, _f(buf))
-                if kind == 'conv':
-                    rc = L.muvo_conv_pack_table_add(C.c_void_p(host.data_ptr()), cap, C.byref(n), C.byref(nblk), C.byref(desc),
-                                                    _f(weight), f_, d_)
-                else:
-                    rc = L.muvo_linear_bf16x3_pack_table_add(C.c_void_p(host.data_ptr()), cap, C.byref(n), C.byref(nblk),
-                                                             desc[0], desc[1], _f(weight), f_, d_)
-                if rc == 0:
-                    batched.append(orig)
-                elif rc != 1:
-                    _ck(rc)
-            R.tabs[which] = dict(n=n.value, nblk=nblk.value, batched=batched,
-                                 dev=host[:max(n.value, 1) * item].to(ents[0][2].device))
+        host = torch.zeros(cap * item, dtype=torch.uint8)
+        n, nblk = C.c_int(0), C.c_int64(0)
+        R.batched = []
+        for e, orig in zip(ents, R.entries):
+            kind, desc, weight, pk, _ = e
+            if pk.fwd is None and pk.dgr is None:
+                continue
+            if _is_alias(pk.fwd, weight) or _is_alias(pk.dgr, weight):      # 1x1 heads: the kernels read the parameter itself
+                continue
+            if kind == 'conv':
+                rc = L.muvo_conv_pack_table_add(C.c_void_p(host.data_ptr()), cap, C.byref(n), C.byref(nblk), C.byref(desc),
+                                                _f(weight), _f(pk.fwd), _f(pk.dgr))
+            else:
+                rc = L.muvo_linear_bf16x3_pack_table_add(C.c_void_p(host.data_ptr()), cap, C.byref(n), C.byref(nblk),
+                                                         desc[0], desc[1], _f(weight), _f(pk.fwd), _f(pk.dgr))
+            if rc == 0:
+                R.batched.append(orig)
+            elif rc != 1:
+                _ck(rc)
+        R.n, R.nblk = n.value, nblk.value
+        R.dev = host[:max(R.n, 1) * item].to(ents[0][2].device)
         R.sig = sig
-    dev = ents[0][2].device
-    for which in ('fwd', 'dgr'):
-        T = R.tabs[which]
-        if not T['n']:
-            continue
-        wst = wgrad_stream(dev) if (which == 'dgr' and DGR_PACK_SIDE) else None
-        cur = torch.cuda.current_stream(dev)
-        if wst is not None and wst != cur:
-            # the data-gradient copies are first read in backward: packed on the weight-gradient stream, idle during forward, they
-            # leave the start of the step (where the pack ran alone on the chip); backward waits for the event (_wait_dgr_pack)
-            wst.wait_stream(cur)
-            with torch.cuda.stream(wst):
-                _ck(L.muvo_pack_table_run(C.c_void_p(T['dev'].data_ptr()), T['n'], _i64(T['nblk']), _st()))
-                ev = torch.cuda.Event()
-                ev.record(wst)
-            _DGR_PACK[dev.index] = (ev, set())
-        else:
-            _ck(L.muvo_pack_table_run(C.c_void_p(T['dev'].data_ptr()), T['n'], _i64(T['nblk']), _st()))
-            if which == 'dgr':
-                _DGR_PACK.pop(dev.index, None)
-        for kind, _, weight, pkref, pkey in T['batched']:
+    if R.n:
+        _ck(L.muvo_pack_table_run(C.c_void_p(R.dev.data_ptr()), R.n, _i64(R.nblk), _st()))
+        for kind, _, weight, pkref, pkey in R.batched:
             pk = pkref()
             if pk is None:
                 continue
             k = _wkey(weight)
-            if which == 'fwd':
+            if pk.fwd is not None:
                 pk.fwd_key = k
-                if kind == 'conv':
-                    pk.fwd_plan = pkey
-            else:
+            if pk.dgr is not None:
                 pk.dgr_key = k
-                if kind == 'conv':
-                    pk.dgr_plan = pkey
-
-
-DGR_PACK_SIDE = os.environ.get('MUVO_DGR_PACK_SIDE', '1') != '0'
-_DGR_PACK = {}      # device index -> (event behind the data-gradient pack on the weight-gradient stream, stream keys that waited for it)
-
-
-def _wait_dgr_pack(device):
-    """called by every backward function before its first read of a packed data-gradient copy"""
-    st = _DGR_PACK.get(torch.device(device).index)
-    if st is not None:
-        key = _stream_key(device)
-        if key not in st[1]:
-            torch.cuda.current_stream(device).wait_event(st[0])
-            st[1].add(key)
+            if kind == 'conv':
+                pk.fwd_plan = pkey if pk.fwd is not None else pk.fwd_plan
+                pk.dgr_plan = pkey if pk.dgr is not None else pk.dgr_plan
 
 
 _KEEP_WS = os.environ.get('MUVO_KEEP_WS', '1') != '0'
@@ -1166,7 +1129,6 @@ class ConvFn(torch.autograd.Function):
         dx = None
         ws_dy, dy_split = None, False
         if ctx.needs_input_grad[0]:
-            _wait_dgr_pack(x.device if not x_ph else dz.device)
             k = _wkey(weight)
             if _head_alias(geom, key, 1, weight):
                 packed.dgr, packed.dgr_key, packed.dgr_plan = weight.detach().view(-1), k, key[1:]
@@ -1331,7 +1293,6 @@ class HeadBranchFn(torch.autograd.Function):
         gy = gy.contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            _wait_dgr_pack(x.device)
             k, pkey = _wkey(weight), (ctx.in_sz, _plan_epoch[0])
             if _head_alias(geom, (x.shape[0], ctx.in_sz, _plan_epoch[0]), 1, weight):
                 packed.dgr, packed.dgr_key, packed.dgr_plan = weight.detach().view(-1), k, pkey
