@@ -5,7 +5,7 @@
 #   <tag>_kernel_stats_streams_off.txt    the same with MUVO_STREAMS=0 (kernel durations without neighbours on the chip)
 #   <tag>_timeline.txt                    busy / small-only / idle shares of the step (tools/rocpd_timeline.py)
 #   <tag>_hbm_traffic.json, _pmc_*.txt    FETCH_SIZE / WRITE_SIZE passes (tools/pmc_step.sh)
-#   <tag>_force_dist.txt                  bench with a one-rank RCCL group attached (MUVO_BENCH_FORCE_DIST=1) next to the plain one
+#   <tag>_dp_evidence.txt                 bench alone / with a one-rank RCCL group / with the stand-in collective of 8 fake peers / on 2 host cores
 set -uo pipefail
 : ${GRAFT_REPO_ROOT:?}
 tag=$1
@@ -15,13 +15,20 @@ cd $R
 python bench.py --layer-table gpurun_out/${tag}_conv_layers.txt > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 echo "bench rc=$?"; cut -c1-300 gpurun_out/${tag}_bench.json | tail -1
 {
-  echo "# python bench.py --steps 20 --warmup 5, one MI355X, same box, alternating"
+  echo "# python bench.py --steps 20 --warmup 5, one MI355X, same box, alternating (ms/step, median; gradient_exchange of the last run)"
+  B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-exact-f32 --no-kernel-timing"
+  P='import sys,json; d=json.loads(sys.stdin.read()); g=d.get("gradient_exchange") or {}; print(sys.argv[1].ljust(44), round(d["ms_per_step"],2), round(d["median_ms_per_step"],2), "host_cpu_ms", round(d["host_cpu_ms"],1), "exposed_ms", g.get("exposed_ms_per_step"))'
   for k in 1 2; do
-    python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-exact-f32 --no-kernel-timing 2>/dev/null | grep "^{" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('alone                      ms/step', round(d['ms_per_step'],2))"
-    MUVO_BENCH_FORCE_DIST=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-exact-f32 --no-kernel-timing 2>/dev/null | grep "^{" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('one-rank RCCL group attached ms/step', round(d['ms_per_step'],2), {k: d[k] for k in d if 'exchange' in k or 'allreduce' in k or 'comm' in k})"
+    $B 2>/dev/null | grep "^{" | python -c "$P" "alone"
+    MUVO_BENCH_FORCE_DIST=1 $B 2>/dev/null | grep "^{" | python -c "$P" "one-rank RCCL group attached"
+    MUVO_DP_FAKE_PEERS=8 $B 2>/dev/null | grep "^{" | python -c "$P" "8 fake peers (stand-in collective kernel)"
+    MUVO_BENCH_CORES=2 $B 2>/dev/null | grep "^{" | python -c "$P" "2 host cores"
+    MUVO_BENCH_CORES=2 MUVO_DP_FAKE_PEERS=8 $B 2>/dev/null | grep "^{" | python -c "$P" "2 host cores + 8 fake peers"
   done
-} > gpurun_out/${tag}_force_dist.txt 2>&1
-cat gpurun_out/${tag}_force_dist.txt
+  echo "# per-segment report of the last fake-peer run:"
+  MUVO_DP_FAKE_PEERS=8 $B 2>/dev/null | grep "^{" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps(d['gradient_exchange'], indent=1))"
+} > gpurun_out/${tag}_dp_evidence.txt 2>&1
+cat gpurun_out/${tag}_dp_evidence.txt | head -14
 cd /tmp && export TMPDIR=/tmp
 GPU_MAX_HW_QUEUES=8 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${tag} -o p -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-exact-f32 > $R/gpurun_out/${tag}_prof.log 2>&1
 cd $R
