@@ -504,6 +504,15 @@ int muvo_bn_train_bwd_planes(const float* x, const float* y, const float* dy, co
 int muvo_conv_forward_planes(const muvo_conv_desc* d, const float* x, const float* wp_fwd, const float* bias, float* y, int act,
                              float slope, void* ws, int ws_valid, void* stream);
 
+/* ---- ResNet-18 stem (timm resnet18 conv1: Conv2d(3 | 4, 64, 7, stride 2, padding 3, bias=False); muvo/models/mile.py:24,81) as a direct
+ * convolution on bf16x3 split products (csrc/conv_stem.hip): the input patch of an output tile in LDS, operands built from it without
+ * a gather.  w / dw: the parameter and its gradient in PyTorch's layout (64, Cin, 7, 7) - no packed copy; dw is accumulated into
+ * (float atomics: not offered in the deterministic mode).  bias may be NULL; relu != 0 applies max(0, .) in the epilogue.
+ * muvo_stem_conv_supported: 1 when the descriptor is such a stem (even input height / width) and MUVO_STEM_KERNEL != 0. */
+int muvo_stem_conv_supported(const muvo_conv_desc* d);
+int muvo_stem_conv_forward(const muvo_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int relu, void* stream);
+int muvo_stem_conv_wgrad(const muvo_conv_desc* d, const float* x, const float* dy, float* dw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

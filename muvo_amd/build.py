@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libmuvo_hip.so')
-SOURCES = ['abi.hip', 'conv_gemm.hip', 'conv_vox.hip', 'conv_pw.hip', 'conv_bf3.hip', 'gemm.hip', 'norm.hip', 'elementwise.hip', 'losses.hip', 'metrics.hip', 'bev.hip', 'input.hip', 'augment.hip', 'attention.hip', 'rssm.hip']
+SOURCES = ['abi.hip', 'conv_gemm.hip', 'conv_vox.hip', 'conv_pw.hip', 'conv_bf3.hip', 'gemm.hip', 'norm.hip', 'elementwise.hip', 'losses.hip', 'metrics.hip', 'bev.hip', 'input.hip', 'augment.hip', 'attention.hip', 'rssm.hip', 'conv_stem.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-munsafe-fp-atomics', '-Wno-unused-result', '-Wno-unused-value',
          '-ffp-contract=off', '-Rpass-analysis=kernel-resource-usage',
          # A by-value kernel argument struct (ConvPhase, 2.8 KB) is first copied to a private alloca by the front end; InstCombine

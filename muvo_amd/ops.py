@@ -9,6 +9,7 @@ Parameter gradients are accumulated by the kernels straight into `param.grad` (p
 view into one flat gradient buffer, see muvo_amd/param_store.py); the autograd Functions therefore
 return None for parameters and only propagate activation gradients.
 """
+import contextlib
 import ctypes as C
 import os
 import threading
@@ -72,6 +73,7 @@ EXPORTS = [
     'muvo_conv_forward_head_supported', 'muvo_conv_forward_head',
     'muvo_adain_affine', 'muvo_conv_affine_supported', 'muvo_conv_forward_affine', 'muvo_conv_wgrad_affine',
     'muvo_fake_allreduce', 'muvo_resize_bilinear_aa', 'muvo_bn_train_fwd_planes', 'muvo_bn_train_bwd_planes', 'muvo_conv_forward_planes',
+    'muvo_stem_conv_supported', 'muvo_stem_conv_forward', 'muvo_stem_conv_wgrad',
     'muvo_rssm_supported', 'muvo_rssm_transposed_floats', 'muvo_rssm_scratch_floats', 'muvo_rssm_forward', 'muvo_rssm_backward',
 ]
 
@@ -990,6 +992,29 @@ class ConvFn(torch.autograd.Function):
         in_sz = tuple(x.shape[2:]) if geom.nd == 3 else (1,) + tuple(x.shape[2:])
         d, out_sz, ff, df = geom.plan(n, in_sz)
         L = lib()
+        # the 7x7 stride-2 stems of the ResNet-18 trunks: direct convolution on bf16x3 products from the fp32 parameter itself
+        # (csrc/conv_stem.hip); only where the arithmetic mode is bf16x3 and the input needs no gradient
+        skey = ('stem', n, in_sz, _plan_epoch[0])
+        stem = geom.family.get(skey)
+        if stem is None:
+            stem = geom.family[skey] = bool(L.muvo_stem_conv_supported(C.byref(d)))
+        ctx.stem = bool(stem and get_conv_mode() != CONV_F32 and bias is None and act == ACT_NONE and moments is None and aff is None
+                        and not x_is_placeholder and not ctx.needs_input_grad[0] and getattr(ctx, '_head_fwd', None) is None
+                        and weight.is_contiguous())
+        if ctx.stem:
+            y = torch.empty((n, geom.cout) + out_sz[1:], device=x.device, dtype=torch.float32)
+            kt = KERNEL_TIMING
+            if kt is not None:
+                e0, e1 = kt.bracket('bf16x3_small_tile:fwd', _conv_flops(geom, n, in_sz, out_sz), 1, _conv_tag(geom, n, in_sz),
+                                    _conv_bytes(geom, n, in_sz, out_sz))
+                e0.record()
+            _ck(L.muvo_stem_conv_forward(C.byref(d), _f(x), _f(weight), None, _f(y), 0, _st()))
+            if kt is not None:
+                e1.record()
+            ctx.geom, ctx.packed, ctx.act, ctx.slope = geom, packed, act, slope
+            ctx.weight, ctx.bias, ctx.in_sz, ctx.ws_x, ctx.x_is_placeholder = weight, bias, in_sz, None, False
+            ctx.save_for_backward(x, None)
+            return y
         k = _wkey(weight)
         pkey = (in_sz, _plan_epoch[0])
         if _head_alias(geom, (n, in_sz, _plan_epoch[0]), 0, weight):
@@ -1060,6 +1085,27 @@ class ConvFn(torch.autograd.Function):
         geom, packed, weight, bias = ctx.geom, ctx.packed, ctx.weight, ctx.bias
         d, out_sz, ff, df = geom.plan(x.shape[0], ctx.in_sz)
         L = lib()
+        if getattr(ctx, 'stem', False):
+            # stem: only the weight gradient exists (the input image needs none); on the weight-gradient stream like the others
+            if weight.requires_grad and dy is not None:
+                dy = dy.contiguous()
+                gw = grad_of(weight)
+                cur, wst = torch.cuda.current_stream(x.device), wgrad_stream(x.device)
+                kt = KERNEL_TIMING
+                side = wst is not None and wst != cur
+                if side:
+                    wst.wait_stream(cur)
+                    x.record_stream(wst)
+                    dy.record_stream(wst)
+                with (torch.cuda.stream(wst) if side else contextlib.nullcontext()):
+                    if kt is not None:
+                        e0, e1 = kt.bracket('bf16x3_small_tile:wgrad', _conv_flops(geom, x.shape[0], ctx.in_sz, out_sz), 1,
+                                            _conv_tag(geom, x.shape[0], ctx.in_sz), _conv_bytes(geom, x.shape[0], ctx.in_sz, out_sz))
+                        e0.record()
+                    _ck(L.muvo_stem_conv_wgrad(C.byref(d), _f(x), _f(dy), _f(gw), _st()))
+                    if kt is not None:
+                        e1.record()
+            return None, None, None, None, None, None, None, None, None, None, None
         dyp = getattr(dy, '_muvo_planes', None) if dy is not None else None     # dy arrives as split planes (BNActFn.backward)
         if dy is not None and dyp is None:
             dy = dy.contiguous()

@@ -1215,3 +1215,46 @@ def test_basic_block_with_planes_equals_without(dev, shape, stride):
         ops.BN_PLANES = os.environ.get('MUVO_BN_PLANES', '1') != '0'
         ops.set_deterministic(was_det)
         ops.set_conv_mode(old_mode, min_gflop=-1.0)
+
+
+@pytest.mark.parametrize('cin,shape', [(3, (2, 64, 832)), (3, (3, 38, 104)), (4, (2, 64, 1024)), (4, (1, 16, 424))])
+def test_stem_convolution_kernel(dev, cin, shape):
+    """The dedicated ResNet-18 stem kernels (csrc/conv_stem.hip: Conv2d(3 | 4, 64, 7, stride 2, padding 3, bias=False) on bf16x3
+    products from an LDS-resident input patch; weight gradient with persistent accumulators) against PyTorch fp32 on the CPU:
+    forward 2e-5 of the output scale, weight gradient 1e-4 of its scale (1e-5-sized bf16x3 rounding over 10^5 ... 10^6 pixel sums);
+    through the module in the bf16x3 mode (the path ConvFn takes when the input needs no gradient), several tiles per row, a
+    ragged last tile, odd row counts."""
+    import ctypes as C
+    from muvo_amd import nn as hnn
+    from muvo_amd import ops
+    n, h, w = shape
+    old = ops.get_conv_mode()
+    ops.set_conv_mode(ops.CONV_BF16X3, min_gflop=-1.0)
+    try:
+        torch.manual_seed(cin * 100 + h)
+        with torch.device(dev):
+            m = hnn.Conv2d(cin, 64, 7, 2, 3, bias=False)
+        x = torch.randn(n, cin, h, w)
+        m.weight.grad = torch.zeros_like(m.weight)
+        y = m(x.to(dev))
+        d = m.geom.plan(n, (1, h, w))[0]
+        assert ops.lib().muvo_stem_conv_supported(C.byref(d)) == 1
+        assert m.geom.family[('stem', n, (1, h, w), ops._plan_epoch[0])] is True
+        wc = m.weight.detach().cpu().clone().requires_grad_(True)
+        yr = F.conv2d(x, wc, None, 2, 3)
+        assert y.shape == yr.shape
+        err = (y.cpu() - yr).abs().max().item()
+        assert err < 2e-5 * yr.abs().max().item(), (err, yr.abs().max().item())
+        g = torch.randn_like(yr)
+        yr.backward(g)
+        y.backward(g.to(dev))
+        ops.join_side_streams()
+        gerr = (m.weight.grad.cpu() - wc.grad).abs().max().item()
+        assert gerr < 1e-4 * wc.grad.abs().max().item(), (gerr, wc.grad.abs().max().item())
+        # accumulation: a second backward adds
+        y2 = m(x.to(dev))
+        y2.backward(g.to(dev))
+        ops.join_side_streams()
+        assert (m.weight.grad.cpu() - 2 * wc.grad).abs().max().item() < 2e-4 * wc.grad.abs().max().item()
+    finally:
+        ops.set_conv_mode(old, min_gflop=-1.0)
