@@ -1,7 +1,9 @@
-"""Which parameters still receive their gradient through an autograd AccumulateGrad node (instead of a kernel writing into the
-flat gradient buffer), and on which stream does that node run?  bench.py's stderr carries autograd's warning "The AccumulateGrad
-node's stream does not match the stream of the node that produced the incoming gradient".
-   python tools/dev/accgrad_params.py   (GPU box)"""
+"""bench.py's stderr carried autograd's warning "The AccumulateGrad node's stream does not match the stream of the node that produced
+the incoming gradient".  This probe answers: (1) which parameters receive a DEFINED gradient tensor through an AccumulateGrad node
+(all others get theirs written by kernels into the flat gradient buffer; their AccumulateGrad node runs on an undefined input and
+does nothing), and on which stream; (2) in which kind of step the warning is raised: the timed configuration (side streams on), or
+the untimed per-class instrumentation steps bench.py runs afterwards with the side streams OFF while the autograd graph of the
+previous step - built on the side streams - is still alive.     python tools/dev/accgrad_params.py   (GPU box)"""
 import os
 import sys
 import warnings
@@ -20,25 +22,41 @@ opt = tr.configure_optimizers()[0][0]
 hits = {}
 main = torch.cuda.current_stream(dev)
 for n, p in tr.model.named_parameters():
-    def hook(param, n=n):
+    def hook(g, n=n):
         cur = torch.cuda.current_stream(dev)
         hits.setdefault(n, []).append('main' if cur == main else hex(cur.cuda_stream))
-    p.register_post_accumulate_grad_hook(hook)
+    p.register_hook(hook)
 batches = [make_batch(2, 10, seed=1234 + k, device=dev) for k in range(2)]
-with warnings.catch_warnings(record=True) as w:
-    warnings.simplefilter('always')
-    for i in range(3):
-        opt.zero_grad()
-        loss = tr.training_step(dict(batches[i % 2]), i)
-        loss.backward()
-        tr.on_after_backward()
-        opt.step()
-    torch.cuda.synchronize()
-print('side streams:', {k: hex(v.cuda_stream) for k, v in ops._side_streams.items()})
-print(f'{len(hits)} parameters went through AccumulateGrad in 3 steps:')
+
+
+def step(i):
+    opt.zero_grad()
+    loss = tr.training_step(dict(batches[i % 2]), i)
+    loss.backward()
+    tr.on_after_backward()
+    opt.step()
+    return loss
+
+
+def count_warnings(fn):
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        out = fn()
+        torch.cuda.synchronize()
+    return out, sum('AccumulateGrad' in str(x.message) for x in w)
+
+
+keep, n_on = count_warnings(lambda: [step(i) for i in range(3)][-1])
+print('side streams:', {k[0]: hex(v.cuda_stream) for k, v in ops._side_streams.items()})
+print(f'{len(hits)} of {sum(1 for _ in tr.model.parameters())} parameters receive a defined gradient tensor through AccumulateGrad (3 steps):')
 for n, s in hits.items():
     p = dict(tr.model.named_parameters())[n]
-    print(f'  {n:60s} {tuple(p.shape)}  streams {s}  grad is flat view: {p.grad is getattr(p, "_muvo_flat_grad", None)}')
-for x in w:
-    if 'AccumulateGrad' in str(x.message):
-        print('WARNING raised:', str(x.message)[:200])
+    print(f'  {n:50s} {str(tuple(p.shape)):18s} hook ran under streams {sorted(set(s))}; p.grad is a view of the flat buffer: '
+          f'{p.grad.data_ptr() == p._muvo_flat_grad.data_ptr()}')
+print(f'AccumulateGrad stream-mismatch warnings in 3 steps with the side streams ON (the timed configuration): {n_on}')
+ops.STREAMS = ops.WGRAD_STREAM = False
+_, n_off_alive = count_warnings(lambda: step(3))          # `keep` (the previous loss) holds the previous graph alive
+print(f'... in one step with the side streams OFF while the previous graph is alive (bench.py\'s per-class instrumentation steps): {n_off_alive}')
+del keep
+_, n_off = count_warnings(lambda: step(4))
+print(f'... in the next side-streams-OFF step: {n_off}')
