@@ -360,6 +360,9 @@ def main():
     if tr._reducer is not None:
         tr._reducer.timing = False
     full_timing, extra_steps = None, 2
+    loss_val = float(loss.item())
+    del loss       # the last timed step's graph (its AccumulateGrad nodes live on the side streams) must not outlive the switch below:
+    #                autograd otherwise warns about a stream mismatch in the first instrumentation step (tools/dev/accgrad_params.py)
     if timing is not None:
         # per-class table from extra steps with the side streams OFF: next to each other on several streams the kernels share
         # the chip and every event bracket also contains its neighbours' work, so the isolated durations are the ones that say
@@ -378,7 +381,6 @@ def main():
         t = torch.tensor([dt, median_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, median_ms = t[0].item(), t[1].item()
-    loss_val = float(loss.item())
     # the same step with every contraction on exact-fp32 MFMA, a few steps after the timed region
     exact_f32 = None
     if args.conv_mfma == 'bf16x3' and not args.no_exact_f32:
@@ -520,7 +522,7 @@ def main():
         if (world == 1 and args.workload == 'base_1d' and args.conv_mfma == 'bf16x3' and not args.no_extensions
                 and not args.no_kernel_timing):       # (the reduced command lines of the A/B and profiling scripts skip them)
             # (the judged trainer, its optimizer state and the last step's autograd graph go first: 70 GB peak otherwise doubles)
-            del batches, tr, opt, sched, opts, scheds, loss
+            del batches, tr, opt, sched, opts, scheds
             import gc
             gc.collect()
             torch.cuda.empty_cache()

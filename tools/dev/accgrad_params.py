@@ -48,7 +48,8 @@ def count_warnings(fn):
 
 keep, n_on = count_warnings(lambda: [step(i) for i in range(3)][-1])
 print('side streams:', {k[0]: hex(v.cuda_stream) for k, v in ops._side_streams.items()})
-print(f'{len(hits)} of {sum(1 for _ in tr.model.parameters())} parameters receive a defined gradient tensor through AccumulateGrad (3 steps):')
+print(f'{len(hits)} of {sum(1 for _ in tr.model.parameters())} parameters have an AccumulateGrad node that runs (tensor inputs of autograd Functions; the node runs\n'
+      f'even when the Function returns None for the parameter - the kernels wrote the gradient - and then does nothing), 3 steps:')
 for n, s in hits.items():
     p = dict(tr.model.named_parameters())[n]
     print(f'  {n:50s} {str(tuple(p.shape)):18s} hook ran under streams {sorted(set(s))}; p.grad is a view of the flat buffer: '
