@@ -590,6 +590,215 @@ vox_bf3_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* __re
 }
 
 // ================================================================================================
+// Plane-streaming form of vox_bf3_kernel for 16 reduction channels per pass (round 4).  The ring form above reads, per output
+// plane and 16-voxel tile, 14 k-steps x 2 fragments of 16 bytes per lane from LDS for 42 MFMAs - with 8 waves per CU that is
+// 917 KB per plane, 3.0 us at 128 B/clk against 2.2 us of MFMA issue: it is bound by its LDS fragment reads, and for <= 8
+// produced channels half the MFMA rows multiply zeros.  Here ONE input plane p is in LDS at a time (double-buffered) and every
+// fragment read serves all three x taps: the nine (dy, dz) taps x 16 channels of plane p are 5 k-steps (144 of 160 k used), and
+// each fragment feeds the dx = 0 weights into the accumulator of output plane p, the dx = -1 weights into that of p + 1 and the
+// dx = +1 weights into that of p - 1 (three rolling accumulator tiles per z tile; plane p - 1 is complete after step p).
+// Fragment reads per output plane: 10 instead of 28; MFMAs 45 instead of 42.  CO8 (<= 8 produced channels): MFMA rows 8-15, idle in
+// the ring form, carry the dx = -1 weights (output plane p + 1) next to the dx = 0 weights in rows 0-7, a second A fragment holds
+// dx = +1 in rows 0-7: 30 MFMAs per output plane; after each plane the rows 8-15 move down to rows 0-7 (lane + 32 -> lane).
+// LDS: 2 buffers of [hi/lo][2 channel groups][TY + 2][Z + 2] x 16 B = 84 KB at Z = 64 (127 KB for the ring), 43 KB at Z = 32.
+// Packed weights (vox_bf3_ps_pack_kernel): fragment f of row block rb: wp[((rb * NF + f) * 2 + hl) * 64 + lane], k = 8 (lane >> 4) + e
+// -> in-plane tap tp = 2 s + (lane >> 5) (= (dy + 1) * 3 + dz + 1; tp = 9: zero), channel ((lane >> 4) & 1) * 8 + e;
+// plain: f = dxi * 5 + s (dxi = dx + 1); CO8: f = s: rows 0-7 dx = 0, rows 8-15 dx = -1; f = 5 + s: rows 0-7 dx = +1, rows 8-15 zero.
+// ================================================================================================
+template <int Z, int TY, bool CO8, bool GENERIC>
+__global__ void __launch_bounds__(64 * TY)
+vox_bf3_ps_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* __restrict__ wp, const float* __restrict__ bias,
+                  float* __restrict__ out, int act, float slope, int xseg, int accum) {
+  constexpr int CK = 16, CG = 2, PSTEPS = 5, ZT = Z / 16, NF = CO8 ? 2 * PSTEPS : 3 * PSTEPS, NACC = CO8 ? 2 : 3;
+  constexpr int ROWS = TY + 2, COLS = Z + 2;
+  constexpr int PLANE = 2 * CG * ROWS * COLS;                   // uint4 per buffer
+  constexpr int NTASK = CG * ROWS * Z, TPT = (NTASK + 64 * TY - 1) / (64 * TY);
+  extern __shared__ vu32x4 vsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nseg = (a.X + xseg - 1) / xseg;
+  int bid = a.xcd_order ? xcd_swizzle(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int seg = bid % nseg; bid /= nseg;
+  const int ytile = bid % a.ytiles, n = bid / a.ytiles;
+  const int y0 = ytile * TY, xs = seg * xseg, xe = xs + xseg < a.X ? xs + xseg : a.X;
+  const long YZ = (long)a.Y * Z;
+  const float* inb = in + (long)n * a.sN_in;
+  const int co0 = blockIdx.y * 16;
+
+  vbf16x8 wh[NF], wl[NF];
+  const vu32x4* wpb = wp + (size_t)blockIdx.y * NF * 2 * 64;
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    wh[f] = __builtin_bit_cast(vbf16x8, wpb[(f * 2) * 64 + lane]);
+    wl[f] = __builtin_bit_cast(vbf16x8, wpb[(f * 2 + 1) * 64 + lane]);
+  }
+  for (int i = tid; i < 2 * PLANE; i += 64 * TY) vsm[i] = vu32x4{0u, 0u, 0u, 0u};      // z halo columns stay zero
+  __syncthreads();
+
+  float stg[TPT][8];
+  unsigned stg_ok = 0u;
+  __shared__ float s_aff[2 * CK];
+  if (a.aff) {
+    if (tid < 2 * CK) s_aff[tid] = a.aff[(long)n * a.Cin * 2 + tid];
+    __syncthreads();
+  }
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)inb, 0, (int)((long)CK * a.XYZ * 4), 0x00020000);
+  const unsigned xyz4 = (unsigned)a.XYZ * 4u;
+  auto stage_load = [&](int x) {
+#pragma unroll
+    for (int k = 0; k < TPT; ++k) {
+      const int t = tid + k * 64 * TY;
+      const int z = t % Z, r = (t / Z) % ROWS, cg = t / (Z * ROWS);
+      const int gy = y0 - 1 + r;
+      const bool ok = t < NTASK && x >= 0 && x < a.X && gy >= 0 && gy < a.Y;
+      stg_ok = k == 0 ? (unsigned)ok : stg_ok | ((unsigned)ok << k);
+      const unsigned off = ok ? (unsigned)(((long)(cg * 8) * a.XYZ + (long)x * YZ + (long)gy * Z + z) * 4) : 0x7fffff00u;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        stg[k][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in, off + (unsigned)e * xyz4, 0, 0));
+    }
+  };
+  auto stage_store = [&](int slot) {
+    vu32x4* P = vsm + slot * PLANE;
+#pragma unroll
+    for (int k = 0; k < TPT; ++k) {
+      const int t = tid + k * 64 * TY;
+      if (t >= NTASK) continue;
+      const int z = t % Z, r = (t / Z) % ROWS, cg = t / (Z * ROWS);
+      if (a.aff) {
+        const bool ok = (stg_ok >> k) & 1u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float sc = s_aff[(cg * 8 + e) * 2], sh = s_aff[(cg * 8 + e) * 2 + 1];
+          stg[k][e] = ok ? stg[k][e] * sc + sh : 0.f;
+        }
+      }
+      unsigned h[4], l[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) vox_split2(stg[k][2 * q], stg[k][2 * q + 1], h[q], l[q]);
+      P[(cg * ROWS + r) * COLS + z + 1] = vu32x4{h[0], h[1], h[2], h[3]};
+      P[((CG + cg) * ROWS + r) * COLS + z + 1] = vu32x4{l[0], l[1], l[2], l[3]};
+    }
+  };
+
+  const int v = lane & 15, g = lane >> 4;
+  float msum[4] = {0.f, 0.f, 0.f, 0.f}, msq[4] = {0.f, 0.f, 0.f, 0.f};
+  float bv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bv[i] = (bias != nullptr && co0 + 4 * g + i < a.Cout) ? bias[co0 + 4 * g + i] : 0.f;
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (long)n * a.sN_out), 0,
+                                                                          (int)((long)a.Cout * a.XYZ * 4), 0x00020000);
+  int foff[PSTEPS];       // uint4 offset of this lane's fragment entry inside a buffer (hi part), z tile 0
+#pragma unroll
+  for (int s = 0; s < PSTEPS; ++s) {
+    int tp = s * 2 + (g >> 1);
+    if (tp > 8) tp = 8;              // the padded tap carries zero weights
+    const int dy = tp / 3 - 1, dz = tp % 3 - 1;
+    foff[s] = ((g & 1) * ROWS + (wave + 1 + dy)) * COLS + (v + 1 + dz);
+  }
+  // rolling accumulators: plain: acc[0] = output plane p - 1, acc[1] = p, acc[2] = p + 1;
+  // CO8: acc[0] rows 0-7 = p - 1; acc[1] rows 0-7 = p, rows 8-15 = p + 1
+  vf32x4 acc[NACC][ZT];
+#pragma unroll
+  for (int j = 0; j < NACC; ++j)
+#pragma unroll
+    for (int zt = 0; zt < ZT; ++zt) acc[j][zt] = vf32x4{0.f, 0.f, 0.f, 0.f};
+
+  stage_load(xs - 1); stage_store((xs - 1) & 1);
+  stage_load(xs);
+  vox_dummy_stores<4 * ZT>(rs_out);
+  __syncthreads();
+  const int gy = y0 + wave;
+  for (int p = xs - 1; p <= xe; ++p) {
+    stage_store((p + 1) & 1);                 // plane p + 1 (in registers) -> the buffer last read while computing plane p - 1
+    if (p + 2 <= xe) stage_load(p + 2);       // lands while this plane is computed
+    const vu32x4* P = vsm + (p & 1) * PLANE;
+#pragma unroll
+    for (int zt = 0; zt < ZT; ++zt) {
+#pragma unroll
+      for (int s = 0; s < PSTEPS; ++s) {
+        const vbf16x8 bh = __builtin_bit_cast(vbf16x8, P[foff[s] + zt * 16]);
+        const vbf16x8 bl = __builtin_bit_cast(vbf16x8, P[foff[s] + zt * 16 + CG * ROWS * COLS]);
+        if constexpr (CO8) {
+          acc[1][zt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[s], bh, acc[1][zt], 0, 0, 0);
+          acc[1][zt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], bl, acc[1][zt], 0, 0, 0);
+          acc[1][zt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], bh, acc[1][zt], 0, 0, 0);
+          acc[0][zt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[PSTEPS + s], bh, acc[0][zt], 0, 0, 0);
+          acc[0][zt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[PSTEPS + s], bl, acc[0][zt], 0, 0, 0);
+          acc[0][zt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[PSTEPS + s], bh, acc[0][zt], 0, 0, 0);
+        } else {
+          // dxi = 0 (dx = -1) -> output plane p + 1; dxi = 1 (dx = 0) -> p; dxi = 2 (dx = +1) -> p - 1
+#pragma unroll
+          for (int dxi = 0; dxi < 3; ++dxi) {
+            const int f = dxi * PSTEPS + s, j = 2 - dxi;
+            acc[j][zt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[f], bh, acc[j][zt], 0, 0, 0);
+            acc[j][zt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[f], bl, acc[j][zt], 0, 0, 0);
+            acc[j][zt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[f], bh, acc[j][zt], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // output plane p - 1 is complete
+    const int xo = p - 1;
+    const bool xok = xo >= xs && xo < xe;
+#pragma unroll
+    for (int zt = 0; zt < ZT; ++zt) {
+      const unsigned ooff = (unsigned)(((long)xo * YZ + (long)gy * Z + zt * 16 + v) * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int co = co0 + 4 * g + i;
+        const bool ok = xok && gy < a.Y && co < a.Cout && (!CO8 || g < 2);
+        const unsigned off = ok ? ooff + (unsigned)co * xyz4 : 0x7fffff00u;
+        float r = acc[0][zt][i] + bv[i];
+        if constexpr (GENERIC) {
+          if (accum) r += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_out, off, 0, 0));
+          r = act_apply(r, act, slope);
+        } else {
+          r = vox_act_simple(r, act, slope);
+        }
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(r), rs_out, off, 0, 0);
+        r = ok ? r : 0.f;
+        msum[i] += r;
+        msq[i] += r * r;
+      }
+    }
+    // roll the accumulators
+#pragma unroll
+    for (int zt = 0; zt < ZT; ++zt) {
+      if constexpr (CO8) {
+        acc[0][zt] = acc[1][zt];                 // rows 0-7 (lanes 0-31): plane p becomes "p - 1"; rows 8-15 of acc[0] are never stored
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float up = __shfl(acc[1][zt][i], (lane + 32) & 63, 64);       // rows 8-15 (plane p + 1) -> rows 0-7
+          acc[1][zt][i] = lane < 32 ? up : 0.f;
+        }
+      } else {
+        acc[0][zt] = acc[1][zt];
+        acc[1][zt] = acc[2][zt];
+        acc[2][zt] = vf32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    __syncthreads();     // plane p + 1 is visible; everybody is done reading plane p's buffer
+  }
+  if (a.moments) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { msum[i] += __shfl_xor(msum[i], o, 64); msq[i] += __shfl_xor(msq[i], o, 64); }
+    float* red = (float*)vsm;
+    if (v == 0)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { red[((wave * 4 + g) * 4 + i) * 2] = msum[i]; red[((wave * 4 + g) * 4 + i) * 2 + 1] = msq[i]; }
+    __syncthreads();
+    if (tid < 32) {
+      const int c = tid >> 1, k = tid & 1;
+      double t = 0.0;
+      for (int w = 0; w < TY; ++w) t += (double)red[((w * 4 + (c >> 2)) * 4 + (c & 3)) * 2 + k];
+      if (co0 + c < a.Cout) atomicAdd(&a.moments[((long)n * a.Cout + co0 + c) * 2 + k], t);
+    }
+  }
+}
+
+// ================================================================================================
 // bf16x3 weight gradient of the small-channel 3x3x3 convolution on v_mfma_f32_16x16x32_bf16:
 //   dW[co][ci][tap] += sum over voxels dz[co][v] * x[ci][v + tap],   dbias[co] += sum dz[co][v]
 // MFMA rows = output channels (padded to 16), columns = 16 input channels, K = 32 consecutive z voxels.  Both operands
@@ -1109,6 +1318,38 @@ vox_bf3_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp
   }
 }
 
+// packed weights of vox_bf3_ps_kernel (layout in its header comment); red = reduction channels (16, or 32 = two halves)
+__global__ void __launch_bounds__(256)
+vox_bf3_ps_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int Cin, int Cout, int dgrad, int co8) {
+  const int rows = dgrad ? Cin : Cout, red = dgrad ? Cout : Cin;
+  const int nrb = (rows + 15) / 16, halves = red / 16, NF = co8 ? 10 : 15;
+  const int total = halves * nrb * NF * 64 * 8;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    const int e = idx & 7, lane = (idx >> 3) & 63, fb = idx >> 9;
+    const int f = fb % NF, rb = (fb / NF) % nrb, half = fb / (NF * nrb);
+    const int g = lane >> 4, s = f % 5;
+    const int tp = 2 * s + (g >> 1), c = half * 16 + (g & 1) * 8 + e;
+    int m = rb * 16 + (lane & 15), dxi;
+    bool live = tp < 9;
+    if (co8) {
+      if (f < 5) { dxi = (lane & 15) < 8 ? 1 : 0; m = rb * 16 + ((lane & 15) & 7); }        // rows 0-7: dx = 0; rows 8-15: dx = -1
+      else { dxi = 2; live = live && (lane & 15) < 8; }                                       // rows 0-7: dx = +1; rows 8-15: zero
+    } else {
+      dxi = f / 5;
+    }
+    const int tap = dxi * 9 + tp;
+    float val = 0.f;
+    if (live && m < rows) val = dgrad ? w[((size_t)c * Cin + m) * 27 + (26 - tap)] : w[((size_t)m * Cin + c) * 27 + tap];
+    unsigned u = __float_as_uint(val);
+    unsigned hu = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    const float rem = val - __uint_as_float(hu << 16);
+    unsigned r = __float_as_uint(rem);
+    unsigned lu = (r + 0x7fffu + ((r >> 16) & 1u)) >> 16;
+    wp[((size_t)(((half * nrb + rb) * NF + f) * 2) * 64 + lane) * 8 + e] = (unsigned short)hu;
+    wp[((size_t)(((half * nrb + rb) * NF + f) * 2 + 1) * 64 + lane) * 8 + e] = (unsigned short)lu;
+  }
+}
+
 // ================================================================================================ host side
 static bool vox_geometry_ok(const muvo_conv_desc* d) {
   if (d->nd != 3 || d->transposed) return false;
@@ -1143,11 +1384,25 @@ bool vox_bf3_shape_ok(const muvo_conv_desc* d, int dgrad) {
 }
 static int vox_bf3_steps(int ck) { return ck == 8 ? 7 : 14; }      // per pass
 long vox_pack_floats(const muvo_conv_desc* d) {
-  const long plain = 27l * d->Cin * d->Cout, bf3 = 14l * 2 * 64 * 4 * 4;   // bf16x3 layout: (halves x row blocks <= 4) x steps x (hi, lo) x 64 lanes x 16 B
+  const long plain = 27l * d->Cin * d->Cout, bf3 = 15l * 2 * 64 * 4 * 4;      // (plane-streaming form: 15 fragments per row block)   // bf16x3 layout: (halves x row blocks <= 4) x steps x (hi, lo) x 64 lanes x 16 B
   return plain > bf3 ? plain : bf3;
 }
 
+// plane-streaming form (vox_bf3_ps_kernel): 16 reduction channels per pass (16, or 32 as two passes), any produced count
+static bool vox_bf3_ps(int red, int cp) {
+  static const int on = getenv("MUVO_VOX_PS") ? atoi(getenv("MUVO_VOX_PS")) : 1;
+  return on && (red == 16 || red == 32) && (cp == 8 || cp == 16 || cp == 32);
+}
+
 int vox_pack(const muvo_conv_desc* d, const float* w, float* wp, int dgrad, hipStream_t st, bool bf3) {
+  if (bf3 && vox_bf3_ps(dgrad ? d->Cout : d->Cin, dgrad ? d->Cin : d->Cout)) {
+    const int red = dgrad ? d->Cout : d->Cin, cp = dgrad ? d->Cin : d->Cout;
+    const int co8 = cp <= 8 ? 1 : 0;
+    hipLaunchKernelGGL(vox_bf3_ps_pack_kernel, dim3(cdiv((red / 16) * cdiv(cp, 16) * (co8 ? 10 : 15) * 512, 256)), dim3(256), 0, st, w,
+                       (unsigned short*)wp, d->Cin, d->Cout, dgrad, co8);
+    MUVO_CHECK_LAUNCH("vox_bf3_ps_pack_kernel");
+    return MUVO_OK;
+  }
   if (bf3 && vox_bf3_two_rows(dgrad ? d->Cout : d->Cin, dgrad ? d->Cin : d->Cout)) {      // two-row variant
     hipLaunchKernelGGL(vox_bf3_pack2_kernel, dim3(36), dim3(256), 0, st, w, (unsigned short*)wp, d->Cin, d->Cout, dgrad);
     MUVO_CHECK_LAUNCH("vox_bf3_pack2_kernel");
@@ -1273,10 +1528,63 @@ static int launch_vox_bf3_2row(const muvo_conv_desc* d, const float* in, const f
   return MUVO_OK;
 }
 
+template <int Z, bool CO8>
+static int launch_vox_bf3_ps(const muvo_conv_desc* d, int Cout, const float* in, const float* wp, const float* bias, float* out, int act,
+                             float slope, hipStream_t st, int cin_total, int accum, double* moments) {
+  constexpr int TY = 8;
+  VoxArgs a{};
+  a.xcd_order = vox_xcd_order();
+  a.aff = t_vox_aff;
+  a.moments = moments;
+  a.N = d->N; a.Cin = 16; a.Cout = Cout; a.X = d->in_sz[0]; a.Y = d->in_sz[1];
+  a.ytiles = cdiv(a.Y, TY);
+  a.xgroups = 0;
+  a.XYZ = a.X * a.Y * Z;
+  a.sN_in = (long)(cin_total ? cin_total : 16) * a.XYZ; a.sN_out = (long)Cout * a.XYZ;
+  int xseg = a.X;
+  while ((long)a.N * a.ytiles * cdiv(a.X, xseg) < vox_blocks_target(0) && xseg > 12) xseg = cdiv(xseg, 2);
+  constexpr size_t lds = (size_t)2 * 2 * 2 * (TY + 2) * (Z + 2) * 16;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)vox_bf3_ps_kernel<Z, TY, CO8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)vox_bf3_ps_kernel<Z, TY, CO8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      muvo_set_error("vox_bf3_ps: cannot raise the dynamic LDS limit to %zu bytes", lds);
+      return MUVO_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  const long blocks = (long)a.N * a.ytiles * cdiv(a.X, xseg);
+  const dim3 grid((unsigned)blocks, cdiv(Cout, 16));
+  if (accum || act > MUVO_ACT_LEAKY)
+    hipLaunchKernelGGL((vox_bf3_ps_kernel<Z, TY, CO8, true>), grid, dim3(64 * TY), lds, st, a, in, (const vu32x4*)wp, bias, out, act, slope, xseg, accum);
+  else
+    hipLaunchKernelGGL((vox_bf3_ps_kernel<Z, TY, CO8, false>), grid, dim3(64 * TY), lds, st, a, in, (const vu32x4*)wp, bias, out, act, slope, xseg, 0);
+  MUVO_CHECK_LAUNCH("vox_bf3_ps_kernel");
+  return MUVO_OK;
+}
+static int launch_vox_bf3_ps_z(const muvo_conv_desc* d, int Cout, const float* in, const float* wp, const float* bias, float* out, int act,
+                               float slope, hipStream_t st, int cin_total, int accum, double* moments) {
+  const int Z = d->in_sz[2];
+  if (Cout <= 8) return Z == 64 ? launch_vox_bf3_ps<64, true>(d, Cout, in, wp, bias, out, act, slope, st, cin_total, accum, moments)
+                                : launch_vox_bf3_ps<32, true>(d, Cout, in, wp, bias, out, act, slope, st, cin_total, accum, moments);
+  return Z == 64 ? launch_vox_bf3_ps<64, false>(d, Cout, in, wp, bias, out, act, slope, st, cin_total, accum, moments)
+                 : launch_vox_bf3_ps<32, false>(d, Cout, in, wp, bias, out, act, slope, st, cin_total, accum, moments);
+}
+
 static int vox_conv_dispatch(const muvo_conv_desc* d, int Cin, int Cout, const float* in, const float* wp, const float* bias,
                              float* out, int act, float slope, hipStream_t st, bool bf3, double* moments = nullptr) {
   if (moments && !bf3) { muvo_set_error("vox_conv: output moments need the bf16x3 kernels"); return MUVO_ERR_INVALID_ARG; }
   const int Z = d->in_sz[2];
+  if (bf3 && vox_bf3_ps(Cin, Cout)) {
+    if (Cin == 32) {        // two accumulating passes over 16 reduction channels each; bias and activation ride on the second
+      const long XYZ = (long)d->in_sz[0] * d->in_sz[1] * Z;
+      const float* wp2 = wp + (size_t)cdiv(Cout, 16) * (Cout <= 8 ? 10 : 15) * 2 * 64 * 4;
+      int rc = launch_vox_bf3_ps_z(d, Cout, in, wp, nullptr, out, MUVO_ACT_NONE, 0.f, st, 32, 0, nullptr);
+      if (rc) return rc;
+      return launch_vox_bf3_ps_z(d, Cout, in + 16 * XYZ, wp2, bias, out, act, slope, st, 32, 1, moments);
+    }
+    return launch_vox_bf3_ps_z(d, Cout, in, wp, bias, out, act, slope, st, 0, 0, moments);
+  }
   if (bf3 && vox_bf3_two_rows(Cin, Cout)) {
     if (Cin == 8) return Z == 64 ? launch_vox_bf3_2row<64, 8>(d, in, wp, bias, out, act, slope, st, moments)
                                  : launch_vox_bf3_2row<32, 8>(d, in, wp, bias, out, act, slope, st, moments);
