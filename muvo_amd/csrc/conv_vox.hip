@@ -1098,6 +1098,256 @@ vox_bf3_wgrad_kernel(const VoxArgs a, const float* __restrict__ x, const float* 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Plane-streaming weight gradient.  Ablations of vox_bf3_wgrad_kernel on the 16 -> 8 layer (2.19 ms): without its MFMAs 2.08 ms,
+// without the staging inside the plane loop 1.52, without the B-fragment reads 1.69 - the matrix pipe is ~25 % busy and the
+// loop is bound by LDS reads, staging and their waits.  Here every x plane is read from LDS ONCE per wave instead of three times:
+//   dW[dx][dy][dz] += dzp[p] * x[p + dx]   <=>   x plane P meets dz plane P + 1 (tap dx = -1), P (0) and P - 1 (+1),
+// so a wave keeps the A fragments (dz, bf16 hi / lo) of three consecutive planes in registers, reads the three B rows
+// (dy = -1, 0, +1) of plane P and issues the MFMAs of all nine (dx, dy) combinations from them: 6 + 6 LDS reads per wave and
+// plane instead of 18 + 18, a third of the v_alignbyte work, two x planes in LDS instead of four.  The A fragments never pass
+// through LDS: a lane's eight voxels of its dz channel are 32 contiguous bytes, loaded one plane ahead and split in registers
+// (the dz staging, its LDS ring and the LDS atomics of the bias sums are gone; the bias sums live in a register per lane).
+// The loop runs over the x planes xs - 1 .. xe (two more iterations than output planes; segments are long, see
+// vox_blocks_target), MFMA groups whose dz plane lies outside the segment are skipped by uniform branches.
+// CI = 8 (8 -> 8 channels): one tile per (dx, dy) combination holds all three z taps - MFMA rows 8-15 are the dz channels
+// shifted by one voxel (as CO8 above), columns 8-15 the x channels shifted by one voxel: quadrant (rows a, columns b) is the
+// tap b - a, i.e. 0, -1, +1 and a discarded duplicate of 0: 27 MFMAs per 32 voxels instead of 30, 9 accumulator tiles.
+// ------------------------------------------------------------------------------------------------
+template <int Z, int CI, bool CO8>
+__global__ void __launch_bounds__(512)
+vox_bf3_wgrad_ps_kernel(const VoxArgs a, const float* __restrict__ x, const float* __restrict__ dz, float* __restrict__ dw,
+                        float* __restrict__ dbias, int xseg) {
+  static_assert(CI == 16 || CO8, "8 input channels: the quadrant tiles hold 8 produced channels");
+  constexpr bool QUAD = CI == 8;
+  constexpr int ZH = Z / 32, WROWS = 8 / ZH, ROWS = WROWS + 2;
+  constexpr int XROW = (Z + 16) * 2;                    // bytes of an x row: 16-byte zero pad on both sides
+  constexpr int XCI = ROWS * XROW + 16;                 // channel stride (bytes), +16 spreads the channels over all banks
+  constexpr int XHL = CI * XCI, XSLOT = 2 * XHL;
+  constexpr int XT = CI * ROWS * (Z / 8), XPT = (XT + 511) / 512;
+  constexpr int TPC = QUAD ? 1 : (CO8 ? 2 : 3), NT = 9 * TPC;
+  static_assert(XPT <= 2, "staging pieces: one per dy group, then the loads");
+  static_assert(2 * XSLOT >= NT * 1024, "the reduction reuses the x planes");
+  extern __shared__ char wsm[];
+  char* xring = wsm;                                    // two x planes: one read by the MFMA phase, one being staged
+  float* dbsum = (float*)(wsm + 2 * XSLOT);             // 16 floats
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nseg = (a.X + xseg - 1) / xseg;
+  int bid = a.xcd_order ? xcd_swizzle(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int seg = bid % nseg; bid /= nseg;
+  const int ytile = bid % a.ytiles, n = bid / a.ytiles;
+  const int y0 = ytile * WROWS, xs = seg * xseg, xe = xs + xseg < a.X ? xs + xseg : a.X;
+  const int ci0 = blockIdx.y * CI;
+  const long YZ = (long)a.Y * Z;
+  const float* xb = x + (long)n * a.sN_in + (long)ci0 * a.XYZ;
+  const float* db = dz + (long)n * a.sN_out;
+  for (int i = tid; i < (2 * XSLOT + 64) / 16; i += 512) ((uint4*)wsm)[i] = uint4{0u, 0u, 0u, 0u};
+  __syncthreads();
+
+  constexpr unsigned OOB = 0x7fffff00u;
+  const int nci = a.Cin - ci0 < CI ? a.Cin - ci0 : CI;
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (int)((long)nci * a.XYZ * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)db, 0, (int)((long)a.Cout * a.XYZ * 4), 0x00020000);
+  // ---- x staging (all waves): tasks of 8 voxels, loaded one plane before they are split and stored
+  vu32x4 xraw[XPT][2];
+  unsigned xok = 0u;
+  float xas[XPT], xab[XPT];
+  int xlds[XPT];                                        // LDS byte offset of task k inside a slot (-1: no task)
+  long xg[XPT];                                         // element offset of task k inside plane 0
+  bool xrow_ok[XPT];
+#pragma unroll
+  for (int k = 0; k < XPT; ++k) {
+    const int t = tid + k * 512;
+    const int z8 = t % (Z / 8), rr = (t / (Z / 8)) % ROWS, ci = t / ((Z / 8) * ROWS);
+    const int gy = y0 - 1 + rr;
+    const bool have = a.aff != nullptr && t < XT && ci0 + ci < a.Cin;
+    xas[k] = have ? a.aff[((long)n * a.Cin + ci0 + ci) * 2] : 1.f;
+    xab[k] = have ? a.aff[((long)n * a.Cin + ci0 + ci) * 2 + 1] : 0.f;
+    xlds[k] = t < XT ? ci * XCI + rr * XROW + 16 + z8 * 16 : -1;
+    xrow_ok[k] = t < XT && gy >= 0 && gy < a.Y;
+    xg[k] = (long)ci * a.XYZ + (long)gy * Z + z8 * 8;
+  }
+  auto xload = [&](int px) {
+#pragma unroll
+    for (int k = 0; k < XPT; ++k) {
+      const bool ok = xrow_ok[k] && px >= 0 && px < a.X;
+      xok = k == 0 ? (unsigned)ok : xok | ((unsigned)ok << k);
+      const unsigned off = ok ? (unsigned)((xg[k] + (long)px * YZ) * 4) : OOB;     // channels past Cin: range check of rs_x
+      xraw[k][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
+      xraw[k][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off + 16u, 0, 0);
+    }
+  };
+  auto split8 = [&](const float (&v)[8], vu32x4& h, vu32x4& l) {
+    unsigned hh[4], ll[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) vox_split2(v[2 * q], v[2 * q + 1], hh[q], ll[q]);
+    h = vu32x4{hh[0], hh[1], hh[2], hh[3]};
+    l = vu32x4{ll[0], ll[1], ll[2], ll[3]};
+  };
+  auto xstore_task = [&](int k, int slot) {
+    if (xlds[k] < 0) return;
+    float v[8] = {__uint_as_float(xraw[k][0].x), __uint_as_float(xraw[k][0].y), __uint_as_float(xraw[k][0].z), __uint_as_float(xraw[k][0].w),
+                  __uint_as_float(xraw[k][1].x), __uint_as_float(xraw[k][1].y), __uint_as_float(xraw[k][1].z), __uint_as_float(xraw[k][1].w)};
+    if (a.aff) {        // (uniform) the operand is scale * x + shift of the producing layer's AdaIN; padding stays zero
+      const bool ok = (xok >> k) & 1u;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = ok ? v[e] * xas[k] + xab[k] : 0.f;
+    }
+    vu32x4 h, l;
+    split8(v, h, l);
+    char* dst = xring + slot * XSLOT + xlds[k];
+    *(vu32x4*)dst = h;
+    *(vu32x4*)(dst + XHL) = l;
+  };
+
+  // ---- A side: this lane's dz entry (channel co, 8 voxels of the wave's row / z half), straight from global memory
+  const int row = wave / ZH, z0 = (wave % ZH) * 32;
+  const int j = lane & 15, kg = lane >> 4;
+  const int aco = CO8 ? (j & 7) : j;
+  const bool a_shift = CO8 && j >= 8;                   // rows 8-15: the same channels, one voxel further along z
+  const bool a_last = z0 + kg * 8 + 8 >= Z;
+  const bool a_ok = y0 + row < a.Y && aco < a.Cout;
+  const long a_g = (long)aco * a.XYZ + (long)(y0 + row) * Z + z0 + kg * 8;
+  vu32x4 araw[2];
+  unsigned anext = 0u;
+  auto aload = [&](int px) {
+    const bool ok = a_ok && px >= xs && px < xe;
+    const unsigned off = ok ? (unsigned)((a_g + (long)px * YZ) * 4) : OOB;
+    araw[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_d, off, 0, 0);
+    araw[1] = __builtin_amdgcn_raw_buffer_load_b128(rs_d, off + 16u, 0, 0);
+    if constexpr (CO8) anext = __builtin_amdgcn_raw_buffer_load_b32(rs_d, ok && !a_last ? off + 32u : OOB, 0, 0);
+  };
+  float dbacc = 0.f;
+  auto asplit = [&](vu32x4& h, vu32x4& l) {
+    float v[8] = {__uint_as_float(araw[0].x), __uint_as_float(araw[0].y), __uint_as_float(araw[0].z), __uint_as_float(araw[0].w),
+                  __uint_as_float(araw[1].x), __uint_as_float(araw[1].y), __uint_as_float(araw[1].z), __uint_as_float(araw[1].w)};
+    dbacc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    if constexpr (CO8) {
+      const float nx = __uint_as_float(anext);
+#pragma unroll
+      for (int e = 0; e < 7; ++e) v[e] = a_shift ? v[e + 1] : v[e];
+      v[7] = a_shift ? nx : v[7];
+    }
+    split8(v, h, l);
+  };
+
+  vf32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = vf32x4{0.f, 0.f, 0.f, 0.f};
+  const int b_off = (j & (CI - 1)) * XCI + 16 + (z0 + kg * 8) * 2;      // B: columns -> channel j & (CI - 1)
+  const bool b_shift = QUAD && j >= 8;                                  // QUAD columns 8-15: x one voxel further along z
+  vu32x4 Ah[3] = {}, Al[3] = {};                        // index d = dx + 1: dz plane P + 1 - d
+
+  const int niter = xe - xs + 2;
+  xload(xs - 1);
+#pragma unroll
+  for (int k = 0; k < XPT; ++k) xstore_task(k, 0);
+  xload(xs);
+  aload(xs);
+  __syncthreads();
+  for (int it = 0; it < niter; ++it) {
+    const int P = xs - 1 + it;
+    Ah[2] = Ah[1]; Al[2] = Al[1]; Ah[1] = Ah[0]; Al[1] = Al[0];
+    asplit(Ah[0], Al[0]);                               // dz plane P + 1 (zeros past the segment)
+    aload(P + 2);
+    const bool xin = P >= 0 && P < a.X;
+    const bool dok[3] = {it < niter - 2, it >= 1 && it < niter - 1, it >= 2};
+    const char* S = xring + (it & 1) * XSLOT + b_off + row * XROW;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      if (xin) {
+        const char* R = S + dy * XROW;                  // source row = row + 1 + (dy - 1)
+        vbf16x8 bm[2], bz[2], bp[2];
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl) {
+          const vu32x4 q = *(const vu32x4*)(R + hl * XHL);
+          const unsigned nw = *(const unsigned*)(R + hl * XHL + 16);
+          const vu32x4 pl = {__builtin_amdgcn_alignbyte(q.y, q.x, 2), __builtin_amdgcn_alignbyte(q.z, q.y, 2),
+                             __builtin_amdgcn_alignbyte(q.w, q.z, 2), __builtin_amdgcn_alignbyte(nw, q.w, 2)};
+          if constexpr (QUAD) {
+            const vu32x4 sel = {b_shift ? pl.x : q.x, b_shift ? pl.y : q.y, b_shift ? pl.z : q.z, b_shift ? pl.w : q.w};
+            bz[hl] = __builtin_bit_cast(vbf16x8, sel);
+          } else {
+            bz[hl] = __builtin_bit_cast(vbf16x8, q);
+            bp[hl] = __builtin_bit_cast(vbf16x8, pl);
+            if constexpr (!CO8) {
+              const unsigned pw = *(const unsigned*)(R + hl * XHL - 4);
+              const vu32x4 m = {__builtin_amdgcn_alignbyte(q.x, pw, 2), __builtin_amdgcn_alignbyte(q.y, q.x, 2),
+                                __builtin_amdgcn_alignbyte(q.z, q.y, 2), __builtin_amdgcn_alignbyte(q.w, q.z, 2)};
+              bm[hl] = __builtin_bit_cast(vbf16x8, m);
+            }
+          }
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          if (!dok[d]) continue;
+          const vbf16x8 ah = __builtin_bit_cast(vbf16x8, Ah[d]), al = __builtin_bit_cast(vbf16x8, Al[d]);
+          const int t0 = (d * 3 + dy) * TPC;
+          if constexpr (QUAD) {
+            acc[t0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bz[0], acc[t0], 0, 0, 0);
+            acc[t0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bz[1], acc[t0], 0, 0, 0);
+            acc[t0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bz[0], acc[t0], 0, 0, 0);
+          } else if constexpr (CO8) {
+            acc[t0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bz[0], acc[t0], 0, 0, 0);
+            acc[t0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bz[1], acc[t0], 0, 0, 0);
+            acc[t0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bz[0], acc[t0], 0, 0, 0);
+            acc[t0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bp[0], acc[t0 + 1], 0, 0, 0);
+            acc[t0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bp[1], acc[t0 + 1], 0, 0, 0);
+            acc[t0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bp[0], acc[t0 + 1], 0, 0, 0);
+          } else {
+            acc[t0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bm[0], acc[t0], 0, 0, 0);
+            acc[t0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[1], acc[t0], 0, 0, 0);
+            acc[t0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[0], acc[t0], 0, 0, 0);
+            acc[t0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bz[0], acc[t0 + 1], 0, 0, 0);
+            acc[t0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bz[1], acc[t0 + 1], 0, 0, 0);
+            acc[t0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bz[0], acc[t0 + 1], 0, 0, 0);
+            acc[t0 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bp[0], acc[t0 + 2], 0, 0, 0);
+            acc[t0 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bp[1], acc[t0 + 2], 0, 0, 0);
+            acc[t0 + 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bp[0], acc[t0 + 2], 0, 0, 0);
+          }
+        }
+      }
+      // staging of x plane P + 1 into the other slot between the MFMA groups, then the loads of plane P + 2
+      if (it + 1 < niter) {
+        if (dy < XPT) xstore_task(dy, (it + 1) & 1);
+        if (dy == 2 && it + 2 < niter) xload(P + 2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+  // bias sums: over the four z groups of the wave in registers, over the waves in LDS
+  dbacc += __shfl_xor(dbacc, 16, 64);
+  dbacc += __shfl_xor(dbacc, 32, 64);
+  if (blockIdx.y == 0 && dbias && kg == 0 && j < (CO8 ? 8 : 16)) atomicAdd(dbsum + j, dbacc);
+  // workgroup reduction of the accumulator tiles through LDS (the x planes are free now), then one set of atomics
+  float* red = (float*)wsm;                                             // [NT][16 rows][16 columns]
+  for (int i = tid; i < NT * 256; i += 512) red[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(red + (t * 16 + 4 * kg + r) * 16 + j, acc[t][r]);
+  __syncthreads();
+  for (int i = tid; i < NT * 256; i += 512) {
+    const int col = i & 15, t = i >> 8;
+    int co = (i >> 4) & 15, ci = col;
+    int tz = t % TPC;                                                   // z tap index 0..2 (dz + 1) of this tile
+    if (QUAD) {                                                         // quadrant (rows a, columns b): tap b - a
+      const int qa = co >> 3, qb = col >> 3;
+      tz = qa == 0 ? (qb == 0 ? 1 : 2) : (qb == 0 ? 0 : -1);
+      co &= 7; ci = col & 7;
+    } else if (CO8) {                                                   // tile 0: rows 0-7 tap 0, rows 8-15 tap -1; tile 1: rows 0-7 tap +1
+      tz = tz == 0 ? (co < 8 ? 1 : 0) : (co < 8 ? 2 : -1);
+      co &= 7;
+    }
+    const int tap = tz >= 0 ? (t / TPC) * 3 + tz : -1;
+    const float vsum = red[i];
+    if (tap >= 0 && co < a.Cout && ci0 + ci < a.Cin && vsum != 0.f) atomicAdd(dw + ((long)co * a.Cin + ci0 + ci) * 27 + tap, vsum);
+  }
+  if (blockIdx.y == 0 && dbias && tid < a.Cout) atomicAdd(dbias + tid, dbsum[tid]);
+}
+
+// ------------------------------------------------------------------------------------------------
 // 8 -> 8 channels: two output rows per MFMA.  With 8 produced channels half of the 16 MFMA rows would idle; instead rows
 // 0-7 hold the channels of output row y and rows 8-15 those of row y + 1.  Both read the same four input rows
 // (y - 1 .. y + 2), so K runs over the 36 "super taps" (dx, ry in 0..3, dz) x 8 channels = 9 steps of 32, with zero
@@ -1698,6 +1948,34 @@ static int launch_vox_bf3_wgrad(const muvo_conv_desc* d, const float* x, const f
   return MUVO_OK;
 }
 
+template <int Z, int CI, bool CO8>
+static int launch_vox_bf3_wgrad_ps(const muvo_conv_desc* d, const float* x, const float* dz, float* dw, float* dbias, hipStream_t st) {
+  constexpr int ZH = Z / 32, WROWS = 8 / ZH, ROWS = WROWS + 2;
+  constexpr size_t lds = (size_t)2 * 2 * CI * (ROWS * (Z + 16) * 2 + 16) + 64;
+  VoxArgs a{};
+  a.xcd_order = vox_xcd_order();
+  a.aff = t_vox_aff;
+  a.N = d->N; a.Cin = d->Cin; a.Cout = d->Cout; a.X = d->in_sz[0]; a.Y = d->in_sz[1];
+  a.ytiles = cdiv(a.Y, WROWS);
+  a.xgroups = 0;
+  a.XYZ = a.X * a.Y * Z;
+  a.sN_in = (long)a.Cin * a.XYZ; a.sN_out = (long)a.Cout * a.XYZ;
+  int xseg = a.X;
+  while ((long)a.N * a.ytiles * cdiv(a.X, xseg) * (a.Cin / CI) < vox_blocks_target(1) && xseg > 12) xseg = cdiv(xseg, 2);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)vox_bf3_wgrad_ps_kernel<Z, CI, CO8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      muvo_set_error("vox_bf3_wgrad_ps: cannot raise the dynamic LDS limit to %zu bytes", lds);
+      return MUVO_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  dim3 grid((unsigned)((long)a.N * a.ytiles * cdiv(a.X, xseg)), a.Cin / CI);
+  hipLaunchKernelGGL((vox_bf3_wgrad_ps_kernel<Z, CI, CO8>), grid, dim3(512), lds, st, a, x, dz, dw, dbias, xseg);
+  MUVO_CHECK_LAUNCH("vox_bf3_wgrad_ps_kernel");
+  return MUVO_OK;
+}
+
 int vox_wgrad(const muvo_conv_desc* d, const float* x, const float* dz, float* dw, float* dbias, hipStream_t st, bool bf3,
               const float* aff) {
   if (aff && !vox_affine_ok(d)) { muvo_set_error("vox_wgrad: no affine staging for this shape"); return MUVO_ERR_INVALID_ARG; }
@@ -1708,6 +1986,13 @@ int vox_wgrad(const muvo_conv_desc* d, const float* x, const float* dz, float* d
     // <= 8 produced channels: the idle half of the MFMA rows carries a second z tap (MUVO_VOX_WGRAD_CO8=0: padded rows, for A/B)
     static const bool co8_on = !(getenv("MUVO_VOX_WGRAD_CO8") && atoi(getenv("MUVO_VOX_WGRAD_CO8")) == 0);
     const bool co8 = d->Cout <= 8 && co8_on;
+    // plane-streaming variant (MUVO_VOX_WGRAD_PS=0: the four-plane ring kernels, for A/B)
+    static const bool ps_on = !(getenv("MUVO_VOX_WGRAD_PS") && atoi(getenv("MUVO_VOX_WGRAD_PS")) == 0);
+    if (ps_on && (d->Cin != 8 || co8)) {
+      if (d->Cin == 8) return Z == 64 ? launch_vox_bf3_wgrad_ps<64, 8, true>(d, x, dz, dw, dbias, st) : launch_vox_bf3_wgrad_ps<32, 8, true>(d, x, dz, dw, dbias, st);
+      if (Z == 64) return co8 ? launch_vox_bf3_wgrad_ps<64, 16, true>(d, x, dz, dw, dbias, st) : launch_vox_bf3_wgrad_ps<64, 16, false>(d, x, dz, dw, dbias, st);
+      return co8 ? launch_vox_bf3_wgrad_ps<32, 16, true>(d, x, dz, dw, dbias, st) : launch_vox_bf3_wgrad_ps<32, 16, false>(d, x, dz, dw, dbias, st);
+    }
     if (d->Cin == 8) {
       if (Z == 64) return co8 ? launch_vox_bf3_wgrad<64, 8, true>(d, x, dz, dw, dbias, st) : launch_vox_bf3_wgrad<64, 8, false>(d, x, dz, dw, dbias, st);
       return co8 ? launch_vox_bf3_wgrad<32, 8, true>(d, x, dz, dw, dbias, st) : launch_vox_bf3_wgrad<32, 8, false>(d, x, dz, dw, dbias, st);
