@@ -1113,6 +1113,9 @@ vox_bf3_wgrad_kernel(const VoxArgs a, const float* __restrict__ x, const float* 
 // shifted by one voxel (as CO8 above), columns 8-15 the x channels shifted by one voxel: quadrant (rows a, columns b) is the
 // tap b - a, i.e. 0, -1, +1 and a discarded duplicate of 0: 27 MFMAs per 32 voxels instead of 30, 9 accumulator tiles.
 // ------------------------------------------------------------------------------------------------
+#ifndef VOX_WGPS_SCHED
+#define VOX_WGPS_SCHED 1     // A/B: staging pieces pinned between the MFMA groups
+#endif
 template <int Z, int CI, bool CO8>
 __global__ void __launch_bounds__(512)
 vox_bf3_wgrad_ps_kernel(const VoxArgs a, const float* __restrict__ x, const float* __restrict__ dz, float* __restrict__ dw,
@@ -1166,15 +1169,16 @@ vox_bf3_wgrad_ps_kernel(const VoxArgs a, const float* __restrict__ x, const floa
     xrow_ok[k] = t < XT && gy >= 0 && gy < a.Y;
     xg[k] = (long)ci * a.XYZ + (long)gy * Z + z8 * 8;
   }
+  auto xload_task = [&](int k, int px) {
+    const bool ok = xrow_ok[k] && px >= 0 && px < a.X;
+    xok = (xok & ~(1u << k)) | ((unsigned)ok << k);
+    const unsigned off = ok ? (unsigned)((xg[k] + (long)px * YZ) * 4) : OOB;     // channels past Cin: range check of rs_x
+    xraw[k][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
+    xraw[k][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off + 16u, 0, 0);
+  };
   auto xload = [&](int px) {
 #pragma unroll
-    for (int k = 0; k < XPT; ++k) {
-      const bool ok = xrow_ok[k] && px >= 0 && px < a.X;
-      xok = k == 0 ? (unsigned)ok : xok | ((unsigned)ok << k);
-      const unsigned off = ok ? (unsigned)((xg[k] + (long)px * YZ) * 4) : OOB;     // channels past Cin: range check of rs_x
-      xraw[k][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
-      xraw[k][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off + 16u, 0, 0);
-    }
+    for (int k = 0; k < XPT; ++k) xload_task(k, px);
   };
   auto split8 = [&](const float (&v)[8], vu32x4& h, vu32x4& l) {
     unsigned hh[4], ll[4];
@@ -1306,12 +1310,16 @@ vox_bf3_wgrad_ps_kernel(const VoxArgs a, const float* __restrict__ x, const floa
           }
         }
       }
-      // staging of x plane P + 1 into the other slot between the MFMA groups, then the loads of plane P + 2
-      if (it + 1 < niter) {
-        if (dy < XPT) xstore_task(dy, (it + 1) & 1);
-        if (dy == 2 && it + 2 < niter) xload(P + 2);
+      // staging of x plane P + 1 into the other slot between the MFMA groups; a task's registers take its piece of plane P + 2
+      // right after its store, so every load has a whole iteration (~2.5 us) to arrive (issued behind the last group it had a
+      // third of one, and the memory latency under load showed: no-staging / no-MFMA ablations 1.19 / 1.20 ms of 1.87)
+      if (dy < XPT && it + 1 < niter) {
+        xstore_task(dy, (it + 1) & 1);
+        if (it + 2 < niter) xload_task(dy, P + 2);
       }
+#if VOX_WGPS_SCHED
       __builtin_amdgcn_sched_barrier(0);
+#endif
     }
     __syncthreads();
   }
