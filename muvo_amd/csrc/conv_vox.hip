@@ -605,6 +605,9 @@ vox_bf3_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* __re
 // -> in-plane tap tp = 2 s + (lane >> 5) (= (dy + 1) * 3 + dz + 1; tp = 9: zero), channel ((lane >> 4) & 1) * 8 + e;
 // plain: f = dxi * 5 + s (dxi = dx + 1); CO8: f = s: rows 0-7 dx = 0, rows 8-15 dx = -1; f = 5 + s: rows 0-7 dx = +1, rows 8-15 zero.
 // ================================================================================================
+#ifndef VOX_PS_PIPE
+#define VOX_PS_PIPE 1       // A/B: staging interleaved with the MFMA groups
+#endif
 template <int Z, int TY, bool CO8, bool GENERIC>
 __global__ void __launch_bounds__(64 * TY)
 vox_bf3_ps_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* __restrict__ wp, const float* __restrict__ bias,
@@ -643,26 +646,26 @@ vox_bf3_ps_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* _
   }
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)inb, 0, (int)((long)CK * a.XYZ * 4), 0x00020000);
   const unsigned xyz4 = (unsigned)a.XYZ * 4u;
+  auto stage_load_task = [&](int k, int x) {
+    const int t = tid + k * 64 * TY;
+    const int z = t % Z, r = (t / Z) % ROWS, cg = t / (Z * ROWS);
+    const int gy = y0 - 1 + r;
+    const bool ok = t < NTASK && x >= 0 && x < a.X && gy >= 0 && gy < a.Y;
+    stg_ok = (stg_ok & ~(1u << k)) | ((unsigned)ok << k);
+    const unsigned off = ok ? (unsigned)(((long)(cg * 8) * a.XYZ + (long)x * YZ + (long)gy * Z + z) * 4) : 0x7fffff00u;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      stg[k][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in, off + (unsigned)e * xyz4, 0, 0));
+  };
   auto stage_load = [&](int x) {
 #pragma unroll
-    for (int k = 0; k < TPT; ++k) {
-      const int t = tid + k * 64 * TY;
-      const int z = t % Z, r = (t / Z) % ROWS, cg = t / (Z * ROWS);
-      const int gy = y0 - 1 + r;
-      const bool ok = t < NTASK && x >= 0 && x < a.X && gy >= 0 && gy < a.Y;
-      stg_ok = k == 0 ? (unsigned)ok : stg_ok | ((unsigned)ok << k);
-      const unsigned off = ok ? (unsigned)(((long)(cg * 8) * a.XYZ + (long)x * YZ + (long)gy * Z + z) * 4) : 0x7fffff00u;
-#pragma unroll
-      for (int e = 0; e < 8; ++e)
-        stg[k][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in, off + (unsigned)e * xyz4, 0, 0));
-    }
+    for (int k = 0; k < TPT; ++k) stage_load_task(k, x);
   };
-  auto stage_store = [&](int slot) {
+  auto stage_store_task = [&](int k, int slot) {
     vu32x4* P = vsm + slot * PLANE;
-#pragma unroll
-    for (int k = 0; k < TPT; ++k) {
+    {
       const int t = tid + k * 64 * TY;
-      if (t >= NTASK) continue;
+      if (t >= NTASK) return;
       const int z = t % Z, r = (t / Z) % ROWS, cg = t / (Z * ROWS);
       if (a.aff) {
         const bool ok = (stg_ok >> k) & 1u;
@@ -678,6 +681,10 @@ vox_bf3_ps_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* _
       P[(cg * ROWS + r) * COLS + z + 1] = vu32x4{h[0], h[1], h[2], h[3]};
       P[((CG + cg) * ROWS + r) * COLS + z + 1] = vu32x4{l[0], l[1], l[2], l[3]};
     }
+  };
+  auto stage_store = [&](int slot) {
+#pragma unroll
+    for (int k = 0; k < TPT; ++k) stage_store_task(k, slot);
   };
 
   const int v = lane & 15, g = lane >> 4;
@@ -709,8 +716,14 @@ vox_bf3_ps_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* _
   __syncthreads();
   const int gy = y0 + wave;
   for (int p = xs - 1; p <= xe; ++p) {
-    stage_store((p + 1) & 1);                 // plane p + 1 (in registers) -> the buffer last read while computing plane p - 1
-    if (p + 2 <= xe) stage_load(p + 2);       // lands while this plane is computed
+    // plane p + 1 (in registers) goes to the buffer last read while computing plane p - 1, one staging task behind each z tile's
+    // MFMA group (VOX_PS_PIPE; before: all of it ahead of the MFMA phase, with the matrix pipe idle); the task's registers take
+    // its piece of plane p + 2 right after the store
+    constexpr bool PIPE = VOX_PS_PIPE && (CO8 || Z == 32);    // 16 produced channels at Z = 64: 254 VGPRs already, the longer live ranges spill
+    if constexpr (!PIPE) {
+      stage_store((p + 1) & 1);
+      if (p + 2 <= xe) stage_load(p + 2);
+    }
     const vu32x4* P = vsm + (p & 1) * PLANE;
 #pragma unroll
     for (int zt = 0; zt < ZT; ++zt) {
@@ -735,6 +748,15 @@ vox_bf3_ps_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* _
             acc[j][zt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[f], bh, acc[j][zt], 0, 0, 0);
           }
         }
+      }
+      if constexpr (PIPE) {
+#pragma unroll
+        for (int k = 0; k < TPT; ++k)
+          if ((k < ZT ? k : ZT - 1) == zt) {
+            stage_store_task(k, (p + 1) & 1);
+            if (p + 2 <= xe) stage_load_task(k, p + 2);
+          }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     // output plane p - 1 is complete
