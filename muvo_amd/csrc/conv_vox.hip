@@ -608,8 +608,11 @@ vox_bf3_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* __re
 #ifndef VOX_PS_PIPE
 #define VOX_PS_PIPE 1       // A/B: staging interleaved with the MFMA groups
 #endif
+#ifndef VOX_PS_TY
+#define VOX_PS_TY 8      // A/B: output rows (= waves) per workgroup; 4: two independent workgroups per CU, 1.5x instead of 1.25x halo rows
+#endif
 template <int Z, int TY, bool CO8, bool GENERIC>
-__global__ void __launch_bounds__(64 * TY)
+__global__ void __launch_bounds__(64 * TY, TY <= 4 ? 2 : 1)
 vox_bf3_ps_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* __restrict__ wp, const float* __restrict__ bias,
                   float* __restrict__ out, int act, float slope, int xseg, int accum) {
   constexpr int CK = 16, CG = 2, PSTEPS = 5, ZT = Z / 16, NF = CO8 ? 2 * PSTEPS : 3 * PSTEPS, NACC = CO8 ? 2 : 3;
@@ -719,6 +722,27 @@ vox_bf3_ps_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* _
     // plane p + 1 (in registers) goes to the buffer last read while computing plane p - 1, one staging task behind each z tile's
     // MFMA group (VOX_PS_PIPE; before: all of it ahead of the MFMA phase, with the matrix pipe idle); the task's registers take
     // its piece of plane p + 2 right after the store
+    // accumulating second pass of a 32-channel reduction: the partial sums of output plane p - 1 are requested here and added
+    // after the MFMA phase (loaded inside the epilogue, every plane waited for them - and, vmcnt being in order, not for the
+    // staged loads behind them - with nothing else to do: 32 -> 16 forward 0.74 ms against 2 x 0.24 for its two halves)
+    constexpr bool ACC_PRE = GENERIC && (CO8 || Z == 32);
+    float accv[ZT][4];
+    if constexpr (ACC_PRE) {
+      if (accum) {
+        const int xo = p - 1;
+        const bool xok = xo >= xs && xo < xe;
+#pragma unroll
+        for (int zt = 0; zt < ZT; ++zt) {
+          const unsigned ooff = (unsigned)(((long)xo * YZ + (long)gy * Z + zt * 16 + v) * 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int co = co0 + 4 * g + i;
+            const bool ok = xok && gy < a.Y && co < a.Cout && (!CO8 || g < 2);
+            accv[zt][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_out, ok ? ooff + (unsigned)co * xyz4 : 0x7fffff00u, 0, 0));
+          }
+        }
+      }
+    }
     constexpr bool PIPE = VOX_PS_PIPE && (CO8 || Z == 32);    // 16 produced channels at Z = 64: 254 VGPRs already, the longer live ranges spill
     if constexpr (!PIPE) {
       stage_store((p + 1) & 1);
@@ -772,7 +796,8 @@ vox_bf3_ps_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* _
         const unsigned off = ok ? ooff + (unsigned)co * xyz4 : 0x7fffff00u;
         float r = acc[0][zt][i] + bv[i];
         if constexpr (GENERIC) {
-          if (accum) r += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_out, off, 0, 0));
+          if constexpr (ACC_PRE) { if (accum) r += accv[zt][i]; }
+          else if (accum) r += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_out, off, 0, 0));
           r = act_apply(r, act, slope);
         } else {
           r = vox_act_simple(r, act, slope);
@@ -1811,7 +1836,7 @@ static int launch_vox_bf3_2row(const muvo_conv_desc* d, const float* in, const f
 template <int Z, bool CO8>
 static int launch_vox_bf3_ps(const muvo_conv_desc* d, int Cout, const float* in, const float* wp, const float* bias, float* out, int act,
                              float slope, hipStream_t st, int cin_total, int accum, double* moments) {
-  constexpr int TY = 8;
+  constexpr int TY = VOX_PS_TY;
   VoxArgs a{};
   a.xcd_order = vox_xcd_order();
   a.aff = t_vox_aff;
