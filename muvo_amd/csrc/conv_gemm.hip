@@ -516,6 +516,8 @@ static bool vox_wgrad_uses_bf3(const muvo_conv_desc* d) {
   const double gflop = 2.0 * d->Cin * d->Cout * 27.0 * (double)d->in_sz[0] * d->in_sz[1] * d->in_sz[2] * 1e-9;
   return gflop >= bf3_wgrad_min_gflop();
 }
+// the voxel weight-gradient kernels take this shape: the fp32 / bf16x3 pair, or a shape only the plane-streaming bf16x3 kernel serves
+static bool vox_wgrad_ok(const muvo_conv_desc* d) { return vox_wgrad_applicable(d) || (vox_wgrad_ps_only(d) && vox_wgrad_uses_bf3(d)); }
 
 static void finish_phase(ConvPhase& g) {
   g.bf3 = 0;
@@ -911,7 +913,7 @@ int64_t muvo_conv_workspace_bytes(const muvo_conv_desc* d, int op) {
   ConvPlan pl;
   if (op >= 2) {  // weight gradient: split planes of x (op 2) and of dy (op 3)
     if (build_plan(d, &pl, 0, false)) return -1;
-    if (pw_applicable(d) || vox_wgrad_applicable(d) || !wgrad_uses_bf3(pl)) return 0;
+    if (pw_applicable(d) || vox_wgrad_ok(d) || !wgrad_uses_bf3(pl)) return 0;
     return op == 2 ? bf3_workspace_bytes(d->N, d->Cin, (long)d->in_sz[0] * d->in_sz[1] * d->in_sz[2])
                    : bf3_workspace_bytes(d->N, d->Cout, (long)d->out_sz[0] * d->out_sz[1] * d->out_sz[2]);
   }
@@ -933,7 +935,7 @@ int muvo_conv_kernel_family(const muvo_conv_desc* d, int op) {
   if (pw_applicable(d)) return 3;
   if (op == 2) {
     if (build_plan(d, &pl, 0, false)) return -1;
-    if (vox_wgrad_applicable(d)) return vox_wgrad_uses_bf3(d) ? 4 : 2;
+    if (vox_wgrad_ok(d)) return vox_wgrad_uses_bf3(d) ? 4 : 2;
     return wgrad_uses_bf3(pl) ? 1 : 0;
   }
   if (build_plan(d, &pl)) return -1;
@@ -1209,7 +1211,7 @@ int muvo_conv_wgrad(const muvo_conv_desc* d, const float* x, const float* dy, fl
   MUVO_CHECK_ARG(x && dy && dwp_scratch && dw, "conv_wgrad: null pointer");
   hipStream_t st = (hipStream_t)stream;
   if (pw_applicable(d)) return pw_wgrad(d, x, dy, dw, dbias, st);
-  if (vox_wgrad_applicable(d)) return vox_wgrad(d, x, dy, dw, dbias, st, vox_wgrad_uses_bf3(d));
+  if (vox_wgrad_ok(d)) return vox_wgrad(d, x, dy, dw, dbias, st, vox_wgrad_uses_bf3(d));
   const long S_out = (long)d->out_sz[0] * d->out_sz[1] * d->out_sz[2];
   if (wgrad_uses_bf3(pl)) {
     // the bf16x3 kernel understands merged sub-pixel phases (one GEMM with nmerge * Cout rows): use them when they exist

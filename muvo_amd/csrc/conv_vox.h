@@ -14,5 +14,6 @@ int vox_forward(const muvo_conv_desc* d, const float* x, const float* wp, const 
 bool vox_affine_ok(const muvo_conv_desc* d);   // forward / weight gradient can apply a per-(n, channel) scale / shift while staging
 int vox_dgrad(const muvo_conv_desc* d, const float* dy, const float* wp, float* dx, hipStream_t st, bool bf3);
 bool vox_bf3_wgrad_shape_ok(const muvo_conv_desc* d);
+bool vox_wgrad_ps_only(const muvo_conv_desc* d);      // shapes only the plane-streaming bf16x3 weight gradient serves (Z = 16, 32 produced channels)
 int vox_wgrad(const muvo_conv_desc* d, const float* x, const float* dz, float* dw, float* dbias, hipStream_t st, bool bf3,
               const float* aff = nullptr);

@@ -1169,7 +1169,8 @@ vox_bf3_wgrad_ps_kernel(const VoxArgs a, const float* __restrict__ x, const floa
                         float* __restrict__ dbias, int xseg) {
   static_assert(CI == 16 || CO8, "8 input channels: the quadrant tiles hold 8 produced channels");
   constexpr bool QUAD = CI == 8;
-  constexpr int ZH = Z / 32, WROWS = 8 / ZH, ROWS = WROWS + 2;
+  // Z >= 32: a wave = one output row x one 32-voxel part of the z line; Z = 16: a wave = two output rows (K = 2 x 16 voxels)
+  constexpr int ZH = Z >= 32 ? Z / 32 : 1, RW = Z >= 32 ? 1 : 32 / Z, WROWS = 8 / ZH * RW, ROWS = WROWS + 2;
   constexpr int XROW = (Z + 16) * 2;                    // bytes of an x row: 16-byte zero pad on both sides
   constexpr int XCI = ROWS * XROW + 16;                 // channel stride (bytes), +16 spreads the channels over all banks
   constexpr int XHL = CI * XCI, XSLOT = 2 * XHL;
@@ -1189,6 +1190,7 @@ vox_bf3_wgrad_ps_kernel(const VoxArgs a, const float* __restrict__ x, const floa
   const int ci0 = blockIdx.y * CI;
   const long YZ = (long)a.Y * Z;
   const float* xb = x + (long)n * a.sN_in + (long)ci0 * a.XYZ;
+  const int co_base = blockIdx.z * 16;                  // 32 produced channels: two row blocks
   const float* db = dz + (long)n * a.sN_out;
   for (int i = tid; i < (2 * XSLOT + 64) / 16; i += 512) ((uint4*)wsm)[i] = uint4{0u, 0u, 0u, 0u};
   __syncthreads();
@@ -1251,13 +1253,14 @@ vox_bf3_wgrad_ps_kernel(const VoxArgs a, const float* __restrict__ x, const floa
   };
 
   // ---- A side: this lane's dz entry (channel co, 8 voxels of the wave's row / z half), straight from global memory
-  const int row = wave / ZH, z0 = (wave % ZH) * 32;
   const int j = lane & 15, kg = lane >> 4;
-  const int aco = CO8 ? (j & 7) : j;
+  const int row = (wave / ZH) * RW + (Z >= 32 ? 0 : kg / (Z / 8));                  // this lane's output row inside the tile
+  const int zl = Z >= 32 ? (wave % ZH) * 32 + kg * 8 : (kg % (Z / 8)) * 8;          // the first of its eight voxels
+  const int aco = co_base + (CO8 ? (j & 7) : j);
   const bool a_shift = CO8 && j >= 8;                   // rows 8-15: the same channels, one voxel further along z
-  const bool a_last = z0 + kg * 8 + 8 >= Z;
+  const bool a_last = zl + 8 >= Z;
   const bool a_ok = y0 + row < a.Y && aco < a.Cout;
-  const long a_g = (long)aco * a.XYZ + (long)(y0 + row) * Z + z0 + kg * 8;
+  const long a_g = (long)aco * a.XYZ + (long)(y0 + row) * Z + zl;
   vu32x4 araw[2];
   unsigned anext = 0u;
   auto aload = [&](int px) {
@@ -1284,7 +1287,7 @@ vox_bf3_wgrad_ps_kernel(const VoxArgs a, const float* __restrict__ x, const floa
   vf32x4 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = vf32x4{0.f, 0.f, 0.f, 0.f};
-  const int b_off = (j & (CI - 1)) * XCI + 16 + (z0 + kg * 8) * 2;      // B: columns -> channel j & (CI - 1)
+  const int b_off = (j & (CI - 1)) * XCI + 16 + zl * 2;                 // B: columns -> channel j & (CI - 1)
   const bool b_shift = QUAD && j >= 8;                                  // QUAD columns 8-15: x one voxel further along z
   vu32x4 Ah[3] = {}, Al[3] = {};                        // index d = dx + 1: dz plane P + 1 - d
 
@@ -1373,7 +1376,7 @@ vox_bf3_wgrad_ps_kernel(const VoxArgs a, const float* __restrict__ x, const floa
   // bias sums: over the four z groups of the wave in registers, over the waves in LDS
   dbacc += __shfl_xor(dbacc, 16, 64);
   dbacc += __shfl_xor(dbacc, 32, 64);
-  if (blockIdx.y == 0 && dbias && kg == 0 && j < (CO8 ? 8 : 16)) atomicAdd(dbsum + j, dbacc);
+  if (blockIdx.y == 0 && dbias && kg == 0 && j < (CO8 ? 8 : 16)) atomicAdd(dbsum + j, dbacc);   // (Z = 16: both rows of the wave summed by the shuffles)
   // workgroup reduction of the accumulator tiles through LDS (the x planes are free now), then one set of atomics
   float* red = (float*)wsm;                                             // [NT][16 rows][16 columns]
   for (int i = tid; i < NT * 256; i += 512) red[i] = 0.f;
@@ -1397,9 +1400,10 @@ vox_bf3_wgrad_ps_kernel(const VoxArgs a, const float* __restrict__ x, const floa
     }
     const int tap = tz >= 0 ? (t / TPC) * 3 + tz : -1;
     const float vsum = red[i];
-    if (tap >= 0 && co < a.Cout && ci0 + ci < a.Cin && vsum != 0.f) atomicAdd(dw + ((long)co * a.Cin + ci0 + ci) * 27 + tap, vsum);
+    if (tap >= 0 && co_base + co < a.Cout && ci0 + ci < a.Cin && vsum != 0.f)
+      atomicAdd(dw + ((long)(co_base + co) * a.Cin + ci0 + ci) * 27 + tap, vsum);
   }
-  if (blockIdx.y == 0 && dbias && tid < a.Cout) atomicAdd(dbias + tid, dbsum[tid]);
+  if (blockIdx.y == 0 && dbias && tid < 16 && co_base + tid < a.Cout) atomicAdd(dbias + co_base + tid, dbsum[tid]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1656,12 +1660,12 @@ vox_bf3_ps_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__
 }
 
 // ================================================================================================ host side
-static bool vox_geometry_ok(const muvo_conv_desc* d) {
+static bool vox_geometry_ok(const muvo_conv_desc* d, bool z16 = false) {
   if (d->nd != 3 || d->transposed) return false;
   for (int a = 0; a < 3; ++a)
     if (d->ksz[a] != 3 || d->stride[a] != 1 || d->pad[a] != 1 || d->dil[a] != 1) return false;
   const int Z = d->in_sz[2];
-  if (Z != 64 && Z != 32) return false;
+  if (Z != 64 && Z != 32 && !(z16 && Z == 16)) return false;
   if (d->Cin % 4 || d->Cout % 4) return false;
   // one sample's tensor is addressed through a buffer descriptor with 32-bit byte offsets (0x7fffff00 = "out of range")
   if ((long)d->in_sz[0] * d->in_sz[1] * Z * (long)(d->Cin > d->Cout ? d->Cin : d->Cout) * 4 >= 0x7fffff00l) return false;
@@ -1969,7 +1973,19 @@ static int launch_vox_wgrad(const muvo_conv_desc* d, const float* x, const float
   return MUVO_OK;
 }
 
+static bool vox_wgrad_ps_on() {      // plane-streaming variant (MUVO_VOX_WGRAD_PS=0: the four-plane ring kernels, for A/B)
+  static const bool on = !(getenv("MUVO_VOX_WGRAD_PS") && atoi(getenv("MUVO_VOX_WGRAD_PS")) == 0);
+  return on;
+}
+// shapes only the plane-streaming bf16x3 weight-gradient kernel serves: z lines of 16 voxels (the 48 x 48 x 16 level of the voxel
+// decoder), 32 produced channels.  The generic bf16x3 weight gradient runs one workgroup per tap there, i.e. stages x and dz 27
+// times (0.71 ms for 64 -> 32, 0.60 for 32 -> 32 at 20 x 48 x 48 x 16).
+bool vox_wgrad_ps_only(const muvo_conv_desc* d) {
+  return vox_wgrad_ps_on() && vox_geometry_ok(d, true) && (d->in_sz[2] == 16 || d->Cout == 32) && d->Cin % 16 == 0 && d->Cin <= 64 &&
+         (d->Cout == 8 || d->Cout == 16 || d->Cout == 32);
+}
 bool vox_bf3_wgrad_shape_ok(const muvo_conv_desc* d) {
+  if (vox_wgrad_ps_only(d)) return true;
   return vox_wgrad_applicable(d) && (d->Cin == 8 || d->Cin % 16 == 0) && d->Cin <= 64 && (d->Cout == 8 || d->Cout == 16);
 }
 
@@ -2005,7 +2021,7 @@ static int launch_vox_bf3_wgrad(const muvo_conv_desc* d, const float* x, const f
 
 template <int Z, int CI, bool CO8>
 static int launch_vox_bf3_wgrad_ps(const muvo_conv_desc* d, const float* x, const float* dz, float* dw, float* dbias, hipStream_t st) {
-  constexpr int ZH = Z / 32, WROWS = 8 / ZH, ROWS = WROWS + 2;
+  constexpr int ZH = Z >= 32 ? Z / 32 : 1, RW = Z >= 32 ? 1 : 32 / Z, WROWS = 8 / ZH * RW, ROWS = WROWS + 2;
   constexpr size_t lds = (size_t)2 * 2 * CI * (ROWS * (Z + 16) * 2 + 16) + 64;
   VoxArgs a{};
   a.xcd_order = vox_xcd_order();
@@ -2016,7 +2032,7 @@ static int launch_vox_bf3_wgrad_ps(const muvo_conv_desc* d, const float* x, cons
   a.XYZ = a.X * a.Y * Z;
   a.sN_in = (long)a.Cin * a.XYZ; a.sN_out = (long)a.Cout * a.XYZ;
   int xseg = a.X;
-  while ((long)a.N * a.ytiles * cdiv(a.X, xseg) * (a.Cin / CI) < vox_blocks_target(1) && xseg > 12) xseg = cdiv(xseg, 2);
+  while ((long)a.N * a.ytiles * cdiv(a.X, xseg) * (a.Cin / CI) * cdiv(a.Cout, 16) < vox_blocks_target(1) && xseg > 12) xseg = cdiv(xseg, 2);
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)vox_bf3_wgrad_ps_kernel<Z, CI, CO8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -2025,7 +2041,7 @@ static int launch_vox_bf3_wgrad_ps(const muvo_conv_desc* d, const float* x, cons
     }
     attr_set = true;
   }
-  dim3 grid((unsigned)((long)a.N * a.ytiles * cdiv(a.X, xseg)), a.Cin / CI);
+  dim3 grid((unsigned)((long)a.N * a.ytiles * cdiv(a.X, xseg)), a.Cin / CI, cdiv(a.Cout, 16));
   hipLaunchKernelGGL((vox_bf3_wgrad_ps_kernel<Z, CI, CO8>), grid, dim3(512), lds, st, a, x, dz, dw, dbias, xseg);
   MUVO_CHECK_LAUNCH("vox_bf3_wgrad_ps_kernel");
   return MUVO_OK;
@@ -2041,8 +2057,11 @@ int vox_wgrad(const muvo_conv_desc* d, const float* x, const float* dz, float* d
     // <= 8 produced channels: the idle half of the MFMA rows carries a second z tap (MUVO_VOX_WGRAD_CO8=0: padded rows, for A/B)
     static const bool co8_on = !(getenv("MUVO_VOX_WGRAD_CO8") && atoi(getenv("MUVO_VOX_WGRAD_CO8")) == 0);
     const bool co8 = d->Cout <= 8 && co8_on;
-    // plane-streaming variant (MUVO_VOX_WGRAD_PS=0: the four-plane ring kernels, for A/B)
-    static const bool ps_on = !(getenv("MUVO_VOX_WGRAD_PS") && atoi(getenv("MUVO_VOX_WGRAD_PS")) == 0);
+    const bool ps_on = vox_wgrad_ps_on();
+    if (Z == 16) {
+      if (!vox_wgrad_ps_only(d)) { muvo_set_error("vox_wgrad: 16-voxel z lines need the plane-streaming kernel"); return MUVO_ERR_INVALID_ARG; }
+      return co8 ? launch_vox_bf3_wgrad_ps<16, 16, true>(d, x, dz, dw, dbias, st) : launch_vox_bf3_wgrad_ps<16, 16, false>(d, x, dz, dw, dbias, st);
+    }
     if (ps_on && (d->Cin != 8 || co8)) {
       if (d->Cin == 8) return Z == 64 ? launch_vox_bf3_wgrad_ps<64, 8, true>(d, x, dz, dw, dbias, st) : launch_vox_bf3_wgrad_ps<32, 8, true>(d, x, dz, dw, dbias, st);
       if (Z == 64) return co8 ? launch_vox_bf3_wgrad_ps<64, 16, true>(d, x, dz, dw, dbias, st) : launch_vox_bf3_wgrad_ps<64, 16, false>(d, x, dz, dw, dbias, st);

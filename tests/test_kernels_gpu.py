@@ -50,6 +50,12 @@ CONV_CASES = [
     (3, False, 16, 16, 3, 1, 1, 0, (6, 5, 64), False, 0),
     (3, False, 8, 8, 3, 1, 1, 0, (1, 1, 64), True, 0),
     (3, False, 16, 8, 3, 1, 1, 0, (19, 12, 32), True, 2),
+    # plane-streaming weight gradient only (conv_vox.hip vox_wgrad_ps_only): z lines of 16 voxels (two rows per wave), 32 produced
+    # channels as two row blocks; forward / data gradient stay on the implicit-GEMM kernels
+    (3, False, 64, 32, 3, 1, 1, 0, (5, 19, 16), True, 2),
+    (3, False, 32, 32, 3, 1, 1, 0, (4, 31, 16), True, 2),      # (at (4, 33, 16) one forward value lands on the other side of the LeakyReLU kink)
+    (3, False, 16, 8, 3, 1, 1, 0, (3, 16, 16), False, 0),
+    (3, False, 32, 32, 3, 1, 1, 0, (3, 7, 32), True, 2),
     # merged sub-pixel phases (ConvTranspose k6 s2 p2 with Cout % 32 == 0: the four phases run as one GEMM)
     (2, True, 48, 64, 6, 2, 2, 0, (7, 9), True, 3),
     (2, True, 64, 32, 6, 2, 2, 0, (5, 13), True, 3),

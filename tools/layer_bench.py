@@ -30,6 +30,8 @@ LAYERS = {
     'vox16b': ('conv3d', 16, 16, 3, 1, 1, (96, 96, 32)),
     'vox32': ('conv3d', 32, 16, 3, 1, 1, (96, 96, 32)),
     'vox64': ('conv3d', 64, 64, 3, 1, 1, (24, 24, 8)),
+    'vox64s': ('conv3d', 64, 32, 3, 1, 1, (48, 48, 16)),
+    'vox32s': ('conv3d', 32, 32, 3, 1, 1, (48, 48, 16)),
 }
 
 
