@@ -897,6 +897,68 @@ __global__ void __launch_bounds__(256) bf3_unpack_wgrad_kernel(const ConvPhase g
   }
 }
 
+// Tiled form: tile = TM rows x 32 channels x all T taps through LDS.  The scratch [t][m][c] is read (and cleared) in 128-byte runs
+// along c, dw is updated in runs along (c, tap) of a row (Conv) or (row, tap) of a channel (ConvTranspose).  The element-wise form
+// above follows the PyTorch layout, so a lane reads and clears 4 bytes of a scratch line M x C x 4 bytes away from its neighbour's
+// (1.45 ms per step over the 88 weight gradients).  LDS: TM x T x 33 floats (the launcher picks TM for <= 48 KB).
+__global__ void __launch_bounds__(256) bf3_unpack_wgrad_tiled_kernel(const ConvPhase g, float* __restrict__ wg, float* __restrict__ dw,
+                                                                     int TM) {
+  extern __shared__ float s_un[];
+  __shared__ int s_tw[8 * MAX_TAPS];
+  const int T = g.T, M = g.M, C = g.C, Msub = g.Msub, nmerge = g.nmerge;
+  for (int i = threadIdx.x; i < (nmerge > 1 ? nmerge * MAX_TAPS : T); i += 256)
+    s_tw[i] = nmerge > 1 ? g.tap_wm[i / MAX_TAPS][i % MAX_TAPS] : g.tap_w[i];
+  const int ctiles = (C + 31) / 32;
+  const int m0 = (blockIdx.x / ctiles) * TM, c0 = (blockIdx.x % ctiles) * 32;
+  float* base = wg + g.wp_off;
+  const int nel = TM * T * 32;
+  const unsigned inv_t = (1u << 20) / (unsigned)T + 1u;             // r / T for r < 2^20 / T, exact
+  constexpr int NB = 6;                                             // elements per lane and batch (all loads of a batch in flight)
+  for (int i0 = threadIdx.x; i0 < nel; i0 += NB * 256) {
+    float x[NB];
+    float* src[NB];
+    int dsto[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const int i = i0 + q * 256;
+      const int cl = i & 31, r = i >> 5;
+      const int ml = (int)(((unsigned)r * inv_t) >> 20), t = r - ml * T;
+      const int m = m0 + ml, c = c0 + cl;
+      const bool ok = i < nel && m < M && c < C;
+      src[q] = ok ? base + ((size_t)t * M + m) * C + c : nullptr;
+      dsto[q] = i < nel ? (ml * T + t) * 33 + cl : -1;
+      x[q] = ok ? *src[q] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      if (src[q]) *src[q] = 0.f;         // cleared as it is read: the scratch stays all-zero between weight gradients
+      if (dsto[q] >= 0) s_un[dsto[q]] = x[q];
+    }
+  }
+  __syncthreads();
+  const bool m_major = g.wsm > g.wsc;
+  const int ltm = 31 - __clz(TM);                                   // TM is a power of two
+  for (int i0 = threadIdx.x; i0 < nel; i0 += NB * 256) {
+    float x[NB];
+    float* dst[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const int i = i0 + q * 256;
+      const int r = (int)(((unsigned)i * inv_t) >> 20), t = i - r * T;
+      const int cl = m_major ? r & 31 : r >> ltm, ml = m_major ? r >> 5 : r & (TM - 1);
+      const int m = m0 + ml, c = c0 + cl;
+      const bool ok = i < nel && m < M && c < C;
+      const int grp = (ok && nmerge > 1) ? m / Msub : 0, co = ok ? m - grp * Msub : 0;
+      const int tw = ok ? s_tw[grp * MAX_TAPS + t] : -1;             // < 0: no such tap in this row group (union of tap sets)
+      dst[q] = tw >= 0 ? dw + (size_t)co * g.wsm + (size_t)c * g.wsc + tw : nullptr;
+      x[q] = tw >= 0 ? *dst[q] + s_un[(ml * T + t) * 33 + cl] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+      if (dst[q]) *dst[q] = x[q];
+  }
+}
+
 // fp32 NCHW [N][C][S] -> bf16 hi / lo planes, channels-last [N][S][Cp] (Cp = roundup(C, 8), zero padded).
 // Tile = 64 pixels x 64 channels through LDS: reads coalesced along pixels (each lane takes two adjacent channels of its
 // pixel so it stores one packed dword), writes one full 128-byte line per pixel and plane.  LDS rows are 33 dwords, which
@@ -1249,6 +1311,9 @@ __global__ void __launch_bounds__(256) bf3_pack_kernel(const ConvPhase g, const 
 // Batched weight packing: every packed copy is stale after an optimizer step, which used to mean ~290 pack launches of a
 // few microseconds each per training step.  A device-resident table (built once per set of plans) lists every phase with
 // its source and destination; ONE launch re-packs them all.  Workgroup b serves table item i with blk0[i] <= b < blk0[i+1].
+// 1.29 ms per step for 2 x 170 M elements = 2.8 GB moved (0.6 ms at the rate AdamW streams).  A tiled form (32 rows x 8 channels x
+// all taps through 38 KB of LDS, coalesced on both sides) measured 1.44 ms (round 4): the gather's lines are reused out of L2 /
+// MALL while its 234 k small workgroups keep far more loads in flight than four 38-KB workgroups per CU; dropped.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) pack_table_kernel(const PackItem* __restrict__ items, int n) {
   int lo = 0, hi = n - 1;
@@ -1640,6 +1705,19 @@ int bf3_wgrad_phase(const ConvPhase& g, const void* ws_x, int Cin_total, const v
                                    : bf3_wgrad_launch<64, 64, 1, 2, 2>(g, ws_x, Cin_total, ws_dz, Cout_total, wg, st);
   if (rc) return rc;
   const long total = (long)g.M * g.C * g.T;
+  static const int tiled = getenv("MUVO_UNPACK_TILED") ? atoi(getenv("MUVO_UNPACK_TILED")) : 1;     // A/B switch
+  if (tiled && total >= 4096) {
+    // LDS per workgroup: 6 KB fits next to a 147-KB convolution tile on the same CU (with 38-KB tiles the weight-gradient stream's
+    // unpack launches waited for whole CUs: 2.8 ms per step against 1.45 element-wise and 1.08 with 6 KB)
+    static const int lds_cap = getenv("MUVO_UNPACK_LDS") ? atoi(getenv("MUVO_UNPACK_LDS")) : 6 * 1024;
+    int TM = 64;
+    while (TM > 1 && (long)TM * g.T * 33 * 4 > lds_cap) TM >>= 1;
+    while (TM > 1 && TM / 2 >= g.M) TM >>= 1;
+    const long tiles = (long)cdiv(g.M, TM) * cdiv(g.C, 32);
+    hipLaunchKernelGGL(bf3_unpack_wgrad_tiled_kernel, dim3((unsigned)tiles), dim3(256), (size_t)TM * g.T * 33 * 4, st, g, wg, dw, TM);
+    MUVO_CHECK_LAUNCH("bf3_unpack_wgrad_tiled_kernel");
+    return MUVO_OK;
+  }
   // one element per thread (no grid-stride loop: its second iteration's loads would wait for the first iteration's stores)
   static const int unpack_cap = getenv("MUVO_UNPACK_GRID_CAP") ? atoi(getenv("MUVO_UNPACK_GRID_CAP")) : (1 << 22);
   const long ublocks = cdiv(total, 256);
