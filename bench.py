@@ -340,6 +340,12 @@ def main():
     if tr._reducer is not None:
         tr._reducer._steps_timed = []          # exchange timing: the timed steps only
         tr._reducer.host_s = 0.0
+    # no cyclic-GC pass inside the timed region: the host is at most ~0.4 steps ahead of the GPU (kernel-argument pool of the
+    # queue), so a generation-2 collection over the module / autograd objects (tens of ms) stalls the
+    # device; reference counting frees the step's tensors as before
+    import gc
+    gc.collect()
+    gc.disable()
     c0 = time.process_time()
     t0 = time.perf_counter()
     marks[0].record()
@@ -352,7 +358,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    gc.enable()
+    step_ms_seq = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    step_ms = sorted(step_ms_seq)
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     timing = ops.KERNEL_TIMING
     ops.KERNEL_TIMING = None
@@ -422,6 +430,7 @@ def main():
             'parity': ('pinned by reference fixtures (tests/golden)' if (args.workload == 'base_1d' and args.conv_mfma != 'bf16')
                        else 'unpinned (extension, own oracle only)'),
             'median_ms_per_step': median_ms, 'value_at_median': args.batch * world / (median_ms * 1e-3),
+            'step_ms': [round(v, 2) for v in step_ms_seq],     # rank 0's stream-side step times, in order (outliers are host stalls)
             'frames_per_s': samples * s / dt,
             'step_tflops_per_gpu': (GFLOP_PER_FRAME * frames_per_gpu_step / (ms * 1e-3) / 1e3) if args.workload == 'base_1d' else None,
             'final_loss': loss_val,
