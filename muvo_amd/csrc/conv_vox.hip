@@ -725,7 +725,7 @@ vox_bf3_ps_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* _
     // accumulating second pass of a 32-channel reduction: the partial sums of output plane p - 1 are requested here and added
     // after the MFMA phase (loaded inside the epilogue, every plane waited for them - and, vmcnt being in order, not for the
     // staged loads behind them - with nothing else to do: 32 -> 16 forward 0.74 ms against 2 x 0.24 for its two halves)
-    constexpr bool ACC_PRE = GENERIC && (CO8 || Z == 32);
+    constexpr bool ACC_PRE = GENERIC && (CO8 || Z <= 32);
     float accv[ZT][4];
     if constexpr (ACC_PRE) {
       if (accum) {
@@ -743,7 +743,7 @@ vox_bf3_ps_kernel(const VoxArgs a, const float* __restrict__ in, const vu32x4* _
         }
       }
     }
-    constexpr bool PIPE = VOX_PS_PIPE && (CO8 || Z == 32);    // 16 produced channels at Z = 64: 254 VGPRs already, the longer live ranges spill
+    constexpr bool PIPE = VOX_PS_PIPE && (CO8 || Z <= 32);    // 16 produced channels at Z = 64: 254 VGPRs already, the longer live ranges spill
     if constexpr (!PIPE) {
       stage_store((p + 1) & 1);
       if (p + 2 <= xe) stage_load(p + 2);
@@ -1684,23 +1684,32 @@ bool vox_wgrad_applicable(const muvo_conv_desc* d) {
 // (with 16 reduction channels the 18 weight steps push the kernel to one wave per SIMD and it loses: measured 3.05 vs 2.81 ms)
 static bool vox_bf3_two_rows(int ck, int cp) { return cp == 8 && ck == 8; }
 // bf16x3 variant: reduction and produced channels in {8, 16}
+static bool vox_bf3_ps(int red, int cp);
 bool vox_bf3_shape_ok(const muvo_conv_desc* d, int dgrad) {
-  if (!vox_geometry_ok(d)) return false;
   const int ck = dgrad ? d->Cout : d->Cin, cp = dgrad ? d->Cin : d->Cout;
+  // the plane-streaming kernels alone: z lines of 16 voxels (the 48 x 48 x 16 level of the voxel decoder), 64 reduction channels
+  static const int z16_on = getenv("MUVO_VOX_Z16") ? atoi(getenv("MUVO_VOX_Z16")) : 1;       // A/B switch
+  if (vox_geometry_ok(d, true) && (d->in_sz[2] == 16 || ck == 64)) return z16_on && vox_bf3_ps(ck, cp);
+  if (!vox_geometry_ok(d)) return false;
   // reduction channels 8 / 16 (the weights of one 16-row block live in registers); produced channels in blocks of 16 rows
   // (32 reduction channels run as two accumulating passes of 16)
   return (ck == 8 || ck == 16 || ck == 32) && (cp == 8 || cp == 16 || cp == 32);
 }
 static int vox_bf3_steps(int ck) { return ck == 8 ? 7 : 14; }      // per pass
 long vox_pack_floats(const muvo_conv_desc* d) {
-  const long plain = 27l * d->Cin * d->Cout, bf3 = 15l * 2 * 64 * 4 * 4;      // (plane-streaming form: 15 fragments per row block)   // bf16x3 layout: (halves x row blocks <= 4) x steps x (hi, lo) x 64 lanes x 16 B
+  const int blocks_f = (d->Cin / 16 > 0 ? d->Cin / 16 : 1) * cdiv(d->Cout, 16), blocks_d = (d->Cout / 16 > 0 ? d->Cout / 16 : 1) * cdiv(d->Cin, 16);
+  const int blocks = blocks_f > blocks_d ? blocks_f : blocks_d;
+  const long plain = 27l * d->Cin * d->Cout, bf3 = 15l * 2 * 64 * 4 * (blocks > 4 ? blocks : 4);      // (plane-streaming form: 15 fragments per row block)   // bf16x3 layout: (halves x row blocks <= 4) x steps x (hi, lo) x 64 lanes x 16 B
   return plain > bf3 ? plain : bf3;
 }
 
-// plane-streaming form (vox_bf3_ps_kernel): 16 reduction channels per pass (16, or 32 as two passes), any produced count
+// plane-streaming form (vox_bf3_ps_kernel): 16 reduction channels per pass (16, or 32 / 64 as two / four accumulating passes), produced
+// channels in row blocks of 16
 static bool vox_bf3_ps(int red, int cp) {
   static const int on = getenv("MUVO_VOX_PS") ? atoi(getenv("MUVO_VOX_PS")) : 1;
-  return on && (red == 16 || red == 32) && (cp == 8 || cp == 16 || cp == 32);
+  // (64 produced channels = four row blocks that each stage the same input: the 64 <- 32 data gradient at 48 x 48 x 16 measured
+  // 0.41 ms here against 0.36 on the implicit-GEMM kernel; not taken)
+  return on && (red == 16 || red == 32 || red == 64) && (cp == 8 || cp == 16 || cp == 32);
 }
 
 int vox_pack(const muvo_conv_desc* d, const float* w, float* wp, int dgrad, hipStream_t st, bool bf3) {
@@ -1874,6 +1883,8 @@ static int launch_vox_bf3_ps(const muvo_conv_desc* d, int Cout, const float* in,
 static int launch_vox_bf3_ps_z(const muvo_conv_desc* d, int Cout, const float* in, const float* wp, const float* bias, float* out, int act,
                                float slope, hipStream_t st, int cin_total, int accum, double* moments) {
   const int Z = d->in_sz[2];
+  if (Z == 16) return Cout <= 8 ? launch_vox_bf3_ps<16, true>(d, Cout, in, wp, bias, out, act, slope, st, cin_total, accum, moments)
+                                : launch_vox_bf3_ps<16, false>(d, Cout, in, wp, bias, out, act, slope, st, cin_total, accum, moments);
   if (Cout <= 8) return Z == 64 ? launch_vox_bf3_ps<64, true>(d, Cout, in, wp, bias, out, act, slope, st, cin_total, accum, moments)
                                 : launch_vox_bf3_ps<32, true>(d, Cout, in, wp, bias, out, act, slope, st, cin_total, accum, moments);
   return Z == 64 ? launch_vox_bf3_ps<64, false>(d, Cout, in, wp, bias, out, act, slope, st, cin_total, accum, moments)
@@ -1885,12 +1896,15 @@ static int vox_conv_dispatch(const muvo_conv_desc* d, int Cin, int Cout, const f
   if (moments && !bf3) { muvo_set_error("vox_conv: output moments need the bf16x3 kernels"); return MUVO_ERR_INVALID_ARG; }
   const int Z = d->in_sz[2];
   if (bf3 && vox_bf3_ps(Cin, Cout)) {
-    if (Cin == 32) {        // two accumulating passes over 16 reduction channels each; bias and activation ride on the second
+    if (Cin > 16) {         // accumulating passes over 16 reduction channels each; bias and activation ride on the last
       const long XYZ = (long)d->in_sz[0] * d->in_sz[1] * Z;
-      const float* wp2 = wp + (size_t)cdiv(Cout, 16) * (Cout <= 8 ? 10 : 15) * 2 * 64 * 4;
-      int rc = launch_vox_bf3_ps_z(d, Cout, in, wp, nullptr, out, MUVO_ACT_NONE, 0.f, st, 32, 0, nullptr);
-      if (rc) return rc;
-      return launch_vox_bf3_ps_z(d, Cout, in + 16 * XYZ, wp2, bias, out, act, slope, st, 32, 1, moments);
+      const size_t wstep = (size_t)cdiv(Cout, 16) * (Cout <= 8 ? 10 : 15) * 2 * 64 * 4;
+      const int npass = Cin / 16;
+      for (int ps = 0; ps < npass - 1; ++ps) {
+        const int rc = launch_vox_bf3_ps_z(d, Cout, in + (size_t)ps * 16 * XYZ, wp + ps * wstep, nullptr, out, MUVO_ACT_NONE, 0.f, st, Cin, ps > 0, nullptr);
+        if (rc) return rc;
+      }
+      return launch_vox_bf3_ps_z(d, Cout, in + (size_t)(npass - 1) * 16 * XYZ, wp + (npass - 1) * wstep, bias, out, act, slope, st, Cin, 1, moments);
     }
     return launch_vox_bf3_ps_z(d, Cout, in, wp, bias, out, act, slope, st, 0, 0, moments);
   }
