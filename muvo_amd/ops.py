@@ -502,14 +502,24 @@ class KernelTiming:
     """only: record events for this kernel class alone (bench.py brackets just the dominant class inside the timed region:
     ~1400 event pairs per step around every conv call cost 2.4 ms/step, ~140 pairs cost 0.2)."""
 
-    def __init__(self, only=None):
+    def __init__(self, only=None, prealloc=0):
+        """prealloc: events created AND recorded once up front.  A torch.cuda.Event gets its HIP event at its first record(), and
+        the first few thousand creations of a process grow the runtime's signal pools: bench.py's timed region paid ~100 ms for
+        that in its first three steps (105 / 107 / 125 ms against 77) until the pool was filled ahead of it."""
         self.rec = []
         self.only = only
+        self.pool = []
+        if prealloc > 0:
+            self.pool = [torch.cuda.Event(enable_timing=True) for _ in range(int(prealloc))]
+            for e in self.pool:
+                e.record()
+            torch.cuda.synchronize()
 
     def bracket(self, cls, flops, launches, tag='', nbytes=0.0):
         if self.only is not None and cls.split(':')[0] != self.only:
             return _NO_EVENT, _NO_EVENT
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0 = self.pool.pop() if self.pool else torch.cuda.Event(enable_timing=True)
+        e1 = self.pool.pop() if self.pool else torch.cuda.Event(enable_timing=True)
         self.rec.append((cls, flops, launches, e0, e1, tag, nbytes))
         return e0, e1
 

@@ -12,7 +12,7 @@ tag=$1
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 cd $R
-python bench.py --layer-table gpurun_out/${tag}_conv_layers.txt > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
+python bench.py --gpus 1 --steps 20 --warmup 5 --layer-table gpurun_out/${tag}_conv_layers.txt > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 echo "bench rc=$?"; cut -c1-300 gpurun_out/${tag}_bench.json | tail -1
 {
   echo "# python bench.py --steps 20 --warmup 5, one MI355X, same box, alternating (ms/step, median; gradient_exchange of the last run)"
