@@ -508,6 +508,7 @@ class KernelTiming:
         that in its first three steps (105 / 107 / 125 ms against 77) until the pool was filled ahead of it."""
         self.rec = []
         self.only = only
+        self.enabled = True          # bench.py brackets every fourth timed step only (each pair costs ~1.5 us of host and queue time)
         self.pool = []
         if prealloc > 0:
             self.pool = [torch.cuda.Event(enable_timing=True) for _ in range(int(prealloc))]
@@ -516,7 +517,7 @@ class KernelTiming:
             torch.cuda.synchronize()
 
     def bracket(self, cls, flops, launches, tag='', nbytes=0.0):
-        if self.only is not None and cls.split(':')[0] != self.only:
+        if not self.enabled or (self.only is not None and cls.split(':')[0] != self.only):
             return _NO_EVENT, _NO_EVENT
         e0 = self.pool.pop() if self.pool else torch.cuda.Event(enable_timing=True)
         e1 = self.pool.pop() if self.pool else torch.cuda.Event(enable_timing=True)
