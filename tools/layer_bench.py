@@ -24,6 +24,8 @@ LAYERS = {
     'lid3': ('convT', 128, 64, 6, 2, 2, (32, 512)),
     'res64': ('conv', 64, 64, 3, 1, 1, (80, 208)),
     'ds128': ('conv', 128, 384, 3, 1, 1, (40, 104)),
+    'res64rv': ('conv', 64, 64, 3, 1, 1, (16, 256)),
+    'ds64': ('conv', 64, 128, 3, 2, 1, (80, 208)),
     'res512': ('conv', 512, 512, 3, 1, 1, (10, 26)),
     'vox16': ('conv3d', 16, 8, 3, 1, 1, (192, 192, 64)),
     'vox8': ('conv3d', 8, 8, 3, 1, 1, (192, 192, 64)),
