@@ -311,7 +311,10 @@ class WorldModelTrainer(_Base):
             self._reducer.accumulating = self._is_accumulating()
             self._reducer.begin_step()
         losses, output, _, _ = self.shared_step(batch, mode='train', noise=noise, use_prior=use_prior)
-        self.last_losses = losses
+        # kept detached: a loss tensor with its grad_fn would keep this step's autograd graph - and the AccumulateGrad nodes of
+        # every parameter, created on the side streams - alive into the next step (memory, and PyTorch's stream-mismatch warning
+        # as soon as a parameter is then used on another stream; Lightning's self.log detaches as well)
+        self.last_losses = {k: v.detach() for k, v in losses.items()}
         self.logging_and_visualisation(batch, output, [], losses, None, batch_idx, prefix='train')
         return self.loss_reducing(losses)
 
@@ -330,6 +333,8 @@ class WorldModelTrainer(_Base):
 
     if pl is None:
         def log(self, name, value, *args, **kwargs):
+            if torch.is_tensor(value):
+                value = value.detach()
             if self.log_fn is not None:
                 self.log_fn(name, value)
             else:
