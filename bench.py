@@ -336,10 +336,16 @@ def main():
     # it counts them, and the timed region's events are created (and recorded once) before it starts (ops.KernelTiming)
     dominant = 'bf16x3_implicit_gemm' if args.conv_mfma in ('bf16x3', 'bf16') else 'f32_implicit_gemm'
     probe = None
+    pool_reserved = 0
     for i in range(args.warmup):
         if i == args.warmup - 1 and not args.no_kernel_timing:
             probe = ops.KERNEL_TIMING = ops.KernelTiming(only=dominant)
         step(i)
+        if i == 0 and os.environ.get('MUVO_POOL_RESERVE', '1') != '0':
+            # the caching allocator's per-stream pools sized after the first step (ops.reserve_memory_pools): 14-16 -> 2-3 hipMalloc
+            # calls inside the timed region, same step time (75.8-76.1 ms either way); MUVO_POOL_RESERVE=0: off
+            torch.cuda.synchronize()
+            pool_reserved = ops.reserve_memory_pools(dev)
     ops.KERNEL_TIMING = None
     if not args.no_kernel_timing:
         per_step = 2 * len(probe.rec) if probe is not None else 800
@@ -358,6 +364,7 @@ def main():
     import gc
     gc.collect()
     gc.disable()
+    ms0 = torch.cuda.memory_stats()
     c0 = time.process_time()
     t0 = time.perf_counter()
     marks[0].record()
@@ -373,6 +380,10 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     gc.enable()
+    ms1 = torch.cuda.memory_stats()
+    # hipMalloc / hipFree calls of the caching allocator inside the timed region: without the reservation above its per-stream pools
+    # still grow after five warm-up steps (blocks freed on one stream while another still reads them come back late)
+    alloc_delta = {k: int(ms1.get(k, 0) - ms0.get(k, 0)) for k in ('num_device_alloc', 'num_device_free', 'num_alloc_retries')}
     step_ms_seq = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     step_ms = sorted(step_ms_seq)
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
@@ -445,6 +456,7 @@ def main():
                        else 'unpinned (extension, own oracle only)'),
             'median_ms_per_step': median_ms, 'value_at_median': args.batch * world / (median_ms * 1e-3),
             'step_ms': [round(v, 2) for v in step_ms_seq],     # rank 0's stream-side step times, in order (outliers are host stalls)
+            'allocator_calls_in_timed_region': alloc_delta, 'pool_reserved_gb': round(pool_reserved / 2 ** 30, 1),
             'frames_per_s': samples * s / dt,
             'step_tflops_per_gpu': (GFLOP_PER_FRAME * frames_per_gpu_step / (ms * 1e-3) / 1e3) if args.workload == 'base_1d' else None,
             'final_loss': loss_val,

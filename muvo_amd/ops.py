@@ -330,6 +330,37 @@ def side_stream(name, device):
     return st
 
 
+def reserve_memory_pools(device, main_gb=None, side_gb=None):
+    """Pre-size PyTorch's caching allocator for a training loop: one large block is allocated and released on the current stream
+    and on every side stream that EXISTS (call it after a first step: creating the streams here, in another order, changes their
+    hardware-queue assignment), so that each stream's pool serves the step's requests by splitting it.  Without this the pools grow
+    while the loop runs - blocks are stream-specific and a block freed on one stream while a kernel of another still reads it
+    (record_stream) comes back late, so the allocator keeps calling hipMalloc for dozens of steps.  MUVO_POOL_MAIN_GB (default 32) +
+    MUVO_POOL_SIDE_GB (default 12) per side stream; returns the bytes reserved."""
+    device = torch.device(device)
+    if device.type != 'cuda':
+        return 0
+    main_gb = float(os.environ.get('MUVO_POOL_MAIN_GB', 32.0)) if main_gb is None else main_gb
+    side_gb = float(os.environ.get('MUVO_POOL_SIDE_GB', 12.0)) if side_gb is None else side_gb
+    cur = torch.cuda.current_stream(device)
+    todo, seen = [(cur, main_gb)], {cur.cuda_stream}
+    for (name, idx), st in sorted(_side_streams.items(), key=lambda kv: kv[0][0]):
+        if idx == device.index and st.cuda_stream not in seen:
+            seen.add(st.cuda_stream)
+            todo.append((st, side_gb))
+    free = torch.cuda.mem_get_info(device)[0]
+    total = 0
+    for st, gb in todo:
+        nbytes = int(gb * 2 ** 30)
+        if nbytes <= 0 or total + nbytes > 0.8 * free:
+            continue
+        with torch.cuda.stream(st):
+            t = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            del t
+        total += nbytes
+    return total
+
+
 # HIP stream priorities of the side streams (MUVO_SIDE_PRIORITY="*=normal" | "s2=low,s0=normal" ...; physical stream names s0..s2).
 # The main stream's chain is the critical path of the step; a low-priority side stream only gets the compute units the main
 # stream's launches leave idle.
