@@ -554,6 +554,15 @@ def main():
                                           hbm_gbs=gb / max(sec, 1e-12), hbm_frac=gb / max(sec, 1e-12) / 8000.0,
                                           ms_at_hbm_roof=gb / extra_steps / 8000.0 * 1e3,
                                           mfma_frac=3.0 * tf / max(sec, 1e-12) / 2500.0)
+                # by level of the voxel decoder (input size of the convolution): until round 4 the class held the 192 and 96 levels only
+                import re
+                lv = {}
+                for cls, _fl, _ln, e0, e1, tag, _nb in full_timing.rec:
+                    if cls.startswith('vox_bf16x3'):
+                        m = re.search(r'in\(([^)]*)\)', tag)
+                        key = 'x'.join(v.strip() for v in m.group(1).split(',')) if m else 'other'
+                        lv[key] = lv.get(key, 0.0) + e0.elapsed_time(e1) / extra_steps
+                out['voxel_class']['ms_per_step_by_level'] = {k: round(v, 3) for k, v in sorted(lv.items())}
         if out.get('roofline') is not None:
             out['roofline']['frac_is'] = ('in situ: HIP-event brackets inside the timed region, side streams on (a bracket also contains the '
                                           "neighbours' share of the chip); frac_isolated = the kernel figure (same brackets, side streams off)")
