@@ -1163,8 +1163,15 @@ vox_bf3_wgrad_kernel(const VoxArgs a, const float* __restrict__ x, const float* 
 #ifndef VOX_WGPS_SCHED
 #define VOX_WGPS_SCHED 1     // A/B: staging pieces pinned between the MFMA groups
 #endif
-template <int Z, int CI, bool CO8>
-__global__ void __launch_bounds__(512)
+#ifndef VOX_WGPS_SW
+#define VOX_WGPS_SW 4     // A/B: staging waves of the variants that fit three waves per SIMD (0: the MFMA waves stage the x planes)
+#endif
+// SW > 0: SW extra waves do nothing but stage the x planes (load, AdaIN, split, LDS stores of plane P + 1) while the eight MFMA
+// waves work on plane P - loops of their own with the same number of workgroup barriers.  The two halves of the kernel (1.20 ms of
+// staging at ~5 TB/s, 1.19 ms of MFMA issue on the 16 -> 8 layer) then no longer alternate inside every wave - and still do not
+// simply overlap: 1.78 -> 1.68 ms, they share the LDS and the memory pipeline.
+template <int Z, int CI, bool CO8, int SW = 0>
+__global__ void __launch_bounds__(512 + 64 * SW)
 vox_bf3_wgrad_ps_kernel(const VoxArgs a, const float* __restrict__ x, const float* __restrict__ dz, float* __restrict__ dw,
                         float* __restrict__ dbias, int xseg) {
   static_assert(CI == 16 || CO8, "8 input channels: the quadrant tiles hold 8 produced channels");
@@ -1174,14 +1181,17 @@ vox_bf3_wgrad_ps_kernel(const VoxArgs a, const float* __restrict__ x, const floa
   constexpr int XROW = (Z + 16) * 2;                    // bytes of an x row: 16-byte zero pad on both sides
   constexpr int XCI = ROWS * XROW + 16;                 // channel stride (bytes), +16 spreads the channels over all banks
   constexpr int XHL = CI * XCI, XSLOT = 2 * XHL;
-  constexpr int XT = CI * ROWS * (Z / 8), XPT = (XT + 511) / 512;
+  constexpr int NTH = 512 + 64 * SW, NS = SW > 0 ? 64 * SW : 512;       // threads of the workgroup / threads that stage
+  constexpr int XT = CI * ROWS * (Z / 8), XPT = (XT + NS - 1) / NS;
   constexpr int TPC = QUAD ? 1 : (CO8 ? 2 : 3), NT = 9 * TPC;
-  static_assert(XPT <= 2, "staging pieces: one per dy group, then the loads");
+  static_assert(SW > 0 || XPT <= 2, "staging pieces: one per dy group, then the loads");
   static_assert(2 * XSLOT >= NT * 1024, "the reduction reuses the x planes");
   extern __shared__ char wsm[];
   char* xring = wsm;                                    // two x planes: one read by the MFMA phase, one being staged
   float* dbsum = (float*)(wsm + 2 * XSLOT);             // 16 floats
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool stager = SW > 0 && wave >= 8;              // (wave-uniform)
+  const int stid = SW > 0 ? tid - 512 : tid;            // index among the staging threads
   const int nseg = (a.X + xseg - 1) / xseg;
   int bid = a.xcd_order ? xcd_swizzle(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int seg = bid % nseg; bid /= nseg;
@@ -1192,7 +1202,7 @@ vox_bf3_wgrad_ps_kernel(const VoxArgs a, const float* __restrict__ x, const floa
   const float* xb = x + (long)n * a.sN_in + (long)ci0 * a.XYZ;
   const int co_base = blockIdx.z * 16;                  // 32 produced channels: two row blocks
   const float* db = dz + (long)n * a.sN_out;
-  for (int i = tid; i < (2 * XSLOT + 64) / 16; i += 512) ((uint4*)wsm)[i] = uint4{0u, 0u, 0u, 0u};
+  for (int i = tid; i < (2 * XSLOT + 64) / 16; i += NTH) ((uint4*)wsm)[i] = uint4{0u, 0u, 0u, 0u};
   __syncthreads();
 
   constexpr unsigned OOB = 0x7fffff00u;
@@ -1208,7 +1218,7 @@ vox_bf3_wgrad_ps_kernel(const VoxArgs a, const float* __restrict__ x, const floa
   bool xrow_ok[XPT];
 #pragma unroll
   for (int k = 0; k < XPT; ++k) {
-    const int t = tid + k * 512;
+    const int t = stid >= 0 ? stid + k * NS : XT;
     const int z8 = t % (Z / 8), rr = (t / (Z / 8)) % ROWS, ci = t / ((Z / 8) * ROWS);
     const int gy = y0 - 1 + rr;
     const bool have = a.aff != nullptr && t < XT && ci0 + ci < a.Cin;
@@ -1292,10 +1302,28 @@ vox_bf3_wgrad_ps_kernel(const VoxArgs a, const float* __restrict__ x, const floa
   vu32x4 Ah[3] = {}, Al[3] = {};                        // index d = dx + 1: dz plane P + 1 - d
 
   const int niter = xe - xs + 2;
-  xload(xs - 1);
+  if (stager) {
+    // staging waves: a loop of their own (the register allocator then keeps the two roles' values apart), same barrier count
+    xload(xs - 1);
 #pragma unroll
-  for (int k = 0; k < XPT; ++k) xstore_task(k, 0);
-  xload(xs);
+    for (int k = 0; k < XPT; ++k) xstore_task(k, 0);
+    xload(xs);
+    __syncthreads();
+    for (int it = 0; it < niter; ++it) {
+      if (it + 1 < niter) {
+#pragma unroll
+        for (int k = 0; k < XPT; ++k) xstore_task(k, (it + 1) & 1);
+        if (it + 2 < niter) xload(xs + 1 + it);       // plane P + 2, P = xs - 1 + it
+      }
+      __syncthreads();
+    }
+  } else {
+  if (SW == 0) {
+    xload(xs - 1);
+#pragma unroll
+    for (int k = 0; k < XPT; ++k) xstore_task(k, 0);
+    xload(xs);
+  }
   aload(xs);
   __syncthreads();
   for (int it = 0; it < niter; ++it) {
@@ -1363,7 +1391,7 @@ vox_bf3_wgrad_ps_kernel(const VoxArgs a, const float* __restrict__ x, const floa
       // staging of x plane P + 1 into the other slot between the MFMA groups; a task's registers take its piece of plane P + 2
       // right after its store, so every load has a whole iteration (~2.5 us) to arrive (issued behind the last group it had a
       // third of one, and the memory latency under load showed: no-staging / no-MFMA ablations 1.19 / 1.20 ms of 1.87)
-      if (dy < XPT && it + 1 < niter) {
+      if (SW == 0 && dy < XPT && it + 1 < niter) {
         xstore_task(dy, (it + 1) & 1);
         if (it + 2 < niter) xload_task(dy, P + 2);
       }
@@ -1373,20 +1401,23 @@ vox_bf3_wgrad_ps_kernel(const VoxArgs a, const float* __restrict__ x, const floa
     }
     __syncthreads();
   }
+  }      // MFMA waves
   // bias sums: over the four z groups of the wave in registers, over the waves in LDS
   dbacc += __shfl_xor(dbacc, 16, 64);
   dbacc += __shfl_xor(dbacc, 32, 64);
-  if (blockIdx.y == 0 && dbias && kg == 0 && j < (CO8 ? 8 : 16)) atomicAdd(dbsum + j, dbacc);   // (Z = 16: both rows of the wave summed by the shuffles)
+  if (!stager && blockIdx.y == 0 && dbias && kg == 0 && j < (CO8 ? 8 : 16)) atomicAdd(dbsum + j, dbacc);   // (Z = 16: both rows of the wave summed by the shuffles)
   // workgroup reduction of the accumulator tiles through LDS (the x planes are free now), then one set of atomics
   float* red = (float*)wsm;                                             // [NT][16 rows][16 columns]
-  for (int i = tid; i < NT * 256; i += 512) red[i] = 0.f;
+  for (int i = tid; i < NT * 256; i += NTH) red[i] = 0.f;
   __syncthreads();
+  if (!stager) {
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) atomicAdd(red + (t * 16 + 4 * kg + r) * 16 + j, acc[t][r]);
+      for (int r = 0; r < 4; ++r) atomicAdd(red + (t * 16 + 4 * kg + r) * 16 + j, acc[t][r]);
+  }
   __syncthreads();
-  for (int i = tid; i < NT * 256; i += 512) {
+  for (int i = tid; i < NT * 256; i += NTH) {
     const int col = i & 15, t = i >> 8;
     int co = (i >> 4) & 15, ci = col;
     int tz = t % TPC;                                                   // z tap index 0..2 (dz + 1) of this tile
@@ -2035,6 +2066,10 @@ static int launch_vox_bf3_wgrad(const muvo_conv_desc* d, const float* x, const f
 
 template <int Z, int CI, bool CO8>
 static int launch_vox_bf3_wgrad_ps(const muvo_conv_desc* d, const float* x, const float* dz, float* dw, float* dbias, hipStream_t st) {
+  // staging waves only for 16 input / <= 8 produced channels (1.78 -> 1.68 ms on 16 -> 8 at 192 x 192 x 64): 27 accumulator tiles
+  // (206 VGPRs) leave no room for three waves per SIMD, and the 8 -> 8 variant (117 VGPRs) loses its second workgroup per CU
+  // (0.98 -> 1.08 ms)
+  constexpr int SW = (CI == 16 && CO8) ? VOX_WGPS_SW : 0;
   constexpr int ZH = Z >= 32 ? Z / 32 : 1, RW = Z >= 32 ? 1 : 32 / Z, WROWS = 8 / ZH * RW, ROWS = WROWS + 2;
   constexpr size_t lds = (size_t)2 * 2 * CI * (ROWS * (Z + 16) * 2 + 16) + 64;
   VoxArgs a{};
@@ -2049,14 +2084,14 @@ static int launch_vox_bf3_wgrad_ps(const muvo_conv_desc* d, const float* x, cons
   while ((long)a.N * a.ytiles * cdiv(a.X, xseg) * (a.Cin / CI) * cdiv(a.Cout, 16) < vox_blocks_target(1) && xseg > 12) xseg = cdiv(xseg, 2);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)vox_bf3_wgrad_ps_kernel<Z, CI, CO8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)vox_bf3_wgrad_ps_kernel<Z, CI, CO8, SW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       muvo_set_error("vox_bf3_wgrad_ps: cannot raise the dynamic LDS limit to %zu bytes", lds);
       return MUVO_ERR_HIP;
     }
     attr_set = true;
   }
   dim3 grid((unsigned)((long)a.N * a.ytiles * cdiv(a.X, xseg)), a.Cin / CI, cdiv(a.Cout, 16));
-  hipLaunchKernelGGL((vox_bf3_wgrad_ps_kernel<Z, CI, CO8>), grid, dim3(512), lds, st, a, x, dz, dw, dbias, xseg);
+  hipLaunchKernelGGL((vox_bf3_wgrad_ps_kernel<Z, CI, CO8, SW>), grid, dim3(512 + 64 * SW), lds, st, a, x, dz, dw, dbias, xseg);
   MUVO_CHECK_LAUNCH("vox_bf3_wgrad_ps_kernel");
   return MUVO_OK;
 }
