@@ -1794,7 +1794,7 @@ static int launch_vox_conv(const muvo_conv_desc* d, int Cin, int Cout, const flo
 // fewer, longer segments win as soon as the chip is roughly covered: measured over all four weight-gradient layers 9.4 ms
 // with a target of 1024, 7.1 with 128 (no segmentation at N = 20); forward / data gradient 8.8 -> 8.4 ms with 256.
 static int vox_blocks_target(int wgrad) {
-  static const int f = getenv("MUVO_VOX_BLOCKS") ? atoi(getenv("MUVO_VOX_BLOCKS")) : 256;
+  static const int f = getenv("MUVO_VOX_BLOCKS") ? atoi(getenv("MUVO_VOX_BLOCKS")) : 128;   // (round 4: 256 -> 128, the plane-streaming kernels pay two extra planes per segment: -0.13 ms over the forward / data-gradient launches)
   static const int w = getenv("MUVO_VOX_WGRAD_BLOCKS") ? atoi(getenv("MUVO_VOX_WGRAD_BLOCKS")) : 128;
   return wgrad ? w : f;
 }
